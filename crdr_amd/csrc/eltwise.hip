@@ -1,0 +1,564 @@
+// HBM-bound fused elementwise / reduction kernels of the CRDR training step (fp32).
+// All reductions are two-stage (per-block partials in a caller workspace, then a fixed-order final sum) so
+// results are bit-reproducible run to run -- no float atomics anywhere in this file.
+
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace crdr {
+
+// ------------------------------------------------------------------------------------------------------------
+// epilogue backward
+// ------------------------------------------------------------------------------------------------------------
+struct EbwdArgs {
+  crdr_ebwd_desc d;
+  crdr_ebwd_io io;
+  float* partial;  // [nblocks][4][C]
+  int rows_per_block;
+};
+
+// block = 64 (channels) x 4 (rows); a block owns rows [b*rpb, (b+1)*rpb)
+__global__ __launch_bounds__(256) void ebwd_kernel(const EbwdArgs p) {
+  __shared__ float red[4][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int f = p.d.flags, C = p.d.C;
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+  const int64_t r1 = r0 + p.rows_per_block < p.d.M ? r0 + p.rows_per_block : p.d.M;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + tx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+      const float sc = (f & CRDR_EPI_AFFINE) ? p.io.scale[c] : 1.f;
+      const float sh = (f & CRDR_EPI_AFFINE) ? p.io.shift[c] : 0.f;
+      const float v2 = (f & CRDR_EPI_VEC2) ? p.io.vec2[c] : 0.f;
+      for (int64_t m = r0 + ty; m < r1; m += 4) {
+        float g = p.io.dout[m * p.d.lddout + c];
+        float o = (f & (CRDR_EPI_AFFINE | CRDR_EPI_RELU | CRDR_EPI_LRELU)) ? p.io.out[m * p.d.ldout + c] : 0.f;
+        if (f & CRDR_EPI_AFFINE) {
+          const float u = (o - sh) / sc;
+          s2 += g * u;
+          s3 += g;
+          g *= sc;
+          o = u;
+        }
+        if (f & CRDR_EPI_GATE) {
+          const float sg = p.io.sig[m * p.d.ldg + c], tr = p.io.gt[m * p.d.ldg + c];
+          p.io.gres[m * p.d.ldgres + c] = g;
+          p.io.dgt[m * p.d.ldg + c] = g * sg;
+          g = g * tr * sg * (1.f - sg);
+        } else if ((f & CRDR_EPI_AFFINE) && (f & CRDR_EPI_RES)) {
+          p.io.gres[m * p.d.ldgres + c] = g;
+        }
+        if (f & CRDR_EPI_VEC2) s1 += g;
+        if (f & CRDR_EPI_RELU) g = (o - v2) > 0.f ? g : 0.f;
+        if (f & CRDR_EPI_LRELU) g = o > 0.f ? g : 0.2f * g;
+        if (p.io.dz) p.io.dz[m * p.d.lddz + c] = g;
+        s0 += g;
+      }
+    }
+    red[0][ty][tx] = s0; red[1][ty][tx] = s1; red[2][ty][tx] = s2; red[3][ty][tx] = s3;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        p.partial[((size_t)blockIdx.x * 4 + k) * C + c] = red[k][0][tx] + red[k][1][tx] + red[k][2][tx] + red[k][3][tx];
+    }
+    __syncthreads();
+  }
+}
+
+// out[k][c] = sum_b partial[b][k][c]   (K sums per block)
+__global__ __launch_bounds__(256) void colsum_final(const float* partial, int nblocks, int K, int C, float* out,
+                                                    int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= K * C) return;
+  float v = 0.f;
+  for (int b = 0; b < nblocks; ++b) v += partial[(size_t)b * K * C + e];
+  out[e] = accumulate ? out[e] + v : v;
+}
+
+static int ebwd_blocks(int64_t M, int* rpb) {
+  int r = 128;
+  while (cdiv64(M, r) > 4096) r *= 2;
+  *rpb = r;
+  return (int)cdiv64(M, r);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// simple maps
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_kernel(const float* x, int ldx, const float* scale, const float* shift,
+                                                     float* y, int ldy, int64_t M, int C) {
+  const int64_t total = M * C;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int64_t m = e / C;
+    const int c = (int)(e - m * C);
+    y[m * ldy + c] = x[m * ldx + c] * scale[c] + shift[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, int64_t M, int C, float* partial,
+                                                     int rows_per_block) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + tx;
+    float s = 0.f;
+    if (c < C)
+      for (int64_t m = r0 + ty; m < r1; m += 4) s += x[m * ldx + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ float softplusf_(float w) { return w > 20.f ? w : log1pf(expf(w)); }
+
+__global__ void interp_ca_params_kernel(const float* W, const float* B, int L, int C, float q, float* scale,
+                                        float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float lf = floorf(q);
+  const float rf = fminf(lf + 1.f, (float)(L - 1));
+  const float a = rf - q;
+  const int l = (int)lf, r = (int)rf;
+  const float w = W[l * C + c] * a + W[r * C + c] * (1.f - a);
+  scale[c] = softplusf_(w);
+  shift[c] = B ? B[l * C + c] * a + B[r * C + c] * (1.f - a) : 0.f;
+}
+
+__global__ void interp_ca_params_bwd_kernel(const float* W, int L, int C, float q, const float* dscale,
+                                            const float* dshift, float* dW, float* dB) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float lf = floorf(q);
+  const float rf = fminf(lf + 1.f, (float)(L - 1));
+  const float a = rf - q;
+  const int l = (int)lf, r = (int)rf;
+  const float w = W[l * C + c] * a + W[r * C + c] * (1.f - a);
+  const float dw = dscale[c] * (w > 20.f ? 1.f : 1.f / (1.f + expf(-w)));  // softplus' = sigmoid
+  // l == r (q == L-1) => a = 0: the reference's out = t[l]*a + t[r]*(1-a) sends the whole gradient through r
+  dW[l * C + c] += dw * a;
+  dW[r * C + c] += dw * (1.f - a);
+  if (dB) {
+    dB[l * C + c] += dshift[c] * a;
+    dB[r * C + c] += dshift[c] * (1.f - a);
+  }
+}
+
+__global__ __launch_bounds__(256) void lrp_kernel(const float* a, int lda, const float* z, int ldz, float* y, int ldy,
+                                                  int64_t M, int C) {
+  const int64_t total = M * C;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int64_t m = e / C;
+    const int c = (int)(e - m * C);
+    y[m * ldy + c] = a[m * lda + c] + 0.5f * tanhf(z[m * ldz + c]);
+  }
+}
+__global__ __launch_bounds__(256) void lrp_bwd_kernel(const float* dy, int lddy, const float* z, int ldz, float* dz,
+                                                      int lddz, int64_t M, int C) {
+  const int64_t total = M * C;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int64_t m = e / C;
+    const int c = (int)(e - m * C);
+    const float t = tanhf(z[m * ldz + c]);
+    dz[m * lddz + c] = dy[m * lddy + c] * 0.5f * (1.f - t * t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// scalar reductions: out = sum f(...)  (partials per block, then one block sums them in order)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return r;
+}
+
+enum { RED_SQDIFF = 0, RED_BCE = 1, RED_SQNORM = 2 };
+template <int OP>
+__global__ __launch_bounds__(256) void reduce_kernel(const float* a, const float* b, int64_t n, float target,
+                                                     float* partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += gridDim.x * 256ll) {
+    if (OP == RED_SQDIFF) { const float d = a[e] - b[e]; s += d * d; }
+    if (OP == RED_SQNORM) { const float d = a[e]; s += d * d; }
+    if (OP == RED_BCE) {  // BCEWithLogits(x, t) = max(x,0) - x t + log(1 + exp(-|x|))
+      const float x = a[e] - b[e];
+      s += fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
+    }
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void reduce_final(const float* partial, int nb, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int e = threadIdx.x; e < nb; e += 256) s += partial[e];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+static int reduce_blocks(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(cdiv64(n, 1024), 1), 1024); }
+
+__global__ __launch_bounds__(256) void sqdiff_bwd_kernel(const float* a, const float* b, int64_t n, const float* g,
+                                                         float gscale, float* da, float* db) {
+  const float k = 2.f * gscale * (g ? g[0] : 1.f);
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += gridDim.x * 256ll) {
+    const float d = (a[e] - b[e]) * k;
+    if (da) da[e] = d;
+    if (db) db[e] = -d;
+  }
+}
+__global__ __launch_bounds__(256) void bce_diff_bwd_kernel(const float* p, const float* q, int64_t n, float target,
+                                                           const float* g, float gscale, float* dp, float* dq) {
+  const float k = gscale * (g ? g[0] : 1.f);
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += gridDim.x * 256ll) {
+    const float x = p[e] - q[e];
+    const float d = (1.f / (1.f + expf(-x)) - target) * k;
+    if (dp) dp[e] = d;
+    if (dq) dq[e] = -d;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Adam
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   const float* sqnorm, float max_norm) {
+  float clip = 1.f;
+  if (sqnorm) {
+    const float c = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
+    clip = c < 1.f ? c : 1.f;
+  }
+  const float step_size = lr / bc1;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += gridDim.x * 256ll) {
+    const float gr = g[e] * clip;
+    const float mm = m[e] + (gr - m[e]) * (1.f - b1);  // torch: exp_avg.lerp_(grad, 1 - beta1)
+    const float vv = v[e] * b2 + (1.f - b2) * gr * gr;  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[e] = mm;
+    v[e] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[e] -= step_size * (mm / denom);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LPIPS helpers (NHWC)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float* x, float* y, int N, int H, int W, int C,
+                                                             int OH, int OW) {
+  const int64_t total = (int64_t)N * OH * OW * C;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int c = (int)(e % C);
+    int64_t r = e / C;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    float best = -INFINITY;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        const int ih = oh * 2 + i, iw = ow * 2 + j;
+        if (ih < H && iw < W) best = fmaxf(best, x[(((int64_t)n * H + ih) * W + iw) * C + c]);
+      }
+    y[e] = best;
+  }
+}
+// gather form: dx[pixel] = sum over the (<=4) windows containing it whose argmax (first max in scan order) is it
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* x, const float* dy, float* dx, int N, int H,
+                                                             int W, int C, int OH, int OW) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int c = (int)(e % C);
+    int64_t r = e / C;
+    const int iw = (int)(r % W); r /= W;
+    const int ih = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc = 0.f;
+    for (int oh = (ih >= 2 ? (ih - 1) / 2 : 0); oh <= ih / 2 && oh < OH; ++oh)
+      for (int ow = (iw >= 2 ? (iw - 1) / 2 : 0); ow <= iw / 2 && ow < OW; ++ow) {
+        // argmax of window (oh, ow), first occurrence in row-major scan
+        float best = -INFINITY; int bi = -1, bj = -1;
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) {
+            const int yy = oh * 2 + i, xx = ow * 2 + j;
+            if (yy < H && xx < W) {
+              const float v = x[(((int64_t)n * H + yy) * W + xx) * C + c];
+              if (v > best) { best = v; bi = yy; bj = xx; }
+            }
+          }
+        if (bi == ih && bj == iw) acc += dy[(((int64_t)n * OH + oh) * OW + ow) * C + c];
+      }
+    dx[e] = acc;
+  }
+}
+
+// one wave per pixel: unit-normalise both feature vectors over C, weighted squared difference
+__global__ __launch_bounds__(256) void lpips_layer_fwd_kernel(const float* f0, const float* f1, const float* lin,
+                                                              int N, int HW, int C, float* partial) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  float acc = 0.f;
+  for (int px = blockIdx.x * 4 + w; px < HW; px += gridDim.x * 4) {
+    const float* a = f0 + ((size_t)n * HW + px) * C;
+    const float* b = f1 + ((size_t)n * HW + px) * C;
+    float sa = 0.f, sb = 0.f;
+    for (int c = lane; c < C; c += 64) { sa += a[c] * a[c]; sb += b[c] * b[c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+    const float ia = 1.f / (sqrtf(sa) + 1e-10f), ib = 1.f / (sqrtf(sb) + 1e-10f);
+    float d = 0.f;
+    for (int c = lane; c < C; c += 64) { const float t = a[c] * ia - b[c] * ib; d += lin[c] * t * t; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    acc += d;
+  }
+  if (lane == 0) red[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(size_t)n * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void lpips_layer_final(const float* partial, int nb, int HW, float* out) {
+  const int n = blockIdx.x;
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(size_t)n * nb + b];
+    out[n] += s / (float)HW;
+  }
+}
+// gradient w.r.t. f1 only (f0 = features of the real image carries no gradient in the training step)
+__global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(const float* f0, const float* f1, const float* lin,
+                                                              int N, int HW, int C, const float* gout, float* df1) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  const float g = gout[n] / (float)HW;
+  for (int px = blockIdx.x * 4 + w; px < HW; px += gridDim.x * 4) {
+    const float* a = f0 + ((size_t)n * HW + px) * C;
+    const float* b = f1 + ((size_t)n * HW + px) * C;
+    float* d = df1 + ((size_t)n * HW + px) * C;
+    float sa = 0.f, sb = 0.f;
+    for (int c = lane; c < C; c += 64) { sa += a[c] * a[c]; sb += b[c] * b[c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+    const float nb_ = sqrtf(sb);
+    const float ia = 1.f / (sqrtf(sa) + 1e-10f), ib = 1.f / (nb_ + 1e-10f);
+    // e_c = dL/d(bhat_c) = -2 g lin_c (ahat_c - bhat_c); bhat = b * ib; d ib / d b_c = -ib^2 * b_c / |b|
+    float dot = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float e = -2.f * g * lin[c] * (a[c] * ia - b[c] * ib);
+      dot += e * b[c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    const float k = nb_ > 0.f ? dot * ib * ib / nb_ : 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float e = -2.f * g * lin[c] * (a[c] * ia - b[c] * ib);
+      d[c] = e * ib - k * b[c];
+    }
+  }
+}
+
+}  // namespace crdr
+
+using namespace crdr;
+
+static inline int grid_for(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(cdiv64(n, 256), 1), 8192); }
+
+extern "C" size_t crdr_epilogue_bwd_workspace(const crdr_ebwd_desc* d) {
+  int rpb;
+  const int nb = ebwd_blocks(d->M, &rpb);
+  return (size_t)nb * 4 * d->C * sizeof(float);
+}
+
+extern "C" int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io, void* ws, size_t ws_bytes,
+                                 crdr_stream_t s) {
+  const int f = d->flags;
+  CRDR_REQUIRE(io->dout && io->colsums, "epilogue_bwd: null dout/colsums");
+  CRDR_REQUIRE(!((f & (CRDR_EPI_RELU | CRDR_EPI_LRELU)) && (f & (CRDR_EPI_RES | CRDR_EPI_GATE | CRDR_EPI_AFFINE))),
+               "epilogue_bwd: activation mask cannot be recovered when RES/GATE/AFFINE follow it");
+  CRDR_REQUIRE(!(f & (CRDR_EPI_AFFINE | CRDR_EPI_RELU | CRDR_EPI_LRELU)) || io->out, "epilogue_bwd: needs saved out");
+  CRDR_REQUIRE(!(f & CRDR_EPI_AFFINE) || (io->scale && io->shift), "epilogue_bwd: AFFINE needs scale/shift");
+  CRDR_REQUIRE(!(f & CRDR_EPI_GATE) || (io->gt && io->sig && io->gres && io->dgt), "epilogue_bwd: GATE needs gt/sig/gres/dgt");
+  CRDR_REQUIRE(!((f & CRDR_EPI_AFFINE) && (f & CRDR_EPI_RES)) || io->gres, "epilogue_bwd: AFFINE+RES needs gres");
+  CRDR_REQUIRE(!(f & CRDR_EPI_VEC2) || io->vec2, "epilogue_bwd: VEC2 needs vec2");
+  EbwdArgs a;
+  a.d = *d; a.io = *io;
+  const int nb = ebwd_blocks(d->M, &a.rows_per_block);
+  CRDR_REQUIRE(ws_bytes >= (size_t)nb * 4 * d->C * sizeof(float), "epilogue_bwd: workspace too small");
+  a.partial = (float*)ws;
+  if (d->M > 0) {
+    hipLaunchKernelGGL(ebwd_kernel, dim3(nb), dim3(256), 0, as_stream(s), a);
+    CRDR_CHECK_LAUNCH("ebwd_kernel");
+  }
+  hipLaunchKernelGGL(colsum_final, dim3(cdiv(4 * d->C, 256)), dim3(256), 0, as_stream(s), (const float*)ws,
+                     d->M > 0 ? nb : 0, 4, d->C, io->colsums, 0);
+  CRDR_CHECK_LAUNCH("colsum_final");
+  return 0;
+}
+
+extern "C" int crdr_affine(const float* x, int ldx, const float* scale, const float* shift, float* y, int ldy,
+                           int64_t M, int C, crdr_stream_t s) {
+  CRDR_REQUIRE(x && y && scale && shift, "affine: null pointer");
+  if (M * C == 0) return 0;
+  hipLaunchKernelGGL(affine_kernel, dim3(grid_for(M * C)), dim3(256), 0, as_stream(s), x, ldx, scale, shift, y, ldy, M, C);
+  CRDR_CHECK_LAUNCH("affine");
+  return 0;
+}
+
+extern "C" size_t crdr_colsum_workspace(int64_t M, int C) {
+  int rpb;
+  return (size_t)ebwd_blocks(M, &rpb) * C * sizeof(float);
+}
+extern "C" int crdr_colsum(const float* x, int ldx, int64_t M, int C, float* out, int accumulate, void* ws,
+                           size_t ws_bytes, crdr_stream_t s) {
+  int rpb;
+  const int nb = ebwd_blocks(M, &rpb);
+  CRDR_REQUIRE(x && out && ws_bytes >= (size_t)nb * C * sizeof(float), "colsum: bad arguments");
+  if (M > 0) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, as_stream(s), x, ldx, M, C, (float*)ws, rpb);
+    CRDR_CHECK_LAUNCH("colsum");
+  }
+  hipLaunchKernelGGL(colsum_final, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(s), (const float*)ws, M > 0 ? nb : 0, 1,
+                     C, out, accumulate);
+  CRDR_CHECK_LAUNCH("colsum_final");
+  return 0;
+}
+
+extern "C" int crdr_interp_ca_params(const float* W, const float* B, int L, int C, float q, float* scale,
+                                     float* shift, crdr_stream_t s) {
+  CRDR_REQUIRE(W && scale && shift, "interp_ca_params: null pointer");
+  CRDR_REQUIRE(q >= 0.f && q <= (float)(L - 1), "interp_ca_params: rate_ind %f outside [0, %d]", q, L - 1);
+  hipLaunchKernelGGL(interp_ca_params_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(s), W, B, L, C, q, scale, shift);
+  CRDR_CHECK_LAUNCH("interp_ca_params");
+  return 0;
+}
+extern "C" int crdr_interp_ca_params_bwd(const float* W, int L, int C, float q, const float* dscale,
+                                         const float* dshift, float* dW, float* dB, crdr_stream_t s) {
+  CRDR_REQUIRE(W && dscale && dW, "interp_ca_params_bwd: null pointer");
+  hipLaunchKernelGGL(interp_ca_params_bwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(s), W, L, C, q, dscale,
+                     dshift, dW, dB);
+  CRDR_CHECK_LAUNCH("interp_ca_params_bwd");
+  return 0;
+}
+
+extern "C" int crdr_lrp(const float* a, int lda, const float* z, int ldz, float* y, int ldy, int64_t M, int C,
+                        crdr_stream_t s) {
+  CRDR_REQUIRE(a && z && y, "lrp: null pointer");
+  if (M * C == 0) return 0;
+  hipLaunchKernelGGL(lrp_kernel, dim3(grid_for(M * C)), dim3(256), 0, as_stream(s), a, lda, z, ldz, y, ldy, M, C);
+  CRDR_CHECK_LAUNCH("lrp");
+  return 0;
+}
+extern "C" int crdr_lrp_bwd(const float* dy, int lddy, const float* z, int ldz, float* dz, int lddz, int64_t M, int C,
+                            crdr_stream_t s) {
+  CRDR_REQUIRE(dy && z && dz, "lrp_bwd: null pointer");
+  if (M * C == 0) return 0;
+  hipLaunchKernelGGL(lrp_bwd_kernel, dim3(grid_for(M * C)), dim3(256), 0, as_stream(s), dy, lddy, z, ldz, dz, lddz, M, C);
+  CRDR_CHECK_LAUNCH("lrp_bwd");
+  return 0;
+}
+
+extern "C" size_t crdr_reduce_workspace(int64_t n) { return (size_t)reduce_blocks(n) * sizeof(float); }
+
+template <int OP>
+static int run_reduce(const float* a, const float* b, int64_t n, float target, float* out, void* ws, size_t ws_bytes,
+                      crdr_stream_t s, const char* what) {
+  const int nb = reduce_blocks(n);
+  CRDR_REQUIRE(a && out && ws_bytes >= (size_t)nb * sizeof(float), "%s: bad arguments", what);
+  hipLaunchKernelGGL(reduce_kernel<OP>, dim3(nb), dim3(256), 0, as_stream(s), a, b, n, target, (float*)ws);
+  CRDR_CHECK_LAUNCH(what);
+  hipLaunchKernelGGL(reduce_final, dim3(1), dim3(256), 0, as_stream(s), (const float*)ws, nb, out);
+  CRDR_CHECK_LAUNCH(what);
+  return 0;
+}
+extern "C" int crdr_sqdiff_sum(const float* a, const float* b, int64_t n, float* out, void* ws, size_t ws_bytes,
+                               crdr_stream_t s) {
+  CRDR_REQUIRE(b, "sqdiff_sum: null pointer");
+  return run_reduce<RED_SQDIFF>(a, b, n, 0.f, out, ws, ws_bytes, s, "sqdiff_sum");
+}
+extern "C" int crdr_bce_diff_sum(const float* p, const float* q, int64_t n, float target, float* out, void* ws,
+                                 size_t ws_bytes, crdr_stream_t s) {
+  CRDR_REQUIRE(q, "bce_diff_sum: null pointer");
+  return run_reduce<RED_BCE>(p, q, n, target, out, ws, ws_bytes, s, "bce_diff_sum");
+}
+extern "C" int crdr_sqnorm(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, crdr_stream_t s) {
+  return run_reduce<RED_SQNORM>(g, nullptr, n, 0.f, out, ws, ws_bytes, s, "sqnorm");
+}
+extern "C" int crdr_sqdiff_bwd(const float* a, const float* b, int64_t n, const float* g, float gscale, float* da,
+                               float* db, crdr_stream_t s) {
+  CRDR_REQUIRE(a && b, "sqdiff_bwd: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sqdiff_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(s), a, b, n, g, gscale, da, db);
+  CRDR_CHECK_LAUNCH("sqdiff_bwd");
+  return 0;
+}
+extern "C" int crdr_bce_diff_bwd(const float* p, const float* q, int64_t n, float target, const float* g, float gscale,
+                                 float* dp, float* dq, crdr_stream_t s) {
+  CRDR_REQUIRE(p && q, "bce_diff_bwd: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(bce_diff_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(s), p, q, n, target, g, gscale, dp, dq);
+  CRDR_CHECK_LAUNCH("bce_diff_bwd");
+  return 0;
+}
+
+extern "C" int crdr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, int step, const float* sqnorm, float max_norm, crdr_stream_t s) {
+  CRDR_REQUIRE(p && g && m && v && step >= 1, "adam_step: bad arguments");
+  if (n == 0) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(s), p, g, m, v, n, lr, beta1, beta2, eps,
+                     bc1, bc2_sqrt, sqnorm, max_norm);
+  CRDR_CHECK_LAUNCH("adam_step");
+  return 0;
+}
+
+extern "C" int crdr_maxpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, crdr_stream_t s) {
+  CRDR_REQUIRE(x && y && H >= 3 && W >= 3, "maxpool: bad arguments");
+  const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(grid_for((int64_t)N * OH * OW * C)), dim3(256), 0, as_stream(s), x, y, N,
+                     H, W, C, OH, OW);
+  CRDR_CHECK_LAUNCH("maxpool_fwd");
+  return 0;
+}
+extern "C" int crdr_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
+                                   crdr_stream_t s) {
+  CRDR_REQUIRE(x && dy && dx && H >= 3 && W >= 3, "maxpool_bwd: bad arguments");
+  const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(256), 0, as_stream(s), x, dy, dx,
+                     N, H, W, C, OH, OW);
+  CRDR_CHECK_LAUNCH("maxpool_bwd");
+  return 0;
+}
+
+extern "C" int crdr_lpips_layer_fwd(const float* f0, const float* f1, const float* lin, int N, int HW, int C,
+                                    float* out, void* ws, size_t ws_bytes, crdr_stream_t s) {
+  CRDR_REQUIRE(f0 && f1 && lin && out && ws, "lpips_layer_fwd: bad arguments");
+  const int nb = std::min(cdiv(HW, 4), 64);
+  CRDR_REQUIRE(ws_bytes >= (size_t)N * nb * sizeof(float), "lpips_layer_fwd: workspace too small");
+  float* part = (float*)ws;
+  hipLaunchKernelGGL(lpips_layer_fwd_kernel, dim3(nb, N), dim3(256), 0, as_stream(s), f0, f1, lin, N, HW, C, part);
+  CRDR_CHECK_LAUNCH("lpips_layer_fwd");
+  hipLaunchKernelGGL(lpips_layer_final, dim3(N), dim3(64), 0, as_stream(s), (const float*)part, nb, HW, out);
+  CRDR_CHECK_LAUNCH("lpips_layer_final");
+  return 0;
+}
+extern "C" int crdr_lpips_layer_bwd(const float* f0, const float* f1, const float* lin, int N, int HW, int C,
+                                    const float* gout, float* df1, crdr_stream_t s) {
+  CRDR_REQUIRE(f0 && f1 && lin && gout && df1, "lpips_layer_bwd: bad arguments");
+  const int nb = std::min(cdiv(HW, 4), 256);
+  hipLaunchKernelGGL(lpips_layer_bwd_kernel, dim3(nb, N), dim3(256), 0, as_stream(s), f0, f1, lin, N, HW, C, gout, df1);
+  CRDR_CHECK_LAUNCH("lpips_layer_bwd");
+  return 0;
+}

@@ -1,0 +1,301 @@
+// Weight gradient of Conv2d / ConvTranspose2d on fp32 MFMA, plus the weight (re)packing kernels.
+//
+//   g[i][j][t] (+)= sum_{n,a,b} P[n,a,b,i] * Q[n, a*S - pad + r(t), b*S - pad + s(t), j]
+//
+// GEMM view per tap: rows i (channels of the dense operand P), cols j (channels of the gathered operand Q),
+// reduction over pixels.  K-tile = 32 pixels; both operand tiles are staged as [32 px][channels] (exactly how
+// NHWC memory is laid out) and MFMA fragments are read down the pixel axis with ds_read_b32: 32 consecutive
+// channels per half-wave -> conflict free.  grid = (I-tiles x J-tiles, taps, pixel splits); every block writes
+// its partial [BI][BJ] tile to a slab, wgrad_reduce sums the slabs in split order (deterministic) and scatters
+// into the parameter layout [I][J][T].
+
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace crdr {
+
+struct FastDiv {  // unsigned division by a runtime constant: n / d == umulhi(n, mul) >> sh   (n < 2^31)
+  unsigned mul, sh, d;
+};
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f; f.d = d;
+  if (d == 1) { f.mul = 0; f.sh = 0; return f; }
+  unsigned l = 0; while ((1u << l) < d) ++l;               // ceil(log2 d)
+  const unsigned long long m = ((1ull << (32 + l)) + d - 1) / d;  // in (2^32, 2^33)
+  f.mul = (unsigned)(m - (1ull << 32)); f.sh = l;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  const unsigned t = __umulhi(n, f.mul);
+  return (t + ((n - t) >> 1)) >> (f.sh - 1);
+}
+
+struct WgradArgs {
+  const float* p;
+  const float* q;
+  float* ws;
+  int N, PH, PW, PC, ldp;
+  int QH, QW, QC, ldq;
+  int kw, stride, pad, T;
+  int M;        // N*PH*PW
+  int ntiles;   // pixel tiles of 32
+  int nsplit;
+  int jtiles;
+  FastDiv d_hw, d_w;
+};
+
+template <int WM, int WN, int MB, int NB>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) {
+  constexpr int BI = 32 * WM * MB, BJ = 32 * WN * NB, NT = 64 * WM * WN;
+  constexpr int PV = (8 * BI + NT - 1) / NT, QV = (8 * BJ + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sP = smem;               // [2][32][BI]
+  float* sQ = smem + 2 * 32 * BI; // [2][32][BJ]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int it = blockIdx.x / p.jtiles, jt = blockIdx.x % p.jtiles;
+  const int i0 = it * BI, j0 = jt * BJ;
+  const int tap = blockIdx.y, split = blockIdx.z;
+  const int dh = tap / p.kw - p.pad, dw = tap % p.kw - p.pad;
+  const int t0 = (int)((long long)p.ntiles * split / p.nsplit), t1 = (int)((long long)p.ntiles * (split + 1) / p.nsplit);
+
+  f32x4 rp[PV], rq[QV];
+  auto load_tile = [&](int t) {
+    const int mbase = t * 32;
+#pragma unroll
+    for (int k = 0; k < PV; ++k) {
+      const int e = tid + k * NT;
+      const int prow = e / (BI / 4), ch = e % (BI / 4);
+      const int m = mbase + prow, c = i0 + ch * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < 8 * BI && m < p.M && c < p.PC) v = *reinterpret_cast<const f32x4*>(p.p + (size_t)m * p.ldp + c);
+      rp[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < QV; ++k) {
+      const int e = tid + k * NT;
+      const int prow = e / (BJ / 4), ch = e % (BJ / 4);
+      const int m = mbase + prow, c = j0 + ch * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < 8 * BJ && m < p.M && c < p.QC) {
+        const unsigned n = fdiv((unsigned)m, p.d_hw), rem = m - n * p.d_hw.d;
+        const unsigned a = fdiv(rem, p.d_w), b = rem - a * p.d_w.d;
+        const int ih = (int)a * p.stride + dh, iw = (int)b * p.stride + dw;
+        if ((unsigned)ih < (unsigned)p.QH && (unsigned)iw < (unsigned)p.QW)
+          v = *reinterpret_cast<const f32x4*>(p.q + ((size_t)(n * p.QH + ih) * p.QW + iw) * p.ldq + c);
+      }
+      rq[k] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* a = sP + buf * 32 * BI;
+    float* b = sQ + buf * 32 * BJ;
+#pragma unroll
+    for (int k = 0; k < PV; ++k) {
+      const int e = tid + k * NT;
+      if (e < 8 * BI) *reinterpret_cast<f32x4*>(a + e * 4) = rp[k];  // [prow][ch*4] is exactly e*4
+    }
+#pragma unroll
+    for (int k = 0; k < QV; ++k) {
+      const int e = tid + k * NT;
+      if (e < 8 * BJ) *reinterpret_cast<f32x4*>(b + e * 4) = rq[k];
+    }
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fcol = lane & 31, fh = lane >> 5;
+  if (t0 < t1) { load_tile(t0); store_tile(0); }
+  __syncthreads();
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    if (t + 1 < t1) load_tile(t + 1);
+    const float* a = sP + buf * 32 * BI + wm * MB * 32 + fcol;
+    const float* b = sQ + buf * 32 * BJ + wn * NB * 32 + fcol;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      float af[MB], bf[NB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) af[i] = a[(2 * s + fh) * BI + i * 32];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bf[j] = b[(2 * s + fh) * BJ + j * 32];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < t1) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // partial tile -> slab ws[split][tap][PC][QC]
+  float* dst = p.ws + ((size_t)split * p.T + tap) * p.PC * p.QC;
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = i0 + (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (row >= p.PC) continue;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int col = j0 + (wn * NB + j) * 32 + fcol;
+        if (col < p.QC) dst[(size_t)row * p.QC + col] = acc[i][j][r];
+      }
+    }
+}
+
+// g[(i*gJ + j)*T + t] (+)= sum_s ws[((s*T + t)*PC + i)*QC + j]
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* ws, float* g, int PC, int QC, int gI, int gJ, int T,
+                                                    int nsplit, int accumulate) {
+  const long long total = (long long)gI * gJ * T;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int j = (int)(e % gJ);
+    const long long r = e / gJ;
+    const int i = (int)(r % gI), t = (int)(r / gI);
+    float v = 0.f;
+    for (int s = 0; s < nsplit; ++s) v += ws[((size_t)(s * T + t) * PC + i) * QC + j];
+    float* d = g + ((size_t)i * gJ + j) * T + t;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// dst[t][rows][cols] <- src[I][J][T]
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, float* dst, int I, int J, int T, int rows,
+                                                          int cols, int transpose) {
+  const long long total = (long long)T * rows * cols;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int c = (int)(e % cols);
+    const long long r2 = e / cols;
+    const int r = (int)(r2 % rows), t = (int)(r2 / rows);
+    const int i = transpose ? c : r, j = transpose ? r : c;
+    dst[e] = (i < I && j < J) ? src[((size_t)i * J + j) * T + t] : 0.f;
+  }
+}
+
+struct WCfg {
+  int wm, wn, mb, nb;
+  void (*kern)(const WgradArgs);
+};
+#define CFG(a, b, c, d) {a, b, c, d, wgrad_kernel<a, b, c, d>}
+static const WCfg kWCfgs[] = {
+    CFG(1, 1, 1, 1),  // 32x32
+    CFG(2, 2, 1, 1),  // 64x64
+    CFG(2, 2, 2, 2),  // 128x128
+    CFG(2, 2, 2, 1),  // 128x64
+    CFG(2, 2, 1, 2),  // 64x128
+    CFG(4, 1, 1, 1),  // 128x32
+    CFG(1, 4, 1, 1),  // 32x128
+    CFG(3, 1, 1, 3),  // 96x96
+    CFG(3, 1, 1, 2),  // 96x64
+    CFG(2, 3, 1, 1),  // 64x96
+    CFG(5, 1, 1, 2),  // 160x64
+    CFG(5, 1, 1, 1),  // 160x32
+    CFG(7, 1, 1, 1),  // 224x32
+    CFG(7, 1, 1, 2),  // 224x64
+    CFG(4, 2, 1, 1),  // 128x64 (8 waves)
+};
+#undef CFG
+static const int kNumWCfgs = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
+
+struct WPlan {
+  WgradArgs a;
+  int cfg;
+  dim3 grid;
+  size_t lds, ws_bytes;
+};
+
+static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl) {
+  WgradArgs& a = pl->a;
+  memset(&a, 0, sizeof(a));
+  CRDR_REQUIRE(d->PC % 4 == 0 && d->QC % 4 == 0 && d->ldp % 4 == 0 && d->ldq % 4 == 0,
+               "wgrad: channel counts / strides must be multiples of 4 (PC=%d QC=%d)", d->PC, d->QC);
+  CRDR_REQUIRE(d->gI <= d->PC && d->gJ <= d->QC && d->gI > 0 && d->gJ > 0, "wgrad: bad g dims");
+  a.N = d->N; a.PH = d->PH; a.PW = d->PW; a.PC = d->PC; a.ldp = d->ldp;
+  a.QH = d->QH; a.QW = d->QW; a.QC = d->QC; a.ldq = d->ldq;
+  a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.T = d->kh * d->kw;
+  const long long M64 = (long long)d->N * d->PH * d->PW;
+  CRDR_REQUIRE(M64 < (1ll << 31) && (long long)d->N * d->QH * d->QW < (1ll << 31), "wgrad: too many pixels");
+  a.M = (int)M64;
+  a.ntiles = cdiv(a.M, 32);
+  a.d_hw = make_fastdiv((unsigned)(d->PH * d->PW));
+  a.d_w = make_fastdiv((unsigned)d->PW);
+  double best = 1e300; int bc = -1, bs = 1;
+  for (int c = 0; c < kNumWCfgs; ++c) {
+    const WCfg& t = kWCfgs[c];
+    const int BI = 32 * t.wm * t.mb, BJ = 32 * t.wn * t.nb;
+    const long long tiles = (long long)cdiv(d->PC, BI) * cdiv(d->QC, BJ) * a.T;
+    const int waves_per_block = t.wm * t.wn;
+    for (int ns = 1; ns <= 256; ns *= 2) {
+      if (ns > 1 && a.ntiles / ns < 4) break;
+      const long long blocks = tiles * ns;
+      const double slots = 256.0 * std::max(1, 4 / waves_per_block);  // blocks that run at full MFMA rate at once
+      const double per_tile = 16.0 * t.mb * t.nb * 64.0 + 400.0;
+      double cost = std::ceil(blocks / slots) * ((double)cdiv(a.ntiles, ns) * per_tile + 4000.0);
+      cost += (double)ns * a.T * d->PC * d->QC * 4.0 / 1500.0;  // slab write + read
+      if (cost < best) { best = cost; bc = c; bs = ns; }
+    }
+  }
+  CRDR_REQUIRE(bc >= 0, "wgrad: no tile config");
+  const WCfg& t = kWCfgs[bc];
+  const int BI = 32 * t.wm * t.mb, BJ = 32 * t.wn * t.nb;
+  pl->cfg = bc; a.nsplit = bs; a.jtiles = cdiv(d->QC, BJ);
+  pl->grid = dim3(cdiv(d->PC, BI) * a.jtiles, a.T, bs);
+  pl->lds = (size_t)2 * 32 * (BI + BJ) * sizeof(float);
+  pl->ws_bytes = (size_t)bs * a.T * d->PC * d->QC * sizeof(float);
+  return 0;
+}
+
+}  // namespace crdr
+
+using namespace crdr;
+
+extern "C" size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d) {
+  WPlan pl;
+  if (build_wplan(d, &pl)) return 0;
+  return pl.ws_bytes;
+}
+
+extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* ws,
+                                 size_t ws_bytes, crdr_stream_t s) {
+  WPlan pl;
+  if (int rc = build_wplan(d, &pl)) return rc;
+  CRDR_REQUIRE(p && q && g && ws, "wgrad: null pointer");
+  CRDR_REQUIRE(pl.ws_bytes <= ws_bytes, "wgrad: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
+  WgradArgs& a = pl.a;
+  a.p = p; a.q = q; a.ws = (float*)ws;
+  const WCfg& t = kWCfgs[pl.cfg];
+  static bool attr_done[64] = {false};
+  if (!attr_done[pl.cfg]) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done[pl.cfg] = true;
+  }
+  hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a);
+  CRDR_CHECK_LAUNCH("wgrad_kernel");
+  const long long total = (long long)d->gI * d->gJ * a.T;
+  const int blocks = (int)std::min<long long>(cdiv64(total, 256), 4096);
+  hipLaunchKernelGGL(wgrad_reduce, dim3(blocks), dim3(256), 0, as_stream(s), (const float*)ws, g, d->PC, d->QC, d->gI,
+                     d->gJ, a.T, a.nsplit, d->accumulate);
+  CRDR_CHECK_LAUNCH("wgrad_reduce");
+  return 0;
+}
+
+extern "C" int crdr_pack_weight(const float* src, float* dst, int I, int J, int T, int rows, int cols, int transpose,
+                                crdr_stream_t s) {
+  CRDR_REQUIRE(src && dst, "pack_weight: null pointer");
+  CRDR_REQUIRE(rows >= (transpose ? J : I) && cols >= (transpose ? I : J), "pack_weight: pack smaller than source");
+  const long long total = (long long)T * rows * cols;
+  const int blocks = (int)std::min<long long>(cdiv64(total, 256), 8192);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(s), src, dst, I, J, T, rows, cols,
+                     transpose);
+  CRDR_CHECK_LAUNCH("pack_weight");
+  return 0;
+}

@@ -1,0 +1,191 @@
+"""Torch-facing wrappers over the C ABI: device memory, streams and autograd plumbing only.
+
+Tensors are logical NCHW with channels_last strides (memory NHWC); a channel slice of such a tensor is passed
+to the kernels in place through its pixel stride (`ld`).  All arithmetic happens in libcrdr_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as L
+
+_ws_cache = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(nbytes: int, device) -> Tuple[int, int]:
+    """Grow-only per-device scratch (kernels on one stream serialise, so one buffer is enough)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf.data_ptr(), buf.numel()
+
+
+def _require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise L.CrdrHipError("crdr_amd ops run on the HIP device only (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise L.CrdrHipError(f"crdr_amd ops are fp32 (got {t.dtype})")
+
+
+def nhwc(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """Return (tensor, pixel stride) for a [N,C,H,W] tensor whose memory is NHWC (possibly a channel slice);
+    copies into channels_last if the layout is anything else."""
+    _require_gpu(t)
+    n, c, h, w = t.shape
+    ld = t.stride(3) if w > 1 else (t.stride(2) if h > 1 else (t.stride(0) if n > 1 else c))
+    ok = (c == 1 or t.stride(1) == 1) and ld >= c
+    ok = ok and (w == 1 or t.stride(3) == ld) and (h == 1 or t.stride(2) == w * ld) and (n == 1 or t.stride(0) == h * w * ld)
+    if not ok or ld % 4 != 0 or (t.data_ptr() % 16) != 0:
+        if c % 4 == 0:
+            t = t.contiguous(memory_format=torch.channels_last)
+            if t.stride(1) != 1 or (w > 1 and t.stride(3) != c):  # degenerate sizes: force real NHWC memory
+                t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            ld = c
+        else:  # pad channels to a multiple of 4 (image tensors)
+            cp = (c + 3) // 4 * 4
+            buf = torch.zeros((n, h, w, cp), dtype=t.dtype, device=t.device)
+            buf[..., :c] = t.permute(0, 2, 3, 1)
+            t = buf.permute(0, 3, 1, 2)[:, :c]
+            ld = cp
+    return t, ld
+
+
+def empty_nhwc(n, c, h, w, device, ld: Optional[int] = None, zero: bool = False) -> torch.Tensor:
+    ld = c if ld is None else ld
+    mk = torch.zeros if (zero or ld != c) else torch.empty
+    buf = mk((n, h, w, ld), dtype=torch.float32, device=device)
+    return buf.permute(0, 3, 1, 2)[:, :c]
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def round32(v: int) -> int:
+    return (v + 31) // 32 * 32
+
+
+def pack_weight(w: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """[I][J][kh][kw] parameter -> [T][rows][cols] pack (rows/cols padded to 32)."""
+    _require_gpu(w)
+    w = w.contiguous()
+    I, J = w.shape[0], w.shape[1]
+    T = w.shape[2] * w.shape[3]
+    rows, cols = (round32(J), round32(I)) if transpose else (round32(I), round32(J))
+    dst = torch.empty((T, rows, cols), dtype=torch.float32, device=w.device)
+    lib = L.load()
+    L.check(lib.crdr_pack_weight(w.data_ptr(), dst.data_ptr(), I, J, T, rows, cols, int(transpose), _stream()), "pack_weight")
+    return dst
+
+
+def conv_out_size(h, k, stride, pad, transposed, out_pad=0):
+    if transposed:
+        return (h - 1) * stride - 2 * pad + k + out_pad
+    return (h + 2 * pad - k) // stride + 1
+
+
+def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int], stride: int, pad: int,
+               transposed: bool, out_hw: Tuple[int, int], *, bias=None, flags: int = 0, vec2=None, res=None,
+               scale=None, shift=None, gate_x=None, gate_t=None, sig_out=None, out: Optional[torch.Tensor] = None):
+    """One fused implicit-GEMM launch. `out` may be a channel slice of a wider NHWC tensor (written in place)."""
+    lib = L.load()
+    x, ldx = nhwc(x)
+    n, c, h, w = x.shape
+    oh, ow = out_hw
+    if out is None:
+        out = empty_nhwc(n, oc, oh, ow, x.device, ld=(oc if oc % 4 == 0 else (oc + 3) // 4 * 4))
+    out_t, ldy = out, (out.stride(3) if ow > 1 else (out.stride(2) if oh > 1 else (out.stride(0) if n > 1 else oc)))
+    d = L.ConvDesc(N=n, H=h, W=w, C=(c + 3) // 4 * 4 if ldx >= (c + 3) // 4 * 4 else c, OH=oh, OW=ow, OC=oc, kh=k[0], kw=k[1],
+                   stride=stride, pad=pad, transposed=int(transposed), ldx=ldx, ldy=ldy, wrows=wpack.shape[1],
+                   wcols=wpack.shape[2], flags=flags, ldres=0, ldg=0, reserved=0)
+    io = L.ConvIO(x=x.data_ptr(), w=wpack.data_ptr(), y=out_t.data_ptr(), bias=_p(bias), vec2=_p(vec2))
+    if res is not None:
+        res, d.ldres = nhwc(res)
+        io.res = res.data_ptr()
+    if scale is not None:
+        io.scale, io.shift = scale.data_ptr(), shift.data_ptr()
+    if gate_x is not None:
+        gate_x, ldg = nhwc(gate_x)
+        gate_t, ldg2 = nhwc(gate_t)
+        if ldg != ldg2 or ldg != oc:
+            gate_x = gate_x.contiguous(memory_format=torch.channels_last)
+            gate_t = gate_t.contiguous(memory_format=torch.channels_last)
+            ldg = oc
+        d.ldg = ldg
+        io.gx, io.gt, io.sig = gate_x.data_ptr(), gate_t.data_ptr(), sig_out.data_ptr()
+    nbytes = lib.crdr_conv2d_workspace(C.byref(d))
+    ws, ws_n = workspace(nbytes, x.device) if nbytes else (None, 0)
+    L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), ws, ws_n, _stream()), "conv2d")
+    return out
+
+
+def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, stride, pad, accumulate: bool):
+    """g[I][J][kh][kw] (+)= sum P[., i] * Q[gathered, j]; P is the dense operand (see crdr_hip.h)."""
+    lib = L.load()
+    p, ldp = nhwc(p)
+    q, ldq = nhwc(q)
+    n, pc, ph, pw = p.shape
+    _, qc, qh, qw = q.shape
+    pc4 = min((pc + 3) // 4 * 4, ldp)
+    qc4 = min((qc + 3) // 4 * 4, ldq)
+    assert g.is_contiguous() and g.shape[0] <= pc4 and g.shape[1] <= qc4
+    d = L.WgradDesc(N=n, PH=ph, PW=pw, PC=pc4, ldp=ldp, QH=qh, QW=qw, QC=qc4, ldq=ldq, kh=k[0], kw=k[1],
+                    stride=stride, pad=pad, gI=g.shape[0], gJ=g.shape[1], accumulate=int(accumulate))
+    nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
+    ws, ws_n = workspace(nbytes, p.device)
+    L.check(lib.crdr_conv2d_wgrad(C.byref(d), p.data_ptr(), q.data_ptr(), g.data_ptr(), ws, ws_n, _stream()), "conv2d_wgrad")
+    return g
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool):
+    lib = L.load()
+    x, ld = nhwc(x)
+    n, c, h, w = x.shape
+    m = n * h * w
+    nbytes = lib.crdr_colsum_workspace(m, c)
+    ws, ws_n = workspace(nbytes, x.device)
+    L.check(lib.crdr_colsum(x.data_ptr(), ld, m, c, out.data_ptr(), int(accumulate), ws, ws_n, _stream()), "colsum")
+    return out
+
+
+def epilogue_bwd(dout, out, flags, *, vec2=None, scale=None, shift=None, gate_t=None, sig=None, need_dz=True):
+    """Returns (dz, gres, dgt, colsums[4][C])."""
+    lib = L.load()
+    dout, lddout = nhwc(dout)
+    n, c, h, w = dout.shape
+    m = n * h * w
+    d = L.EbwdDesc(M=m, C=c, flags=flags, lddout=lddout, ldout=0, lddz=c, ldgres=c, ldg=c)
+    io = L.EbwdIO(dout=dout.data_ptr(), vec2=_p(vec2), scale=_p(scale), shift=_p(shift))
+    if out is not None:
+        out, d.ldout = nhwc(out)
+        io.out = out.data_ptr()
+    dz = gres = dgt = None
+    if need_dz:
+        dz = empty_nhwc(n, c, h, w, dout.device)
+        io.dz = dz.data_ptr()
+    if flags & L.EPI_GATE:
+        gate_t, ldg = nhwc(gate_t)
+        sig, ldg2 = nhwc(sig)
+        assert ldg == c and ldg2 == c
+        io.gt, io.sig = gate_t.data_ptr(), sig.data_ptr()
+        gres = empty_nhwc(n, c, h, w, dout.device)
+        dgt = empty_nhwc(n, c, h, w, dout.device)
+        io.gres, io.dgt = gres.data_ptr(), dgt.data_ptr()
+    elif (flags & L.EPI_AFFINE) and (flags & L.EPI_RES):
+        gres = empty_nhwc(n, c, h, w, dout.device)
+        io.gres = gres.data_ptr()
+    colsums = torch.empty((4, c), dtype=torch.float32, device=dout.device)
+    io.colsums = colsums.data_ptr()
+    nbytes = lib.crdr_epilogue_bwd_workspace(C.byref(d))
+    ws, ws_n = workspace(nbytes, dout.device)
+    L.check(lib.crdr_epilogue_bwd(C.byref(d), C.byref(io), ws, ws_n, _stream()), "epilogue_bwd")
+    return dz, gres, dgt, colsums

@@ -1,0 +1,263 @@
+/*
+ * crdr_hip.h -- C ABI of libcrdr_hip.so, the MI355X (gfx950) arithmetic behind the CRDR codec hot path.
+ *
+ * Boundary contract:
+ *   - flat extern "C", plain pointers + sizes, no torch / C++ types, no exceptions cross the boundary;
+ *   - every device entry enqueues on the caller's hipStream_t only, allocates nothing, retains no pointer;
+ *   - return 0 on success, negative on error; message via crdr_last_error() (thread local);
+ *   - activations are NHWC fp32 (a torch channels_last tensor), `ld*` = pixel stride in elements so that
+ *     channel slices of a wider tensor can be read / written in place (no concat copies);
+ *   - host entries (rANS, pmf_to_quantized_cdf) take no stream.
+ *
+ * Each entry cites the reference interface it replaces (paths relative to the iwa-shi/CRDR tree).
+ */
+#ifndef CRDR_HIP_H
+#define CRDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* crdr_stream_t; /* hipStream_t */
+
+/* ------------------------------------------------------------------------------------------------ */
+/* library                                                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+const char* crdr_last_error(void);
+int crdr_version(void);
+const char* crdr_arch(void); /* "gfx950" */
+
+/* ------------------------------------------------------------------------------------------------ */
+/* implicit-GEMM convolution family (fp32 in / fp32 MFMA v_mfma_f32_32x32x2_f32 / fp32 out)          */
+/*   replaces nn.Conv2d / nn.ConvTranspose2d forward + input-gradient as used by                     */
+/*   src/models/layer/elic_layers.py:14-36, src/models/layer/cheng_nlam.py:31-46,                    */
+/*   src/models/subnet/autoencoder/elic_autoencoder.py:42-53,                                         */
+/*   src/models/subnet/hyperprior/minnen20_hyperprior.py:16-18,50-52,                                 */
+/*   src/models/subnet/context_model/minnen20_charm_context_model.py:29-35,                           */
+/*   src/models/discriminator/clic21_gvae_discriminator.py:12-40                                      */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* epilogue flags, applied in this order on v = acc:                                                 */
+#define CRDR_EPI_BIAS 1    /* v += bias[oc]                                                          */
+#define CRDR_EPI_RELU 2    /* v = max(v, 0)                                                          */
+#define CRDR_EPI_LRELU 4   /* v = v > 0 ? v : 0.2 v        (clic21_gvae_discriminator.py:24)        */
+#define CRDR_EPI_VEC2 8    /* v += vec2[oc]  (beta-cond proj added AFTER the ReLU,                   */
+                           /*                 elic_interpca_beta_cond_autoencoder.py:56-66)          */
+#define CRDR_EPI_RES 16    /* v += res[pix][oc]            (elic_layers.py:36, cheng_nlam.py:45)    */
+#define CRDR_EPI_GATE 32   /* s = sigmoid(v); sig[pix][oc] = s; v = gx + gt * s (cheng_nlam.py:23-29) */
+#define CRDR_EPI_AFFINE 64 /* v = v * scale[oc] + shift[oc] (InterpChAtt, interp_channel_attention.py:68-72) */
+#define CRDR_EPI_ACCUM 128 /* y[pix][oc] += v  instead of  = v (gradient accumulation)              */
+
+typedef struct crdr_conv_desc {
+  /* "in" tensor [N][H][W][C] (NHWC, pixel stride ldx) and "out" tensor [N][OH][OW][OC] (pixel stride ldy) */
+  int32_t N, H, W, C;
+  int32_t OH, OW, OC;
+  int32_t kh, kw, stride, pad;
+  /* transposed = 0: out[o] = sum_r in[o*stride - pad + r] * w[r]            (Conv2d fwd, ConvT dgrad)
+   * transposed = 1: out[i*stride - pad + r] += in[i] * w[r]                 (ConvT fwd, Conv2d dgrad) */
+  int32_t transposed;
+  int32_t ldx, ldy;
+  /* weight pack [kh*kw][wrows][wcols] fp32, wrows >= OC (multiple of 32), wcols >= C (multiple of 32),
+   * made by crdr_pack_weight; element [t][oc][c] multiplies in-channel c for out-channel oc at tap t */
+  int32_t wrows, wcols;
+  int32_t flags;
+  int32_t ldres; /* pixel stride of res                                    */
+  int32_t ldg;   /* pixel stride of gx, gt and sig                          */
+  int32_t reserved;
+} crdr_conv_desc;
+
+typedef struct crdr_conv_io {
+  const float* x;
+  const float* w;
+  float* y;
+  const float* bias;
+  const float* vec2;
+  const float* res;
+  const float* scale;
+  const float* shift;
+  const float* gx;
+  const float* gt;
+  float* sig;
+} crdr_conv_io;
+
+/* bytes of workspace crdr_conv2d needs for this problem (split-K partial slabs; may be 0) */
+size_t crdr_conv2d_workspace(const crdr_conv_desc* d);
+int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);
+/* algorithmic FLOPs of the call (2 * MACs actually needed, padding taps excluded approx.) for roofline maths */
+double crdr_conv2d_flops(const crdr_conv_desc* d);
+
+/* weight gradient.  P = dense operand [N][PH][PW][PC] (dy for Conv2d, x for ConvT), Q = gathered operand
+ * [N][QH][QW][QC] (x for Conv2d, dy for ConvT): g[i][j][t] (+)= sum_{n,a,b} P[n,a,b,i] * Q[n,a*stride-pad+r,b*stride-pad+s,j]
+ * which is exactly Conv2d.weight.grad [OC][IC][kh][kw] resp. ConvTranspose2d.weight.grad [IC][OC][kh][kw]. */
+typedef struct crdr_wgrad_desc {
+  int32_t N, PH, PW, PC, ldp;
+  int32_t QH, QW, QC, ldq;
+  int32_t kh, kw, stride, pad;
+  int32_t gI, gJ;     /* dims of g (<= PC, QC): channels beyond them are layout padding and are dropped */
+  int32_t accumulate; /* 1: g += ; 0: g = */
+} crdr_wgrad_desc;
+size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d);
+int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* ws, size_t ws_bytes,
+                      crdr_stream_t s);
+
+/* src[I][J][T] (a Conv2d / ConvTranspose2d parameter, T = kh*kw) -> dst[T][rows][cols] zero padded.
+ * transpose = 0: dst[t][i][j] = src[i][j][t] (rows >= I, cols >= J); transpose = 1: dst[t][j][i] = src[i][j][t]. */
+int crdr_pack_weight(const float* src, float* dst, int I, int J, int T, int rows, int cols, int transpose,
+                     crdr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* fused elementwise / reductions (HBM-bound)                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* backward of the fused conv epilogue: given dout and the saved forward output, produce dz (gradient at the
+ * accumulator) plus per-channel sums.  Mirrors the flag order above in reverse.
+ *   colsums layout (floats, each C long, zero-initialised by the call): [0]=sum dz (dbias) [1]=sum g after
+ *   affine/res (dvec2) [2]=sum dout*u (dscale) [3]=sum dout (dshift).  gres (optional) receives the gradient
+ *   flowing to res / gx when AFFINE or GATE is set (otherwise it equals dout and is not written).         */
+typedef struct crdr_ebwd_desc {
+  int64_t M; /* pixels */
+  int32_t C;
+  int32_t flags;
+  int32_t lddout, ldout, lddz, ldgres, ldg;
+} crdr_ebwd_desc;
+typedef struct crdr_ebwd_io {
+  const float* dout;
+  const float* out;
+  const float* vec2;
+  const float* scale;
+  const float* shift;
+  const float* gt;  /* trunk  */
+  const float* sig; /* saved sigmoid */
+  float* dz;
+  float* gres; /* grad to res / gx */
+  float* dgt;  /* grad to trunk    */
+  float* colsums; /* [4][C] */
+} crdr_ebwd_io;
+size_t crdr_epilogue_bwd_workspace(const crdr_ebwd_desc* d);
+int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);
+
+/* y[m][c] = x[m][c] * scale[c] + shift[c]   (stand-alone InterpChAtt apply) */
+int crdr_affine(const float* x, int ldx, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
+                crdr_stream_t s);
+/* out[c] (+)= sum_m x[m][c] */
+size_t crdr_colsum_workspace(int64_t M, int C);
+int crdr_colsum(const float* x, int ldx, int64_t M, int C, float* out, int accumulate, void* ws, size_t ws_bytes,
+                crdr_stream_t s);
+
+/* InterpChAtt parameters -> per-channel scale/shift (interp_channel_attention.py:39-73):
+ *   l = floor(q), r = min(l+1, L-1), a = r - q; scale = softplus(a W[l] + (1-a) W[r]); shift = a B[l] + (1-a) B[r] */
+int crdr_interp_ca_params(const float* W, const float* B, int L, int C, float q, float* scale, float* shift,
+                          crdr_stream_t s);
+/* dW[l] += a * dscale * sigmoid(w);  dW[r] += (1-a) * ...;  dB likewise (accumulating) */
+int crdr_interp_ca_params_bwd(const float* W, int L, int C, float q, const float* dscale, const float* dshift,
+                              float* dW, float* dB, crdr_stream_t s);
+
+/* y = a + 0.5*tanh(z)  (latent residual prediction, minnen20_charm_context_model.py:127-131) and its backward */
+int crdr_lrp(const float* a, int lda, const float* z, int ldz, float* y, int ldy, int64_t M, int C, crdr_stream_t s);
+int crdr_lrp_bwd(const float* dy, int lddy, const float* z, int ldz, float* dz, int lddz, int64_t M, int C,
+                 crdr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* entropy models (CompressAI 1.2.4 semantics as called from the reference)                          */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* GaussianConditional, mean+scale, STE output.  Replaces SteGaussianMeanScaleConditional.forward
+ * (ste_gaussian_conditional.py:20-27) called twice per slice (noisy + quantised,
+ * minnen20_charm_context_model.py:118-124) and likelihood_to_bit (hyperprior_model.py:41-46).
+ *   yhat = round(y - mu) + mu
+ *   lik_noisy = P(y + noise | mu, max(sigma, bound)), lik_quant = P(yhat | ...), both floored at 1e-9
+ *   bits_noisy[n] += sum -log2 lik_noisy, bits_quant[n] += sum -log2 lik_quant (per image; caller zeroes)
+ * noise: U(-1/2,1/2) samples, same shape as y (dense, pixel stride C); NULL = quantised outputs only (eval). */
+typedef struct crdr_gc_desc {
+  int32_t N;
+  int32_t HW; /* pixels per image */
+  int32_t C;
+  int32_t ldy, ldmu, ldsigma, ldyhat;
+  float scale_bound;      /* 0.11 */
+  float likelihood_bound; /* 1e-9 */
+} crdr_gc_desc;
+int crdr_gauss_cond_fwd(const crdr_gc_desc* d, const float* y, const float* mu, const float* sigma, const float* noise,
+                        float* yhat, float* lik_noisy, float* lik_quant, float* bits_noisy, float* bits_quant,
+                        crdr_stream_t s);
+/* backward of bits_noisy w.r.t. (y, mu, sigma) scaled by gbits[n], plus the STE path dyhat -> dy.
+ * LowerBound gradients follow CompressAI's rule (pass if x >= bound or grad < 0). Outputs are dense (ld = C). */
+int crdr_gauss_cond_bwd(const crdr_gc_desc* d, const float* y, const float* mu, const float* sigma, const float* noise,
+                        const float* gbits, const float* dyhat, int lddyhat, float* dy, float* dmu, float* dsigma,
+                        crdr_stream_t s);
+
+/* factorised prior (EntropyBottleneck, filters (3,3,3,3)); parameters are passed as one packed block per
+ * channel made by the host: see crdr_amd/models/subnet/entropy_model. Replaces SteEntropyBottleneck.forward
+ * (entropy_bottleneck.py:18-30).  z is NHWC [N][HW][C]; noise NULL => quantised. */
+#define CRDR_EB_PARAMS 58 /* 3+3+3 + 9+3+3 + 9+3+3 + 9+3+3 + 3+1 = 58 floats per channel */
+int crdr_entropy_bottleneck_fwd(const float* z, const float* noise, const float* params, const float* medians, int N,
+                                int HW, int C, float likelihood_bound, float* zhat, float* lik, float* bits,
+                                crdr_stream_t s);
+int crdr_entropy_bottleneck_bwd(const float* z, const float* noise, const float* params, int N, int HW, int C,
+                                float likelihood_bound, const float* gbits, const float* dzhat, float* dz,
+                                float* dparams, crdr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* losses                                                                                            */
+/* ------------------------------------------------------------------------------------------------ */
+/* out[0] (+)= sum (a-b)^2 ; backward da = 2 (a-b) g, db = -da   (distortion_loss.py:41-46)         */
+size_t crdr_reduce_workspace(int64_t n);
+int crdr_sqdiff_sum(const float* a, const float* b, int64_t n, float* out, void* ws, size_t ws_bytes, crdr_stream_t s);
+int crdr_sqdiff_bwd(const float* a, const float* b, int64_t n, const float* g, float gscale, float* da, float* db,
+                    crdr_stream_t s);
+/* BCEWithLogits(sign * (p - q), target) summed: out[0] = sum softplus-form loss; gradient wrt p and q
+ * (gan_loss.py:28-31 applied to logit differences, multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:56-62) */
+int crdr_bce_diff_sum(const float* p, const float* q, int64_t n, float target, float* out, void* ws, size_t ws_bytes,
+                      crdr_stream_t s);
+int crdr_bce_diff_bwd(const float* p, const float* q, int64_t n, float target, const float* g, float gscale, float* dp,
+                      float* dq, crdr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* optimiser (build_optimizer_scheduler.py:11-19; rate_distortion_trainer.py:83-85)                  */
+/* ------------------------------------------------------------------------------------------------ */
+/* out[0] = sum g^2 (deterministic two-stage) */
+int crdr_sqnorm(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, crdr_stream_t s);
+/* torch.optim.Adam step (no amsgrad, no weight decay) on a flat buffer; the gradient is multiplied by
+ * min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) when sqnorm != NULL (clip_grad_norm_ semantics).              */
+int crdr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, int step, const float* sqnorm, float max_norm, crdr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* LPIPS helpers (perceptual_loss.py:25-30; lpips 0.1.4 AlexNet)                                      */
+/* ------------------------------------------------------------------------------------------------ */
+int crdr_maxpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, crdr_stream_t s);
+int crdr_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, crdr_stream_t s);
+/* per-pixel: d = sum_c lin[c] * (f0/|f0| - f1/|f1|)^2 ; out[n] += mean_pixels d */
+/* ws: N*64 floats */
+int crdr_lpips_layer_fwd(const float* f0, const float* f1, const float* lin, int N, int HW, int C, float* out,
+                         void* ws, size_t ws_bytes, crdr_stream_t s);
+int crdr_lpips_layer_bwd(const float* f0, const float* f1, const float* lin, int N, int HW, int C, const float* gout,
+                         float* df1, crdr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* host-side entropy coder (third-party in the reference: compressai 1.2.4 `compressai.ans`,         */
+/* call sites hyperprior_model.py:150-155,190-198; minnen20_charm_context_model.py:186-187,201-224)  */
+/* ------------------------------------------------------------------------------------------------ */
+/* cdf_out has pmf_len+1 entries. returns 0 / <0 */
+int crdr_pmf_to_quantized_cdf(const float* pmf, int pmf_len, int precision, uint32_t* cdf_out);
+/* encode; cdfs is [ncdf][cdf_stride] int32. returns bytes written, or -needed if out_cap too small, < -2^30 on error */
+int64_t crdr_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, int64_t n, const int32_t* cdfs,
+                                      int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int ncdf,
+                                      uint8_t* out, int64_t out_cap);
+typedef struct crdr_rans_decoder crdr_rans_decoder;
+crdr_rans_decoder* crdr_rans_decoder_create(void);
+void crdr_rans_decoder_destroy(crdr_rans_decoder*);
+int crdr_rans_decoder_set_stream(crdr_rans_decoder*, const uint8_t* data, int64_t nbytes);
+int crdr_rans_decoder_decode_stream(crdr_rans_decoder*, const int32_t* indexes, int64_t n, const int32_t* cdfs,
+                                    int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int ncdf,
+                                    int32_t* out);
+int crdr_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int32_t* indexes, int64_t n,
+                                  const int32_t* cdfs, int cdf_stride, const int32_t* cdf_sizes,
+                                  const int32_t* offsets, int ncdf, int32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRDR_HIP_H */

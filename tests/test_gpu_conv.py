@@ -1,0 +1,204 @@
+"""GPU parity of the implicit-GEMM conv family (through the C ABI) against stock fp32/fp64 torch on the CPU.
+
+Covers every conv shape family of the CRDR generator / discriminator at reduced spatial size: 1x1, 3x3, 5x5,
+stride 2, transposed 5x5 s2 (+output_padding) and 3x3 s1, channel counts that are not powers of two, channel
+slices (ld > C), split-K shapes (16x16 spatial, deep K) and every fused epilogue.
+Tolerance: fp32 MFMA is an exact fp32 fma chain, so the only difference to the reference is summation order:
+|err| <= 2e-5 * sum|a*b| style bound, checked as rtol 2e-4 on the output scale (fp64 reference).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test needs a HIP device"
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _close(got, ref, what, rtol=2e-4):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err/scale:.3e})"
+
+
+CONV_CASES = [
+    # name, N, Cin, H, W, Cout, k, stride, pad
+    ("1x1_96_192", 2, 96, 20, 24, 192, 1, 1, 0),
+    ("3x3_96_96", 2, 96, 16, 16, 96, 3, 1, 1),
+    ("5x5s2_stem", 2, 3, 32, 32, 192, 5, 2, 2),
+    ("5x5s2_192_320", 2, 192, 16, 16, 320, 5, 2, 2),
+    ("5x5_charm_352_224", 3, 352, 8, 8, 224, 5, 1, 2),
+    ("5x5_224_128", 2, 224, 8, 8, 128, 5, 1, 2),
+    ("3x3_128_32", 2, 128, 8, 8, 32, 3, 1, 1),
+    ("3x3s2_64_64", 2, 64, 18, 22, 64, 3, 2, 1),
+    ("3x3_512_1", 2, 512, 4, 4, 1, 3, 1, 1),
+    ("3x3_3_64", 1, 3, 24, 24, 64, 3, 1, 1),
+    ("1x1_320_160", 1, 320, 6, 10, 160, 1, 1, 0),
+    ("11x11s4_alex", 1, 3, 63, 63, 64, 11, 4, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case):
+    from crdr_amd.hip import ops
+    name, n, ci, h, w, co, k, s, p = case
+    dev = _dev()
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(co, ci, k, k, seed=2, scale=(ci * k * k) ** -0.5)
+    b = _rand(co, seed=3)
+    xr = x.double().requires_grad_(True)
+    wr = wt.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, b.double(), stride=s, padding=p)
+    oh, ow = ref.shape[2:]
+    dy = _rand(*ref.shape, seed=4)
+    ref.backward(dy.double())
+
+    xd, wd, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
+    wp = ops.pack_weight(wd, transpose=False)
+    out = ops.conv2d_raw(xd, wp, co, (k, k), s, p, False, (oh, ow), bias=bd, flags=1)
+    torch.cuda.synchronize()
+    _close(out, ref, name + " fwd")
+
+    wq = ops.pack_weight(wd, transpose=True)  # [T][Cin][Cout]
+    dx = ops.conv2d_raw(dyd, wq, ci, (k, k), s, p, True, (h, w))
+    _close(dx, xr.grad, name + " dgrad")
+
+    g = torch.zeros_like(wd)
+    ops.conv2d_wgrad_raw(dyd, xd, g, (k, k), s, p, accumulate=False)
+    _close(g, wr.grad, name + " wgrad")
+    ops.conv2d_wgrad_raw(dyd, xd, g, (k, k), s, p, accumulate=True)
+    _close(g, 2 * wr.grad, name + " wgrad accumulate")
+
+
+CONVT_CASES = [
+    ("T5x5s2_320_256", 2, 320, 6, 6, 256, 5, 2, 2, 1),
+    ("T5x5s2_256_3", 2, 256, 10, 12, 3, 5, 2, 2, 1),
+    ("T3x3s1_256_320", 2, 256, 8, 8, 320, 3, 1, 1, 0),
+    ("T5x5s2_192_192", 1, 192, 4, 4, 192, 5, 2, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES, ids=[c[0] for c in CONVT_CASES])
+def test_convT_fwd_dgrad_wgrad(case):
+    from crdr_amd.hip import ops
+    name, n, ci, h, w, co, k, s, p, op = case
+    dev = _dev()
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(ci, co, k, k, seed=2, scale=(ci * k * k / (s * s)) ** -0.5)
+    b = _rand(co, seed=3)
+    xr = x.double().requires_grad_(True)
+    wr = wt.double().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, b.double(), stride=s, padding=p, output_padding=op)
+    oh, ow = ref.shape[2:]
+    dy = _rand(*ref.shape, seed=4)
+    ref.backward(dy.double())
+
+    xd, wd, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
+    wp = ops.pack_weight(wd, transpose=True)  # rows = Cout, cols = Cin
+    out = ops.conv2d_raw(xd, wp, co, (k, k), s, p, True, (oh, ow), bias=bd, flags=1)
+    _close(out, ref, name + " fwd")
+    wq = ops.pack_weight(wd, transpose=False)  # rows = Cin, cols = Cout
+    dx = ops.conv2d_raw(dyd, wq, ci, (k, k), s, p, False, (h, w))
+    _close(dx, xr.grad, name + " dgrad")
+    g = torch.zeros_like(wd)
+    ops.conv2d_wgrad_raw(xd, dyd, g, (k, k), s, p, accumulate=False)
+    _close(g, wr.grad, name + " wgrad")
+
+
+def test_conv_epilogues_and_slices():
+    from crdr_amd.hip import ops, lib as L
+    dev = _dev()
+    n, ci, h, w, co = 2, 128, 12, 12, 96
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(co, ci, 3, 3, seed=2, scale=0.03)
+    b, v2, sc, sh = _rand(co, seed=3), _rand(co, seed=4), _rand(co, seed=5) + 1.5, _rand(co, seed=6)
+    res, gx, gt = _rand(n, co, h, w, seed=7), _rand(n, co, h, w, seed=8), _rand(n, co, h, w, seed=9)
+    z = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    view = lambda t: t.double().view(1, -1, 1, 1)
+    wp = ops.pack_weight(wt.to(dev), False)
+    d = lambda t: t.to(dev)
+    chl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+
+    out = ops.conv2d_raw(chl(x), wp, co, (3, 3), 1, 1, False, (h, w), bias=d(b), vec2=d(v2), flags=L.EPI_BIAS | L.EPI_RELU | L.EPI_VEC2)
+    _close(out, F.relu(z) + view(v2), "bias+relu+vec2")
+    out = ops.conv2d_raw(chl(x), wp, co, (3, 3), 1, 1, False, (h, w), bias=d(b), flags=L.EPI_BIAS | L.EPI_LRELU)
+    _close(out, F.leaky_relu(z, 0.2), "bias+lrelu")
+    out = ops.conv2d_raw(chl(x), wp, co, (3, 3), 1, 1, False, (h, w), bias=d(b), vec2=d(v2), res=chl(res), scale=d(sc), shift=d(sh),
+                         flags=L.EPI_BIAS | L.EPI_VEC2 | L.EPI_RES | L.EPI_AFFINE)
+    _close(out, (z + view(v2) + res.double()) * view(sc) + view(sh), "bias+vec2+res+affine")
+    sig = ops.empty_nhwc(n, co, h, w, dev)
+    out = ops.conv2d_raw(chl(x), wp, co, (3, 3), 1, 1, False, (h, w), bias=d(b), gate_x=chl(gx), gate_t=chl(gt), sig_out=sig,
+                         scale=d(sc), shift=d(sh), flags=L.EPI_BIAS | L.EPI_GATE | L.EPI_AFFINE)
+    _close(out, (gx.double() + gt.double() * torch.sigmoid(z)) * view(sc) + view(sh), "gate+affine")
+    _close(sig, torch.sigmoid(z), "gate sig")
+
+    # channel slices: read channels [32:160) of a 192-wide tensor, write into channels [64:160) of a 256-wide one
+    wide = chl(_rand(n, 192, h, w, seed=10))
+    xs = wide[:, 32:160]
+    dst = chl(_rand(n, 256, h, w, seed=11))
+    before = dst.clone()
+    ops.conv2d_raw(xs, wp, co, (3, 3), 1, 1, False, (h, w), bias=d(b), flags=L.EPI_BIAS, out=dst[:, 64:160])
+    zs = F.conv2d(wide.cpu().double()[:, 32:160], wt.double(), b.double(), padding=1)
+    _close(dst[:, 64:160], zs, "slice in/out")
+    assert torch.equal(dst[:, :64], before[:, :64]) and torch.equal(dst[:, 160:], before[:, 160:]), "slice write spilled"
+    # accumulate
+    ops.conv2d_raw(xs, wp, co, (3, 3), 1, 1, False, (h, w), bias=d(b), flags=L.EPI_BIAS | L.EPI_ACCUM, out=dst[:, 64:160])
+    _close(dst[:, 64:160], 2 * zs, "accumulate")
+
+
+def test_epilogue_bwd():
+    from crdr_amd.hip import ops, lib as L
+    dev = _dev()
+    n, c, h, w = 2, 96, 10, 10
+    chl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    z = _rand(n, c, h, w, seed=1).double().requires_grad_(True)
+    v2 = _rand(c, seed=2).double().requires_grad_(True)
+    sc = (_rand(c, seed=3) + 1.5).double().requires_grad_(True)
+    sh = _rand(c, seed=4).double().requires_grad_(True)
+    res = _rand(n, c, h, w, seed=5).double().requires_grad_(True)
+    dout = _rand(n, c, h, w, seed=6)
+    view = lambda t: t.view(1, -1, 1, 1)
+    # relu + vec2
+    out = F.relu(z) + view(v2)
+    out.backward(dout.double())
+    dz, _, _, cs = ops.epilogue_bwd(chl(dout), chl(out.detach().float()), L.EPI_BIAS | L.EPI_RELU | L.EPI_VEC2, vec2=v2.detach().float().to(dev))
+    _close(dz, z.grad, "ebwd relu dz")
+    _close(cs[0], z.grad.sum((0, 2, 3)), "ebwd dbias")
+    _close(cs[1], v2.grad, "ebwd dvec2")
+    # vec2 + res + affine
+    for t in (z, v2, sc, sh, res):
+        t.grad = None
+    out = (z + view(v2) + res) * view(sc) + view(sh)
+    out.backward(dout.double())
+    dz, gres, _, cs = ops.epilogue_bwd(chl(dout), chl(out.detach().float()), L.EPI_BIAS | L.EPI_VEC2 | L.EPI_RES | L.EPI_AFFINE,
+                                       vec2=v2.detach().float().to(dev), scale=sc.detach().float().to(dev), shift=sh.detach().float().to(dev))
+    _close(dz, z.grad, "ebwd affine dz")
+    _close(gres, res.grad, "ebwd gres")
+    _close(cs[2], sc.grad, "ebwd dscale", rtol=1e-3)
+    _close(cs[3], sh.grad, "ebwd dshift")
+    # gate + affine
+    gx = _rand(n, c, h, w, seed=7).double().requires_grad_(True)
+    gt = _rand(n, c, h, w, seed=8).double().requires_grad_(True)
+    for t in (z, sc, sh):
+        t.grad = None
+    sg = torch.sigmoid(z)
+    out = (gx + gt * sg) * view(sc) + view(sh)
+    out.backward(dout.double())
+    dz, gres, dgt, cs = ops.epilogue_bwd(chl(dout), chl(out.detach().float()), L.EPI_BIAS | L.EPI_GATE | L.EPI_AFFINE,
+                                         scale=sc.detach().float().to(dev), shift=sh.detach().float().to(dev),
+                                         gate_t=chl(gt.detach().float()), sig=chl(sg.detach().float()))
+    _close(dz, z.grad, "ebwd gate dz")
+    _close(gres, gx.grad, "ebwd gate gx")
+    _close(dgt, gt.grad, "ebwd gate gt")
+    _close(cs[2], sc.grad, "ebwd gate dscale", rtol=1e-3)
