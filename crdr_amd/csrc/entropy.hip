@@ -286,9 +286,41 @@ __global__ __launch_bounds__(1024) void bits_kernel(const float* lik, int per_im
   if (threadIdx.x == 0) bits[n] += s * 1.4426950408889634f;
 }
 
+// single block: loss = sum |logits(q) - target|, dq = sign(.) * dlogits/dq
+__global__ __launch_bounds__(256) void eb_quantile_kernel(const float* quantiles, const float* params,
+                                                          const float* target, int C, float* loss, float* dq) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < C * 3; e += blockDim.x) {
+    const int c = e / 3, j = e - c * 3;
+    EbParams P;
+    eb_load(params + (size_t)c * CRDR_EB_PARAMS, P);
+    EbTape T;
+    float g[CRDR_EB_PARAMS];
+#pragma unroll
+    for (int i = 0; i < CRDR_EB_PARAMS; ++i) g[i] = 0.f;
+    const float x = quantiles[e];
+    const float d = eb_logits(P, x, T) - target[j];
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    acc += fabsf(d);
+    dq[e] = eb_logits_bwd(P, x, T, sgn, g);
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) loss[0] = acc;
+}
+
 }  // namespace crdr
 
 using namespace crdr;
+
+extern "C" int crdr_eb_quantile_loss(const float* quantiles, const float* params, const float* target, int C,
+                                     float* loss, float* dquantiles, crdr_stream_t s) {
+  CRDR_REQUIRE(quantiles && params && target && loss && dquantiles, "eb_quantile_loss: null pointer");
+  hipLaunchKernelGGL(eb_quantile_kernel, dim3(1), dim3(256), 0, as_stream(s), quantiles, params, target, C, loss,
+                     dquantiles);
+  CRDR_CHECK_LAUNCH("eb_quantile_loss");
+  return 0;
+}
 
 extern "C" int crdr_gauss_cond_fwd(const crdr_gc_desc* d, const float* y, const float* mu, const float* sigma,
                                    const float* noise, float* yhat, float* lik_noisy, float* lik_quant,

@@ -1,0 +1,503 @@
+"""torch.autograd plumbing around the HIP kernels.
+
+Each Function's forward/backward is one or a few C-ABI launches; torch only owns the graph, the memory and the
+stream.  Parameter gradients of conv layers are accumulated by the kernels straight into `param.grad` (so the
+trainer can keep all gradients in one flat buffer for a single RCCL all-reduce).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops
+
+_weights_epoch = 0
+
+
+def bump_weights_epoch() -> None:
+    """Call after parameters were modified behind torch's back (the fused Adam kernel): invalidates weight packs."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _grad_slot(p: torch.Tensor) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+class ConvSpec:
+    """Static description of one conv layer + cache of its two weight packs."""
+
+    def __init__(self, in_ch, out_ch, k, stride, pad, transposed=False, out_pad=0):
+        self.in_ch, self.out_ch, self.k = in_ch, out_ch, (k, k) if isinstance(k, int) else tuple(k)
+        self.stride, self.pad, self.transposed, self.out_pad = stride, pad, transposed, out_pad
+        self._packs = {}
+
+    def out_hw(self, h, w):
+        return (ops.conv_out_size(h, self.k[0], self.stride, self.pad, self.transposed, self.out_pad),
+                ops.conv_out_size(w, self.k[1], self.stride, self.pad, self.transposed, self.out_pad))
+
+    def pack(self, weight: torch.Tensor, for_dgrad: bool) -> torch.Tensor:
+        # forward pack has rows = out channels: Conv2d weight [O][I] -> no transpose; ConvT weight [I][O] -> transpose
+        transpose = (self.transposed != for_dgrad)
+        key = (weight.data_ptr(), weight._version, _weights_epoch)
+        hit = self._packs.get(transpose)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w4 = weight if weight.dim() == 4 else weight.reshape(weight.shape[0], weight.shape[1], 1, 1)
+        pk = ops.pack_weight(w4.detach(), transpose)
+        self._packs[transpose] = (key, pk)
+        return pk
+
+
+def _flags(bias, act, vec2, res, gate, affine) -> int:
+    f = 0
+    if bias is not None:
+        f |= L.EPI_BIAS
+    if act == "relu":
+        f |= L.EPI_RELU
+    elif act == "lrelu":
+        f |= L.EPI_LRELU
+    elif act is not None:
+        raise ValueError(act)
+    if vec2 is not None:
+        f |= L.EPI_VEC2
+    if res is not None:
+        f |= L.EPI_RES
+    if gate:
+        f |= L.EPI_GATE
+    if affine:
+        f |= L.EPI_AFFINE
+    return f
+
+
+class _FusedConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, vec2, res, scale, shift, gx, gt, spec: ConvSpec, act):
+        flags = _flags(bias, act, vec2, res, gx is not None, scale is not None)
+        n, _, h, w = x.shape
+        oh, ow = spec.out_hw(h, w)
+        sig = ops.empty_nhwc(n, spec.out_ch, oh, ow, x.device) if gx is not None else None
+        out = ops.conv2d_raw(x, spec.pack(weight, False), spec.out_ch, spec.k, spec.stride, spec.pad, spec.transposed,
+                             (oh, ow), bias=bias, flags=flags, vec2=vec2, res=res, scale=scale, shift=shift,
+                             gate_x=gx, gate_t=gt, sig_out=sig)
+        ctx.spec, ctx.flags, ctx.in_hw = spec, flags, (h, w)
+        ctx.has = (bias is not None, vec2 is not None, res is not None, scale is not None, gx is not None)
+        need_out = flags & (L.EPI_RELU | L.EPI_LRELU | L.EPI_AFFINE)
+        ctx.save_for_backward(x, weight, bias, vec2, scale, shift, gt, sig, out if need_out else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, bias, vec2, scale, shift, gt, sig, out = ctx.saved_tensors
+        spec, flags = ctx.spec, ctx.flags
+        has_bias, has_vec2, has_res, has_aff, has_gate = ctx.has
+        needs = ctx.needs_input_grad
+        dout, _ = ops.nhwc(dout)
+        heavy = flags & (L.EPI_RELU | L.EPI_LRELU | L.EPI_AFFINE | L.EPI_GATE)
+        gres = dgt = dscale = dshift = dvec2 = None
+        if heavy or has_vec2:
+            dz, gres, dgt, cs = ops.epilogue_bwd(dout, out, flags, vec2=vec2, scale=scale, shift=shift, gate_t=gt, sig=sig,
+                                                 need_dz=bool(heavy))
+            if dz is None:
+                dz = dout
+            if has_bias and needs[2]:
+                _grad_slot(bias).add_(cs[0])
+            if has_vec2:
+                dvec2 = cs[1]
+            if has_aff:
+                dscale, dshift = cs[2], cs[3]
+        else:
+            dz = dout
+            if has_bias and needs[2]:
+                ops.colsum(dz, _grad_slot(bias), accumulate=True)
+        if gres is None and (has_res or has_gate):
+            gres = dout  # no affine in front: the residual branch sees dout itself
+        dx = None
+        if needs[0]:
+            dx = ops.conv2d_raw(dz, spec.pack(weight, True), x.shape[1], spec.k, spec.stride, spec.pad,
+                                not spec.transposed, ctx.in_hw)
+        if needs[1]:
+            g = _grad_slot(weight)
+            g4 = g if g.dim() == 4 else g.view(g.shape[0], g.shape[1], 1, 1)
+            if spec.transposed:
+                ops.conv2d_wgrad_raw(x, dz, g4, spec.k, spec.stride, spec.pad, accumulate=True)
+            else:
+                ops.conv2d_wgrad_raw(dz, x, g4, spec.k, spec.stride, spec.pad, accumulate=True)
+        return (dx, None, None, dvec2, gres if has_res else None, dscale, dshift, gres if has_gate else None,
+                dgt, None, None)
+
+
+def fused_conv(x, weight, bias, spec: ConvSpec, *, act: Optional[str] = None, vec2=None, res=None,
+               affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+               gate: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    scale, shift = affine if affine is not None else (None, None)
+    gx, gt = gate if gate is not None else (None, None)
+    return _FusedConv.apply(x, weight, bias, vec2, res, scale, shift, gx, gt, spec, act)
+
+
+class _InterpCaVectors(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, B, q: float):
+        lib = L.load()
+        Lv, Cc = W.shape[0], W.shape[2]
+        scale = torch.empty(Cc, dtype=torch.float32, device=W.device)
+        shift = torch.empty(Cc, dtype=torch.float32, device=W.device)
+        L.check(lib.crdr_interp_ca_params(W.data_ptr(), None if B is None else B.data_ptr(), Lv, Cc, float(q),
+                                          scale.data_ptr(), shift.data_ptr(), ops._stream()), "interp_ca_params")
+        ctx.q, ctx.has_b = float(q), B is not None
+        ctx.save_for_backward(W)
+        return scale, shift
+
+    @staticmethod
+    def backward(ctx, dscale, dshift):
+        (W,) = ctx.saved_tensors
+        lib = L.load()
+        Lv, Cc = W.shape[0], W.shape[2]
+        dW = torch.zeros_like(W)
+        dB = torch.zeros_like(W) if ctx.has_b else None
+        L.check(lib.crdr_interp_ca_params_bwd(W.data_ptr(), Lv, Cc, ctx.q, dscale.contiguous().data_ptr(),
+                                              dshift.contiguous().data_ptr(), dW.data_ptr(),
+                                              None if dB is None else dB.data_ptr(), ops._stream()), "interp_ca_params_bwd")
+        return dW, dB, None
+
+
+def interp_ca_vectors(W, B, q: float):
+    return _InterpCaVectors.apply(W, B, float(q))
+
+
+class _Affine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        lib = L.load()
+        x, ld = ops.nhwc(x)
+        n, c, h, w = x.shape
+        y = ops.empty_nhwc(n, c, h, w, x.device)
+        L.check(lib.crdr_affine(x.data_ptr(), ld, scale.data_ptr(), shift.data_ptr(), y.data_ptr(), c, n * h * w, c,
+                                ops._stream()), "affine")
+        ctx.save_for_backward(y, scale, shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, scale, shift = ctx.saved_tensors
+        dz, _, _, cs = ops.epilogue_bwd(dy, y, L.EPI_AFFINE, scale=scale, shift=shift)
+        return dz, cs[2], cs[3]
+
+
+def affine(x, scale, shift):
+    return _Affine.apply(x, scale, shift)
+
+
+class _Lrp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, z):
+        lib = L.load()
+        a, lda = ops.nhwc(a)
+        z, ldz = ops.nhwc(z)
+        n, c, h, w = a.shape
+        y = ops.empty_nhwc(n, c, h, w, a.device)
+        L.check(lib.crdr_lrp(a.data_ptr(), lda, z.data_ptr(), ldz, y.data_ptr(), c, n * h * w, c, ops._stream()), "lrp")
+        ctx.save_for_backward(z)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        lib = L.load()
+        dy, lddy = ops.nhwc(dy)
+        z, ldz = ops.nhwc(z)
+        n, c, h, w = z.shape
+        dz = ops.empty_nhwc(n, c, h, w, z.device)
+        L.check(lib.crdr_lrp_bwd(dy.data_ptr(), lddy, z.data_ptr(), ldz, dz.data_ptr(), c, n * h * w, c, ops._stream()), "lrp_bwd")
+        return dy, dz
+
+
+def lrp(a, z):
+    """a + 0.5 * tanh(z)"""
+    return _Lrp.apply(a, z)
+
+
+def _gc_desc(y, ldy, ldmu, ldsg, ldyh, scale_bound, lik_bound):
+    n, c, h, w = y.shape
+    return L.GcDesc(N=n, HW=h * w, C=c, ldy=ldy, ldmu=ldmu, ldsigma=ldsg, ldyhat=ldyh, scale_bound=scale_bound,
+                    likelihood_bound=lik_bound)
+
+
+class _GaussCond(torch.autograd.Function):
+    """(y, mu, sigma, noise) -> (y_hat, bits_noisy[N], bits_quant[N], lik_noisy?, lik_quant?)"""
+
+    @staticmethod
+    def forward(ctx, y, mu, sigma, noise, scale_bound, lik_bound, want_lik):
+        lib = L.load()
+        y, ldy = ops.nhwc(y)
+        mu, ldmu = ops.nhwc(mu)
+        sigma, ldsg = ops.nhwc(sigma)
+        n, c, h, w = y.shape
+        dev = y.device
+        yhat = ops.empty_nhwc(n, c, h, w, dev)
+        bits_n = torch.zeros(n, dtype=torch.float32, device=dev)
+        bits_q = torch.zeros(n, dtype=torch.float32, device=dev)
+        lik_n = ops.empty_nhwc(n, c, h, w, dev) if (want_lik and noise is not None) else None
+        lik_q = ops.empty_nhwc(n, c, h, w, dev) if want_lik else None
+        if noise is not None:
+            noise, ldn = ops.nhwc(noise)
+            if ldn != c:
+                noise = noise.contiguous(memory_format=torch.channels_last)
+        d = _gc_desc(y, ldy, ldmu, ldsg, c, scale_bound, lik_bound)
+        L.check(lib.crdr_gauss_cond_fwd(C.byref(d), y.data_ptr(), mu.data_ptr(), sigma.data_ptr(), ops._p(noise),
+                                        yhat.data_ptr(), ops._p(lik_n), ops._p(lik_q), bits_n.data_ptr(),
+                                        bits_q.data_ptr(), ops._stream()), "gauss_cond_fwd")
+        ctx.bounds = (scale_bound, lik_bound)
+        ctx.save_for_backward(y, mu, sigma, noise)
+        ctx.mark_non_differentiable(bits_q)
+        if lik_n is not None:
+            ctx.mark_non_differentiable(lik_n)
+        if lik_q is not None:
+            ctx.mark_non_differentiable(lik_q)
+        return yhat, bits_n, bits_q, lik_n, lik_q
+
+    @staticmethod
+    def backward(ctx, dyhat, dbits_n, _dq, _dln, _dlq):
+        y, mu, sigma, noise = ctx.saved_tensors
+        if noise is None:
+            raise L.CrdrHipError("gauss_cond: backward needs the noisy (training) forward")
+        lib = L.load()
+        y, ldy = ops.nhwc(y)
+        mu, ldmu = ops.nhwc(mu)
+        sigma, ldsg = ops.nhwc(sigma)
+        n, c, h, w = y.shape
+        dev = y.device
+        if dbits_n is None:
+            dbits_n = torch.zeros(n, dtype=torch.float32, device=dev)
+        lddyh = 0
+        if dyhat is not None:
+            dyhat, lddyh = ops.nhwc(dyhat)
+        dy, dmu, dsg = (ops.empty_nhwc(n, c, h, w, dev) for _ in range(3))
+        d = _gc_desc(y, ldy, ldmu, ldsg, c, *ctx.bounds)
+        L.check(lib.crdr_gauss_cond_bwd(C.byref(d), y.data_ptr(), mu.data_ptr(), sigma.data_ptr(), noise.data_ptr(),
+                                        dbits_n.contiguous().data_ptr(), ops._p(dyhat), lddyh, dy.data_ptr(),
+                                        dmu.data_ptr(), dsg.data_ptr(), ops._stream()), "gauss_cond_bwd")
+        return dy, dmu, dsg, None, None, None, None
+
+
+def gauss_cond(y, mu, sigma, noise, scale_bound=0.11, lik_bound=1e-9, want_lik=False):
+    return _GaussCond.apply(y, mu, sigma, noise, float(scale_bound), float(lik_bound), bool(want_lik))
+
+
+class _EntropyBottleneck(torch.autograd.Function):
+    """(z, params[C,58], medians[C], noise) -> (z_hat, lik, bits[N])"""
+
+    @staticmethod
+    def forward(ctx, z, params, medians, noise, lik_bound):
+        lib = L.load()
+        z, ldz = ops.nhwc(z)
+        n, c, h, w = z.shape
+        if ldz != c:
+            z = z.contiguous(memory_format=torch.channels_last)
+        if noise is not None:
+            noise, ldn = ops.nhwc(noise)
+            if ldn != c:
+                noise = noise.contiguous(memory_format=torch.channels_last)
+        dev = z.device
+        zhat, lik = ops.empty_nhwc(n, c, h, w, dev), ops.empty_nhwc(n, c, h, w, dev)
+        bits = torch.zeros(n, dtype=torch.float32, device=dev)
+        params = params.contiguous()
+        medians = medians.contiguous()
+        L.check(lib.crdr_entropy_bottleneck_fwd(z.data_ptr(), ops._p(noise), params.data_ptr(), medians.data_ptr(), n, h * w,
+                                                c, lik_bound, zhat.data_ptr(), lik.data_ptr(), bits.data_ptr(), ops._stream()),
+                "entropy_bottleneck_fwd")
+        ctx.lik_bound = lik_bound
+        ctx.save_for_backward(z, params, noise)
+        ctx.mark_non_differentiable(lik)
+        return zhat, lik, bits
+
+    @staticmethod
+    def backward(ctx, dzhat, _dlik, dbits):
+        z, params, noise = ctx.saved_tensors
+        if noise is None:
+            raise L.CrdrHipError("entropy_bottleneck: backward needs the noisy (training) forward")
+        lib = L.load()
+        n, c, h, w = z.shape
+        dev = z.device
+        if dbits is None:
+            dbits = torch.zeros(n, dtype=torch.float32, device=dev)
+        if dzhat is not None:
+            dzhat, ldd = ops.nhwc(dzhat)
+            if ldd != c:
+                dzhat = dzhat.contiguous(memory_format=torch.channels_last)
+        dz = ops.empty_nhwc(n, c, h, w, dev)
+        dparams = torch.empty_like(params)
+        L.check(lib.crdr_entropy_bottleneck_bwd(z.data_ptr(), noise.data_ptr(), params.data_ptr(), n, h * w, c, ctx.lik_bound,
+                                                dbits.contiguous().data_ptr(), ops._p(dzhat), dz.data_ptr(),
+                                                dparams.data_ptr(), ops._stream()), "entropy_bottleneck_bwd")
+        # z_hat = ste_round(z - median) + median: no gradient reaches the medians through it
+        return dz, dparams, None, None, None
+
+
+def entropy_bottleneck(z, params, medians, noise, lik_bound=1e-9):
+    return _EntropyBottleneck.apply(z, params, medians, noise, float(lik_bound))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------------------------
+def _flat(t: torch.Tensor) -> torch.Tensor:
+    """The memory behind a (possibly channel-padded NHWC) tensor as a flat contiguous buffer.  Padding lanes
+    must hold equal values in both operands of a difference (they are zero by construction)."""
+    ops._require_gpu(t)
+    if t.is_contiguous():
+        return t.reshape(-1)
+    if t.dim() == 4:
+        t2, ld = ops.nhwc(t)
+        n, c, h, w = t2.shape
+        return torch.as_strided(t2, (n * h * w * ld,), (1,), t2.storage_offset())
+    return t.contiguous().reshape(-1)
+
+
+def _same_layout(a, b):
+    fa, fb = _flat(a), _flat(b)
+    if fa.numel() != fb.numel():
+        a = a.contiguous(memory_format=torch.channels_last)
+        b = b.contiguous(memory_format=torch.channels_last)
+        fa, fb = _flat(a), _flat(b)
+    return fa, fb
+
+
+class _SqDiffSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = L.load()
+        fa, fb = _same_layout(a, b)
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        nb = lib.crdr_reduce_workspace(fa.numel())
+        ws, wsn = ops.workspace(nb, a.device)
+        L.check(lib.crdr_sqdiff_sum(fa.data_ptr(), fb.data_ptr(), fa.numel(), out.data_ptr(), ws, wsn, ops._stream()), "sqdiff_sum")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        lib = L.load()
+        fa, fb = _same_layout(a, b)
+        da = torch.empty_like(fa) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(fb) if ctx.needs_input_grad[1] else None
+        L.check(lib.crdr_sqdiff_bwd(fa.data_ptr(), fb.data_ptr(), fa.numel(), g.contiguous().data_ptr(), 1.0, ops._p(da),
+                                    ops._p(db), ops._stream()), "sqdiff_bwd")
+
+        def back(flat, like):
+            if flat is None:
+                return None
+            like2, ld = ops.nhwc(like) if like.dim() == 4 and not like.is_contiguous() else (like, None)
+            if ld is None:
+                return flat.view(like.shape)
+            n, c, h, w = like2.shape
+            return flat.view(n, h, w, ld).permute(0, 3, 1, 2)[:, :c]
+        return back(da, a), back(db, b)
+
+
+def sqdiff_sum(a, b):
+    return _SqDiffSum.apply(a, b)
+
+
+class _BceDiffSum(torch.autograd.Function):
+    """sum BCEWithLogits(p - q, target)"""
+
+    @staticmethod
+    def forward(ctx, p, q, target):
+        lib = L.load()
+        fp, fq = p.contiguous().reshape(-1), q.contiguous().reshape(-1)
+        out = torch.empty(1, dtype=torch.float32, device=p.device)
+        nb = lib.crdr_reduce_workspace(fp.numel())
+        ws, wsn = ops.workspace(nb, p.device)
+        L.check(lib.crdr_bce_diff_sum(fp.data_ptr(), fq.data_ptr(), fp.numel(), float(target), out.data_ptr(), ws, wsn,
+                                      ops._stream()), "bce_diff_sum")
+        ctx.target = float(target)
+        ctx.save_for_backward(fp, fq)
+        ctx.shape = p.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fp, fq = ctx.saved_tensors
+        lib = L.load()
+        dp = torch.empty_like(fp) if ctx.needs_input_grad[0] else None
+        dq = torch.empty_like(fq) if ctx.needs_input_grad[1] else None
+        L.check(lib.crdr_bce_diff_bwd(fp.data_ptr(), fq.data_ptr(), fp.numel(), ctx.target, g.contiguous().data_ptr(), 1.0,
+                                      ops._p(dp), ops._p(dq), ops._stream()), "bce_diff_bwd")
+        return (None if dp is None else dp.view(ctx.shape)), (None if dq is None else dq.view(ctx.shape)), None
+
+
+def bce_diff_sum(p, q, target: float):
+    return _BceDiffSum.apply(p, q, float(target))
+
+
+class _MaxPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = L.load()
+        x, ld = ops.nhwc(x)
+        n, c, h, w = x.shape
+        if ld != c:
+            x = x.contiguous(memory_format=torch.channels_last)
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        y = ops.empty_nhwc(n, c, oh, ow, x.device)
+        L.check(lib.crdr_maxpool3s2_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, ops._stream()), "maxpool_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        lib = L.load()
+        n, c, h, w = x.shape
+        dy, ld = ops.nhwc(dy)
+        if ld != c:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = ops.empty_nhwc(n, c, h, w, x.device)
+        L.check(lib.crdr_maxpool3s2_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, h, w, c, ops._stream()), "maxpool_bwd")
+        return dx
+
+
+def maxpool3s2(x):
+    return _MaxPool3s2.apply(x)
+
+
+class _LpipsLayer(torch.autograd.Function):
+    """(f_real, f_fake, lin[C]) -> per-image distance [N]; gradient flows to f_fake only."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, lin):
+        lib = L.load()
+        f0, l0 = ops.nhwc(f0)
+        f1, l1 = ops.nhwc(f1)
+        n, c, h, w = f0.shape
+        if l0 != c:
+            f0 = f0.contiguous(memory_format=torch.channels_last)
+        if l1 != c:
+            f1 = f1.contiguous(memory_format=torch.channels_last)
+        out = torch.zeros(n, dtype=torch.float32, device=f0.device)
+        ws, wsn = ops.workspace(n * 64 * 4, f0.device)
+        L.check(lib.crdr_lpips_layer_fwd(f0.data_ptr(), f1.data_ptr(), lin.data_ptr(), n, h * w, c, out.data_ptr(), ws, wsn,
+                                         ops._stream()), "lpips_layer_fwd")
+        ctx.save_for_backward(f0, f1, lin)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        f0, f1, lin = ctx.saved_tensors
+        lib = L.load()
+        n, c, h, w = f0.shape
+        df1 = ops.empty_nhwc(n, c, h, w, f0.device)
+        L.check(lib.crdr_lpips_layer_bwd(f0.data_ptr(), f1.data_ptr(), lin.data_ptr(), n, h * w, c, g.contiguous().data_ptr(),
+                                         df1.data_ptr(), ops._stream()), "lpips_layer_bwd")
+        return None, df1, None
+
+
+def lpips_layer(f_real, f_fake, lin):
+    return _LpipsLayer.apply(f_real, f_fake, lin)

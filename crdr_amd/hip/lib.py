@@ -78,6 +78,7 @@ SIGNATURES = {
     "crdr_gauss_cond_bwd": (_I, [C.POINTER(GcDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "crdr_entropy_bottleneck_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
     "crdr_entropy_bottleneck_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
+    "crdr_eb_quantile_loss": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "crdr_reduce_workspace": (_SZ, [_I64]),
     "crdr_sqdiff_sum": (_I, [_P, _P, _I64, _P, _P, _SZ, _P]),
     "crdr_sqdiff_bwd": (_I, [_P, _P, _I64, _P, _F, _P, _P, _P]),

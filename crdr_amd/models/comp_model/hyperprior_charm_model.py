@@ -1,0 +1,173 @@
+"""Stage-1 model: ELIC transforms + Minnen20 hyperprior + Charm context model
+(src/models/comp_model/hyperprior_model.py:21-264 and hyperprior_charm_model.py:20-147, merged: the plain
+hyperprior variants without Charm are ablations outside the CRDR hot path)."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import pandas as pd
+import torch
+from torch import Tensor
+
+from crdr_amd.models.subnet import build_subnet
+from crdr_amd.models.subnet.entropy_model.gaussian_conditional import get_scale_table
+from crdr_amd.utils.codec_utils import HeaderHandler
+from crdr_amd.utils.registry import MODEL_REGISTRY
+
+from .base_model import BaseModel
+
+
+@MODEL_REGISTRY.register()
+class HyperpriorCharmModel(BaseModel):
+    def _build_subnets(self):
+        sn = self.opt.subnet
+        self.encoder = build_subnet(sn.encoder, "encoder")
+        self.decoder = build_subnet(sn.decoder, "decoder")
+        self.hyperencoder = build_subnet(sn.hyperencoder, "hyperencoder")
+        self.hyperdecoder = build_subnet(sn.hyperdecoder, "hyperdecoder")
+        self.entropy_model_z = build_subnet(sn.entropy_model_z, "entropy_model")
+        self.entropy_model_y = build_subnet(sn.entropy_model_y, "entropy_model")
+        self.context_model = build_subnet(sn.context_model, "context_model")
+        self.return_likelihoods = bool(self.opt.get("return_likelihoods", False))
+
+    # ---- hooks the rate/beta-conditioned subclasses override
+    def _encode(self, x, **cond):
+        return self.encoder(x)
+
+    def _decode(self, y_hat, **cond):
+        return self.decoder(y_hat)
+
+    def _extra_outputs(self, **cond) -> Dict:
+        return {}
+
+    # ---- training / evaluation forward
+    def run_model(self, real_images, is_train: bool = True, noise: Optional[Dict[str, Tensor]] = None, **cond):
+        N, _, H, W = real_images.size()
+        x = self.data_preprocess(real_images, is_train=is_train)
+        out = self.forward(x, is_train=is_train, noise=noise, **cond)
+        rate = self.get_rate_summary_dict(out, H * W)
+        real, fake = self.data_postprocess(x, out["fake_images"], size=(H, W), is_train=is_train)
+        return dict(real_images=real, fake_images=fake, y_hat=out["quantized_code"]["y"], z_hat=out["quantized_code"]["z"],
+                    **self._extra_outputs(**cond), **rate, **out.get("others", {}))
+
+    def get_rate_summary_dict(self, out_dict: Dict, num_pixel: int) -> Dict[str, Tensor]:
+        """bpp[n] = (bits_y[n] + bits_z[n]) / (H*W): noisy (`bpp`) and quantised (`qbpp`) (hyperprior_model.py:60-85).
+        The bit sums come straight out of the fused entropy kernels."""
+        b = out_dict["bits"]
+        return dict(y_likelihood=out_dict["likelihoods"]["y"], z_likelihood=out_dict["likelihoods"]["z"],
+                    bpp=(b["y"] + b["z"]) / num_pixel,
+                    y_q_likelihood=out_dict["q_likelihoods"]["y"], z_q_likelihood=out_dict["q_likelihoods"]["z"],
+                    qbpp=(b["y_q"] + b["z_q"]).detach() / num_pixel)
+
+    @staticmethod
+    def likelihood_to_bit(likelihood: Tensor, num_pixel: int) -> Tuple[Tensor, Tensor]:
+        bit = -(torch.log(likelihood).sum(dim=tuple(range(1, likelihood.ndim)))) / np.log(2)
+        return bit, bit / num_pixel
+
+    def forward(self, real_images, is_train: bool = True, noise: Optional[Dict[str, Tensor]] = None, **cond):
+        noise = noise or {}
+        y = self._encode(real_images, **cond)
+        z = self.hyperencoder(y)
+        z_hat, z_lik, z_bits = self.entropy_model_z(z, is_train=is_train, noise=noise.get("z"), want_bits=True)
+        hyper_out = self.hyperdecoder(z_hat)
+        want_lik = self.return_likelihoods or not is_train
+        y_hat, y_lik, y_qlik = self.context_model(y, hyper_out, self.entropy_model_y, is_train=is_train,
+                                                  calc_q_likelihood=True, noise=noise.get("y"), want_lik=want_lik)
+        y_bits, y_qbits = self.context_model.last_bits
+        fake = self._decode(y_hat, **cond)
+        if not is_train:
+            fake = torch.clamp(fake, min=-1.0, max=1.0)
+        with torch.no_grad():
+            if is_train:
+                _, z_qlik, z_qbits = self.entropy_model_z(z.detach(), is_train=False, want_bits=True)
+            else:
+                z_qlik, z_qbits = z_lik, z_bits
+        return {
+            "fake_images": fake,
+            "likelihoods": {"y": y_lik, "z": z_lik},
+            "latent_code": {"y": y, "z": z},
+            "quantized_code": {"y": y_hat, "z": z_hat},
+            "q_likelihoods": {"y": y_qlik, "z": z_qlik},
+            "bits": {"y": y_bits, "z": z_bits, "y_q": y_qbits, "z_q": z_qbits},
+        }
+
+    # ---- codec
+    def _make_header_handler(self):
+        return HeaderHandler(use_non_zero_ind=False)
+
+    def codec_setup(self):
+        """CDF tables for z and y.  Unlike the reference (hyperprior_model.py:126-129; hyperprior_charm_model.py:80-82)
+        nothing is moved to the CPU: the HIP kernels are deterministic (fixed reduction order, no atomics), so the
+        encoder and decoder sides reproduce the same mu / sigma bit for bit on the GPU; only rANS stays on the host."""
+        self.header_handler = self._make_header_handler()
+        self.entropy_model_z.update(force=True)
+        self.entropy_model_y.update_scale_table(get_scale_table(), force=True)
+        self.yC = self.encoder.latent_ch
+        self.zC = self.hyperencoder.latent_ch
+        self.y_stride = 2 ** self.encoder.num_downscale
+        self.model_stride = self.y_stride * 2 ** self.hyperencoder.num_downscale
+
+    def _header_encode(self, size, y_hat, **cond) -> bytes:
+        return self.header_handler.encode(size, y_hat)
+
+    def _header_cond(self, header: Dict) -> Dict:
+        return {}
+
+    @torch.no_grad()
+    def compress(self, real_images: Tensor, **cond) -> Dict:
+        N, _, H, W = real_images.shape
+        assert N == 1, f"In compress mode, batchsize must be 1, but {N}"
+        x = self.data_preprocess(real_images, is_train=False)
+        y = self._encode(x, **cond)
+        z = self.hyperencoder(y)
+        z_hat, z_lik = self.entropy_model_z(z, is_train=False)
+        z_str = self.entropy_model_z.compress(z)
+        hyper_out = self.hyperdecoder(z_hat)
+        y_str, y_hat, y_lik = self.context_model.forward_compress(y, hyper_out, self.entropy_model_y)
+        header = self._header_encode((H, W), y_hat, **cond)
+        y_bit, y_bpp = self.likelihood_to_bit(y_lik, H * W)
+        z_bit, z_bpp = self.likelihood_to_bit(z_lik, H * W)
+        return {"string_list": [header, z_str[0], y_str[0]], "z_hat": z_hat, "y_hat": y_hat, "z_likelihood": z_lik,
+                "y_likelihood": y_lik, "pred_y_bit": y_bit.item(), "pred_y_bpp": y_bpp.item(), "pred_z_bit": z_bit.item(),
+                "pred_z_bpp": z_bpp.item()}
+
+    @torch.no_grad()
+    def decompress(self, string_list: List, **cond) -> Tuple[Tensor, Tensor, Tensor]:
+        assert len(string_list) == 3, f"String list length should be 3 (header, z, and y), but got {len(string_list)}"
+        header = self.header_handler.decode(string_list[0])
+        H, W = header["img_size"]
+        s = self.model_stride
+        zH, zW = int(np.ceil(H / s)), int(np.ceil(W / s))
+        z_symbol = self.entropy_model_z.decompress([string_list[1]], (zH, zW)).to(self.device)
+        z_hat = self.entropy_model_z.dequantize(z_symbol)
+        hyper_out = self.hyperdecoder(z_hat)
+        y_hat, _ = self.context_model.forward_decompress(string_list[2], hyper_out, self.entropy_model_y)
+        fake = self._decode(y_hat, **self._header_cond(header), **cond)
+        fake = self.data_postprocess(fake, size=(H, W), is_train=False)
+        return fake, z_hat, y_hat
+
+    # ---- validation (bpp / PSNR over a loader)
+    def _validation_conditions(self, **kw) -> List[Tuple[str, Dict]]:
+        return [("", {})]
+
+    @torch.no_grad()
+    def validation(self, dataloader, max_sample_size: int, save_img: bool = False, save_dir: str = "", use_tqdm: bool = False, **kw) -> pd.DataFrame:
+        from crdr_amd.utils.img_utils import calc_psnr, imwrite
+        rows = []
+        n = min(len(dataloader), max_sample_size)
+        if save_img:
+            assert os.path.exists(save_dir), f'save_dir: "{save_dir}" does not exist.'
+        for idx, data in enumerate(dataloader):
+            row = {"idx": idx + 1}
+            for suffix, cond in self._validation_conditions(**kw):
+                out = self.run_model(**data, is_train=False, **cond)
+                row[f"bpp{suffix}"] = out["bpp"].mean().item()
+                row[f"psnr{suffix}"] = calc_psnr(out["real_images"], out["fake_images"], 255)
+                if save_img:
+                    imwrite(os.path.join(save_dir, f"sample_{idx + 1}_fake{suffix}.jpg"), out["fake_images"])
+            rows.append(row)
+            if idx + 1 == n:
+                break
+        return pd.json_normalize(rows)

@@ -1,0 +1,5 @@
+import os.path as osp
+
+from crdr_amd.utils.misc import import_modules
+
+import_modules("crdr_amd.models.subnet.autoencoder", osp.dirname(osp.abspath(__file__)), suffix="_autoencoder.py")

@@ -199,6 +199,12 @@ int crdr_entropy_bottleneck_bwd(const float* z, const float* noise, const float*
                                 float likelihood_bound, const float* gbits, const float* dzhat, float* dz,
                                 float* dparams, crdr_stream_t s);
 
+/* aux ("quantile") loss of the factorised prior, compressai EntropyBottleneck.loss() as called from
+ * base_model.py:68-78: loss = sum_{c,j} |logits_c(quantiles[c][j]) - target[j]|, dq = d loss / d quantiles
+ * (density parameters are constants here). */
+int crdr_eb_quantile_loss(const float* quantiles, const float* params, const float* target, int C, float* loss,
+                          float* dquantiles, crdr_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* losses                                                                                            */
 /* ------------------------------------------------------------------------------------------------ */

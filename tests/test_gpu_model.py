@@ -1,0 +1,227 @@
+"""GPU parity of the HIP product modules (through the C ABI) against the CPU oracle on the same seeded weights
+and inputs: forward values and gradients of every generator sub-network, the entropy models, the full generator
+and the discriminator.  Tolerances: outputs rtol 2e-4 of the tensor scale (fp32 MFMA vs CPU fp32 summation
+order through ~60 stacked convs); gradients are compared tensor-by-tensor by relative L2 error <= 2e-3."""
+import pytest
+import torch
+
+from tests.golden.seeded_weights import seeded_input, seeded_tensor
+
+pytestmark = pytest.mark.gpu
+CA = dict(actv="softplus", use_interp=True, use_bias=True)
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def seed_module(module, prefix):
+    """Fill the (CPU) module with the seeded weights, return the oracle state dict (CPU, fp32)."""
+    sd = module.state_dict()
+    out = {}
+    for k, v in sd.items():
+        if torch.is_floating_point(v) and v.numel() > 0:
+            t = seeded_tensor(prefix + k, v.shape)
+            sd[k] = t
+            out[prefix + k] = t.clone()
+    module.load_state_dict(sd)
+    return out
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def close(got, ref, what, rtol=2e-4):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} scale {scale:.3e}"
+
+
+def check_grads(module, prefix, ref_sd, what, tol=2e-3):
+    bad = []
+    for k, p in module.named_parameters():
+        r = ref_sd[prefix + k].grad
+        if r is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0, f"{what}: {k} has a gradient but the oracle has none"
+            continue
+        assert p.grad is not None, f"{what}: {k} got no gradient"
+        e = rel(p.grad, r)
+        if e > tol:
+            bad.append((k, e))
+    assert not bad, f"{what}: gradient mismatch {bad[:8]} ({len(bad)} tensors)"
+
+
+def grad_sd(sd):
+    return {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+
+def test_encoder_fwd_bwd():
+    from oracle import crdr_oracle as O
+    from crdr_amd.models.subnet.autoencoder.elic_interpca_autoencoder import ElicInterpCaEncoder
+    m = ElicInterpCaEncoder(rate_level=5, in_ch=3, out_ch=320, main_ch=192, block_mid_ch=96, ca_kwargs=CA)
+    sd = seed_module(m, "encoder.")
+    m.to(dev())
+    x = seeded_input("image", (2, 3, 64, 64))
+    r = seeded_input("enc.cot", (2, 320, 4, 4))
+    for q in (0.0, 2.5, 4.0):
+        close(m(x.to(dev()), q), O.encoder(sd, x, q), f"encoder q={q}")
+    sdg = grad_sd(sd)
+    xg = x.clone().requires_grad_(True)
+    (O.encoder(sdg, xg, 1.5) * r).sum().backward()
+    xd = x.to(dev()).requires_grad_(True)
+    (m(xd, 1.5) * r.to(dev())).sum().backward()
+    assert rel(xd.grad, xg.grad) < 2e-3, rel(xd.grad, xg.grad)
+    check_grads(m, "encoder.", sdg, "encoder")
+
+
+def test_decoder_fwd_bwd():
+    from oracle import crdr_oracle as O
+    from crdr_amd.models.subnet.autoencoder.elic_interpca_beta_cond_autoencoder import ElicInterpCaBetaCondDecoder
+    m = ElicInterpCaBetaCondDecoder(rate_level=5, L=10, max_beta=5.12, cond_ch=512, weight_init=True, in_ch=320, out_ch=3,
+                                    main_ch=256, block_mid_ch=128, pixel_shuffle=False, use_tanh=False, use_pi=False, ca_kwargs=CA)
+    sd = seed_module(m, "decoder.")
+    m.to(dev())
+    y = seeded_input("latent", (2, 320, 4, 4), scale=3.0)
+    r = seeded_input("dec.cot", (2, 3, 64, 64))
+    for q, b in ((0.0, 0.0), (2.25, 3.84)):
+        close(m(y.to(dev()).contiguous(memory_format=torch.channels_last), q, b), O.decoder(sd, y, q, b), f"decoder q={q} b={b}")
+    sdg = grad_sd(sd)
+    yg = y.clone().requires_grad_(True)
+    (O.decoder(sdg, yg, 1.5, 2.56) * r).sum().backward()
+    yd = y.to(dev()).requires_grad_(True)
+    (m(yd, 1.5, 2.56) * r.to(dev())).sum().backward()
+    assert rel(yd.grad, yg.grad) < 2e-3, rel(yd.grad, yg.grad)
+    check_grads(m, "decoder.", sdg, "decoder")
+
+
+def test_gauss_cond_fwd_bwd():
+    from oracle import crdr_oracle as O
+    from crdr_amd.hip import functional as HF
+    n, c, h, w = 3, 32, 6, 5
+    y = seeded_input("gc.y", (n, c, h, w), 6.0)
+    mu = seeded_input("gc.mu", (n, c, h, w), 4.0)
+    sg = seeded_input("gc.sg", (n, c, h, w), 2.0)  # includes values below the 0.11 bound and negatives
+    noise = seeded_input("gc.noise", (n, c, h, w), 0.5)
+    gb = torch.tensor([0.7, 1.3, 0.2])
+    gyh = seeded_input("gc.gyh", (n, c, h, w))
+    t = [v.clone().requires_grad_(True) for v in (y, mu, sg)]
+    yh, lik = O.gaussian_conditional(t[0], t[1], t[2], noise)
+    _, qlik = O.gaussian_conditional(y, mu, sg, None)
+    ((O.bits_per_image(lik) * gb).sum() + (yh * gyh).sum()).backward()
+    d = [v.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True) for v in (y, mu, sg)]
+    yh_d, bn, bq, ln, lq = HF.gauss_cond(d[0], d[1], d[2], noise.to(dev()), 0.11, 1e-9, True)
+    close(yh_d, yh, "gc yhat", 1e-6)
+    close(ln, lik, "gc lik noisy", 2e-5)
+    close(lq, qlik, "gc lik quant", 2e-5)
+    close(bn, O.bits_per_image(lik), "gc bits noisy", 1e-5)
+    close(bq, O.bits_per_image(qlik), "gc bits quant", 1e-5)
+    ((bn * gb.to(dev())).sum() + (yh_d * gyh.to(dev())).sum()).backward()
+    for a, b, nm in zip(d, t, ("dy", "dmu", "dsigma")):
+        close(a.grad, b.grad, "gc " + nm, 2e-4)
+    # analytic known answers: p(y = mu, sigma = 1) = erf(1 / (2 sqrt 2)); sigma below the bound clamps to 0.11
+    one = torch.zeros(1, 4, 1, 1, device=dev())
+    _, _, _, _, l = HF.gauss_cond(one, one, one + 1.0, None, 0.11, 1e-9, True)
+    assert abs(l.flatten()[0].item() - 0.3829249) < 1e-6
+    _, _, _, _, la = HF.gauss_cond(one, one, one + 0.01, None, 0.11, 1e-9, True)
+    _, _, _, _, lb = HF.gauss_cond(one, one, one + 0.11, None, 0.11, 1e-9, True)
+    assert torch.equal(la, lb)
+
+
+def test_entropy_bottleneck_fwd_bwd_aux():
+    from oracle import crdr_oracle as O
+    from crdr_amd.models.subnet.entropy_model.entropy_bottleneck import SteEntropyBottleneck
+    m = SteEntropyBottleneck(channels=24)
+    sd = seed_module(m, "entropy_model_z.")
+    m.to(dev())
+    z = seeded_input("eb.z", (3, 24, 4, 4), 5.0)
+    noise = seeded_input("eb.noise", (3, 24, 4, 4), 0.5)
+    gb = torch.tensor([0.7, 1.3, 0.2])
+    gzh = seeded_input("eb.gzh", (3, 24, 4, 4))
+    sdg = grad_sd(sd)
+    zg = z.clone().requires_grad_(True)
+    zh, lik = O.entropy_bottleneck(sdg, "entropy_model_z", zg, noise)
+    ((O.bits_per_image(lik) * gb).sum() + (zh * gzh).sum()).backward()
+    zd = z.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    zh_d, lik_d, bits_d = m(zd, is_train=True, noise=noise.to(dev()), want_bits=True)
+    close(zh_d, zh, "eb zhat", 1e-6)
+    close(lik_d, lik, "eb lik", 5e-5)
+    close(bits_d, O.bits_per_image(lik), "eb bits", 2e-5)
+    ((bits_d * gb.to(dev())).sum() + (zh_d * gzh.to(dev())).sum()).backward()
+    close(zd.grad, zg.grad, "eb dz", 5e-4)
+    check_grads(m, "entropy_model_z.", sdg, "eb params", tol=2e-3)
+    # eval path + aux loss
+    zq, qlik = O.entropy_bottleneck(sd, "entropy_model_z", z, None)
+    zq_d, qlik_d = m(z.to(dev()), is_train=False)
+    close(zq_d, zq, "eb eval zhat", 1e-6)
+    close(qlik_d, qlik, "eb eval lik", 5e-5)
+    m.zero_grad()
+    sdg = grad_sd(sd)
+    aux = O.eb_aux_loss(sdg, "entropy_model_z")
+    aux.backward()
+    aux_d = m.loss()
+    aux_d.backward()
+    close(aux_d, aux, "eb aux", 2e-5)
+    close(m.quantiles.grad, sdg["entropy_model_z.quantiles"].grad, "eb aux dquantiles", 5e-4)
+
+
+def _full_model(stage3=True):
+    from crdr_amd.models import build_comp_model
+    from crdr_amd.utils.options import BaseConfig, ConfigDict
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "_base_", "model")
+    cfg, _, _ = BaseConfig._file2dict_yaml(os.path.join(root, "beta_cond_interp_ca_elic_charm.yaml" if stage3 else "elic_charm.yaml"))
+    cfg["device"] = "cuda:0"
+    model = build_comp_model(ConfigDict(cfg))
+    sd = seed_module(model, "")
+    return model.to(dev()), sd
+
+
+@pytest.mark.parametrize("stage3", [True, False], ids=["stage3", "stage1"])
+def test_generator_forward_backward(stage3):
+    from oracle import crdr_oracle as O
+    model, sd = _full_model(stage3)
+    x = seeded_input("image", (2, 3, 64, 64))
+    ny = seeded_input("noise.y", (2, 320, 4, 4), 0.5)
+    nz = seeded_input("noise.z", (2, 192, 1, 1), 0.5)
+    q, beta = (2.0, 3.84) if stage3 else (None, None)
+    sdg = grad_sd(sd)
+    ref = O.generator_forward(sdg, x, q, beta, ny, nz)
+    loss_ref = O.mse_loss(x, ref["fake_images"]) + 0.4 * ref["bpp"].mean()
+    loss_ref.backward()
+    kw = dict(rate_ind=q, beta=beta) if stage3 else {}
+    out = model.run_model(x, is_train=True, noise={"y": ny.to(dev()), "z": nz.to(dev())}, **kw)
+    close(out["y_hat"], ref["y_hat"], "y_hat", 3e-4)
+    close(out["z_hat"], ref["z_hat"], "z_hat", 1e-6)
+    close(out["fake_images"], ref["fake_images"], "fake_images", 5e-4)
+    close(out["bpp"], ref["bpp"], "bpp", 1e-4)
+    close(out["qbpp"], ref["qbpp"], "qbpp", 1e-4)
+    from crdr_amd.hip import functional as HF
+    mse = HF.sqdiff_sum(out["real_images"], out["fake_images"]) / (x.numel() * 4.0) * 150.0
+    close(mse.reshape(()), O.mse_loss(x, ref["fake_images"]), "mse", 1e-4)
+    (mse + 0.4 * out["bpp"].mean()).backward()
+    check_grads(model, "", sdg, "generator", tol=5e-3)
+
+
+def test_discriminator_fwd_bwd():
+    from oracle import crdr_oracle as O
+    from crdr_amd.models.discriminator import build_discriminator
+    D = build_discriminator(dict(type="ModuleListDiscriminator", _subd_type="CLIC21GVAEDiscriminator", _num_subd=5, in_ch=3,
+                                 out_ch=1, main_ch=64, norm_type="none"))
+    sd = seed_module(D, "")
+    D.to(dev())
+    x = seeded_input("image", (2, 3, 64, 64))
+    r = seeded_input("disc.cot", (2, 1, 4, 4))
+    sdg = grad_sd(sd)
+    xg = x.clone().requires_grad_(True)
+    (O.discriminator(sdg, xg, 3) * r).sum().backward()
+    xd = x.to(dev()).requires_grad_(True)
+    out = D(xd, rate_ind=torch.tensor([3]))
+    close(out, O.discriminator(sd, x, 3), "disc logits")
+    (out * r.to(dev())).sum().backward()
+    assert rel(xd.grad, xg.grad) < 2e-3
+    check_grads(D, "", sdg, "discriminator")
