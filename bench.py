@@ -1,0 +1,161 @@
+"""Headline benchmark: stage-3 CRDR training throughput (img/s) at 256x256 crops, bs 16 per GPU.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full `MultirateBetaCondHrrGanRateDistortionTrainer.optimize_parameters` iteration (generator
+forward + no-grad high-rate pass + LPIPS + discriminator passes + backward + clip + Adam for G, aux and D) on a
+device-resident synthetic batch, fp32 end to end (the reference's precision).  Prints ONE JSON line on rank 0.
+`roofline`: the implicit-GEMM conv kernel family (forward + input-gradient launches of igemm_kernel), algorithmic
+FLOPs / HIP-event time per launch, against the dense fp32 MFMA peak.  `cpu_baseline`: the oracle's same step on
+the host cores (bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+GFLOP_PER_IMG_STAGE3 = 644.6    # 3.8 F_G + 7.8 F_D + LPIPS, 2 FLOP per MAC
+GFLOP_PER_IMG_STAGE1 = 434.0
+
+
+def build_trainer(stage: int, bs: int, size: int, device: str):
+    import torch
+    from crdr_amd.trainer import build_trainer as _bt
+    from crdr_amd.utils.options import BaseConfig, ConfigDict
+    cfg, _, _ = BaseConfig._file2dict_yaml(os.path.join(ROOT, "config", f"crdr_stage_{stage}.yaml"))
+    cfg.pop("pretrained_weight_path", None)
+    cfg["device"] = device
+    cfg["dataset"] = {"batch_size": bs, "train_dataset": {"type": "SyntheticDataset", "image_size": size}}
+    cfg["path"] = None
+    torch.manual_seed(0)
+    return _bt(ConfigDict(cfg))
+
+
+def cpu_baseline(stage: int, size: int, budget_s: float = 25.0):
+    """The oracle's training step (same losses, fwd + bwd for G and D) in stock torch on the host cores."""
+    import torch
+    from oracle import crdr_oracle as O
+    from crdr_amd.models import build_comp_model
+    from crdr_amd.models.discriminator import build_discriminator
+    from crdr_amd.losses.perceptual_loss import LpipsAlex
+    from crdr_amd.utils.options import BaseConfig, ConfigDict
+    cfg, _, _ = BaseConfig._file2dict_yaml(os.path.join(ROOT, "config", f"crdr_stage_{stage}.yaml"))
+    cfg["device"] = "cpu"
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in build_comp_model(ConfigDict(cfg)).state_dict().items() if v.numel() > 0}
+    lp = {"lpips." + k: v.detach() for k, v in LpipsAlex().state_dict().items()}
+    n = 1
+    x = torch.rand(n, 3, size, size) * 2 - 1
+    ny, nz = torch.rand(n, 320, size // 16, size // 16) - 0.5, torch.rand(n, 192, size // 64, size // 64) - 0.5
+    d = None
+    if stage == 3:
+        d = {k: v.detach().clone().requires_grad_(True) for k, v in build_discriminator(ConfigDict(cfg).discriminator).state_dict().items()}
+
+    def step():
+        if stage == 3:
+            losses, out = O.stage3_g_losses(g, d, lp, x, 2, 2.56, ny, nz)
+            losses["total"].backward()
+            O.stage3_d_losses(d, x, out["fake_images"], 2)["d_total"].backward()
+        else:
+            losses, _ = O.stage1_losses(g, lp, x, ny, nz)
+            losses["total"].backward()
+    t0 = time.time()
+    step()  # warm-up (allocations, oneDNN primitive creation)
+    warm = time.time() - t0
+    t0, k = time.time(), 0
+    while k == 0 or (time.time() - t0 < budget_s - warm and k < 8):
+        step()
+        k += 1
+    dt = (time.time() - t0) / k
+    return {"value": round(n / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (stock torch fp32, oneDNN) stage-{stage} step at N={n}, {size}x{size}, q=2: {k} timed iteration(s) after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--stage", type=int, default=3)
+    ap.add_argument("--bs", type=int, default=16)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from crdr_amd.hip import ops
+    from crdr_amd.trainer import dist as D
+    local = D.init_from_env()
+    ws, rk = D.world_size(), D.rank()
+    assert ws == a.gpus or (a.gpus == 1 and ws == 1), f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+    device = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    tr = build_trainer(a.stage, a.bs, a.size, device)
+    loader = iter(tr.train_loader)
+
+    def barrier():
+        if ws > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(a.warmup):
+        it += 1
+        tr.optimize_parameters(it, next(loader))
+    barrier()
+    ops.PROFILE = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        it += 1
+        tr.optimize_parameters(it, next(loader))
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if ws > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rk != 0:
+        return
+    imgs = ws * a.bs * a.steps
+    value = imgs / dt
+    gflop = GFLOP_PER_IMG_STAGE3 if a.stage == 3 else GFLOP_PER_IMG_STAGE1
+
+    def fam(kind):
+        rec = prof.get(kind, [])
+        if not rec:
+            return None
+        fl = sum(r[0] for r in rec)
+        ms = sum(r[1].elapsed_time(r[2]) for r in rec)
+        return {"launches_per_step": len(rec) / a.steps, "avg_launch_us": round(ms * 1e3 / len(rec), 2),
+                "avg_gflop_per_launch": round(fl / len(rec) / 1e9, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                "ms_per_step": round(ms / a.steps, 2)}
+    ig, wg = fam("igemm"), fam("wgrad")
+    roof = {"bound": "mfma", "achieved": ig["tflops"] if ig else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None, "traffic": None,
+            "kernel": "igemm_kernel<*> (conv / convT forward + input-gradient launches, v_mfma_f32_32x32x2_f32)",
+            "detail": ig, "wgrad_kernel": wg,
+            "whole_step": {"algorithmic_gflop_per_img": gflop, "achieved": round(value / ws * gflop / 1e3, 2),
+                           "frac": round(value / ws * gflop / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}}
+    line = {"metric": f"stage-{a.stage} training img/s at {a.size}x{a.size}", "value": round(value, 3), "unit": "img/s",
+            "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": f"config/crdr_stage_{a.stage}.yaml -b {a.bs}: full GAN step (G + 5x CLIC21GVAE D + LPIPS-Alex, random-init weights)"
+                                   if a.stage == 3 else f"config/crdr_stage_1.yaml -b {a.bs}: R-D step (+LPIPS-Alex, random-init weights)",
+                       "global_batch": ws * a.bs, "crop": a.size, "parallelism": f"dp{ws}"},
+            "roofline": roof}
+    if ws == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(a.stage, a.size)
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

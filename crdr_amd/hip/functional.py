@@ -177,7 +177,7 @@ class _Affine(torch.autograd.Function):
         x, ld = ops.nhwc(x)
         n, c, h, w = x.shape
         y = ops.empty_nhwc(n, c, h, w, x.device)
-        L.check(lib.crdr_affine(x.data_ptr(), ld, scale.data_ptr(), shift.data_ptr(), y.data_ptr(), c, n * h * w, c,
+        L.check(lib.crdr_affine(x.data_ptr(), ld, scale.data_ptr(), shift.data_ptr(), y.data_ptr(), ops.ld_for(c), n * h * w, c,
                                 ops._stream()), "affine")
         ctx.save_for_backward(y, scale, shift)
         return y

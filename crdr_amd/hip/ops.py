@@ -14,6 +14,26 @@ from . import lib as L
 
 _ws_cache = {}
 
+# Optional per-launch timing (bench.py): {"igemm": [(flops, ev0, ev1), ...], "wgrad": [...]} or None.
+# Events are recorded on the stream the kernels are launched on (torch's current stream).
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(kind: str, flops: float, e0) -> None:
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.setdefault(kind, []).append((flops, e0, e1))
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -59,8 +79,13 @@ def nhwc(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
     return t, ld
 
 
+def ld_for(c: int) -> int:
+    """Pixel stride the library's own allocations use: channels rounded up to a multiple of 4 (16-byte rows)."""
+    return (c + 3) // 4 * 4
+
+
 def empty_nhwc(n, c, h, w, device, ld: Optional[int] = None, zero: bool = False) -> torch.Tensor:
-    ld = c if ld is None else ld
+    ld = ld_for(c) if ld is None else ld
     mk = torch.zeros if (zero or ld != c) else torch.empty
     buf = mk((n, h, w, ld), dtype=torch.float32, device=device)
     return buf.permute(0, 3, 1, 2)[:, :c]
@@ -102,7 +127,7 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
     n, c, h, w = x.shape
     oh, ow = out_hw
     if out is None:
-        out = empty_nhwc(n, oc, oh, ow, x.device, ld=(oc if oc % 4 == 0 else (oc + 3) // 4 * 4))
+        out = empty_nhwc(n, oc, oh, ow, x.device)
     out_t, ldy = out, (out.stride(3) if ow > 1 else (out.stride(2) if oh > 1 else (out.stride(0) if n > 1 else oc)))
     d = L.ConvDesc(N=n, H=h, W=w, C=(c + 3) // 4 * 4 if ldx >= (c + 3) // 4 * 4 else c, OH=oh, OW=ow, OC=oc, kh=k[0], kw=k[1],
                    stride=stride, pad=pad, transposed=int(transposed), ldx=ldx, ldy=ldy, wrows=wpack.shape[1],
@@ -124,7 +149,9 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
         io.gx, io.gt, io.sig = gate_x.data_ptr(), gate_t.data_ptr(), sig_out.data_ptr()
     nbytes = lib.crdr_conv2d_workspace(C.byref(d))
     ws, ws_n = workspace(nbytes, x.device) if nbytes else (None, 0)
+    e0 = _prof_begin()
     L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), ws, ws_n, _stream()), "conv2d")
+    _prof_end("igemm", 2.0 * n * (h * w if transposed else oh * ow) * c * oc * k[0] * k[1], e0)
     return out
 
 
@@ -142,7 +169,9 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
                     stride=stride, pad=pad, gI=g.shape[0], gJ=g.shape[1], accumulate=int(accumulate))
     nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
     ws, ws_n = workspace(nbytes, p.device)
+    e0 = _prof_begin()
     L.check(lib.crdr_conv2d_wgrad(C.byref(d), p.data_ptr(), q.data_ptr(), g.data_ptr(), ws, ws_n, _stream()), "conv2d_wgrad")
+    _prof_end("wgrad", 2.0 * n * ph * pw * g.shape[0] * g.shape[1] * k[0] * k[1], e0)
     return g
 
 
@@ -163,7 +192,7 @@ def epilogue_bwd(dout, out, flags, *, vec2=None, scale=None, shift=None, gate_t=
     dout, lddout = nhwc(dout)
     n, c, h, w = dout.shape
     m = n * h * w
-    d = L.EbwdDesc(M=m, C=c, flags=flags, lddout=lddout, ldout=0, lddz=c, ldgres=c, ldg=c)
+    d = L.EbwdDesc(M=m, C=c, flags=flags, lddout=lddout, ldout=0, lddz=ld_for(c), ldgres=ld_for(c), ldg=c)
     io = L.EbwdIO(dout=dout.data_ptr(), vec2=_p(vec2), scale=_p(scale), shift=_p(shift))
     if out is not None:
         out, d.ldout = nhwc(out)

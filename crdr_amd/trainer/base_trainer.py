@@ -1,0 +1,161 @@
+"""Training loop skeleton (src/trainer/base_trainer.py:17-238): build models / optimisers / losses / loaders, then
+iterate `optimize_parameters`, logging, validation and checkpointing on the reference's step schedule.
+
+Data-parallel extension (the reference is single-GPU): one process per GPU, replicas broadcast from rank 0,
+rank 0 alone logs / validates / saves."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Union
+
+import torch
+
+from crdr_amd.models import build_comp_model
+from crdr_amd.utils.logger import AvgMeter, CSVLogger, bolded_log, get_root_logger, log_dict_items
+from crdr_amd.utils.model_saver import Saver
+from crdr_amd.utils.path import PathHandler
+from crdr_amd.utils.timer import Timer
+
+from . import dist as D
+
+
+class BaseTrainer:
+    def __init__(self, opt) -> None:
+        self.opt = opt
+        self.device = opt.device
+        self.logger = get_root_logger()
+        self.is_main = D.rank() == 0
+        self.set_models()
+        self.set_optimizer_scheduler()
+        self.set_losses()
+        self.set_dataloader()
+        self.use_wandb = False  # wandb is not part of the hot path; rank-0 CSV logs carry the same numbers
+        self.loss_recorder = AvgMeter()
+        self.time_recorder = Timer(start_iter=opt.get("start_iter", 0), end_iter=opt.get("total_iter", 0))
+        if opt.get("path") is not None and self.is_main:
+            self.set_csv_loggers()
+            self.model_saver = Saver(opt.path.ckpt_root, opt.exp, opt.save_step, opt.keep_step)
+        if opt.get("start_iter", 0) > 0:
+            self.load_checkpoint(opt.exp, opt.start_iter)
+        if opt.get("load_checkpoint", None):
+            lc = dict(opt.load_checkpoint)
+            self.load_checkpoint(lc.pop("exp"), lc.pop("iter"), **lc)
+        if opt.get("dry_run", False):
+            self.print_models()
+            raise SystemExit(0)
+
+    # ---- construction
+    def set_models(self) -> None:
+        bolded_log("Model", level="INFO", new_line=True)
+        self._set_models()
+
+    def _set_models(self) -> None:
+        self.comp_model = build_comp_model(self.opt).to(self.device)
+        if self.opt.get("pretrained_weight_path", None):
+            self.comp_model.load_learned_weight(self.opt.pretrained_weight_path)
+        D.broadcast_module_(self.comp_model)
+        self.comp_model.train()
+
+    def set_optimizer_scheduler(self) -> None:
+        bolded_log("Optimizers & Schedulers", level="INFO", new_line=True)
+        self._set_optimizer_scheduler()
+
+    def set_losses(self) -> None:
+        bolded_log("Loss functions", level="INFO", new_line=True)
+        self._set_losses()
+
+    def set_dataloader(self) -> None:
+        """`opt.dataset.train_dataset.type == 'SyntheticDataset'` (or a missing dataset section) yields device-resident
+        random crops; otherwise the image-folder datasets of crdr_amd.dataset (reference: base_trainer.py:74-80)."""
+        from crdr_amd.dataset import build_loaders
+        self.train_loader, self.eval_loader = build_loaders(self.opt, self.device)
+
+    def set_csv_loggers(self) -> None:
+        resume = self.opt.get("start_iter", 0) > 0
+        self.train_logger = CSVLogger(log_path=self.opt.path.log_loss_path, resume=resume)
+        self.eval_logger = CSVLogger(log_path=self.opt.path.log_eval_path, resume=resume)
+
+    def load_checkpoint(self, exp: str, itr: int, **kwargs) -> None:
+        bolded_log("Load checkpoint", level="INFO", new_line=True)
+        log_dict_items(dict(exp=exp, iter=itr, **kwargs), level="INFO")
+        self._load_checkpoint(exp, itr, **kwargs)
+
+    def print_models(self) -> None:
+        self.logger.debug(str(self.comp_model))
+
+    # ---- main loop
+    def train_data_generator(self, dataloader, start_itr: int, end_itr: int):
+        it = iter(dataloader)
+        for i in range(start_itr, end_itr):
+            try:
+                data = next(it)
+            except StopIteration:
+                it = iter(dataloader)
+                data = next(it)
+            yield i + 1, data
+
+    def train_loop(self) -> None:
+        bolded_log("train_loop start", new_line=True)
+        self.time_recorder.start()
+        o = self.opt
+        for itr, data in self.train_data_generator(self.train_loader, o.get("start_iter", 0), o.total_iter):
+            loss_dict = self.optimize_parameters(itr, data)
+            if loss_dict is not None:
+                self.update_loss_recorder(loss_dict)
+            if not self.is_main:
+                continue
+            if itr % o.log_step == 0:
+                self.log_train_loss(itr)
+            if self.eval_loader is not None and itr % o.eval_step == 0:
+                self.validation(itr)
+            if itr % o.save_step == 0:
+                self.save(itr)
+
+    def optimize_parameters(self, itr: int, data: Dict) -> Optional[Dict]:
+        raise NotImplementedError()
+
+    def update_loss_recorder(self, loss_dict: Dict) -> None:
+        """One device->host copy for all logged scalars (the reference does one `.item()` per entry)."""
+        keys = list(loss_dict)
+        vals = [loss_dict[k] if isinstance(loss_dict[k], torch.Tensor) else torch.tensor(float(loss_dict[k])) for k in keys]
+        dev = next((v.device for v in vals if v.is_cuda), torch.device("cpu"))
+        flat = torch.stack([v.detach().float().mean().to(dev) for v in vals]).tolist()
+        self.loss_recorder.update(dict(zip(keys, flat)))
+
+    def validation(self, current_iter: int) -> None:
+        self.comp_model.eval()
+        df = self.comp_model.validation(self.eval_loader, max_sample_size=100, save_img=False, use_tqdm=False)
+        res = df.drop("idx", axis=1).mean().to_dict()
+        row = {"iter": current_iter}
+        row.update(res)
+        self.eval_logger.update(row)
+        self.comp_model.train()
+
+    def log_train_loss(self, current_iter: int) -> None:
+        row = {"iter": current_iter}
+        row.update(self.loss_recorder.get_avg_values())
+        self.train_logger.update(row)
+        self.loss_recorder.reset()
+
+    def save(self, current_iter: int) -> None:
+        raise NotImplementedError()
+
+    # ---- utilities
+    @staticmethod
+    def update_learning_rate(optimizer, new_lr: float) -> None:
+        assert isinstance(new_lr, float)
+        for g in optimizer.param_groups:
+            g["lr"] = new_lr
+        if hasattr(optimizer, "base_lrs"):
+            optimizer.base_lrs = [new_lr for _ in optimizer.param_groups]
+
+    @staticmethod
+    def check_loss_nan_inf(loss_total) -> Union[str, bool]:
+        """'nan' / 'inf' / 'huge' (> 1e4) or False (base_trainer.py:228-238); one host sync."""
+        v = float(loss_total.detach().reshape(-1)[0])
+        if v != v:
+            return "nan"
+        if v in (float("inf"), float("-inf")):
+            return "inf"
+        if v > 10000:
+            return "huge"
+        return False

@@ -1,0 +1,72 @@
+"""Data-parallel helpers: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) or gloo for
+the CPU tests. The reference is single-GPU only (README.md:63); this is the MI355X scale-out of its training step:
+full replicas, one flat-buffer all-reduce per optimiser, and rank-consistent control decisions."""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size() -> int:
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend: Optional[str] = None) -> int:
+    """Initialise from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*). Returns the local rank."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend)
+    return local
+
+
+def all_reduce_mean_(buffers: List[torch.Tensor]) -> None:
+    """In-place average of each flat buffer across ranks (one collective per buffer)."""
+    if not is_dist():
+        return
+    ws = dist.get_world_size()
+    for b in buffers:
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        b.div_(ws)
+
+
+def all_reduce_scalars_mean(t: torch.Tensor) -> torch.Tensor:
+    if not is_dist():
+        return t
+    t = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t / dist.get_world_size()
+
+
+def any_rank_true(flag: bool, device) -> bool:
+    """Logical OR across ranks (so that every rank takes the same skip-update decision)."""
+    if not is_dist():
+        return flag
+    t = torch.tensor([1.0 if flag else 0.0], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0)
+
+
+def broadcast_module_(module: torch.nn.Module, src: int = 0) -> None:
+    if not is_dist():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.numel() > 0:
+            dist.broadcast(t.data, src=src)

@@ -1,0 +1,183 @@
+"""Optimisers and LR schedulers behind the reference's registry names (`Adam`, `MultiStepLR`;
+src/trainer/optimizer/build_optimizer_scheduler.py:11-77).
+
+`Adam` keeps every parameter of a group, its gradient and both moments in ONE flat fp32 buffer each: the
+update is a single fused HIP launch (with clip_grad_norm_ folded in as a device-side scale), the gradient
+norm is one reduction, and data-parallel training all-reduces one contiguous buffer over RCCL."""
+from __future__ import annotations
+
+from copy import deepcopy
+from typing import Dict, Iterable, List, Optional
+
+import torch
+
+from crdr_amd.hip import functional as HF
+from crdr_amd.hip import lib as L
+from crdr_amd.hip import ops
+from crdr_amd.utils.registry import OPTIMIZER_REGISTRY, SCHEDULER_REGISTRY
+
+
+class _Group(dict):
+    pass
+
+
+class Adam:
+    """torch.optim.Adam semantics (no amsgrad / weight decay) on flat buffers; state_dict() round-trips through the
+    torch.optim.Adam format so `training_state_iter*.pth.tar` files stay interchangeable."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, amsgrad: bool = False):
+        assert weight_decay == 0.0 and not amsgrad, "not used by the CRDR recipes"
+        params = list(params)
+        groups = params if params and isinstance(params[0], dict) else [{"params": params}]
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps)
+        self.param_groups: List[Dict] = []
+        for g in groups:
+            ps = [p for p in g["params"] if p.requires_grad]
+            grp = _Group(params=ps, lr=g.get("lr", lr), betas=tuple(g.get("betas", betas)), eps=g.get("eps", eps), step=0)
+            self._flatten(grp)
+            self.param_groups.append(grp)
+
+    @staticmethod
+    def _flatten(grp) -> None:
+        ps = grp["params"]
+        total = sum(p.numel() for p in ps)
+        if total == 0:
+            grp["flat"] = grp["grad"] = grp["m"] = grp["v"] = None
+            return
+        dev = ps[0].device
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = grad[off:off + n].view(p.shape)
+            off += n
+        grp["flat"], grp["grad"] = flat, grad
+        grp["m"], grp["v"] = torch.zeros_like(flat), torch.zeros_like(flat)
+
+    # ---- gradient buffers
+    def flat_grads(self) -> List[torch.Tensor]:
+        return [g["grad"] for g in self.param_groups if g["grad"] is not None]
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        for g in self.param_groups:
+            if g["grad"] is not None:
+                g["grad"].zero_()
+                off = 0
+                for p in g["params"]:  # re-attach in case autograd replaced a .grad tensor
+                    n = p.numel()
+                    if p.grad is None or p.grad.data_ptr() != g["grad"].data_ptr() + 4 * off:
+                        p.grad = g["grad"][off:off + n].view(p.shape)
+                    off += n
+
+    def grad_sqnorm(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """sum of squared gradients over all groups -> 1-element device tensor (no host sync)."""
+        lib = L.load()
+        total = None
+        for g in self.flat_grads():
+            o = torch.empty(1, dtype=torch.float32, device=g.device)
+            ws, wsn = ops.workspace(lib.crdr_reduce_workspace(g.numel()), g.device)
+            L.check(lib.crdr_sqnorm(g.data_ptr(), g.numel(), o.data_ptr(), ws, wsn, ops._stream()), "sqnorm")
+            total = o if total is None else total + o
+        if out is not None:
+            out.copy_(total)
+            return out
+        return total
+
+    def step(self, sqnorm: Optional[torch.Tensor] = None, max_norm: float = 0.0) -> None:
+        """One Adam update. With `sqnorm` (1-element device tensor holding the squared global gradient norm) the
+        gradient is scaled by min(1, max_norm / (sqrt(sqnorm) + 1e-6)) inside the kernel (clip_grad_norm_)."""
+        lib = L.load()
+        for g in self.param_groups:
+            if g["flat"] is None:
+                continue
+            g["step"] += 1
+            b1, b2 = g["betas"]
+            L.check(lib.crdr_adam_step(g["flat"].data_ptr(), g["grad"].data_ptr(), g["m"].data_ptr(), g["v"].data_ptr(),
+                                       g["flat"].numel(), float(g["lr"]), b1, b2, g["eps"], g["step"],
+                                       None if sqnorm is None else sqnorm.data_ptr(), float(max_norm), ops._stream()), "adam_step")
+        HF.bump_weights_epoch()
+
+    # ---- torch.optim-compatible checkpoint format
+    def state_dict(self) -> Dict:
+        state, groups, idx = {}, [], 0
+        for g in self.param_groups:
+            ids, off = [], 0
+            for p in g["params"]:
+                n = p.numel()
+                if g["step"] > 0:
+                    state[idx] = {"step": torch.tensor(float(g["step"])), "exp_avg": g["m"][off:off + n].view(p.shape).clone(),
+                                  "exp_avg_sq": g["v"][off:off + n].view(p.shape).clone()}
+                ids.append(idx)
+                idx += 1
+                off += n
+            groups.append({"lr": g["lr"], "betas": g["betas"], "eps": g["eps"], "weight_decay": 0, "amsgrad": False, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            g["lr"], g["betas"], g["eps"] = sg["lr"], tuple(sg["betas"]), sg["eps"]
+            off = 0
+            for p, pid in zip(g["params"], sg["params"]):
+                n = p.numel()
+                st = sd["state"].get(pid)
+                if st is not None:
+                    g["m"][off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    g["v"][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    g["step"] = int(st["step"])
+                off += n
+
+
+class MultiStepLR:
+    def __init__(self, optimizer, milestones: Iterable[int], gamma: float = 0.1):
+        self.optimizer, self.milestones, self.gamma = optimizer, sorted(milestones), gamma
+        self.base_lrs = [g["lr"] for g in optimizer.param_groups]
+        self.last_epoch = 0
+
+    def _apply(self) -> None:
+        k = sum(1 for m in self.milestones if m <= self.last_epoch)
+        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = base * self.gamma ** k
+
+    def step(self) -> None:
+        self.last_epoch += 1
+        self._apply()
+
+    def state_dict(self) -> Dict:
+        return {"milestones": list(self.milestones), "gamma": self.gamma, "base_lrs": self.base_lrs, "last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        self.last_epoch = sd["last_epoch"]
+        self.base_lrs = sd.get("base_lrs", self.base_lrs)
+        self._apply()
+
+
+OPTIMIZER_REGISTRY.register()(Adam)
+SCHEDULER_REGISTRY.register()(MultiStepLR)
+
+
+def get_params_list(parameters_dict, paramwise_opt, base_lr):
+    """Per-key lr multipliers: keys containing any query string form a group with lr = lr_mult * base_lr."""
+    groups, remaining = [], dict(parameters_dict)
+    for o in paramwise_opt:
+        hit = [k for k in sorted(remaining) if any(q in k for q in o["keys"])]
+        groups.append({"params": [remaining.pop(k) for k in hit if parameters_dict[k].requires_grad], "lr": o["lr_mult"] * base_lr})
+    groups.append({"params": [v for k, v in sorted(remaining.items()) if v.requires_grad]})
+    return groups
+
+
+def build_optimizer(parameters_dict: Dict, optimizer_opt: Dict):
+    opt = deepcopy(optimizer_opt)
+    opt = opt.to_dict() if hasattr(opt, "to_dict") else dict(opt)
+    cls = OPTIMIZER_REGISTRY.get(opt.pop("type"))
+    paramwise = opt.pop("paramwise_opt", [])
+    params = get_params_list(parameters_dict, paramwise, opt["lr"]) if paramwise else [v for v in parameters_dict.values() if v.requires_grad]
+    return cls(params=params, **opt)
+
+
+def build_scheduler(optimizer, scheduler_opt: Dict):
+    opt = deepcopy(scheduler_opt)
+    opt = opt.to_dict() if hasattr(opt, "to_dict") else dict(opt)
+    return SCHEDULER_REGISTRY.get(opt.pop("type"))(optimizer, **opt)

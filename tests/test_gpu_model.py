@@ -49,7 +49,9 @@ def check_grads(module, prefix, ref_sd, what, tol=2e-3):
         if r is None:
             assert p.grad is None or p.grad.abs().max().item() == 0, f"{what}: {k} has a gradient but the oracle has none"
             continue
-        assert p.grad is not None, f"{what}: {k} got no gradient"
+        if p.grad is None:  # e.g. quantiles under STE rounding: the oracle's autograd yields exact zeros
+            assert r.abs().max().item() == 0, f"{what}: {k} got no gradient but the oracle's is non-zero"
+            continue
         e = rel(p.grad, r)
         if e > tol:
             bad.append((k, e))

@@ -1,0 +1,174 @@
+"""GPU parity of one full training step (stage 3 and stage 1) against the CPU oracle: every loss term, every
+generator / discriminator gradient tensor before the optimiser (relative L2 <= 5e-3), the fused Adam + global-norm
+clip against torch.optim.Adam + clip_grad_norm_, LPIPS and the GAN/MSE reductions."""
+import os
+
+import pytest
+import torch
+
+from tests.golden.seeded_weights import seeded_input, seeded_tensor
+from tests.test_gpu_model import check_grads, close, dev, grad_sd, rel, seed_module
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _opt(stage: int, bs: int = 2, size: int = 64):
+    from crdr_amd.utils.options import BaseConfig, ConfigDict
+    cfg, _, _ = BaseConfig._file2dict_yaml(os.path.join(ROOT, "config", f"crdr_stage_{stage}.yaml"))
+    cfg.pop("pretrained_weight_path", None)
+    cfg["device"] = "cuda:0"
+    cfg["dataset"] = {"batch_size": bs, "train_dataset": {"type": "SyntheticDataset", "image_size": size}}
+    cfg["path"] = None
+    return ConfigDict(cfg)
+
+
+def _seed_params(module, prefix):
+    out = {}
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            t = seeded_tensor(prefix + k, p.shape)
+            p.copy_(t.to(p.device))
+            out[prefix + k] = t.clone()
+    return out
+
+
+def test_lpips_and_reductions():
+    from oracle import crdr_oracle as O
+    from crdr_amd.losses.perceptual_loss import LpipsAlex
+    m = LpipsAlex().to(dev())
+    sd = _seed_params(m, "lpips.")
+    a, b = seeded_input("lp.a", (2, 3, 64, 64)), seeded_input("lp.b", (2, 3, 64, 64))
+    bg = b.clone().requires_grad_(True)
+    ref = O.lpips_alex(sd, a, bg)
+    ref.mean().backward()
+    bd = b.to(dev()).requires_grad_(True)
+    got = m(a.to(dev()), bd)
+    close(got, ref, "lpips value", 2e-4)
+    got.mean().backward()
+    assert rel(bd.grad, bg.grad) < 2e-3, rel(bd.grad, bg.grad)
+
+
+def test_adam_matches_torch():
+    from crdr_amd.trainer.optimizer import build_optimizer
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in ((37, 5), (128,), (3, 3, 3, 3))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    for p in ps:
+        p.data = p.data.to(dev())
+    opt = build_optimizer({str(i): p for i, p in enumerate(ps)}, {"type": "Adam", "lr": 1e-2})
+    topt = torch.optim.Adam(ref, lr=1e-2)
+    for step in range(4):
+        gs = [torch.randn(p.shape) * (10.0 if step == 1 else 0.1) for p in ref]
+        opt.zero_grad()
+        for p, r, g in zip(ps, ref, gs):
+            p.grad.copy_(g.to(dev()))
+            r.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        topt.step()
+        opt.step(sqnorm=opt.grad_sqnorm(), max_norm=1.0)
+        for p, r in zip(ps, ref):
+            close(p, r, f"adam step {step}", 2e-6)
+    sd = opt.state_dict()
+    topt.load_state_dict(sd)  # format compatibility
+    assert len(sd["state"]) == 3
+
+
+def test_stage3_step():
+    from oracle import crdr_oracle as O
+    from crdr_amd.trainer import build_trainer
+    tr = build_trainer(_opt(3))
+    # the optimisers flattened the parameters on the device: seed in place (views are preserved)
+    sd_g = _seed_params(tr.comp_model, "")
+    sd_d = _seed_params(tr.discriminator, "")
+    sd_l = _seed_params(tr.perceptual_loss.lpips, "lpips.")
+    x = seeded_input("image", (2, 3, 64, 64))
+    ny = seeded_input("noise.y", (2, 320, 4, 4), 0.5)
+    nz = seeded_input("noise.z", (2, 192, 1, 1), 0.5)
+    q, beta = 2, 2.56
+
+    g_ref, d_ref = grad_sd(sd_g), grad_sd(sd_d)
+    losses, out = O.stage3_g_losses(g_ref, d_ref, sd_l, x, q, beta, ny, nz)
+    losses["total"].backward()
+    d_ref = grad_sd(sd_d)
+    d_losses = O.stage3_d_losses(d_ref, x, out["fake_images"], q)
+    d_losses["d_total"].backward()
+    aux_ref = grad_sd(sd_g)
+    O.eb_aux_loss(aux_ref, "entropy_model_z").backward()
+
+    captured = {}
+    g_step, d_step, a_step = tr.g_optimizer.step, tr.d_optimizer.step, tr.aux_optimizer.step
+
+    def cap(name, module, fn):
+        def wrapped(*a, **k):
+            captured[name] = {n: (p.grad.clone() if p.grad is not None else None) for n, p in module.named_parameters()}
+            return fn(*a, **k)
+        return wrapped
+    tr.g_optimizer.step = cap("g", tr.comp_model, g_step)
+    tr.d_optimizer.step = cap("d", tr.discriminator, d_step)
+    tr.aux_optimizer.step = cap("aux", tr.comp_model, a_step)
+    before = {n: p.detach().clone() for n, p in tr.comp_model.named_parameters()}
+
+    data = {"real_images": x.to(dev()), "rate_ind": torch.tensor([q]), "beta": beta,
+            "noise": {"y": ny.to(dev()), "z": nz.to(dev())}}
+    log = tr.optimize_parameters(1, data)
+    assert log is not None
+    for k in ("distortion", "rate", "perceptual", "adv"):
+        close(log[k], losses[k], f"loss {k}", 3e-4)
+    for k in ("d_real", "d_fake"):
+        close(log[k], d_losses[k], f"loss {k}", 3e-4)
+    close(log["aux"], O.eb_aux_loss(sd_g, "entropy_model_z"), "aux loss", 1e-4)
+    close(log["qbpp"], out["qbpp"], "qbpp", 1e-4)
+
+    def cmp(cap_d, ref_sd, what, only=None, tol=5e-3):
+        bad = []
+        for n, g in cap_d.items():
+            if only is not None and not only(n):
+                continue
+            r = ref_sd[n].grad
+            if r is None or r.abs().max() == 0:
+                assert g is None or g.abs().max().item() == 0, f"{what}: unexpected gradient for {n}"
+                continue
+            e = rel(g, r)
+            if e > tol:
+                bad.append((n, e))
+        assert not bad, f"{what}: {bad[:8]} ({len(bad)})"
+    cmp(captured["g"], g_ref, "G grads", only=lambda n: not n.endswith(".quantiles"))
+    cmp(captured["d"], d_ref, "D grads")
+    cmp(captured["aux"], aux_ref, "aux grads", only=lambda n: n.endswith(".quantiles"))
+    # the generator update really happened, with the clipped step size bounded by lr
+    moved = max((p.detach() - before[n]).abs().max().item() for n, p in tr.comp_model.named_parameters())
+    assert 0 < moved <= 1.0e-3 + 1e-6
+
+
+def test_stage1_step():
+    from oracle import crdr_oracle as O
+    from crdr_amd.trainer import build_trainer
+    tr = build_trainer(_opt(1))
+    sd_g = _seed_params(tr.comp_model, "")
+    sd_l = _seed_params(tr.perceptual_loss.lpips, "lpips.")
+    x = seeded_input("image", (2, 3, 64, 64))
+    ny = seeded_input("noise.y", (2, 320, 4, 4), 0.5)
+    nz = seeded_input("noise.z", (2, 192, 1, 1), 0.5)
+    g_ref = grad_sd(sd_g)
+    losses, out = O.stage1_losses(g_ref, sd_l, x, ny, nz)
+    losses["total"].backward()
+    captured = {}
+    g_step = tr.g_optimizer.step
+
+    def wrapped(*a, **k):
+        captured.update({n: (p.grad.clone() if p.grad is not None else None) for n, p in tr.comp_model.named_parameters()})
+        return g_step(*a, **k)
+    tr.g_optimizer.step = wrapped
+    log = tr.optimize_parameters(1, {"real_images": x.to(dev()), "noise": {"y": ny.to(dev()), "z": nz.to(dev())}})
+    for k in ("distortion", "rate", "perceptual"):
+        close(log[k], losses[k], f"loss {k}", 3e-4)
+    bad = []
+    for n, g in captured.items():
+        r = g_ref[n].grad
+        if n.endswith(".quantiles") or r is None or r.abs().max() == 0:
+            continue
+        e = rel(g, r)
+        if e > 5e-3:
+            bad.append((n, e))
+    assert not bad, bad[:8]
