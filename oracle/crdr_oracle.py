@@ -210,14 +210,34 @@ def ste_round(x):
     return (torch.round(x) - x).detach() + x  # ste_round.py:4-5
 
 
-def gaussian_conditional(y, mu, sigma, noise=None, scale_bound=SCALE_BOUND):
+FORCE_TOL = 2e-3
+
+
+def forced_round(v, forced=None, report=None):
+    """round(v); where v sits within FORCE_TOL of a rounding boundary the decision of another implementation
+    (`forced`, integer-valued) is adopted instead -- fp32 summation-order noise may legitimately flip those --
+    while everywhere else the two decisions must agree exactly (recorded in `report["mismatch"]`)."""
+    q = torch.round(v.detach())
+    if forced is None:
+        return q
+    f = v.detach() - torch.floor(v.detach())
+    near = (f - 0.5).abs() < FORCE_TOL
+    if report is not None:
+        report["mismatch"] = report.get("mismatch", 0) + int(((q != forced) & ~near).sum())
+        report["adopted"] = report.get("adopted", 0) + int(((q != forced) & near).sum())
+    return torch.where(near, forced.to(q.dtype), q)
+
+
+def gaussian_conditional(y, mu, sigma, noise=None, scale_bound=SCALE_BOUND, forced=None, report=None):
     """SteGaussianMeanScaleConditional.forward (ste_gaussian_conditional.py:20-27).
     noise given (training): likelihood of y + noise, output ste_round(y - mu) + mu.
     noise None (is_train False): likelihood of, and output, round(y - mu) + mu."""
+    v = y - mu
+    q = forced_round(v, forced, report)
     if noise is not None:
-        return ste_round(y - mu) + mu, gaussian_likelihood(y + noise, mu, sigma, scale_bound)
-    q = torch.round(y - mu) + mu
-    return q, gaussian_likelihood(q, mu, sigma, scale_bound)
+        return (q - v).detach() + v + mu, gaussian_likelihood(y + noise, mu, sigma, scale_bound)
+    qm = q + mu
+    return qm, gaussian_likelihood(qm, mu, sigma, scale_bound)
 
 
 EB_FILTERS = (1, 3, 3, 3, 3, 1)
@@ -257,13 +277,14 @@ def eb_likelihood(sd: SD, p: str, v):
     return lik.reshape(c, n, *v.shape[2:]).transpose(0, 1)
 
 
-def entropy_bottleneck(sd: SD, p: str, z, noise=None):
+def entropy_bottleneck(sd: SD, p: str, z, noise=None, forced=None, report=None):
     """SteEntropyBottleneck.forward (entropy_bottleneck.py:23-30): training -> likelihood of z + noise and
     z_hat = ste_round(z - median) + median; eval -> both from round(z - median) + median."""
     med = sd[p + ".quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
     if noise is not None:
-        return ste_round(z - med) + med, eb_likelihood(sd, p, z + noise)
-    q = torch.round(z - med.detach()) + med.detach()
+        v = z - med
+        return (forced_round(v, forced, report) - v).detach() + v + med, eb_likelihood(sd, p, z + noise)
+    q = forced_round(z - med.detach(), forced, report) + med.detach()
     return q, eb_likelihood(sd, p, q)
 
 
@@ -282,7 +303,15 @@ def bits_per_image(lik):
 # ------------------------------------------------------------------------------------------------------------
 
 
-def charm_forward(sd: SD, y, hyper_out, noise=None, p: str = "context_model", num_slices=10, max_support=5):
+def rounding_margin(v) -> float:
+    """Smallest distance of any element of v from a rounding boundary (k + 1/2): inputs whose margin is tiny
+    can legitimately round differently under a different fp32 summation order."""
+    f = v.detach() - torch.floor(v.detach())
+    return float((f - 0.5).abs().min())
+
+
+def charm_forward(sd: SD, y, hyper_out, noise=None, p: str = "context_model", num_slices=10, max_support=5, diag=None,
+                  forced=None, report=None):
     """Minnen20CharmContextModel.forward (minnen20_charm_context_model.py:88-141).
     Support = the FIRST min(i, 5) decoded slices; mean and LRP transforms see hyper_mean, scale sees hyper_scale;
     the coded symbol excludes the LRP residual, the slice handed on includes it."""
@@ -296,30 +325,39 @@ def charm_forward(sd: SD, y, hyper_out, noise=None, p: str = "context_model", nu
         ss = torch.cat([h_sc] + sup, 1)
         mu = slice_transform(sd, f"{p}.mean_slice_transforms.{i}", ms)
         sg = slice_transform(sd, f"{p}.scale_slice_transforms.{i}", ss)
-        yh, lik = gaussian_conditional(ysl, mu, sg, None if ns is None else ns[i])
+        fq = None if forced is None else forced[i]
+        yh, lik = gaussian_conditional(ysl, mu, sg, None if ns is None else ns[i], forced=fq, report=report)
+        if diag is not None:
+            diag["margin"] = min(diag.get("margin", 1.0), rounding_margin(ysl - mu))
         liks.append(lik)
         with torch.no_grad():
-            qliks.append(gaussian_conditional(ysl, mu, sg, None)[1])
+            qliks.append(gaussian_conditional(ysl, mu, sg, None, forced=fq)[1])
         lrp = slice_transform(sd, f"{p}.lrp_slice_transforms.{i}", torch.cat([ms, yh], 1))
         hats.append(yh + 0.5 * torch.tanh(lrp))
     return torch.cat(hats, 1), torch.cat(liks, 1), torch.cat(qliks, 1)
 
 
-def generator_forward(sd: SD, x, q: Optional[float], beta: Optional[float], noise_y=None, noise_z=None, is_train=True):
+def generator_forward(sd: SD, x, q: Optional[float], beta: Optional[float], noise_y=None, noise_z=None, is_train=True, diag=None,
+                      forced=None, report=None):
+    # forced = {"z": integer symbols [N,192,h,w], "y": list of 10 integer-symbol tensors} from another implementation
     """{HyperpriorCharmModel, BetaCondInterpCaHyperpriorCharmModel}.forward + get_rate_summary_dict
     (hyperprior_charm_model.py:41-79; beta_cond_interpca_hyperprior_charm_model.py:34-78; hyperprior_model.py:60-85).
     q None -> stage-1 model (no InterpCA, no beta)."""
     n, _, H, W = x.shape
     y = encoder(sd, x, q)
     z = hyper_encoder(sd, y)
-    z_hat, z_lik = entropy_bottleneck(sd, "entropy_model_z", z, noise_z if is_train else None)
+    fz = None if forced is None else forced["z"]
+    fy = None if forced is None else forced["y"]
+    z_hat, z_lik = entropy_bottleneck(sd, "entropy_model_z", z, noise_z if is_train else None, forced=fz, report=report)
     hyper = hyper_decoder(sd, z_hat)
-    y_hat, y_lik, y_qlik = charm_forward(sd, y, hyper, noise_y if is_train else None)
+    if diag is not None:
+        diag["margin"] = min(diag.get("margin", 1.0), rounding_margin(z - sd["entropy_model_z.quantiles"][:, 0, 1].reshape(1, -1, 1, 1)))
+    y_hat, y_lik, y_qlik = charm_forward(sd, y, hyper, noise_y if is_train else None, diag=diag, forced=fy, report=report)
     fake = decoder(sd, y_hat, q, beta)
     if not is_train:
         fake = fake.clamp(-1, 1)
     with torch.no_grad():
-        z_qlik = entropy_bottleneck(sd, "entropy_model_z", z, None)[1]
+        z_qlik = entropy_bottleneck(sd, "entropy_model_z", z, None, forced=fz)[1]
     npix = H * W
     bpp = (bits_per_image(y_lik) + bits_per_image(z_lik)) / npix
     qbpp = (bits_per_image(y_qlik) + bits_per_image(z_qlik)) / npix
@@ -396,17 +434,18 @@ STAGE3 = dict(lambda_a=(3.4, 1.3, 0.4, 0.12, 0.05), lambda_b=2 ** -6, target=(0.
 STAGE1 = dict(lambda_a=0.05, lambda_b=2 ** -6, target=1.5, w_mse=150.0, w_lpips=1.0)
 
 
-def stage3_g_losses(sd_g: SD, sd_d: SD, sd_lpips: SD, real, q: int, beta: float, noise_y, noise_z, hr_noise=None, cfg=STAGE3):
+def stage3_g_losses(sd_g: SD, sd_d: SD, sd_lpips: SD, real, q: int, beta: float, noise_y, noise_z, hr_noise=None, cfg=STAGE3,
+                    forced=None, hr_forced=None, report=None):
     """Generator phase of MultirateBetaCondHrrGanRateDistortionTrainer.optimize_parameters
     (multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:19-64). Returns (loss dict, generator outputs)."""
-    out = generator_forward(sd_g, real, float(q), beta, noise_y, noise_z)
+    out = generator_forward(sd_g, real, float(q), beta, noise_y, noise_z, forced=forced, report=report)
     fake = out["fake_images"]
     if q + 1 > cfg["rate_level"] - 1:
         rel = real
     else:
         with torch.no_grad():
             hn_y, hn_z = hr_noise if hr_noise is not None else (noise_y, noise_z)
-            rel = generator_forward(sd_g, real, float(q + 1), beta, hn_y, hn_z)["fake_images"]
+            rel = generator_forward(sd_g, real, float(q + 1), beta, hn_y, hn_z, forced=hr_forced, report=report)["fake_images"]
     losses = {
         "distortion": mse_loss(real, fake, cfg["w_mse"]),
         "rate": rate_loss(out["bpp"], out["qbpp"], cfg["lambda_a"][q], cfg["lambda_b"], cfg["target"][q]),
@@ -433,9 +472,9 @@ def stage3_d_losses(sd_d: SD, real, fake, q: int):
     return {"d_real": l_real, "d_fake": l_fake, "d_total": l_real + l_fake}
 
 
-def stage1_losses(sd_g: SD, sd_lpips: SD, real, noise_y, noise_z, cfg=STAGE1):
+def stage1_losses(sd_g: SD, sd_lpips: SD, real, noise_y, noise_z, cfg=STAGE1, forced=None, report=None):
     """RateDistortionTrainer.optimize_parameters loss assembly (rate_distortion_trainer.py:57-75)."""
-    out = generator_forward(sd_g, real, None, None, noise_y, noise_z)
+    out = generator_forward(sd_g, real, None, None, noise_y, noise_z, forced=forced, report=report)
     losses = {
         "distortion": mse_loss(real, out["fake_images"], cfg["w_mse"]),
         "rate": rate_loss(out["bpp"], out["qbpp"], cfg["lambda_a"], cfg["lambda_b"], cfg["target"]),
@@ -455,7 +494,8 @@ def get_scale_table(lo=0.11, hi=256.0, levels=64):
 
 
 def pmf_to_quantized_cdf(pmf: Sequence[float], precision: int = 16) -> List[int]:
-    cdf = [0] + [int(np.round(np.float32(p) * np.float32(1 << precision))) for p in pmf]
+    # C++ std::round: halves round away from zero (numpy's round would go to even)
+    cdf = [0] + [int(math.floor(float(np.float32(p) * np.float32(1 << precision)) + 0.5)) for p in pmf]
     total = sum(cdf)
     assert total > 0
     cdf = [((1 << precision) * c) // total for c in cdf]
@@ -542,7 +582,7 @@ def rans_encode(symbols, indexes, cdfs, cdf_sizes, offsets, precision=16, bypass
     ops = []
     for s, ci in zip(symbols, indexes):
         cdf = cdfs[ci]
-        mv = cdf_sizes[ci] - 2
+        mv = int(cdf_sizes[ci]) - 2
         v = int(s) - int(offsets[ci])
         raw = 0
         if v < 0:
@@ -605,7 +645,7 @@ class RansDecoder:
         maxb = (1 << bypass) - 1
         out = []
         for ci in indexes:
-            cdf, size = cdfs[ci], cdf_sizes[ci]
+            cdf, size = cdfs[ci], int(cdf_sizes[ci])
             mv = size - 2
             cum = self.x & ((1 << precision) - 1)
             s = 0

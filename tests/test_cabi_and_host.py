@@ -1,0 +1,208 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/crdr_hip.h declares; the
+host entropy coder (rANS + CDF quantiser) agrees byte-for-byte with the oracle's independent pure-python
+restatement, round-trips, and handles the edge cases (empty input, out-of-range "bypass" symbols, zero-frequency
+repair); registry / config / optimizer-builder host logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from crdr_amd.hip import lib as L
+    if not os.path.exists(L.LIB_PATH):
+        L.build()
+    return L.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from crdr_amd.hip import lib as L
+    header = open(os.path.join(ROOT, "include", "crdr_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(crdr_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    missing_binding = declared - set(L.SIGNATURES)
+    assert not missing_binding, f"declared in the header but not bound in lib.py: {missing_binding}"
+    raw = ctypes.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"libcrdr_hip.so does not export {name}"
+    assert lib.crdr_arch() == b"gfx950"
+    assert lib.crdr_version() >= 100
+
+
+def test_product_fails_loudly_on_cpu():
+    from crdr_amd.hip import lib as L, ops
+    with pytest.raises(L.CrdrHipError):
+        ops.nhwc(torch.zeros(1, 4, 2, 2))
+
+
+def _tables(rng, ncdf=5, maxlen=40):
+    from oracle import crdr_oracle as O
+    cdfs = np.zeros((ncdf, maxlen + 2), dtype=np.int32)
+    sizes, offs = np.zeros(ncdf, np.int32), np.zeros(ncdf, np.int32)
+    for i in range(ncdf):
+        n = int(rng.integers(3, maxlen))
+        pmf = rng.random(n).astype(np.float32) ** 3
+        pmf /= pmf.sum()
+        c = O.pmf_to_quantized_cdf(list(pmf) + [1e-4], 16)
+        cdfs[i, :len(c)] = c
+        sizes[i] = len(c)
+        offs[i] = -(n // 2)
+    return cdfs, sizes, offs
+
+
+def test_pmf_to_quantized_cdf_matches_oracle(lib):
+    from oracle import crdr_oracle as O
+    from crdr_amd.codec.tables import pmf_to_quantized_cdf
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        n = int(rng.integers(2, 300))
+        pmf = rng.random(n).astype(np.float32) ** rng.integers(1, 12)  # many (near-)zero entries -> repair loop
+        if trial % 5 == 0:
+            pmf[rng.integers(0, n, size=n // 2)] = 0.0
+        pmf[rng.integers(0, n)] += 1.0
+        pmf = (pmf / pmf.sum()).astype(np.float32)
+        got = pmf_to_quantized_cdf(pmf, 16)
+        ref = O.pmf_to_quantized_cdf(list(pmf), 16)
+        assert list(got) == ref
+        assert got[0] == 0 and got[-1] == 1 << 16 and np.all(np.diff(got) > 0)
+    with pytest.raises(Exception):
+        pmf_to_quantized_cdf(np.array([0.5, float("nan")], np.float32))
+
+
+def test_rans_roundtrip_and_oracle_bytes(lib):
+    from oracle import crdr_oracle as O
+    from crdr_amd.codec import rans
+    rng = np.random.default_rng(1)
+    cdfs, sizes, offs = _tables(rng)
+    for n in (0, 1, 7, 1000):
+        idx = rng.integers(0, len(sizes), size=n).astype(np.int32)
+        # symbols mostly inside the table, some far outside on both sides (bypass coding, multi-nibble escapes)
+        sym = np.array([int(rng.integers(offs[i] - 2, offs[i] + sizes[i])) for i in idx], dtype=np.int32)
+        if n >= 7:
+            sym[::5] += rng.integers(-70000, 70000, size=len(sym[::5])).astype(np.int32)
+        data = rans.encode_with_indexes(sym, idx, cdfs, sizes, offs)
+        assert len(data) % 4 == 0 and len(data) >= 8
+        ref = O.rans_encode(sym.tolist(), idx.tolist(), cdfs, sizes, offs)
+        assert data == ref, "C coder and oracle restatement disagree"
+        out = rans.decode_with_indexes(data, idx, cdfs, sizes, offs)
+        assert np.array_equal(out, sym)
+        assert O.RansDecoder(data).decode(idx.tolist(), cdfs, sizes, offs) == sym.tolist()
+        # streaming decode in 3 chunks == one-shot (the Charm decoder reads one slice at a time)
+        dec = rans.RansDecoder()
+        dec.set_stream(data)
+        parts = [dec.decode_stream(p, cdfs, sizes, offs) for p in np.array_split(idx, 3)]
+        assert np.array_equal(np.concatenate(parts), sym)
+    with pytest.raises(Exception):
+        rans.decode_with_indexes(b"\x00\x01\x02", np.zeros(1, np.int32), cdfs, sizes, offs)
+
+
+def test_gaussian_tables_match_oracle(lib):
+    from oracle import crdr_oracle as O
+    from crdr_amd.models.subnet.entropy_model.gaussian_conditional import GaussianMeanScaleConditional, get_scale_table
+    m = GaussianMeanScaleConditional(scale_bound=0.11)
+    m.update_scale_table(get_scale_table(), force=True)
+    table, length, offset = O.gaussian_cdf_tables()
+    assert np.array_equal(m._quantized_cdf.numpy(), table)
+    assert np.array_equal(m._cdf_length.numpy(), length) and np.array_equal(m._offset.numpy(), offset)
+    assert m._quantized_cdf.shape[0] == 64
+    s = torch.tensor([[0.01, 0.11, 0.12, 1.0, 255.0, 300.0]])
+    assert torch.equal(m.build_indexes(s), O.build_indexes(s))
+    # known answers: the smallest scale is the bound, index 0; anything above the table's top maps to the last entry
+    assert m.build_indexes(torch.tensor([0.05])).item() == 0 and m.build_indexes(torch.tensor([1e4])).item() == 63
+
+
+def test_entropy_bottleneck_tables_and_schema(lib):
+    from oracle import crdr_oracle as O
+    from crdr_amd.models.subnet.entropy_model.entropy_bottleneck import SteEntropyBottleneck
+    from tests.golden.seeded_weights import seeded_tensor
+    m = SteEntropyBottleneck(channels=12)
+    assert [k for k, _ in m.named_parameters()] == O.eb_param_names("")[:0] + [n[1:] for n in O.eb_param_names("")]
+    sd = m.state_dict()
+    ref = {}
+    for k, v in sd.items():
+        if torch.is_floating_point(v) and v.numel() > 0 and k != "target":
+            sd[k] = seeded_tensor("entropy_model_z." + k, v.shape)
+            ref["entropy_model_z." + k] = sd[k]
+    m.load_state_dict(sd)
+    assert m.update(force=True)
+    table, length, offset = O.eb_cdf_tables(ref)
+    assert np.array_equal(m._quantized_cdf.numpy(), table)
+    assert np.array_equal(m._cdf_length.numpy(), length) and np.array_equal(m._offset.numpy(), offset)
+    # compress / decompress of integers around the medians round-trips through the C coder
+    z = torch.round(torch.randn(2, 12, 3, 5) * 4) + m._get_medians().detach().reshape(1, -1, 1, 1)
+    strings = m.compress(z)
+    sym = m.decompress(strings, (3, 5))
+    assert torch.allclose(m.dequantize(sym), z)
+    assert m.packed_params().shape == (12, 58)
+
+
+def test_registry_and_builders():
+    from crdr_amd.utils.registry import Registry
+    r = Registry("x")
+
+    @r.register()
+    class Foo:
+        pass
+    assert r.get("Foo") is Foo and "Foo" in r and r.keys() == ["Foo"]
+    with pytest.raises(AssertionError):
+        r.register()(Foo)
+    with pytest.raises(KeyError):
+        r.get("Bar")
+    import crdr_amd.losses, crdr_amd.models, crdr_amd.trainer  # noqa: F401
+    from crdr_amd.utils import registry as R
+    assert {"HyperpriorCharmModel", "InterpCaHyperpriorCharmModel", "BetaCondInterpCaHyperpriorCharmModel"} <= set(R.MODEL_REGISTRY.keys())
+    assert {"ElicEncoder", "ElicInterpCaEncoder"} <= set(R.ENCODER_REGISTRY.keys())
+    assert {"ElicDecoder", "ElicInterpCaDecoder", "ElicInterpCaBetaCondDecoder"} <= set(R.DECODER_REGISTRY.keys())
+    assert {"RateDistortionTrainer", "MultirateBetaCondHrrGanRateDistortionTrainer"} <= set(R.TRAINER_REGISTRY.keys())
+    assert {"MSELoss", "HificRateLoss", "HificVariableRateLoss", "LPIPSLoss", "VanillaGANLoss"} <= set(R.LOSS_REGISTRY.keys())
+    assert {"ModuleListDiscriminator", "CLIC21GVAEDiscriminator"} <= set(R.DISCRIMINATOR_REGISTRY.keys())
+    assert "Adam" in R.OPTIMIZER_REGISTRY and "MultiStepLR" in R.SCHEDULER_REGISTRY
+
+
+def test_train_config_cli_overlay(tmp_path, monkeypatch):
+    from crdr_amd.utils.options import ConfigDict, TrainConfig
+    monkeypatch.chdir(ROOT)
+    os.makedirs(tmp_path / "ck", exist_ok=True)
+    cfgdir = tmp_path / "cfg"
+    os.makedirs(cfgdir)
+    (cfgdir / "base.yaml").write_text("ckpt_root: %s\na: {x: 1, y: 2}\ndataset: {batch_size: 8}\n" % (tmp_path / "ck"))
+    (cfgdir / "exp7.yaml").write_text("_base_: ./base.yaml\na: {y: 3}\nb: {_delete_: true, k: 1}\n")
+    opt = TrainConfig.get_opt(argv=[str(cfgdir / "exp7.yaml"), "-b", "16", "-d", "cuda:3", "-ti", "100"])
+    assert opt.exp == "exp7" and opt.device == "cuda:3" and opt.total_iter == 100
+    assert opt.dataset.batch_size == 16 and opt.a.x == 1 and opt.a.y == 3 and opt.is_train
+    assert opt.path.model_dir.endswith(os.path.join("exp7", "model"))
+    with pytest.raises(AttributeError):
+        opt.nope
+    assert opt.get("nope", 5) == 5
+    c = ConfigDict({"p": {"q": [1, {"r": 2}]}})
+    assert c.p.q[1].r == 2 and c.to_dict() == {"p": {"q": [1, {"r": 2}]}}
+    opt.dump(str(tmp_path / "dump.yaml"))
+    assert "total_iter: 100" in open(tmp_path / "dump.yaml").read()
+
+
+def test_multistep_lr_and_rate_loss_host_logic():
+    from crdr_amd.losses.rate_loss import HificRateLoss, HificVariableRateLoss
+    from crdr_amd.trainer.optimizer.build_optimizer_scheduler import MultiStepLR
+
+    class FakeOpt:
+        param_groups = [{"lr": 1e-4}]
+    s = MultiStepLR(FakeOpt(), milestones=[3], gamma=0.1)
+    lrs = []
+    for _ in range(4):
+        s.step()
+        lrs.append(FakeOpt.param_groups[0]["lr"])
+    assert lrs[:2] == [1e-4, 1e-4] and abs(lrs[2] - 1e-5) < 1e-12 and abs(lrs[3] - 1e-5) < 1e-12
+    bpp, qbpp = torch.tensor([0.31, 0.52]), torch.tensor([0.29, 0.49])
+    vr = HificVariableRateLoss(lambda_A=[3.6, 1.8, 0.8, 0.4, 0.1], lambda_B=0.015625, target_rate=[0.08, 0.16, 0.36, 0.72, 1.2])
+    assert abs(vr(bpp, qbpp=qbpp, current_iter=1, rate_ind=torch.tensor([2])).item() - 0.8 * 0.415) < 1e-6
+    assert abs(vr(bpp, qbpp=qbpp, current_iter=1, rate_ind=3).item() - 0.015625 * 0.415) < 1e-7
+    assert abs(HificRateLoss(0.05, 0.015625, 1.5)(bpp, qbpp=qbpp, current_iter=1).item() - 0.015625 * 0.415) < 1e-7
+    with pytest.raises(AssertionError):
+        HificVariableRateLoss(lambda_A=[1.0, 2.0], lambda_B=0.1, target_rate=[0.1, 0.2])

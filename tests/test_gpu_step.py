@@ -87,15 +87,6 @@ def test_stage3_step():
     nz = seeded_input("noise.z", (2, 192, 1, 1), 0.5)
     q, beta = 2, 2.56
 
-    g_ref, d_ref = grad_sd(sd_g), grad_sd(sd_d)
-    losses, out = O.stage3_g_losses(g_ref, d_ref, sd_l, x, q, beta, ny, nz)
-    losses["total"].backward()
-    d_ref = grad_sd(sd_d)
-    d_losses = O.stage3_d_losses(d_ref, x, out["fake_images"], q)
-    d_losses["d_total"].backward()
-    aux_ref = grad_sd(sd_g)
-    O.eb_aux_loss(aux_ref, "entropy_model_z").backward()
-
     captured = {}
     g_step, d_step, a_step = tr.g_optimizer.step, tr.d_optimizer.step, tr.aux_optimizer.step
 
@@ -111,8 +102,33 @@ def test_stage3_step():
 
     data = {"real_images": x.to(dev()), "rate_ind": torch.tensor([q]), "beta": beta,
             "noise": {"y": ny.to(dev()), "z": nz.to(dev())}}
+    tr.check_loss_nan_inf = lambda l: False  # seeded random weights give a loss > 1e4, which the trainer would skip
+    tr.comp_model.context_model.record_symbols = []
+    z_hats = []
+    run_model = tr.comp_model.run_model
+
+    def spy(*a, **k):
+        o = run_model(*a, **k)
+        z_hats.append(o["z_hat"].detach().cpu())
+        return o
+    tr.comp_model.run_model = spy
     log = tr.optimize_parameters(1, data)
     assert log is not None
+    syms = [t.cpu() for t in tr.comp_model.context_model.record_symbols]
+    assert len(syms) == 20 and len(z_hats) == 2
+    med = sd_g["entropy_model_z.quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
+    forced = {"y": syms[:10], "z": torch.round(z_hats[0] - med)}
+    hr_forced = {"y": syms[10:], "z": torch.round(z_hats[1] - med)}
+    g_ref, d_ref, rep = grad_sd(sd_g), grad_sd(sd_d), {}
+    losses, out = O.stage3_g_losses(g_ref, d_ref, sd_l, x, q, beta, ny, nz, forced=forced, hr_forced=hr_forced, report=rep)
+    assert rep.get("mismatch", 0) == 0, rep
+    losses["total"].backward()
+    d_ref = grad_sd(sd_g), grad_sd(sd_d)
+    d_ref = d_ref[1]
+    d_losses = O.stage3_d_losses(d_ref, x, out["fake_images"], q)
+    d_losses["d_total"].backward()
+    aux_ref = grad_sd(sd_g)
+    O.eb_aux_loss(aux_ref, "entropy_model_z").backward()
     for k in ("distortion", "rate", "perceptual", "adv"):
         close(log[k], losses[k], f"loss {k}", 3e-4)
     for k in ("d_real", "d_fake"):
@@ -150,17 +166,30 @@ def test_stage1_step():
     x = seeded_input("image", (2, 3, 64, 64))
     ny = seeded_input("noise.y", (2, 320, 4, 4), 0.5)
     nz = seeded_input("noise.z", (2, 192, 1, 1), 0.5)
-    g_ref = grad_sd(sd_g)
-    losses, out = O.stage1_losses(g_ref, sd_l, x, ny, nz)
-    losses["total"].backward()
     captured = {}
     g_step = tr.g_optimizer.step
+    tr.check_loss_nan_inf = lambda l: False
+    tr.comp_model.context_model.record_symbols = []
+    z_hats = []
+    run_model = tr.comp_model.run_model
+
+    def spy(*a, **k):
+        o = run_model(*a, **k)
+        z_hats.append(o["z_hat"].detach().cpu())
+        return o
+    tr.comp_model.run_model = spy
 
     def wrapped(*a, **k):
         captured.update({n: (p.grad.clone() if p.grad is not None else None) for n, p in tr.comp_model.named_parameters()})
         return g_step(*a, **k)
     tr.g_optimizer.step = wrapped
     log = tr.optimize_parameters(1, {"real_images": x.to(dev()), "noise": {"y": ny.to(dev()), "z": nz.to(dev())}})
+    med = sd_g["entropy_model_z.quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
+    forced = {"y": [t.cpu() for t in tr.comp_model.context_model.record_symbols], "z": torch.round(z_hats[0] - med)}
+    g_ref, rep = grad_sd(sd_g), {}
+    losses, out = O.stage1_losses(g_ref, sd_l, x, ny, nz, forced=forced, report=rep)
+    assert rep.get("mismatch", 0) == 0, rep
+    losses["total"].backward()
     for k in ("distortion", "rate", "perceptual"):
         close(log[k], losses[k], f"loss {k}", 3e-4)
     bad = []
