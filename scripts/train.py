@@ -1,0 +1,41 @@
+"""Training entry point, argument compatible with the reference's scripts/train.py:16-27:
+
+    python scripts/train.py config/crdr_stage_3.yaml -d cuda:0 -b 16 [-si N -e N -l N -s N -ti N --debug]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train.py config/crdr_stage_3.yaml -b 16
+
+Under torchrun every rank trains a full replica on its own GPU (data parallel, RCCL all-reduce of the flat
+gradient buffers); rank 0 writes config.yaml, logs and checkpoints."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from crdr_amd.trainer import build_trainer  # noqa: E402
+from crdr_amd.trainer import dist as D  # noqa: E402
+from crdr_amd.utils.logger import bolded_log, get_root_logger  # noqa: E402
+from crdr_amd.utils.misc import dict2str  # noqa: E402
+from crdr_amd.utils.options import TrainConfig  # noqa: E402
+from crdr_amd.utils.path import PathHandler  # noqa: E402
+
+
+def main():
+    local = D.init_from_env()
+    opt = TrainConfig.get_opt(config_dir="./config")
+    if D.world_size() > 1:
+        opt.device = f"cuda:{local}"
+    if D.rank() == 0:
+        ph = PathHandler(opt.ckpt_root, opt.exp)
+        ph.make_job_dir()
+        opt.dump(filename=os.path.join(ph.job_dir, "config.yaml"))
+        logger = get_root_logger(log_level="DEBUG" if opt.get("debug") else "INFO", log_file=opt.path.log_msg_path)
+        bolded_log("Config", level="DEBUG")
+        logger.debug(dict2str(opt._cfg_dict.to_dict()))
+    if str(opt.device).startswith("cuda"):
+        import torch
+        torch.cuda.set_device(int(str(opt.device).split(":")[1]) if ":" in str(opt.device) else 0)
+    trainer = build_trainer(opt)
+    trainer.train_loop()
+
+
+if __name__ == "__main__":
+    main()
