@@ -19,7 +19,7 @@ struct EbwdArgs {
   int rows_per_block;
 };
 
-// block = 64 (channels) x 4 (rows); a block owns rows [b*rpb, (b+1)*rpb)
+// Generic (any C, any ld) path: block = 64 (channels) x 4 (rows); grid (strips, 1).
 __global__ __launch_bounds__(256) void ebwd_kernel(const EbwdArgs p) {
   __shared__ float red[4][4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -69,19 +69,88 @@ __global__ __launch_bounds__(256) void ebwd_kernel(const EbwdArgs p) {
   }
 }
 
-// out[k][c] = sum_b partial[b][k][c]   (K sums per block)
-__global__ __launch_bounds__(256) void colsum_final(const float* partial, int nblocks, int K, int C, float* out,
-                                                    int accumulate) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= K * C) return;
-  float v = 0.f;
-  for (int b = 0; b < nblocks; ++b) v += partial[(size_t)b * K * C + e];
-  out[e] = accumulate ? out[e] + v : v;
+// Vector path (C % 4 == 0, all strides % 4 == 0): 16 B per lane.  block = 16 channel-quads (64 channels) x 16 rows;
+// grid (strips, ceil(C/64)).  Each thread keeps 4 sums x 4 channels; rows are reduced through LDS in fixed order.
+__global__ __launch_bounds__(256) void ebwd_kernel_v4(const EbwdArgs p) {
+  __shared__ f32x4 red[4][16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int f = p.d.flags, C = p.d.C;
+  const int c = blockIdx.y * 64 + tx * 4;
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+  const int64_t r1 = r0 + p.rows_per_block < p.d.M ? r0 + p.rows_per_block : p.d.M;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+  f32x4 s0 = zero, s1 = zero, s2 = zero, s3 = zero;
+  if (c < C) {
+    const f32x4 sc = (f & CRDR_EPI_AFFINE) ? *reinterpret_cast<const f32x4*>(p.io.scale + c) : one;
+    const f32x4 sh = (f & CRDR_EPI_AFFINE) ? *reinterpret_cast<const f32x4*>(p.io.shift + c) : zero;
+    const f32x4 v2 = (f & CRDR_EPI_VEC2) ? *reinterpret_cast<const f32x4*>(p.io.vec2 + c) : zero;
+    const bool need_out = f & (CRDR_EPI_AFFINE | CRDR_EPI_RELU | CRDR_EPI_LRELU);
+#pragma unroll 2
+    for (int64_t m = r0 + ty; m < r1; m += 16) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(p.io.dout + m * p.d.lddout + c);
+      f32x4 o = need_out ? *reinterpret_cast<const f32x4*>(p.io.out + m * p.d.ldout + c) : zero;
+      if (f & CRDR_EPI_AFFINE) {
+        const f32x4 u = (o - sh) / sc;
+        s2 += g * u;
+        s3 += g;
+        g *= sc;
+        o = u;
+      }
+      if (f & CRDR_EPI_GATE) {
+        const f32x4 sg = *reinterpret_cast<const f32x4*>(p.io.sig + m * p.d.ldg + c);
+        const f32x4 tr = *reinterpret_cast<const f32x4*>(p.io.gt + m * p.d.ldg + c);
+        *reinterpret_cast<f32x4*>(p.io.gres + m * p.d.ldgres + c) = g;
+        *reinterpret_cast<f32x4*>(p.io.dgt + m * p.d.ldg + c) = g * sg;
+        g = g * tr * sg * (one - sg);
+      } else if ((f & CRDR_EPI_AFFINE) && (f & CRDR_EPI_RES)) {
+        *reinterpret_cast<f32x4*>(p.io.gres + m * p.d.ldgres + c) = g;
+      }
+      if (f & CRDR_EPI_VEC2) s1 += g;
+      if (f & CRDR_EPI_RELU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = (o[k] - v2[k]) > 0.f ? g[k] : 0.f;
+      }
+      if (f & CRDR_EPI_LRELU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = o[k] > 0.f ? g[k] : 0.2f * g[k];
+      }
+      if (p.io.dz) *reinterpret_cast<f32x4*>(p.io.dz + m * p.d.lddz + c) = g;
+      s0 += g;
+    }
+  }
+  red[0][ty][tx] = s0; red[1][ty][tx] = s1; red[2][ty][tx] = s2; red[3][ty][tx] = s3;
+  __syncthreads();
+  if (threadIdx.x < 64) {  // thread -> (sum k = tid >> 4, channel quad tx)
+    const int k = threadIdx.x >> 4;
+    f32x4 a = red[k][0][tx];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) a += red[k][r][tx];
+    if (c < C) *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.x * 4 + k) * C + c) = a;
+  }
 }
 
+// out[e] (+)= sum_b partial[b][e], e over K*C columns; 64 columns x 4 block-groups per workgroup, fixed order
+__global__ __launch_bounds__(256) void colsum_final(const float* partial, int nblocks, int K, int C, float* out,
+                                                    int accumulate) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + tx;
+  const int KC = K * C;
+  float v = 0.f;
+  if (e < KC)
+    for (int b = ty; b < nblocks; b += 4) v += partial[(size_t)b * KC + e];
+  red[ty][tx] = v;
+  __syncthreads();
+  if (ty == 0 && e < KC) {
+    const float t = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    out[e] = accumulate ? out[e] + t : t;
+  }
+}
+
+// rows per strip: large enough that the second stage sums <= 512 partials per column
 static int ebwd_blocks(int64_t M, int* rpb) {
-  int r = 128;
-  while (cdiv64(M, r) > 4096) r *= 2;
+  int r = 64;
+  while (cdiv64(M, r) > 512) r *= 2;
   *rpb = r;
   return (int)cdiv64(M, r);
 }
@@ -114,6 +183,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, in
     __syncthreads();
     if (ty == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
     __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel_v4(const float* x, int ldx, int64_t M, int C, float* partial,
+                                                        int rows_per_block) {
+  __shared__ f32x4 red[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.y * 64 + tx * 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (int64_t m = r0 + ty; m < r1; m += 16) s += *reinterpret_cast<const f32x4*>(x + m * ldx + c);
+  red[ty][tx] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && c < C) {
+    f32x4 a = red[0][tx];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) a += red[r][tx];
+    *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * C + c) = a;
   }
 }
 
@@ -397,11 +486,17 @@ extern "C" int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io
   const int nb = ebwd_blocks(d->M, &a.rows_per_block);
   CRDR_REQUIRE(ws_bytes >= (size_t)nb * 4 * d->C * sizeof(float), "epilogue_bwd: workspace too small");
   a.partial = (float*)ws;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool vec = (d->C % 4 == 0) && (d->lddout % 4 == 0) && (d->ldout % 4 == 0) && (d->lddz % 4 == 0) &&
+                   (d->ldgres % 4 == 0) && (d->ldg % 4 == 0) && al16(io->dout) && al16(io->out) && al16(io->dz) &&
+                   al16(io->gres) && al16(io->dgt) && al16(io->gt) && al16(io->sig) && al16(io->vec2) &&
+                   al16(io->scale) && al16(io->shift);
   if (d->M > 0) {
-    hipLaunchKernelGGL(ebwd_kernel, dim3(nb), dim3(256), 0, as_stream(s), a);
+    if (vec) hipLaunchKernelGGL(ebwd_kernel_v4, dim3(nb, cdiv(d->C, 64)), dim3(256), 0, as_stream(s), a);
+    else hipLaunchKernelGGL(ebwd_kernel, dim3(nb), dim3(256), 0, as_stream(s), a);
     CRDR_CHECK_LAUNCH("ebwd_kernel");
   }
-  hipLaunchKernelGGL(colsum_final, dim3(cdiv(4 * d->C, 256)), dim3(256), 0, as_stream(s), (const float*)ws,
+  hipLaunchKernelGGL(colsum_final, dim3(cdiv(4 * d->C, 64)), dim3(256), 0, as_stream(s), (const float*)ws,
                      d->M > 0 ? nb : 0, 4, d->C, io->colsums, 0);
   CRDR_CHECK_LAUNCH("colsum_final");
   return 0;
@@ -426,10 +521,13 @@ extern "C" int crdr_colsum(const float* x, int ldx, int64_t M, int C, float* out
   const int nb = ebwd_blocks(M, &rpb);
   CRDR_REQUIRE(x && out && ws_bytes >= (size_t)nb * C * sizeof(float), "colsum: bad arguments");
   if (M > 0) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, as_stream(s), x, ldx, M, C, (float*)ws, rpb);
+    if ((C % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0))
+      hipLaunchKernelGGL(colsum_kernel_v4, dim3(nb, cdiv(C, 64)), dim3(256), 0, as_stream(s), x, ldx, M, C, (float*)ws, rpb);
+    else
+      hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, as_stream(s), x, ldx, M, C, (float*)ws, rpb);
     CRDR_CHECK_LAUNCH("colsum");
   }
-  hipLaunchKernelGGL(colsum_final, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(s), (const float*)ws, M > 0 ? nb : 0, 1,
+  hipLaunchKernelGGL(colsum_final, dim3(cdiv(C, 64)), dim3(256), 0, as_stream(s), (const float*)ws, M > 0 ? nb : 0, 1,
                      C, out, accumulate);
   CRDR_CHECK_LAUNCH("colsum_final");
   return 0;

@@ -72,11 +72,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p) 
   constexpr int BM = 32 * WM * MB, BN = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;  // float4 per thread per K-tile
   static_assert(AV * NT == BM * 8 && BV * NT == BN * 8, "tile/threads mismatch");
+  static_assert(AV <= 16 && BV <= 16, "mask bits");
   constexpr int ROWS_PER_PASS = NT / 8;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                // [2][BM*32]
-  float* sB = smem + 2 * BM * 32;  // [2][BN*32]
+  float* sA = smem;                                        // [2][BM*32]
+  float* sB = smem + 2 * BM * 32;                          // [2][BN*32]
+  int* sTap = reinterpret_cast<int*>(smem + 2 * (BM + BN) * 32);  // [<=128] packed (dh, dw, widx) of this phase
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -86,63 +88,75 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p) 
   const int KT = (te - tb) * p.kchunks;
   const int it0 = (int)((long long)KT * split / p.nsplit), it1 = (int)((long long)KT * (split + 1) / p.nsplit);
   const int poh = p.poh[phase], pow_ = p.pow[phase];
+  const int H = p.H, W = p.W, ldx = p.ldx, Cin = p.Cin, kchunks = p.kchunks;
+
+  for (int t = tid; t < te - tb; t += NT)
+    sTap[t] = (p.dh[tb + t] & 0xff) | ((p.dw[tb + t] & 0xff) << 8) | ((int)p.widx[tb + t] << 16);
 
   // ---- staging assignment: thread owns chunk (tid&7) of rows (tid>>3) + j*ROWS_PER_PASS
   const int chunk = tid & 7, srow = tid >> 3;
-  int a_pix[AV], a_ih[AV], a_iw[AV];  // base pixel index n*H*W (or -1), base coords
+  int a_pix[AV], a_ih[AV], a_iw[AV];
+  unsigned a_ok = 0;  // bit j: row j of this thread is a real output position
 #pragma unroll
   for (int j = 0; j < AV; ++j) {
     const int m = m0 + srow + j * ROWS_PER_PASS;
     const int hw = p.GH * p.GW;
     const int n = m / hw, rem = m - n * hw, a = rem / p.GW, b = rem - a * p.GW;
     const bool ok = (m < p.M) && (a * p.so + poh < p.OH) && (b * p.so + pow_ < p.OW);
-    a_pix[j] = ok ? n * p.H * p.W : -1;
-    a_ih[j] = a * p.si;
-    a_iw[j] = b * p.si;
+    a_ok |= (ok ? 1u : 0u) << j;
+    a_pix[j] = ok ? n * H * W : 0;
+    a_ih[j] = ok ? a * p.si : 0;
+    a_iw[j] = ok ? b * p.si : 0;
   }
   const float* b_ptr[BV];
-  bool b_ok[BV];
+  unsigned b_okm = 0;
 #pragma unroll
   for (int j = 0; j < BV; ++j) {
     const int oc = n0 + srow + j * ROWS_PER_PASS;
-    b_ok[j] = oc < p.wrows;
-    b_ptr[j] = p.w + (size_t)(b_ok[j] ? oc : 0) * p.wcols + chunk * 4;
+    const bool ok = oc < p.wrows;
+    b_okm |= (ok ? 1u : 0u) << j;
+    b_ptr[j] = p.w + (size_t)(ok ? oc : 0) * p.wcols + chunk * 4;
   }
+  __syncthreads();  // sTap visible
 
+  // K-iteration cursor of the NEXT tile to load: tap index (relative to tb) and channel chunk
+  int lt = it0 / kchunks, lc = it0 - lt * kchunks;
   f32x4 ra[AV], rb[BV];
-  auto load_tile = [&](int it) {
-    const int t = tb + it / p.kchunks;
-    const int c0 = (it % p.kchunks) * 32 + chunk * 4;
-    const int dh = p.dh[t], dw = p.dw[t];
-    const size_t woff = (size_t)p.widx[t] * p.wrows * p.wcols + (size_t)(c0 - chunk * 4);
-    const bool cok = c0 < p.Cin;
+  unsigned ra_mask = 0;
+  auto load_tile = [&]() {
+    const int tp = __builtin_amdgcn_readfirstlane(sTap[lt]);
+    const int dh = (int)(signed char)(tp & 0xff), dw = (int)(signed char)((tp >> 8) & 0xff), wi = tp >> 16;
+    const int c0 = lc * 32 + chunk * 4;
+    const bool cok = c0 < Cin;
+    const int c0c = cok ? c0 : 0;
+    const size_t woff = (size_t)wi * p.wrows * p.wcols + (size_t)(lc * 32);
+    unsigned mask = 0;
 #pragma unroll
     for (int j = 0; j < AV; ++j) {
       const int ih = a_ih[j] + dh, iw = a_iw[j] + dw;
-      const bool ok = cok && (a_pix[j] >= 0) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_pix[j] + ih * p.W + iw) * p.ldx + c0);
-      ra[j] = v;
+      const bool ok = cok && ((a_ok >> j) & 1u) && ((unsigned)ih < (unsigned)H) && ((unsigned)iw < (unsigned)W);
+      mask |= (ok ? 1u : 0u) << j;
+      const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);  // always a legal address; masked at store
+      ra[j] = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_pix[j] + ihc * W + iwc) * ldx + c0c);
     }
 #pragma unroll
-    for (int j = 0; j < BV; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ok[j]) v = *reinterpret_cast<const f32x4*>(b_ptr[j] + woff);
-      rb[j] = v;
-    }
+    for (int j = 0; j < BV; ++j) rb[j] = *reinterpret_cast<const f32x4*>(b_ptr[j] + woff);
+    ra_mask = mask;
+    if (++lc == kchunks) { lc = 0; ++lt; }
   };
   auto store_tile = [&](int buf) {
     float* a = sA + buf * BM * 32;
     float* b = sB + buf * BN * 32;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < AV; ++j) {
       const int r = srow + j * ROWS_PER_PASS;
-      *reinterpret_cast<f32x4*>(a + lds_off(r, chunk)) = ra[j];
+      *reinterpret_cast<f32x4*>(a + lds_off(r, chunk)) = ((ra_mask >> j) & 1u) ? ra[j] : zero;
     }
 #pragma unroll
     for (int j = 0; j < BV; ++j) {
       const int r = srow + j * ROWS_PER_PASS;
-      *reinterpret_cast<f32x4*>(b + lds_off(r, chunk)) = rb[j];
+      *reinterpret_cast<f32x4*>(b + lds_off(r, chunk)) = ((b_okm >> j) & 1u) ? rb[j] : zero;
     }
   };
 
@@ -156,13 +170,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p) 
 
   const int frow = lane & 31, fh = lane >> 5;
   if (it0 < it1) {
-    load_tile(it0);
+    load_tile();
     store_tile(0);
   }
   __syncthreads();
   for (int it = it0; it < it1; ++it) {
     const int buf = (it - it0) & 1;
-    if (it + 1 < it1) load_tile(it + 1);
+    if (it + 1 < it1) load_tile();
     const float* a = sA + buf * BM * 32 + (wm * MB * 32) * 32;
     const float* b = sB + buf * BN * 32 + (wn * NB * 32) * 32;
 #pragma unroll
@@ -185,7 +199,20 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p) 
   }
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int f = p.flags;
   const int hw = p.GH * p.GW;
+  const bool direct = (p.nphase == 1) && (p.so == 1);  // output pixel index == GEMM row
+  int oc_[NB];
+  float bias_[NB], vec2_[NB], scale_[NB], shift_[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    oc_[j] = n0 + (wn * NB + j) * 32 + frow;
+    const bool v = oc_[j] < p.Cout;
+    bias_[j] = (v && (f & CRDR_EPI_BIAS)) ? p.bias[oc_[j]] : 0.f;
+    vec2_[j] = (v && (f & CRDR_EPI_VEC2)) ? p.vec2[oc_[j]] : 0.f;
+    scale_[j] = (v && (f & CRDR_EPI_AFFINE)) ? p.scale[oc_[j]] : 1.f;
+    shift_[j] = (v && (f & CRDR_EPI_AFFINE)) ? p.shift[oc_[j]] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
 #pragma unroll
@@ -199,14 +226,31 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p) 
         for (int j = 0; j < NB; ++j) dst[j * 32] = acc[i][j][r];
         continue;
       }
-      const int n = m / hw, rem = m - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
-      const int oh = ga * p.so + poh, ow = gb * p.so + pow_;
-      if (oh >= p.OH || ow >= p.OW) continue;
-      const size_t opix = ((size_t)n * p.OH + oh) * p.OW + ow;
+      size_t opix = (size_t)m;
+      if (!direct) {
+        const int n = m / hw, rem = m - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
+        const int oh = ga * p.so + poh, ow = gb * p.so + pow_;
+        if (oh >= p.OH || ow >= p.OW) continue;
+        opix = ((size_t)n * p.OH + oh) * p.OW + ow;
+      }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int oc = n0 + (wn * NB + j) * 32 + frow;
-        if (oc < p.Cout) epilogue_store(p, opix, oc, acc[i][j][r]);
+        if (oc_[j] >= p.Cout) continue;
+        const int oc = oc_[j];
+        float v = acc[i][j][r] + bias_[j];
+        if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
+        if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
+        v += vec2_[j];
+        if (f & CRDR_EPI_RES) v += p.res[opix * p.ldres + oc];
+        if (f & CRDR_EPI_GATE) {
+          const float sgm = 1.0f / (1.0f + expf(-v));
+          p.sig[opix * p.ldg + oc] = sgm;
+          v = p.gx[opix * p.ldg + oc] + p.gt[opix * p.ldg + oc] * sgm;
+        }
+        v = v * scale_[j] + shift_[j];
+        float* dst = p.y + opix * p.ldy + oc;
+        if (f & CRDR_EPI_ACCUM) v += *dst;
+        *dst = v;
       }
     }
   }
@@ -338,7 +382,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
   a.nsplit = bs;
   pl->grid = dim3(cdiv(a.M, BM), cdiv(d->OC, BN), a.nphase * bs);
   a.ws_ld = pl->grid.y * BN;
-  pl->lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+  pl->lds = (size_t)2 * (BM + BN) * 32 * sizeof(float) + 128 * sizeof(int);
   pl->ws_bytes = bs > 1 ? (size_t)a.nphase * bs * a.M * a.ws_ld * sizeof(float) : 0;
   return 0;
 }

@@ -63,45 +63,50 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
   const int t0 = (int)((long long)p.ntiles * split / p.nsplit), t1 = (int)((long long)p.ntiles * (split + 1) / p.nsplit);
 
   f32x4 rp[PV], rq[QV];
+  unsigned pmask = 0, qmask = 0;
+  const int Mlast = p.M - 1;
   auto load_tile = [&](int t) {
     const int mbase = t * 32;
+    unsigned pm = 0, qm = 0;
 #pragma unroll
     for (int k = 0; k < PV; ++k) {
       const int e = tid + k * NT;
       const int prow = e / (BI / 4), ch = e % (BI / 4);
       const int m = mbase + prow, c = i0 + ch * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (e < 8 * BI && m < p.M && c < p.PC) v = *reinterpret_cast<const f32x4*>(p.p + (size_t)m * p.ldp + c);
-      rp[k] = v;
+      const bool ok = (e < 8 * BI) && (m < p.M) && (c < p.PC);
+      pm |= (ok ? 1u : 0u) << k;
+      rp[k] = *reinterpret_cast<const f32x4*>(p.p + (size_t)min(m, Mlast) * p.ldp + (c < p.PC ? c : 0));
     }
 #pragma unroll
     for (int k = 0; k < QV; ++k) {
       const int e = tid + k * NT;
       const int prow = e / (BJ / 4), ch = e % (BJ / 4);
-      const int m = mbase + prow, c = j0 + ch * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (e < 8 * BJ && m < p.M && c < p.QC) {
-        const unsigned n = fdiv((unsigned)m, p.d_hw), rem = m - n * p.d_hw.d;
-        const unsigned a = fdiv(rem, p.d_w), b = rem - a * p.d_w.d;
-        const int ih = (int)a * p.stride + dh, iw = (int)b * p.stride + dw;
-        if ((unsigned)ih < (unsigned)p.QH && (unsigned)iw < (unsigned)p.QW)
-          v = *reinterpret_cast<const f32x4*>(p.q + ((size_t)(n * p.QH + ih) * p.QW + iw) * p.ldq + c);
-      }
-      rq[k] = v;
+      const int m = min(mbase + prow, Mlast), c = j0 + ch * 4;
+      const unsigned n = fdiv((unsigned)m, p.d_hw), rem = m - n * p.d_hw.d;
+      const unsigned a = fdiv(rem, p.d_w), b = rem - a * p.d_w.d;
+      const int ih = (int)a * p.stride + dh, iw = (int)b * p.stride + dw;
+      const bool ok = (e < 8 * BJ) && (mbase + prow < p.M) && (c < p.QC) && ((unsigned)ih < (unsigned)p.QH) &&
+                      ((unsigned)iw < (unsigned)p.QW);
+      qm |= (ok ? 1u : 0u) << k;
+      const int ihc = min(max(ih, 0), p.QH - 1), iwc = min(max(iw, 0), p.QW - 1);
+      rq[k] = *reinterpret_cast<const f32x4*>(p.q + ((size_t)(n * p.QH + ihc) * p.QW + iwc) * p.ldq + (c < p.QC ? c : 0));
     }
+    pmask = pm;
+    qmask = qm;
   };
   auto store_tile = [&](int buf) {
     float* a = sP + buf * 32 * BI;
     float* b = sQ + buf * 32 * BJ;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < PV; ++k) {
       const int e = tid + k * NT;
-      if (e < 8 * BI) *reinterpret_cast<f32x4*>(a + e * 4) = rp[k];  // [prow][ch*4] is exactly e*4
+      if (e < 8 * BI) *reinterpret_cast<f32x4*>(a + e * 4) = ((pmask >> k) & 1u) ? rp[k] : zero;  // [prow][ch*4] == e*4
     }
 #pragma unroll
     for (int k = 0; k < QV; ++k) {
       const int e = tid + k * NT;
-      if (e < 8 * BJ) *reinterpret_cast<f32x4*>(b + e * 4) = rq[k];
+      if (e < 8 * BJ) *reinterpret_cast<f32x4*>(b + e * 4) = ((qmask >> k) & 1u) ? rq[k] : zero;
     }
   };
 

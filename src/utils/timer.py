@@ -1,0 +1,3 @@
+from crdr_amd.utils.timer import *  # noqa: F401,F403
+from crdr_amd.utils import timer as _m
+globals().update({k: getattr(_m, k) for k in dir(_m) if not k.startswith('__')})
