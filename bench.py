@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shape-table", default=None, help="write per-shape conv timing of the timed region to this file")
+    ap.add_argument("--no-autotune", action="store_true", help="use the library's built-in tile heuristic instead of timing candidates once per shape")
+    ap.add_argument("--tune-log", default=None)
     a = ap.parse_args()
 
     import torch
@@ -100,6 +103,7 @@ def main():
     torch.cuda.set_device(local)
     tr = build_trainer(a.stage, a.bs, a.size, device)
     loader = iter(tr.train_loader)
+    ops.AUTOTUNE = not a.no_autotune  # the reference runs with cudnn.benchmark = True (base_trainer.py:20)
 
     def barrier():
         if ws > 1:
@@ -139,6 +143,19 @@ def main():
                 "avg_gflop_per_launch": round(fl / len(rec) / 1e9, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                 "ms_per_step": round(ms / a.steps, 2)}
     ig, wg = fam("igemm"), fam("wgrad")
+    if a.tune_log:
+        with open(a.tune_log, "w") as f:
+            for key, best, t0, t1 in ops.TUNE_LOG:
+                f.write(f"{t0 * 1e3:9.1f}us -> {t1 * 1e3:9.1f}us  algo cfg={(best & 0xff) - 1} split={1 << (best >> 8)}  {key}\n")
+    if a.shape_table:
+        agg = {}
+        for kind, rec in prof.items():
+            for fl, e0, e1, label in rec:
+                t = agg.setdefault((kind, label), [0, 0.0, 0.0])
+                t[0] += 1; t[1] += e0.elapsed_time(e1); t[2] += fl
+        with open(a.shape_table, "w") as f:
+            for (kind, label), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{ms / a.steps:8.3f} ms/step  {cnt / a.steps:6.1f} calls/step  {fl / (ms * 1e-3) / 1e12:6.1f} TF  {kind:5s} {label}\n")
     roof = {"bound": "mfma", "achieved": ig["tflops"] if ig else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None, "traffic": None,
             "kernel": "igemm_kernel<*> (conv / convT forward + input-gradient launches, v_mfma_f32_32x32x2_f32)",
@@ -148,6 +165,7 @@ def main():
     line = {"metric": f"stage-{a.stage} training img/s at {a.size}x{a.size}", "value": round(value, 3), "unit": "img/s",
             "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "autotune": bool(ops.AUTOTUNE),
             "config": {"workload": f"config/crdr_stage_{a.stage}.yaml -b {a.bs}: full GAN step (G + 5x CLIC21GVAE D + LPIPS-Alex, random-init weights)"
                                    if a.stage == 3 else f"config/crdr_stage_1.yaml -b {a.bs}: R-D step (+LPIPS-Alex, random-init weights)",
                        "global_batch": ws * a.bs, "crop": a.size, "parallelism": f"dp{ws}"},

@@ -13,6 +13,9 @@
 // h owns k = 4h..4h+3 of every 8-wide k group, identically for A and B, so the sum over k is complete.
 // Split-K (blockIdx.z) writes raw partial slabs; igemm_splitk_epilogue reduces them in a fixed order.
 
+#include <algorithm>
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace crdr {
@@ -40,10 +43,15 @@ struct IgemmArgs {
   int nphase, nsplit;
   int kchunks;
   int ws_ld;  // columns of a partial slab row (= gridDim.y * BN)
-  int8_t poh[16], pow[16];
+  int vec_epi;  // 1: y / res / gx / gt / sig rows are 16-byte aligned -> vector epilogue
+};
+
+// Tap / phase tables travel as a second by-value kernel argument that is only ever indexed with wave-uniform
+// indices in the kernel prologue (keeps the scalar argument block above in SGPRs).
+struct IgemmTaps {
+  int packed[128];  // (dh & 0xff) | (dw & 0xff) << 8 | widx << 16
   short tap_begin[17];
-  int8_t dh[128], dw[128];
-  uint8_t widx[128];
+  int8_t poh[16], pow[16];
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
@@ -68,7 +76,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, 
 }
 
 template <int WM, int WN, int MB, int NB>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, const IgemmTaps tp) {
   constexpr int BM = 32 * WM * MB, BN = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;  // float4 per thread per K-tile
   static_assert(AV * NT == BM * 8 && BV * NT == BN * 8, "tile/threads mismatch");
@@ -84,14 +92,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p) 
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int phase = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
-  const int tb = p.tap_begin[phase], te = p.tap_begin[phase + 1];
+  const int tb = tp.tap_begin[phase], te = tp.tap_begin[phase + 1];
   const int KT = (te - tb) * p.kchunks;
   const int it0 = (int)((long long)KT * split / p.nsplit), it1 = (int)((long long)KT * (split + 1) / p.nsplit);
-  const int poh = p.poh[phase], pow_ = p.pow[phase];
+  const int poh = tp.poh[phase], pow_ = tp.pow[phase];
   const int H = p.H, W = p.W, ldx = p.ldx, Cin = p.Cin, kchunks = p.kchunks;
 
-  for (int t = tid; t < te - tb; t += NT)
-    sTap[t] = (p.dh[tb + t] & 0xff) | ((p.dw[tb + t] & 0xff) << 8) | ((int)p.widx[tb + t] << 16);
+  for (int t = 0; t < te - tb; ++t) {  // wave-uniform index: scalar loads from the kernarg segment
+    const int v = tp.packed[tb + t];
+    if (tid == 0) sTap[t] = v;
+  }
 
   // ---- staging assignment: thread owns chunk (tid&7) of rows (tid>>3) + j*ROWS_PER_PASS
   const int chunk = tid & 7, srow = tid >> 3;
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p) 
   int lt = it0 / kchunks, lc = it0 - lt * kchunks;
   f32x4 ra[AV], rb[BV];
   unsigned ra_mask = 0;
-  auto load_tile = [&]() {
+  auto load_tile = [&]() __attribute__((always_inline)) {
     const int tp = __builtin_amdgcn_readfirstlane(sTap[lt]);
     const int dh = (int)(signed char)(tp & 0xff), dw = (int)(signed char)((tp >> 8) & 0xff), wi = tp >> 16;
     const int c0 = lc * 32 + chunk * 4;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p) 
     ra_mask = mask;
     if (++lc == kchunks) { lc = 0; ++lt; }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
     float* a = sA + buf * BM * 32;
     float* b = sB + buf * BN * 32;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -198,66 +208,106 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p) 
     __syncthreads();
   }
 
-  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // ---- epilogue.  The accumulators go through LDS (the staging buffers are free now) so that every lane handles
+  // 4 consecutive channels of one pixel: 16-byte residual / gate loads and 16-byte stores, 512 B contiguous per
+  // 32 lanes.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  constexpr int G = NB < 4 ? NB : 4;          // 32-column blocks staged per pass
+  constexpr int CLD = 32 * G;                 // floats per staged row
+  float* sC = smem + wave * (32 * CLD);       // per-wave [32][CLD]
   const int f = p.flags;
   const int hw = p.GH * p.GW;
   const bool direct = (p.nphase == 1) && (p.so == 1);  // output pixel index == GEMM row
-  int oc_[NB];
-  float bias_[NB], vec2_[NB], scale_[NB], shift_[NB];
+  const bool vec = p.vec_epi != 0;
+  // one pass = GC column blocks [JG, JG+GC) of accumulator row-block I (all compile-time so acc stays in registers)
+  auto pass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+    constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    oc_[j] = n0 + (wn * NB + j) * 32 + frow;
-    const bool v = oc_[j] < p.Cout;
-    bias_[j] = (v && (f & CRDR_EPI_BIAS)) ? p.bias[oc_[j]] : 0.f;
-    vec2_[j] = (v && (f & CRDR_EPI_VEC2)) ? p.vec2[oc_[j]] : 0.f;
-    scale_[j] = (v && (f & CRDR_EPI_AFFINE)) ? p.scale[oc_[j]] : 1.f;
-    shift_[j] = (v && (f & CRDR_EPI_AFFINE)) ? p.shift[oc_[j]] : 0.f;
-  }
+    for (int jj = 0; jj < GC; ++jj)
 #pragma unroll
-  for (int i = 0; i < MB; ++i) {
+      for (int r = 0; r < 16; ++r)
+        sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      const int m = m0 + row;
-      if (m >= p.M) continue;
+    for (int k = 0; k < 4 * GC; ++k) {
+      const int q = lane + 64 * k;
+      const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * CLD + c4 * 4);
+      const int m = m0 + (wm * MB + I) * 32 + row;
+      const int oc0 = n0 + (wn * NB + JG) * 32 + c4 * 4;
+      bool live_row = m < p.M;
       if (p.nsplit > 1) {
-        float* dst = p.ws + ((size_t)(phase * p.nsplit + split) * p.M + m) * p.ws_ld + n0 + wn * NB * 32 + frow;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) dst[j * 32] = acc[i][j][r];
-        continue;
-      }
-      size_t opix = (size_t)m;
-      if (!direct) {
-        const int n = m / hw, rem = m - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
-        const int oh = ga * p.so + poh, ow = gb * p.so + pow_;
-        if (oh >= p.OH || ow >= p.OW) continue;
-        opix = ((size_t)n * p.OH + oh) * p.OW + ow;
-      }
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        if (oc_[j] >= p.Cout) continue;
-        const int oc = oc_[j];
-        float v = acc[i][j][r] + bias_[j];
-        if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
-        if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
-        v += vec2_[j];
-        if (f & CRDR_EPI_RES) v += p.res[opix * p.ldres + oc];
-        if (f & CRDR_EPI_GATE) {
-          const float sgm = 1.0f / (1.0f + expf(-v));
-          p.sig[opix * p.ldg + oc] = sgm;
-          v = p.gx[opix * p.ldg + oc] + p.gt[opix * p.ldg + oc] * sgm;
+        if (live_row)
+          *reinterpret_cast<f32x4*>(p.ws + ((size_t)(phase * p.nsplit + split) * p.M + m) * p.ws_ld + oc0) = a4;
+      } else {
+        size_t opix = (size_t)m;
+        if (!direct) {
+          const int mm = live_row ? m : 0;
+          const int n = mm / hw, rem = mm - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
+          const int oh = ga * p.so + poh, ow = gb * p.so + pow_;
+          live_row = live_row && (oh < p.OH) && (ow < p.OW);
+          opix = ((size_t)n * p.OH + oh) * p.OW + ow;
         }
-        v = v * scale_[j] + shift_[j];
-        float* dst = p.y + opix * p.ldy + oc;
-        if (f & CRDR_EPI_ACCUM) v += *dst;
-        *dst = v;
+        if (live_row && oc0 < p.Cout) {
+          const bool full = vec && (oc0 + 3 < p.Cout);
+          f32x4 res4 = {0.f, 0.f, 0.f, 0.f}, gx4 = res4, gt4 = res4, old4 = res4;
+          if (full) {
+            if (f & CRDR_EPI_RES) res4 = *reinterpret_cast<const f32x4*>(p.res + opix * p.ldres + oc0);
+            if (f & CRDR_EPI_GATE) {
+              gx4 = *reinterpret_cast<const f32x4*>(p.gx + opix * p.ldg + oc0);
+              gt4 = *reinterpret_cast<const f32x4*>(p.gt + opix * p.ldg + oc0);
+            }
+            if (f & CRDR_EPI_ACCUM) old4 = *reinterpret_cast<const f32x4*>(p.y + opix * p.ldy + oc0);
+          }
+          f32x4 o4, s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int oc = oc0 + e;
+            const bool live = oc < p.Cout;
+            float v = a4[e];
+            if (f & CRDR_EPI_BIAS) v += live ? p.bias[oc] : 0.f;
+            if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
+            if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
+            if (f & CRDR_EPI_VEC2) v += live ? p.vec2[oc] : 0.f;
+            if (f & CRDR_EPI_RES) v += full ? res4[e] : (live ? p.res[opix * p.ldres + oc] : 0.f);
+            if (f & CRDR_EPI_GATE) {
+              const float sgm = 1.0f / (1.0f + expf(-v));
+              s4[e] = sgm;
+              const float gxv = full ? gx4[e] : (live ? p.gx[opix * p.ldg + oc] : 0.f);
+              const float gtv = full ? gt4[e] : (live ? p.gt[opix * p.ldg + oc] : 0.f);
+              v = gxv + gtv * sgm;
+            }
+            if (f & CRDR_EPI_AFFINE) v = live ? v * p.scale[oc] + p.shift[oc] : v;
+            if (f & CRDR_EPI_ACCUM) v += full ? old4[e] : (live ? p.y[opix * p.ldy + oc] : 0.f);
+            o4[e] = v;
+          }
+          if (full) {
+            *reinterpret_cast<f32x4*>(p.y + opix * p.ldy + oc0) = o4;
+            if (f & CRDR_EPI_GATE) *reinterpret_cast<f32x4*>(p.sig + opix * p.ldg + oc0) = s4;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (oc0 + e < p.Cout) {
+                p.y[opix * p.ldy + oc0 + e] = o4[e];
+                if (f & CRDR_EPI_GATE) p.sig[opix * p.ldg + oc0 + e] = s4[e];
+              }
+          }
+        }
       }
     }
+    __syncthreads();
+  };
+  using std::integral_constant;
+  pass(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+  if constexpr (NB > 4) pass(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+  if constexpr (MB > 1) {
+    pass(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+    if constexpr (NB > 4) pass(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
   }
+  static_assert(MB <= 2 && NB <= 8, "epilogue passes are written out for MB <= 2, NB <= 8");
 }
 
 // reduce split-K slabs in split order, then the same epilogue. grid: (ceil(Cout/64), M rows chunked, nphase)
-__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p) {
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p, const IgemmTaps tp) {
   const int phase = blockIdx.z;
   const int oc = blockIdx.x * 64 + (threadIdx.x & 63);
   const int hw = p.GH * p.GW;
@@ -266,7 +316,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p) 
     float v = 0.f;
     for (int s = 0; s < p.nsplit; ++s) v += p.ws[((size_t)(phase * p.nsplit + s) * p.M + m) * p.ws_ld + oc];
     const int n = m / hw, rem = m - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
-    const int oh = ga * p.so + p.poh[phase], ow = gb * p.so + p.pow[phase];
+    const int oh = ga * p.so + tp.poh[phase], ow = gb * p.so + tp.pow[phase];
     if (oh >= p.OH || ow >= p.OW) continue;
     epilogue_store(p, ((size_t)n * p.OH + oh) * p.OW + ow, oc, v);
   }
@@ -277,7 +327,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p) 
 // ------------------------------------------------------------------------------------------------------------
 struct TileCfg {
   int wm, wn, mb, nb;
-  void (*kern)(const IgemmArgs);
+  void (*kern)(const IgemmArgs, const IgemmTaps);
 };
 #define CFG(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d>}
 static const TileCfg kCfgs[] = {
@@ -301,6 +351,7 @@ static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 struct Plan {
   IgemmArgs a;
+  IgemmTaps t;
   int cfg;
   dim3 grid;
   size_t lds;
@@ -314,7 +365,10 @@ static int floordiv(int a, int b) {
 
 static int build_plan(const crdr_conv_desc* d, Plan* pl) {
   IgemmArgs& a = pl->a;
+  IgemmTaps& tp = pl->t;
   memset(&a, 0, sizeof(a));
+  memset(&tp, 0, sizeof(tp));
+  auto pack_tap = [](int dh, int dw, int widx) { return (dh & 0xff) | ((dw & 0xff) << 8) | (widx << 16); };
   CRDR_REQUIRE(d->kh * d->kw <= 128, "conv2d: kernel %dx%d has more than 128 taps", d->kh, d->kw);
   CRDR_REQUIRE(d->stride >= 1 && d->stride <= 4, "conv2d: stride %d unsupported", d->stride);
   CRDR_REQUIRE(d->C % 4 == 0 && d->ldx % 4 == 0, "conv2d: C (%d) and ldx (%d) must be multiples of 4", d->C, d->ldx);
@@ -329,28 +383,27 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
   int nt = 0;
   if (!d->transposed) {
     a.nphase = 1; a.GH = d->OH; a.GW = d->OW; a.so = 1; a.si = S;
-    a.poh[0] = 0; a.pow[0] = 0; a.tap_begin[0] = 0;
+    tp.poh[0] = 0; tp.pow[0] = 0; tp.tap_begin[0] = 0;
     for (int r = 0; r < d->kh; ++r)
       for (int s = 0; s < d->kw; ++s) {
-        a.dh[nt] = (int8_t)(r - P); a.dw[nt] = (int8_t)(s - P); a.widx[nt] = (uint8_t)(r * d->kw + s); ++nt;
+        tp.packed[nt++] = pack_tap(r - P, s - P, r * d->kw + s);
       }
-    a.tap_begin[1] = (short)nt;
+    tp.tap_begin[1] = (short)nt;
   } else {
     a.nphase = S * S; a.GH = cdiv(d->OH, S); a.GW = cdiv(d->OW, S); a.so = S; a.si = 1;
     int ph = 0;
     for (int py = 0; py < S; ++py)
       for (int px = 0; px < S; ++px, ++ph) {
-        a.poh[ph] = (int8_t)py; a.pow[ph] = (int8_t)px; a.tap_begin[ph] = (short)nt;
+        tp.poh[ph] = (int8_t)py; tp.pow[ph] = (int8_t)px; tp.tap_begin[ph] = (short)nt;
         for (int r = 0; r < d->kh; ++r) {
           if (((py + P - r) % S + S) % S) continue;
           for (int s = 0; s < d->kw; ++s) {
             if (((px + P - s) % S + S) % S) continue;
-            a.dh[nt] = (int8_t)floordiv(py + P - r, S); a.dw[nt] = (int8_t)floordiv(px + P - s, S);
-            a.widx[nt] = (uint8_t)(r * d->kw + s); ++nt;
+            tp.packed[nt++] = pack_tap(floordiv(py + P - r, S), floordiv(px + P - s, S), r * d->kw + s);
           }
         }
       }
-    a.tap_begin[ph] = (short)nt;
+    tp.tap_begin[ph] = (short)nt;
   }
   const long long M64 = (long long)d->N * a.GH * a.GW;
   CRDR_REQUIRE(M64 < (1ll << 31) && (long long)d->N * d->H * d->W < (1ll << 31), "conv2d: too many pixels");
@@ -358,7 +411,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
 
   // ---- choose tile config + split-K with a small cost model (MFMA cycles per block x waves of blocks)
   int maxtaps = 0;
-  for (int ph = 0; ph < a.nphase; ++ph) maxtaps = std::max(maxtaps, (int)(a.tap_begin[ph + 1] - a.tap_begin[ph]));
+  for (int ph = 0; ph < a.nphase; ++ph) maxtaps = std::max(maxtaps, (int)(tp.tap_begin[ph + 1] - tp.tap_begin[ph]));
   const int KT = maxtaps * a.kchunks;
   double best = 1e300; int bc = -1, bs = 1;
   for (int c = 0; c < kNumCfgs; ++c) {
@@ -375,6 +428,12 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
       if (cost < best) { best = cost; bc = c; bs = ns; }
     }
   }
+  if (d->reserved != 0) {  // caller-forced algorithm (autotuner): (config index + 1) | log2(split) << 8
+    bc = (d->reserved & 0xff) - 1;
+    bs = 1 << ((d->reserved >> 8) & 0xf);
+    CRDR_REQUIRE(bc >= 0 && bc < kNumCfgs, "conv2d: forced config %d out of range", bc);
+    CRDR_REQUIRE(bs == 1 || KT / bs >= 2, "conv2d: forced split %d too deep for %d K-iterations", bs, KT);
+  }
   CRDR_REQUIRE(bc >= 0, "conv2d: no tile config");
   const TileCfg& t = kCfgs[bc];
   const int BM = 32 * t.wm * t.mb, BN = 32 * t.wn * t.nb;
@@ -390,6 +449,8 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
 }  // namespace crdr
 
 using namespace crdr;
+
+extern "C" int crdr_conv2d_num_configs(void) { return kNumCfgs; }
 
 extern "C" size_t crdr_conv2d_workspace(const crdr_conv_desc* d) {
   Plan pl;
@@ -419,17 +480,24 @@ extern "C" int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_GATE) || (a.gx && a.gt && a.sig), "conv2d: GATE flag without gx/gt/sig");
   CRDR_REQUIRE(pl.ws_bytes <= ws_bytes, "conv2d: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
   if (a.M == 0) return 0;
+  {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    bool v = (a.ldy % 4 == 0) && al16(a.y);
+    if (a.flags & CRDR_EPI_RES) v = v && (a.ldres % 4 == 0) && al16(a.res);
+    if (a.flags & CRDR_EPI_GATE) v = v && (a.ldg % 4 == 0) && al16(a.gx) && al16(a.gt) && al16(a.sig);
+    a.vec_epi = v ? 1 : 0;
+  }
   const TileCfg& t = kCfgs[pl.cfg];
   static bool attr_done[64] = {false};
   if (!attr_done[pl.cfg]) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[pl.cfg] = true;
   }
-  hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a);
+  hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, pl.t);
   CRDR_CHECK_LAUNCH("igemm_kernel");
   if (a.nsplit > 1) {
     dim3 g(cdiv(a.Cout, 64), std::min(cdiv(a.M, 4), 2048), a.nphase);
-    hipLaunchKernelGGL(igemm_splitk_epilogue, g, dim3(256), 0, as_stream(s), a);
+    hipLaunchKernelGGL(igemm_splitk_epilogue, g, dim3(256), 0, as_stream(s), a, pl.t);
     CRDR_CHECK_LAUNCH("igemm_splitk_epilogue");
   }
   return 0;

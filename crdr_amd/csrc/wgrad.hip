@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
   f32x4 rp[PV], rq[QV];
   unsigned pmask = 0, qmask = 0;
   const int Mlast = p.M - 1;
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
     const int mbase = t * 32;
     unsigned pm = 0, qm = 0;
 #pragma unroll
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
     pmask = pm;
     qmask = qm;
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
     float* a = sP + buf * 32 * BI;
     float* b = sQ + buf * 32 * BJ;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -249,6 +249,12 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl) {
       if (cost < best) { best = cost; bc = c; bs = ns; }
     }
   }
+  if (d->algo != 0) {  // caller-forced algorithm (autotuner): (config index + 1) | log2(split) << 8
+    bc = (d->algo & 0xff) - 1;
+    bs = 1 << ((d->algo >> 8) & 0xf);
+    CRDR_REQUIRE(bc >= 0 && bc < kNumWCfgs, "wgrad: forced config %d out of range", bc);
+    CRDR_REQUIRE(bs == 1 || a.ntiles / bs >= 1, "wgrad: forced split %d too deep for %d pixel tiles", bs, a.ntiles);
+  }
   CRDR_REQUIRE(bc >= 0, "wgrad: no tile config");
   const WCfg& t = kWCfgs[bc];
   const int BI = 32 * t.wm * t.mb, BJ = 32 * t.wn * t.nb;
@@ -262,6 +268,8 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl) {
 }  // namespace crdr
 
 using namespace crdr;
+
+extern "C" int crdr_conv2d_wgrad_num_configs(void) { return kNumWCfgs; }
 
 extern "C" size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d) {
   WPlan pl;

@@ -32,7 +32,7 @@ class ConvIO(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "N", "PH", "PW", "PC", "ldp", "QH", "QW", "QC", "ldq", "kh", "kw", "stride", "pad", "gI", "gJ",
-        "accumulate")]
+        "accumulate", "algo")]
 
 
 class EbwdDesc(C.Structure):
@@ -59,6 +59,8 @@ SIGNATURES = {
     "crdr_last_error": (C.c_char_p, []),
     "crdr_version": (_I, []),
     "crdr_arch": (C.c_char_p, []),
+    "crdr_conv2d_num_configs": (_I, []),
+    "crdr_conv2d_wgrad_num_configs": (_I, []),
     "crdr_conv2d_workspace": (_SZ, [C.POINTER(ConvDesc)]),
     "crdr_conv2d": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvIO), _P, _SZ, _P]),
     "crdr_conv2d_flops": (_D, [C.POINTER(ConvDesc)]),

@@ -14,6 +14,45 @@ from . import lib as L
 
 _ws_cache = {}
 
+# Algorithm selection per problem shape, the analogue of the reference's `cudnn.benchmark = True`
+# (base_trainer.py:20): with AUTOTUNE on, the first call of a shape times every tile configuration x split depth
+# of the library on the real operands and caches the fastest; off, the library's built-in cost model decides.
+AUTOTUNE = False
+_algo_cache = {}
+TUNE_LOG = []
+
+
+def _time_call(fn, reps: int = 2) -> float:
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _autotune(key, ncfg: int, max_log2_split: int, run) -> int:
+    """run(algo) -> bool (False if the library rejects the combination). Returns the fastest algo id."""
+    best, best_t = 0, _time_call(lambda: run(0))
+    base_t = best_t
+    for c in range(ncfg):
+        for ls in range(max_log2_split + 1):
+            algo = (c + 1) | (ls << 8)
+            try:
+                if not run(algo):
+                    continue
+                t = _time_call(lambda: run(algo))
+            except L.CrdrHipError:
+                continue
+            if t < best_t:
+                best, best_t = algo, t
+    _algo_cache[key] = best
+    TUNE_LOG.append((key, best, base_t, best_t))
+    return best
+
+
 # Optional per-launch timing (bench.py): {"igemm": [(flops, ev0, ev1), ...], "wgrad": [...]} or None.
 # Events are recorded on the stream the kernels are launched on (torch's current stream).
 PROFILE = None
@@ -27,12 +66,12 @@ def _prof_begin():
     return e
 
 
-def _prof_end(kind: str, flops: float, e0) -> None:
+def _prof_end(kind: str, flops: float, e0, label: str = "") -> None:
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.setdefault(kind, []).append((flops, e0, e1))
+    PROFILE.setdefault(kind, []).append((flops, e0, e1, label))
 
 
 def _stream() -> int:
@@ -147,11 +186,23 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
             ldg = oc
         d.ldg = ldg
         io.gx, io.gt, io.sig = gate_x.data_ptr(), gate_t.data_ptr(), sig_out.data_ptr()
+    if AUTOTUNE and not (flags & L.EPI_ACCUM):
+        key = ("c", n, h, w, d.C, oh, ow, oc, k, stride, pad, int(transposed), ldx, ldy, flags, d.ldres, d.ldg)
+        algo = _algo_cache.get(key)
+        if algo is None:
+            def run(a):
+                d.reserved = a
+                nb = lib.crdr_conv2d_workspace(C.byref(d))
+                w_, wn_ = workspace(nb, x.device) if nb else (None, 0)
+                return lib.crdr_conv2d(C.byref(d), C.byref(io), w_, wn_, _stream()) == 0
+            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run)
+        d.reserved = algo
     nbytes = lib.crdr_conv2d_workspace(C.byref(d))
     ws, ws_n = workspace(nbytes, x.device) if nbytes else (None, 0)
     e0 = _prof_begin()
     L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), ws, ws_n, _stream()), "conv2d")
-    _prof_end("igemm", 2.0 * n * (h * w if transposed else oh * ow) * c * oc * k[0] * k[1], e0)
+    _prof_end("igemm", 2.0 * n * (h * w if transposed else oh * ow) * c * oc * k[0] * k[1], e0,
+              f"{'T' if transposed else 'C'} {c}->{oc} k{k[0]}s{stride} in{h}x{w} f{flags}")
     return out
 
 
@@ -166,12 +217,29 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
     qc4 = min((qc + 3) // 4 * 4, ldq)
     assert g.is_contiguous() and g.shape[0] <= pc4 and g.shape[1] <= qc4
     d = L.WgradDesc(N=n, PH=ph, PW=pw, PC=pc4, ldp=ldp, QH=qh, QW=qw, QC=qc4, ldq=ldq, kh=k[0], kw=k[1],
-                    stride=stride, pad=pad, gI=g.shape[0], gJ=g.shape[1], accumulate=int(accumulate))
+                    stride=stride, pad=pad, gI=g.shape[0], gJ=g.shape[1], accumulate=int(accumulate), algo=0)
+    if AUTOTUNE:
+        key = ("w", n, ph, pw, pc4, ldp, qh, qw, qc4, ldq, k, stride, pad, g.shape[0], g.shape[1])
+        algo = _algo_cache.get(key)
+        if algo is None:
+            tmp = torch.empty_like(g)
+
+            def run(a):
+                d.algo, d.accumulate = a, 0
+                nb = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
+                if nb > (8 << 30):
+                    return False
+                w_, wn_ = workspace(nb, p.device)
+                return lib.crdr_conv2d_wgrad(C.byref(d), p.data_ptr(), q.data_ptr(), tmp.data_ptr(), w_, wn_, _stream()) == 0
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run)
+            d.accumulate = int(accumulate)
+        d.algo = algo
     nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
     ws, ws_n = workspace(nbytes, p.device)
     e0 = _prof_begin()
     L.check(lib.crdr_conv2d_wgrad(C.byref(d), p.data_ptr(), q.data_ptr(), g.data_ptr(), ws, ws_n, _stream()), "conv2d_wgrad")
-    _prof_end("wgrad", 2.0 * n * ph * pw * g.shape[0] * g.shape[1] * k[0] * k[1], e0)
+    _prof_end("wgrad", 2.0 * n * ph * pw * g.shape[0] * g.shape[1] * k[0] * k[1], e0,
+              f"W {g.shape[0]}x{g.shape[1]} k{k[0]}s{stride} p{ph}x{pw}")
     return g
 
 

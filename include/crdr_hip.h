@@ -66,7 +66,9 @@ typedef struct crdr_conv_desc {
   int32_t flags;
   int32_t ldres; /* pixel stride of res                                    */
   int32_t ldg;   /* pixel stride of gx, gt and sig                          */
-  int32_t reserved;
+  int32_t reserved; /* 0: built-in heuristic; else a forced algorithm = (config index + 1) | log2(split-K) << 8
+                     * (what cudnn.benchmark=True does for the reference, base_trainer.py:20: time the candidates
+                     * once per shape and keep the fastest; see crdr_amd/hip/ops.py) */
 } crdr_conv_desc;
 
 typedef struct crdr_conv_io {
@@ -83,6 +85,8 @@ typedef struct crdr_conv_io {
   float* sig;
 } crdr_conv_io;
 
+/* number of tile configurations a forced algorithm may name */
+int crdr_conv2d_num_configs(void);
 /* bytes of workspace crdr_conv2d needs for this problem (split-K partial slabs; may be 0) */
 size_t crdr_conv2d_workspace(const crdr_conv_desc* d);
 int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);
@@ -98,7 +102,9 @@ typedef struct crdr_wgrad_desc {
   int32_t kh, kw, stride, pad;
   int32_t gI, gJ;     /* dims of g (<= PC, QC): channels beyond them are layout padding and are dropped */
   int32_t accumulate; /* 1: g += ; 0: g = */
+  int32_t algo;       /* 0: heuristic; else forced (config index + 1) | log2(pixel split) << 8 */
 } crdr_wgrad_desc;
+int crdr_conv2d_wgrad_num_configs(void);
 size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d);
 int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* ws, size_t ws_bytes,
                       crdr_stream_t s);
