@@ -345,6 +345,17 @@ static const TileCfg kCfgs[] = {
     // BM=32: small-M layers
     CFG(1, 4, 1, 1),  // 32x128
     CFG(1, 4, 1, 2),  // 32x256
+    // 8-wave blocks: two waves per SIMD share one staged tile (more MFMA work per staged byte, latency hiding)
+    CFG(4, 2, 1, 1),  // 128x64
+    CFG(4, 2, 1, 2),  // 128x128
+    CFG(4, 2, 1, 3),  // 128x192
+    CFG(4, 2, 2, 1),  // 256x64
+    CFG(4, 2, 2, 2),  // 256x128
+    CFG(2, 4, 1, 1),  // 64x128
+    CFG(2, 4, 2, 1),  // 128x128
+    CFG(2, 4, 1, 2),  // 64x256
+    CFG(2, 2, 2, 1),  // 128x64 (4 waves)
+    CFG(2, 2, 2, 3),  // 128x192 (4 waves)
 };
 #undef CFG
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -441,7 +452,11 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
   a.nsplit = bs;
   pl->grid = dim3(cdiv(a.M, BM), cdiv(d->OC, BN), a.nphase * bs);
   a.ws_ld = pl->grid.y * BN;
-  pl->lds = (size_t)2 * (BM + BN) * 32 * sizeof(float) + 128 * sizeof(int);
+  {
+    const size_t staging = (size_t)2 * (BM + BN) * 32 * sizeof(float) + 128 * sizeof(int);
+    const size_t epi = (size_t)t.wm * t.wn * 32 * 32 * std::min(t.nb, 4) * sizeof(float);
+    pl->lds = std::max(staging, epi);
+  }
   pl->ws_bytes = bs > 1 ? (size_t)a.nphase * bs * a.M * a.ws_ld * sizeof(float) : 0;
   return 0;
 }
@@ -490,7 +505,7 @@ extern "C" int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void
   const TileCfg& t = kCfgs[pl.cfg];
   static bool attr_done[64] = {false};
   if (!attr_done[pl.cfg]) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[pl.cfg] = true;
   }
   hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, pl.t);

@@ -207,6 +207,14 @@ static const WCfg kWCfgs[] = {
     CFG(7, 1, 1, 1),  // 224x32
     CFG(7, 1, 1, 2),  // 224x64
     CFG(4, 2, 1, 1),  // 128x64 (8 waves)
+    CFG(2, 4, 1, 1),  // 64x128 (8 waves)
+    CFG(4, 2, 1, 2),  // 128x128 (8 waves)
+    CFG(3, 2, 1, 1),  // 96x64 (6 waves)
+    CFG(3, 3, 1, 1),  // 96x96 (9 waves)
+    CFG(2, 2, 1, 1),  // dup guard (kept for index stability)
+    CFG(4, 4, 1, 1),  // 128x128 (16 waves)
+    CFG(2, 1, 1, 1),  // 64x32
+    CFG(1, 2, 1, 1),  // 32x64
 };
 #undef CFG
 static const int kNumWCfgs = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
@@ -288,7 +296,7 @@ extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const
   const WCfg& t = kWCfgs[pl.cfg];
   static bool attr_done[64] = {false};
   if (!attr_done[pl.cfg]) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[pl.cfg] = true;
   }
   hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a);

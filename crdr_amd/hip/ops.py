@@ -159,7 +159,8 @@ def conv_out_size(h, k, stride, pad, transposed, out_pad=0):
 
 def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int], stride: int, pad: int,
                transposed: bool, out_hw: Tuple[int, int], *, bias=None, flags: int = 0, vec2=None, res=None,
-               scale=None, shift=None, gate_x=None, gate_t=None, sig_out=None, out: Optional[torch.Tensor] = None):
+               scale=None, shift=None, gate_x=None, gate_t=None, sig_out=None, out: Optional[torch.Tensor] = None,
+               algo: int = 0):
     """One fused implicit-GEMM launch. `out` may be a channel slice of a wider NHWC tensor (written in place)."""
     lib = L.load()
     x, ldx = nhwc(x)
@@ -186,7 +187,9 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
             ldg = oc
         d.ldg = ldg
         io.gx, io.gt, io.sig = gate_x.data_ptr(), gate_t.data_ptr(), sig_out.data_ptr()
-    if AUTOTUNE and not (flags & L.EPI_ACCUM):
+    if algo:
+        d.reserved = algo
+    elif AUTOTUNE and not (flags & L.EPI_ACCUM):
         key = ("c", n, h, w, d.C, oh, ow, oc, k, stride, pad, int(transposed), ldx, ldy, flags, d.ldres, d.ldg)
         algo = _algo_cache.get(key)
         if algo is None:
@@ -206,7 +209,7 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
     return out
 
 
-def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, stride, pad, accumulate: bool):
+def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, stride, pad, accumulate: bool, algo: int = 0):
     """g[I][J][kh][kw] (+)= sum P[., i] * Q[gathered, j]; P is the dense operand (see crdr_hip.h)."""
     lib = L.load()
     p, ldp = nhwc(p)
@@ -218,7 +221,9 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
     assert g.is_contiguous() and g.shape[0] <= pc4 and g.shape[1] <= qc4
     d = L.WgradDesc(N=n, PH=ph, PW=pw, PC=pc4, ldp=ldp, QH=qh, QW=qw, QC=qc4, ldq=ldq, kh=k[0], kw=k[1],
                     stride=stride, pad=pad, gI=g.shape[0], gJ=g.shape[1], accumulate=int(accumulate), algo=0)
-    if AUTOTUNE:
+    if algo:
+        d.algo = algo
+    elif AUTOTUNE:
         key = ("w", n, ph, pw, pc4, ldp, qh, qw, qc4, ldq, k, stride, pad, g.shape[0], g.shape[1])
         algo = _algo_cache.get(key)
         if algo is None:

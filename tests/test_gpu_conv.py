@@ -202,3 +202,38 @@ def test_epilogue_bwd():
     _close(gres, gx.grad, "ebwd gate gx")
     _close(dgt, gt.grad, "ebwd gate gt")
     _close(cs[2], sc.grad, "ebwd gate dscale", rtol=1e-3)
+
+
+def test_every_tile_config_and_split():
+    """Each tile configuration of the library, with and without split-K / pixel split, on shapes whose sizes are
+    not multiples of any tile (forced algorithm ids, the same ids the autotuner uses)."""
+    from crdr_amd.hip import ops, lib as L
+    dev = _dev()
+    lib = L.load()
+    n, ci, h, w, co, k = 3, 72, 13, 11, 104, 3
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(co, ci, k, k, seed=2, scale=0.05)
+    b = _rand(co, seed=3)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, b.double(), padding=1)
+    dy = _rand(*ref.shape, seed=4)
+    ref.backward(dy.double())
+    wtT = _rand(ci, co, 5, 5, seed=5, scale=0.05)  # transposed 5x5 s2: four phases with different tap counts
+    refT = F.conv_transpose2d(x.double(), wtT.double(), b.double(), stride=2, padding=2, output_padding=1)
+    xd, dyd, bd = x.to(dev), dy.to(dev), b.to(dev)
+    wp, wpT = ops.pack_weight(wt.to(dev), False), ops.pack_weight(wtT.to(dev), True)
+    tried = 0
+    for c in range(lib.crdr_conv2d_num_configs()):
+        for ls in (0, 2):
+            algo = (c + 1) | (ls << 8)
+            out = ops.conv2d_raw(xd, wp, co, (k, k), 1, 1, False, (h, w), bias=bd, flags=1, algo=algo)
+            _close(out, ref, f"fwd cfg {c} split {1 << ls}")
+            outT = ops.conv2d_raw(xd, wpT, co, (5, 5), 2, 2, True, tuple(refT.shape[2:]), bias=bd, flags=1, algo=algo)
+            _close(outT, refT, f"convT cfg {c} split {1 << ls}")
+            tried += 1
+    assert tried >= 30
+    for c in range(lib.crdr_conv2d_wgrad_num_configs()):
+        for ls in (0, 1, 3):
+            g = torch.zeros_like(wt, device=dev)
+            ops.conv2d_wgrad_raw(dyd, xd, g, (k, k), 1, 1, accumulate=False, algo=(c + 1) | (ls << 8))
+            _close(g, wr.grad, f"wgrad cfg {c} split {1 << ls}")
