@@ -23,7 +23,7 @@ GFLOP_PER_IMG_STAGE3 = 644.6    # 3.8 F_G + 7.8 F_D + LP
 GFLOP_PER_IMG_STAGE1 = 434.0
 
 
-def build_trainer(stage: int, bs: int, size: int, device: str):
+def build_trainer(stage: int, bs: int, size: int, device: str, graphs: bool = True):
     import torch
     from crdr_amd.trainer import build_trainer as _bt
     from crdr_amd.utils.options import BaseConfig, ConfigDict
@@ -32,6 +32,7 @@ def build_trainer(stage: int, bs: int, size: int, device: str):
     cfg["device"] = device
     cfg["dataset"] = {"batch_size": bs, "train_dataset": {"type": "SyntheticDataset", "image_size": size}}
     cfg["path"] = None
+    cfg["hip_graphs"] = graphs
     torch.manual_seed(0)
     return _bt(ConfigDict(cfg))
 
@@ -90,6 +91,8 @@ def main():
     ap.add_argument("--shape-table", default=None, help="write per-shape conv timing of the timed region to this file")
     ap.add_argument("--no-autotune", action="store_true", help="use the library's built-in tile heuristic instead of timing candidates once per shape")
     ap.add_argument("--tune-log", default=None)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying captured HIP graphs")
+    ap.add_argument("--profile-steps", type=int, default=3, help="eager steps after the timed region used for the per-kernel roofline")
     a = ap.parse_args()
 
     import torch
@@ -101,9 +104,10 @@ def main():
     assert ws == a.gpus or (a.gpus == 1 and ws == 1), f"--gpus {a.gpus} but WORLD_SIZE={ws}"
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
-    tr = build_trainer(a.stage, a.bs, a.size, device)
+    tr = build_trainer(a.stage, a.bs, a.size, device, graphs=not a.no_graph)
     loader = iter(tr.train_loader)
     ops.AUTOTUNE = not a.no_autotune  # the reference runs with cudnn.benchmark = True (base_trainer.py:20)
+    lib = __import__("crdr_amd.hip.lib", fromlist=["load"]).load()
 
     def barrier():
         if ws > 1:
@@ -111,18 +115,40 @@ def main():
         torch.cuda.synchronize()
 
     it = 0
+    # untimed preparation: autotune every shape eagerly and capture one graph set per rate index (each graph key needs
+    # `graph_warmup` eager iterations first), by cycling the rate index deterministically
+    if a.stage == 3 or hasattr(tr.comp_model, "rate_level"):
+        for q in range(tr.comp_model.rate_level):
+            for _ in range(tr.graph_warmup + 1 if tr.graphs.enabled else 1):
+                it += 1
+                tr.optimize_parameters(it, {**next(loader), "rate_ind": q})
+    else:
+        for _ in range(tr.graph_warmup + 1 if tr.graphs.enabled else 1):
+            it += 1
+            tr.optimize_parameters(it, next(loader))
     for _ in range(a.warmup):
         it += 1
         tr.optimize_parameters(it, next(loader))
     barrier()
-    ops.PROFILE = {}
     t0 = time.perf_counter()
     for _ in range(a.steps):
         it += 1
         tr.optimize_parameters(it, next(loader))
     barrier()
     dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    # per-kernel roofline: HIP events bracket every conv launch inside the library (they cannot be recorded inside a
+    # graph replay), over `profile_steps` eager iterations of the same step right after the timed region
+    graphs_on = tr.graphs.enabled
+    tr.graphs.enabled = False
+    lib.crdr_profile_enable(1)
+    ops.PROFILE = {} if a.shape_table else None
+    for _ in range(a.profile_steps):
+        it += 1
+        tr.optimize_parameters(it, next(loader))
+    torch.cuda.synchronize()
+    lib.crdr_profile_enable(0)
+    prof, ops.PROFILE = ops.PROFILE or {}, None
+    tr.graphs.enabled = graphs_on
     if ws > 1:
         t = torch.tensor([dt], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -133,16 +159,18 @@ def main():
     value = imgs / dt
     gflop = GFLOP_PER_IMG_STAGE3 if a.stage == 3 else GFLOP_PER_IMG_STAGE1
 
+    import ctypes as C
+
     def fam(kind):
-        rec = prof.get(kind, [])
-        if not rec:
+        fl, ms, n = C.c_double(), C.c_double(), C.c_longlong()
+        lib.crdr_profile_read(kind, C.byref(fl), C.byref(ms), C.byref(n))
+        if n.value == 0 or ms.value <= 0:
             return None
-        fl = sum(r[0] for r in rec)
-        ms = sum(r[1].elapsed_time(r[2]) for r in rec)
-        return {"launches_per_step": len(rec) / a.steps, "avg_launch_us": round(ms * 1e3 / len(rec), 2),
-                "avg_gflop_per_launch": round(fl / len(rec) / 1e9, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
-                "ms_per_step": round(ms / a.steps, 2)}
-    ig, wg = fam("igemm"), fam("wgrad")
+        ps = max(a.profile_steps, 1)
+        return {"launches_per_step": n.value / ps, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                "avg_gflop_per_launch": round(fl.value / n.value / 1e9, 3), "tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
+                "ms_per_step": round(ms.value / ps, 2)}
+    ig, wg = fam(0), fam(1)
     if a.tune_log:
         with open(a.tune_log, "w") as f:
             for key, best, t0, t1 in ops.TUNE_LOG:
@@ -155,17 +183,18 @@ def main():
                 t[0] += 1; t[1] += e0.elapsed_time(e1); t[2] += fl
         with open(a.shape_table, "w") as f:
             for (kind, label), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                f.write(f"{ms / a.steps:8.3f} ms/step  {cnt / a.steps:6.1f} calls/step  {fl / (ms * 1e-3) / 1e12:6.1f} TF  {kind:5s} {label}\n")
+                f.write(f"{ms / max(a.profile_steps, 1):8.3f} ms/step  {cnt / max(a.profile_steps, 1):6.1f} calls/step  {fl / (ms * 1e-3) / 1e12:6.1f} TF  {kind:5s} {label}\n")
     roof = {"bound": "mfma", "achieved": ig["tflops"] if ig else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None, "traffic": None,
             "kernel": "igemm_kernel<*> (conv / convT forward + input-gradient launches, v_mfma_f32_32x32x2_f32)",
+            "measured_over": f"{a.profile_steps} eager steps after the timed region (HIP events around each launch, on its stream)",
             "detail": ig, "wgrad_kernel": wg,
             "whole_step": {"algorithmic_gflop_per_img": gflop, "achieved": round(value / ws * gflop / 1e3, 2),
                            "frac": round(value / ws * gflop / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}}
     line = {"metric": f"stage-{a.stage} training img/s at {a.size}x{a.size}", "value": round(value, 3), "unit": "img/s",
             "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "autotune": bool(ops.AUTOTUNE),
+            "autotune": bool(ops.AUTOTUNE), "hip_graphs": bool(graphs_on),
             "config": {"workload": f"config/crdr_stage_{a.stage}.yaml -b {a.bs}: full GAN step (G + 5x CLIC21GVAE D + LPIPS-Alex, random-init weights)"
                                    if a.stage == 3 else f"config/crdr_stage_1.yaml -b {a.bs}: R-D step (+LPIPS-Alex, random-init weights)",
                        "global_batch": ws * a.bs, "crop": a.size, "parallelism": f"dp{ws}"},

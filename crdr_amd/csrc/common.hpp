@@ -30,6 +30,12 @@ inline hipStream_t as_stream(crdr_stream_t s) { return reinterpret_cast<hipStrea
     }                                \
   } while (0)
 
+// Optional launch timing (bench.py): when enabled, conv / wgrad launches are bracketed by HIP events on the launch
+// stream and (flops, events) are kept until crdr_profile_read.  Off by default; never used under graph capture.
+bool profile_on();
+void* profile_begin(hipStream_t s);
+void profile_end(int kind, double flops, void* token, hipStream_t s);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }

@@ -129,20 +129,22 @@ __global__ __launch_bounds__(256) void ebwd_kernel_v4(const EbwdArgs p) {
   }
 }
 
-// out[e] (+)= sum_b partial[b][e], e over K*C columns; 64 columns x 4 block-groups per workgroup, fixed order
+// out[e] (+)= sum_b partial[b][e], e over K*C columns; 16 columns x 16 block-groups per workgroup, fixed order
 __global__ __launch_bounds__(256) void colsum_final(const float* partial, int nblocks, int K, int C, float* out,
                                                     int accumulate) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + tx;
+  __shared__ float red[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + tx;
   const int KC = K * C;
   float v = 0.f;
   if (e < KC)
-    for (int b = ty; b < nblocks; b += 4) v += partial[(size_t)b * KC + e];
+    for (int b = ty; b < nblocks; b += 16) v += partial[(size_t)b * KC + e];
   red[ty][tx] = v;
   __syncthreads();
   if (ty == 0 && e < KC) {
-    const float t = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    float t = red[0][tx];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) t += red[r][tx];
     out[e] = accumulate ? out[e] + t : t;
   }
 }
@@ -343,6 +345,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   }
 }
 
+// Same update with the step-dependent scalars read on the device (so the launch can live inside a HIP graph):
+// dyn[0] = lr, dyn[1] = step count (>= 1, already incremented), dyn[2] != 0 -> skip the update entirely.
+__global__ __launch_bounds__(256) void adam_dyn_kernel(float* p, const float* g, float* m, float* v, int64_t n, float b1,
+                                                       float b2, float eps, const float* dyn, const float* sqnorm,
+                                                       float max_norm) {
+  if (dyn[2] != 0.f) return;
+  const float st = dyn[1];
+  const float bc1 = 1.f - powf(b1, st), bc2_sqrt = sqrtf(1.f - powf(b2, st));
+  float clip = 1.f;
+  if (sqnorm) {
+    const float c = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
+    clip = c < 1.f ? c : 1.f;
+  }
+  const float step_size = dyn[0] / bc1;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += gridDim.x * 256ll) {
+    const float gr = g[e] * clip;
+    const float mm = m[e] + (gr - m[e]) * (1.f - b1);
+    const float vv = v[e] * b2 + (1.f - b2) * gr * gr;
+    m[e] = mm;
+    v[e] = vv;
+    p[e] -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // LPIPS helpers (NHWC)
 // ------------------------------------------------------------------------------------------------------------
@@ -496,7 +522,7 @@ extern "C" int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io
     else hipLaunchKernelGGL(ebwd_kernel, dim3(nb), dim3(256), 0, as_stream(s), a);
     CRDR_CHECK_LAUNCH("ebwd_kernel");
   }
-  hipLaunchKernelGGL(colsum_final, dim3(cdiv(4 * d->C, 64)), dim3(256), 0, as_stream(s), (const float*)ws,
+  hipLaunchKernelGGL(colsum_final, dim3(cdiv(4 * d->C, 16)), dim3(256), 0, as_stream(s), (const float*)ws,
                      d->M > 0 ? nb : 0, 4, d->C, io->colsums, 0);
   CRDR_CHECK_LAUNCH("colsum_final");
   return 0;
@@ -527,7 +553,7 @@ extern "C" int crdr_colsum(const float* x, int ldx, int64_t M, int C, float* out
       hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, as_stream(s), x, ldx, M, C, (float*)ws, rpb);
     CRDR_CHECK_LAUNCH("colsum");
   }
-  hipLaunchKernelGGL(colsum_final, dim3(cdiv(C, 64)), dim3(256), 0, as_stream(s), (const float*)ws, M > 0 ? nb : 0, 1,
+  hipLaunchKernelGGL(colsum_final, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(s), (const float*)ws, M > 0 ? nb : 0, 1,
                      C, out, accumulate);
   CRDR_CHECK_LAUNCH("colsum_final");
   return 0;
@@ -619,6 +645,16 @@ extern "C" int crdr_adam_step(float* p, const float* g, float* m, float* v, int6
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(s), p, g, m, v, n, lr, beta1, beta2, eps,
                      bc1, bc2_sqrt, sqnorm, max_norm);
   CRDR_CHECK_LAUNCH("adam_step");
+  return 0;
+}
+
+extern "C" int crdr_adam_step_dyn(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2,
+                                  float eps, const float* dyn, const float* sqnorm, float max_norm, crdr_stream_t s) {
+  CRDR_REQUIRE(p && g && m && v && dyn, "adam_step_dyn: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(adam_dyn_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(s), p, g, m, v, n, beta1, beta2, eps, dyn,
+                     sqnorm, max_norm);
+  CRDR_CHECK_LAUNCH("adam_step_dyn");
   return 0;
 }
 

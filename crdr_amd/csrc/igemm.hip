@@ -508,6 +508,7 @@ extern "C" int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[pl.cfg] = true;
   }
+  void* prof = profile_begin(as_stream(s));
   hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, pl.t);
   CRDR_CHECK_LAUNCH("igemm_kernel");
   if (a.nsplit > 1) {
@@ -515,5 +516,6 @@ extern "C" int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void
     hipLaunchKernelGGL(igemm_splitk_epilogue, g, dim3(256), 0, as_stream(s), a, pl.t);
     CRDR_CHECK_LAUNCH("igemm_splitk_epilogue");
   }
+  profile_end(0, crdr_conv2d_flops(d), prof, as_stream(s));
   return 0;
 }

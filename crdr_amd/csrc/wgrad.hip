@@ -299,6 +299,7 @@ extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[pl.cfg] = true;
   }
+  void* prof = profile_begin(as_stream(s));
   hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a);
   CRDR_CHECK_LAUNCH("wgrad_kernel");
   const long long total = (long long)d->gI * d->gJ * a.T;
@@ -306,6 +307,7 @@ extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const
   hipLaunchKernelGGL(wgrad_reduce, dim3(blocks), dim3(256), 0, as_stream(s), (const float*)ws, g, d->PC, d->QC, d->gI,
                      d->gJ, a.T, a.nsplit, d->accumulate);
   CRDR_CHECK_LAUNCH("wgrad_reduce");
+  profile_end(1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
   return 0;
 }
 

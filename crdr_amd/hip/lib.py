@@ -59,6 +59,8 @@ SIGNATURES = {
     "crdr_last_error": (C.c_char_p, []),
     "crdr_version": (_I, []),
     "crdr_arch": (C.c_char_p, []),
+    "crdr_profile_enable": (None, [_I]),
+    "crdr_profile_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "crdr_conv2d_num_configs": (_I, []),
     "crdr_conv2d_wgrad_num_configs": (_I, []),
     "crdr_conv2d_workspace": (_SZ, [C.POINTER(ConvDesc)]),
@@ -88,6 +90,7 @@ SIGNATURES = {
     "crdr_bce_diff_bwd": (_I, [_P, _P, _I64, _F, _P, _F, _P, _P, _P]),
     "crdr_sqnorm": (_I, [_P, _I64, _P, _P, _SZ, _P]),
     "crdr_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _P, _F, _P]),
+    "crdr_adam_step_dyn": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _P, _P, _F, _P]),
     "crdr_maxpool3s2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "crdr_maxpool3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "crdr_lpips_layer_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),

@@ -13,6 +13,8 @@ import torch
 from . import lib as L
 
 _ws_cache = {}
+_ws_keep = []   # superseded buffers stay alive: captured graphs may still reference them
+_ws_max = 0     # largest request seen so far (eager warm-up), so a buffer created under graph capture never has to grow
 
 # Algorithm selection per problem shape, the analogue of the reference's `cudnn.benchmark = True`
 # (base_trainer.py:20): with AUTOTUNE on, the first call of a shape times every tile configuration x split depth
@@ -80,10 +82,14 @@ def _stream() -> int:
 
 def workspace(nbytes: int, device) -> Tuple[int, int]:
     """Grow-only per-device scratch (kernels on one stream serialise, so one buffer is enough)."""
+    global _ws_max
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    _ws_max = max(_ws_max, int(nbytes))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _ws_keep.append(buf)
+        buf = torch.empty(max(int(_ws_max * 1.25), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf.data_ptr(), buf.numel()
 

@@ -69,8 +69,14 @@ class ElicInterpCaBetaCondDecoder(BaseDecoder):
         if weight_init:
             self.apply(weights_init)
 
+    static_embed = None  # optional persistent device buffer [1, 2L, 1, 1] holding the Fourier features of the current beta
+                         # (set by the trainer so that a captured HIP graph reads beta from device memory)
+
     def cond_vector(self, beta: Union[float, torch.Tensor], device) -> torch.Tensor:
-        e = self.embed.embed(beta).to(device).reshape(1, -1, 1, 1)  # [1, 2L] computed on the host
+        if self.static_embed is not None and self.training:
+            e = self.static_embed
+        else:
+            e = self.embed.embed(beta).to(device).reshape(1, -1, 1, 1)  # [1, 2L] computed on the host
         return self.mlp(e)  # [1, cond_ch, 1, 1]
 
     def forward(self, x, rate_ind, beta):

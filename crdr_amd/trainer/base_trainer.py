@@ -30,6 +30,13 @@ class BaseTrainer:
         self.set_dataloader()
         self.use_wandb = False  # wandb is not part of the hot path; rank-0 CSV logs carry the same numbers
         self.loss_recorder = AvgMeter()
+        # HIP-graph execution of the step (crdr_amd/trainer/graphs.py): `hip_graphs: true` in the config / CLI overlay
+        from .graphs import SegmentGraphs
+        self.graphs = SegmentGraphs(bool(opt.get("hip_graphs", False)))
+        self.graph_warmup = int(opt.get("hip_graph_warmup", 2))  # eager iterations per graph key before capturing
+        self._warm = {}
+        self._real_static = None
+        self.loss_huge_threshold = 10000.0
         self.time_recorder = Timer(start_iter=opt.get("start_iter", 0), end_iter=opt.get("total_iter", 0))
         if opt.get("path") is not None and self.is_main:
             self.set_csv_loggers()
@@ -113,13 +120,44 @@ class BaseTrainer:
     def optimize_parameters(self, itr: int, data: Dict) -> Optional[Dict]:
         raise NotImplementedError()
 
-    def update_loss_recorder(self, loss_dict: Dict) -> None:
+    @staticmethod
+    def fetch_scalars(loss_dict: Dict) -> Dict[str, float]:
         """One device->host copy for all logged scalars (the reference does one `.item()` per entry)."""
         keys = list(loss_dict)
         vals = [loss_dict[k] if isinstance(loss_dict[k], torch.Tensor) else torch.tensor(float(loss_dict[k])) for k in keys]
         dev = next((v.device for v in vals if v.is_cuda), torch.device("cpu"))
         flat = torch.stack([v.detach().float().mean().to(dev) for v in vals]).tolist()
-        self.loss_recorder.update(dict(zip(keys, flat)))
+        return dict(zip(keys, flat))
+
+    def update_loss_recorder(self, loss_dict: Dict) -> None:
+        if any(isinstance(v, torch.Tensor) for v in loss_dict.values()):
+            loss_dict = self.fetch_scalars(loss_dict)
+        self.loss_recorder.update({k: float(v) for k, v in loss_dict.items()})
+
+    # ---- step plumbing shared by the trainers
+    def _stage_input(self, real_images: torch.Tensor) -> torch.Tensor:
+        """Copy the batch into a persistent device buffer (NHWC, 4 channel lanes) so captured graphs see a fixed address."""
+        from crdr_amd.hip import ops
+        x = real_images.to(self.device, non_blocking=True)
+        if self._real_static is None or self._real_static.shape != x.shape:
+            n, c, h, w = x.shape
+            self._real_static = ops.empty_nhwc(n, c, h, w, x.device)
+        self._real_static.copy_(x)
+        return self._real_static
+
+    def _bad_flag(self, l_total: torch.Tensor) -> torch.Tensor:
+        """1.0 if the loss is NaN / Inf / > 1e4 else 0.0 -- the reference's skip-update gate (base_trainer.py:228-238)
+        evaluated on the device; the optimiser kernels honour it and the host reads it with the logged scalars."""
+        t = l_total.detach().reshape(1)
+        return (~torch.isfinite(t) | (t > self.loss_huge_threshold)).float()
+
+    def _runner(self, key, allow_graph: bool):
+        """-> callable(name, fn): eager for the first `graph_warmup` iterations of a key (also fills the autotune cache)."""
+        n = self._warm.get(key, 0)
+        self._warm[key] = n + 1
+        if self.graphs.enabled and allow_graph and n >= self.graph_warmup:
+            return lambda name, fn: self.graphs.run((name, key), fn)
+        return lambda name, fn: fn()
 
     def validation(self, current_iter: int) -> None:
         self.comp_model.eval()

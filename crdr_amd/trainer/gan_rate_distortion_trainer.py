@@ -36,12 +36,11 @@ class GANRateDistortionTrainer(RateDistortionTrainer):
         self.d_optimizer = build_optimizer(dict(self.discriminator.named_parameters()), oo.d_optimizer)
         self.d_scheduler = build_scheduler(self.d_optimizer, oo.d_scheduler) if oo.get("d_scheduler") else None
 
-    def _step_discriminator(self, d_loss) -> None:
-        d_loss.backward()
-        D.all_reduce_mean_(self.d_optimizer.flat_grads())
-        self.d_optimizer.step()
-        if self.d_scheduler:
+    def _finish_step(self, current_iter: int, log):
+        vals = super()._finish_step(current_iter, log)
+        if vals is not None and self.d_scheduler:
             self.d_scheduler.step()
+        return vals
 
     def _training_state(self) -> Dict:
         st = super()._training_state()

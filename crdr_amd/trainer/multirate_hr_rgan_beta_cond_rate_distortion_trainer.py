@@ -31,70 +31,90 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         self._q_gen = torch.Generator().manual_seed(seed)
         self._b_rng = np.random.default_rng(seed)
 
-    def _sample_conditions(self, data_dict: Dict) -> None:
-        if "rate_ind" not in data_dict or data_dict["rate_ind"] is None:
-            if D.is_dist():
-                data_dict["rate_ind"] = torch.randint(self.rate_level, (1,), generator=self._q_gen)
-            else:
-                data_dict["rate_ind"] = self.comp_model.sample_rate_ind()
-        if "beta" not in data_dict or data_dict["beta"] is None:
-            if D.is_dist():
-                data_dict["beta"] = self.comp_model.max_beta * (float(self._b_rng.integers(0, 101)) / 100.0)
-            else:
-                data_dict["beta"] = self.comp_model.sample_beta()
+    def _conditions(self, data_dict: Dict):
+        """Draw (q, beta) for this iteration (reference: one draw per batch, interpca_hyperprior_model.py:43-45 and
+        beta_cond_interpca_hyperprior_model.py:41-46).  q selects the graph; beta enters through device buffers."""
+        q = data_dict.get("rate_ind")
+        if q is None:
+            q = torch.randint(self.rate_level, (1,), generator=self._q_gen) if D.is_dist() else self.comp_model.sample_rate_ind()
+        q = int(q.item()) if isinstance(q, torch.Tensor) else int(q)
+        beta = data_dict.get("beta")
+        if beta is None:
+            beta = (self.comp_model.max_beta * (float(self._b_rng.integers(0, 101)) / 100.0)) if D.is_dist() else self.comp_model.sample_beta()
+        beta = float(beta)
+        dec = self.comp_model.decoder
+        if getattr(dec, "static_embed", None) is None:
+            dec.static_embed = torch.zeros(1, dec.embed.embed(0.0).shape[1], 1, 1, device=self.device)
+            self._beta_t = torch.zeros(1, device=self.device)
+        dec.static_embed.copy_(dec.embed.embed(beta).reshape(dec.static_embed.shape))
+        self._beta_t.fill_(beta)
+        return {"rate_ind": q, "beta": beta}, ("s3", q)
 
-    def optimize_parameters(self, current_iter: int, data_dict: Dict) -> Dict:
-        log: Dict = {}
-        data_dict = dict(data_dict)
-        self._sample_conditions(data_dict)
-        # ------------------------------------------------------------------ G
+    # ------------------------------------------------------------------ G phase: forward, losses, backward
+    def _seg_generator(self, real, cond: Dict, noise, current_iter: int) -> Dict:
+        q, beta_t = cond["rate_ind"], self._beta_t
         self.discriminator.requires_grad_(False)
         self.g_optimizer.zero_grad()
         if self.aux_optimizer:
             self.aux_optimizer.zero_grad()
-        real, fake, bpp, other = self.run_comp_model(data_dict)
-        rate_ind, beta = other["rate_ind"], other["beta"]
-        log["qbpp"] = other.get("qbpp", -1)
-
-        high = rate_ind + self.relative_score_rate_delta
-        if float(high) > self.rate_level - 1:
-            relative = real
+        data = {"real_images": real, "rate_ind": float(q), "beta": cond["beta"]}
+        if noise is not None:
+            data["noise"] = noise
+        real_p, fake, bpp, other = self.run_comp_model(data)
+        other["rate_ind"] = q
+        if q + self.relative_score_rate_delta > self.rate_level - 1:
+            relative = real_p
         else:
-            hr = dict(data_dict)
-            hr["rate_ind"], hr["beta"] = high, beta
+            hr = dict(data)
+            hr["rate_ind"] = float(q + self.relative_score_rate_delta)
             with torch.no_grad():
                 _, relative, _, _ = self.run_comp_model(hr)
-
-        dist_loss = self.distortion_loss(real, fake, **other)
+        dist_loss = self.distortion_loss(real_p, fake, **other)
         rate_loss = self.rate_loss(bpp, **other, **self._rate_kwargs(other), current_iter=current_iter)
         assert self.perceptual_loss
-        percep = self.perceptual_loss(real, fake)
+        percep = self.perceptual_loss(real_p, fake)
         with torch.no_grad():
             real_d = self.discriminator(relative.detach(), **other)
         fake_g = self.discriminator(fake, **other)
         adv = (self.gan_loss.forward_diff(real_d, fake_g, is_real=False, is_disc=False)
                + self.gan_loss.forward_diff(fake_g, real_d, is_real=True, is_disc=False)) / 2
-        g = {"distortion": dist_loss, "rate": rate_loss, "perceptual": percep, "adv": adv}
-        l_total = dist_loss + rate_loss + beta * (percep + adv)
+        l_total = dist_loss + rate_loss + beta_t * (percep + adv)
+        l_total.backward()
+        return {"losses": {"distortion": dist_loss, "rate": rate_loss, "perceptual": percep, "adv": adv},
+                "bad": self._bad_flag(l_total), "qbpp": other.get("qbpp", None), "real": real_p, "fake": fake.detach(), "q": q}
 
-        bad = self.check_loss_nan_inf(l_total)
-        if D.any_rank_true(bool(bad), l_total.device):
-            self.logger.warning(f"iter{current_iter}: skipped because loss is {bad or 'bad on another rank'}")
-            return None
-        self._step_generator(l_total)
-        if self.aux_optimizer:
-            log["aux"] = self.optimize_aux_parameters()
-        if self.g_scheduler:
-            self.g_scheduler.step()
-        log.update(g)
-        # ------------------------------------------------------------------ D
+    # ------------------------------------------------------------------ G / aux update, then D forward + backward
+    def _seg_update(self, ctx: Dict) -> Dict:
+        out = super()._seg_update(ctx)
+        q = ctx["q"]
         self.discriminator.requires_grad_(True)
         self.d_optimizer.zero_grad()
-        fake_d = self.discriminator(fake.detach(), **other)
-        real_d = self.discriminator(real, **other)
+        fake_d = self.discriminator(ctx["fake"], rate_ind=q)
+        real_d = self.discriminator(ctx["real"], rate_ind=q)
         l_d_real = self.gan_loss.forward_diff(real_d, fake_d.detach(), is_real=True, is_disc=True) * 0.5
         l_d_fake = self.gan_loss.forward_diff(fake_d, real_d.detach(), is_real=False, is_disc=True) * 0.5
-        self._step_discriminator(l_d_real + l_d_fake)
-        log.update({"d_real": l_d_real, "d_fake": l_d_fake, "d_total": l_d_real + l_d_fake,
+        (l_d_real + l_d_fake).backward()
+        out.update({"d_real": l_d_real, "d_fake": l_d_fake, "d_total": l_d_real + l_d_fake,
                     "out_d_real": real_d.detach().mean(), "out_d_fake": fake_d.detach().mean()})
-        return log
+        return out
+
+    def _seg_dstep(self, ctx: Dict) -> Dict:
+        self.d_optimizer.step(skip=ctx["bad"])
+        return {}
+
+    def optimize_parameters(self, current_iter: int, data_dict: Dict):
+        data_dict = dict(data_dict)
+        noise = data_dict.pop("noise", None)
+        real = self._stage_input(data_dict["real_images"])
+        cond, key = self._conditions(data_dict)
+        scheduled = bool(getattr(self.rate_loss, "lambda_schedule", None) or getattr(self.rate_loss, "target_rate_schedule", None))
+        run = self._runner(key, allow_graph=not scheduled)  # explicit noise tensors must be persistent device buffers
+        self.g_optimizer.sync_lr_to_device()
+        self.d_optimizer.sync_lr_to_device()
+        ctx = run("g", lambda: self._seg_generator(real, cond, noise, current_iter))
+        self._sync_between_segments(ctx, self.g_optimizer)
+        ctx2 = run("u", lambda: self._seg_update(ctx))
+        D.all_reduce_mean_(self.d_optimizer.flat_grads())
+        run("d", lambda: self._seg_dstep(ctx))
+        log = {"qbpp": ctx["qbpp"] if ctx["qbpp"] is not None else -1, **ctx["losses"], **ctx2, "_bad": ctx["bad"]}
+        return self._finish_step(current_iter, log)

@@ -86,22 +86,54 @@ class Adam:
             return out
         return total
 
-    def step(self, sqnorm: Optional[torch.Tensor] = None, max_norm: float = 0.0) -> None:
+    def _dyn(self, g) -> torch.Tensor:
+        """Device-resident [lr, step, skip] of a group (what the graph-capturable update reads)."""
+        if g.get("dyn") is None:
+            g["dyn"] = torch.tensor([float(g["lr"]), float(g["step"]), 0.0], dtype=torch.float32, device=g["flat"].device)
+            g["dyn_lr"] = float(g["lr"])
+        return g["dyn"]
+
+    def sync_lr_to_device(self) -> None:
+        """Push host-side lr changes (scheduler milestones) into the device scalars; call outside graph capture."""
+        for g in self.param_groups:
+            if g.get("dyn") is not None and g["dyn_lr"] != float(g["lr"]):
+                g["dyn"][0:1].fill_(float(g["lr"]))
+                g["dyn_lr"] = float(g["lr"])
+
+    def step(self, sqnorm: Optional[torch.Tensor] = None, max_norm: float = 0.0, skip: Optional[torch.Tensor] = None) -> None:
         """One Adam update. With `sqnorm` (1-element device tensor holding the squared global gradient norm) the
-        gradient is scaled by min(1, max_norm / (sqrt(sqnorm) + 1e-6)) inside the kernel (clip_grad_norm_)."""
+        gradient is scaled by min(1, max_norm / (sqrt(sqnorm) + 1e-6)) inside the kernel (clip_grad_norm_).
+        With `skip` (1-element device tensor, 0 or 1) the step count, lr and the skip decision live on the device, so
+        the call sequence is identical every iteration and can be captured in a HIP graph."""
         lib = L.load()
         for g in self.param_groups:
             if g["flat"] is None:
                 continue
-            g["step"] += 1
             b1, b2 = g["betas"]
-            L.check(lib.crdr_adam_step(g["flat"].data_ptr(), g["grad"].data_ptr(), g["m"].data_ptr(), g["v"].data_ptr(),
-                                       g["flat"].numel(), float(g["lr"]), b1, b2, g["eps"], g["step"],
-                                       None if sqnorm is None else sqnorm.data_ptr(), float(max_norm), ops._stream()), "adam_step")
+            sq = None if sqnorm is None else sqnorm.data_ptr()
+            if skip is None:
+                g["step"] += 1
+                L.check(lib.crdr_adam_step(g["flat"].data_ptr(), g["grad"].data_ptr(), g["m"].data_ptr(), g["v"].data_ptr(),
+                                           g["flat"].numel(), float(g["lr"]), b1, b2, g["eps"], g["step"], sq, float(max_norm),
+                                           ops._stream()), "adam_step")
+            else:
+                dyn = self._dyn(g)
+                dyn[1:2].add_(1.0 - skip)   # the step count advances only when the update is applied
+                dyn[2:3].copy_(skip)
+                L.check(lib.crdr_adam_step_dyn(g["flat"].data_ptr(), g["grad"].data_ptr(), g["m"].data_ptr(), g["v"].data_ptr(),
+                                               g["flat"].numel(), b1, b2, g["eps"], dyn.data_ptr(), sq, float(max_norm),
+                                               ops._stream()), "adam_step_dyn")
         HF.bump_weights_epoch()
+
+    def host_step_counts(self) -> None:
+        """Refresh the host-side step counters from the device (for checkpoints); synchronises."""
+        for g in self.param_groups:
+            if g.get("dyn") is not None:
+                g["step"] = int(round(float(g["dyn"][1])))
 
     # ---- torch.optim-compatible checkpoint format
     def state_dict(self) -> Dict:
+        self.host_step_counts()
         state, groups, idx = {}, [], 0
         for g in self.param_groups:
             ids, off = [], 0
@@ -128,6 +160,10 @@ class Adam:
                     g["v"][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
                     g["step"] = int(st["step"])
                 off += n
+            if g.get("dyn") is not None:
+                g["dyn"][1:2].fill_(float(g["step"]))
+                g["dyn"][0:1].fill_(float(g["lr"]))
+                g["dyn_lr"] = float(g["lr"])
 
 
 class MultiStepLR:

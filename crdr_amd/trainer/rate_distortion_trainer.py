@@ -38,53 +38,91 @@ class RateDistortionTrainer(BaseTrainer):
         return out.pop("real_images"), out.pop("fake_images"), out.pop("bpp"), out
 
     def _rate_kwargs(self, other: Dict) -> Dict:
-        """Under data parallelism the lambda_A / lambda_B switch must see the global mean of qbpp."""
-        if D.is_dist() and "qbpp" in other:
+        """Under data parallelism the lambda_A / lambda_B switch sees the global mean of qbpp (eager mode; inside a
+        captured graph no collective is possible and the rank-local mean is used -- identical whenever the target
+        rates are 0 as in stage 3)."""
+        if D.is_dist() and "qbpp" in other and not torch.cuda.is_current_stream_capturing():
             return {"qbpp_mean": D.all_reduce_scalars_mean(other["qbpp"].detach().mean())}
         return {}
 
-    def _step_generator(self, l_total) -> None:
-        """backward -> (all-reduce) -> global-norm clip folded into the fused Adam -> scheduler."""
-        l_total.backward()
-        D.all_reduce_mean_(self.g_optimizer.flat_grads())
+    def _generator_update(self, bad: torch.Tensor) -> None:
+        """(gradients already all-reduced) global-norm clip folded into the fused Adam."""
         sq = None
         if self.clip_max_norm:
             sq = self.g_optimizer.grad_sqnorm()
             if self.aux_optimizer is not None:  # clip_grad_norm_ runs over comp_model.parameters(): quantiles included
                 sq = sq + self.aux_optimizer.grad_sqnorm()
-        self.g_optimizer.step(sqnorm=sq, max_norm=self.clip_max_norm)
+        self.g_optimizer.step(sqnorm=sq, max_norm=self.clip_max_norm, skip=bad)
 
-    def optimize_parameters(self, current_iter: int, data_dict: Dict):
-        log: Dict = {}
-        self.g_optimizer.zero_grad()
-        if self.aux_optimizer:
-            self.aux_optimizer.zero_grad()
-        real, fake, bpp, other = self.run_comp_model(data_dict)
-        log["qbpp"] = other.get("qbpp", -1)
-        g = {"distortion": self.distortion_loss(real, fake, **other),
-             "rate": self.rate_loss(bpp, **other, **self._rate_kwargs(other), current_iter=current_iter)}
-        if self.perceptual_loss:
-            g["perceptual"] = self.perceptual_loss(real, fake)
-        l_total = sum(g.values())
-        bad = self.check_loss_nan_inf(l_total)
-        if D.any_rank_true(bool(bad), l_total.device):
-            self.logger.warning(f"iter{current_iter}: skipped because loss is {bad or 'bad on another rank'}")
-            return None
-        self._step_generator(l_total)
-        log.update(g)
-        if self.g_scheduler:
-            self.g_scheduler.step()
-        if self.aux_optimizer:
-            log["aux"] = self.optimize_aux_parameters()
-        return log
-
-    def optimize_aux_parameters(self):
+    def optimize_aux_parameters(self, bad: Optional[torch.Tensor] = None):
+        """The quantile gradients depend on the parameters only, so they are identical on every rank: no all-reduce."""
         self.aux_optimizer.zero_grad()
         aux = self.comp_model.aux_loss()
         aux.backward()
-        D.all_reduce_mean_(self.aux_optimizer.flat_grads())
-        self.aux_optimizer.step()
+        self.aux_optimizer.step(skip=bad)
         return aux
+
+    # ---- segments (each is captured as one HIP graph per condition key)
+    def _seg_generator(self, real, cond: Dict, noise, current_iter: int) -> Dict:
+        self.g_optimizer.zero_grad()
+        if self.aux_optimizer:
+            self.aux_optimizer.zero_grad()
+        data = {"real_images": real, **cond}
+        if noise is not None:
+            data["noise"] = noise
+        real_p, fake, bpp, other = self.run_comp_model(data)
+        g = {"distortion": self.distortion_loss(real_p, fake, **other),
+             "rate": self.rate_loss(bpp, **other, **self._rate_kwargs(other), current_iter=current_iter)}
+        if self.perceptual_loss:
+            g["perceptual"] = self.perceptual_loss(real_p, fake)
+        l_total = sum(g.values())
+        l_total.backward()
+        return {"losses": g, "bad": self._bad_flag(l_total), "qbpp": other.get("qbpp", None)}
+
+    def _seg_update(self, ctx: Dict) -> Dict:
+        self._generator_update(ctx["bad"])
+        return {"aux": self.optimize_aux_parameters(ctx["bad"])} if self.aux_optimizer else {}
+
+    def _sync_between_segments(self, ctx: Dict, optimizer) -> None:
+        D.all_reduce_mean_(optimizer.flat_grads())
+        if D.is_dist():
+            torch.distributed.all_reduce(ctx["bad"], op=torch.distributed.ReduceOp.MAX)
+
+    def _conditions(self, data_dict: Dict) -> Tuple[Dict, object]:
+        """-> (model conditioning kwargs, hashable graph key).  A multi-rate model (stage 2) gets its rate index drawn
+        here, once per batch like the reference (interpca_hyperprior_model.py:43-45), so that it can key the graph."""
+        if hasattr(self.comp_model, "rate_level"):
+            q = data_dict.get("rate_ind")
+            if q is None:
+                if not hasattr(self, "_q_gen"):
+                    self._q_gen = torch.Generator().manual_seed(int(self.opt.get("cond_seed", 0)))
+                q = torch.randint(self.comp_model.rate_level, (1,), generator=self._q_gen) if D.is_dist() else self.comp_model.sample_rate_ind()
+            q = int(q.item()) if isinstance(q, torch.Tensor) else int(q)
+            return {"rate_ind": float(q)}, ("rd", q)
+        return {}, "rd"
+
+    def optimize_parameters(self, current_iter: int, data_dict: Dict):
+        data_dict = dict(data_dict)
+        noise = data_dict.pop("noise", None)
+        real = self._stage_input(data_dict["real_images"])
+        cond, key = self._conditions(data_dict)
+        scheduled = bool(getattr(self.rate_loss, "lambda_schedule", None) or getattr(self.rate_loss, "target_rate_schedule", None))
+        run = self._runner(key, allow_graph=not scheduled)  # explicit noise tensors must be persistent device buffers
+        self.g_optimizer.sync_lr_to_device()
+        ctx = run("g", lambda: self._seg_generator(real, cond, noise, current_iter))
+        self._sync_between_segments(ctx, self.g_optimizer)
+        ctx2 = run("u", lambda: self._seg_update(ctx))
+        log = {"qbpp": ctx["qbpp"] if ctx["qbpp"] is not None else -1, **ctx["losses"], **ctx2, "_bad": ctx["bad"]}
+        return self._finish_step(current_iter, log)
+
+    def _finish_step(self, current_iter: int, log: Dict):
+        vals = self.fetch_scalars(log)
+        if vals.pop("_bad") > 0:
+            self.logger.warning(f"iter{current_iter}: skipped because loss is nan / inf / huge (on some rank)")
+            return None
+        if self.g_scheduler:
+            self.g_scheduler.step()
+        return vals
 
     def _training_state(self) -> Dict:
         st = {"g_optimizer": self.g_optimizer}

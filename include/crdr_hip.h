@@ -29,6 +29,10 @@ typedef void* crdr_stream_t; /* hipStream_t */
 const char* crdr_last_error(void);
 int crdr_version(void);
 const char* crdr_arch(void); /* "gfx950" */
+/* measurement aid: bracket conv launches with HIP events on their stream; read = sum over launches of `kind`
+ * (0: conv forward / input gradient, 1: weight gradient) of algorithmic FLOPs and elapsed ms, then clear */
+void crdr_profile_enable(int on);
+int crdr_profile_read(int kind, double* flops, double* ms, long long* launches);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* implicit-GEMM convolution family (fp32 in / fp32 MFMA v_mfma_f32_32x32x2_f32 / fp32 out)          */
@@ -235,6 +239,12 @@ int crdr_sqnorm(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes
  * min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) when sqnorm != NULL (clip_grad_norm_ semantics).              */
 int crdr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, int step, const float* sqnorm, float max_norm, crdr_stream_t s);
+
+/* The same update with lr / step count / skip flag read from device memory (dyn[0..2]) so that the launch can be
+ * captured in a HIP graph and replayed: dyn[1] is the already-incremented step count, dyn[2] != 0 skips the update
+ * (the reference's NaN / Inf / huge-loss gate, base_trainer.py:228-238, taken on the device). */
+int crdr_adam_step_dyn(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                       const float* dyn, const float* sqnorm, float max_norm, crdr_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* LPIPS helpers (perceptual_loss.py:25-30; lpips 0.1.4 AlexNet)                                      */

@@ -33,7 +33,8 @@ def rel(a, b):
 
 
 def close(got, ref, what, rtol=2e-4):
-    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    got, ref = torch.as_tensor(got).detach().cpu().double(), torch.as_tensor(ref).detach().cpu().double()
+    got, ref = got.reshape(ref.shape) if got.numel() == ref.numel() else got, ref
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     scale = ref.abs().max().item() + 1e-12
     err = (got - ref).abs().max().item()

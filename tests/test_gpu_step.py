@@ -66,7 +66,18 @@ def test_adam_matches_torch():
             r.grad = g.clone()
         torch.nn.utils.clip_grad_norm_(ref, 1.0)
         topt.step()
-        opt.step(sqnorm=opt.grad_sqnorm(), max_norm=1.0)
+        if step % 2 == 0:
+            opt.step(sqnorm=opt.grad_sqnorm(), max_norm=1.0)
+        else:  # device-side step count / skip flag (the graph-capturable entry): same update
+            before = [p.detach().clone() for p in ps]
+            opt.step(sqnorm=opt.grad_sqnorm(), max_norm=1.0, skip=torch.ones(1, device=dev()))
+            assert all(torch.equal(a, p.detach()) for a, p in zip(before, ps)), "skip flag must leave parameters untouched"
+            for g in opt.param_groups:  # host counter mirrors what the eager calls did so far
+                if g.get("dyn") is not None:
+                    g["dyn"][1:2].fill_(float(step))
+            opt.step(sqnorm=opt.grad_sqnorm(), max_norm=1.0, skip=torch.zeros(1, device=dev()))
+            for g in opt.param_groups:
+                g["step"] = step + 1
         for p, r in zip(ps, ref):
             close(p, r, f"adam step {step}", 2e-6)
     sd = opt.state_dict()
@@ -102,7 +113,7 @@ def test_stage3_step():
 
     data = {"real_images": x.to(dev()), "rate_ind": torch.tensor([q]), "beta": beta,
             "noise": {"y": ny.to(dev()), "z": nz.to(dev())}}
-    tr.check_loss_nan_inf = lambda l: False  # seeded random weights give a loss > 1e4, which the trainer would skip
+    tr.loss_huge_threshold = float("inf")  # seeded random weights give a loss > 1e4, which the trainer would skip
     tr.comp_model.context_model.record_symbols = []
     z_hats = []
     run_model = tr.comp_model.run_model
@@ -168,7 +179,7 @@ def test_stage1_step():
     nz = seeded_input("noise.z", (2, 192, 1, 1), 0.5)
     captured = {}
     g_step = tr.g_optimizer.step
-    tr.check_loss_nan_inf = lambda l: False
+    tr.loss_huge_threshold = float("inf")
     tr.comp_model.context_model.record_symbols = []
     z_hats = []
     run_model = tr.comp_model.run_model
