@@ -145,7 +145,7 @@ def test_stage3_step():
     for k in ("d_real", "d_fake"):
         close(log[k], d_losses[k], f"loss {k}", 3e-4)
     close(log["aux"], O.eb_aux_loss(sd_g, "entropy_model_z"), "aux loss", 1e-4)
-    close(log["qbpp"], out["qbpp"], "qbpp", 1e-4)
+    close(log["qbpp"], out["qbpp"].mean(), "qbpp", 1e-4)
 
     def cmp(cap_d, ref_sd, what, only=None, tol=5e-3):
         bad = []
