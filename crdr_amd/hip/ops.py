@@ -87,11 +87,28 @@ def workspace(nbytes: int, device) -> Tuple[int, int]:
     _ws_max = max(_ws_max, int(nbytes))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            # a buffer born inside a capture would belong to that graph's private pool and die with it
+            raise L.CrdrHipError("workspace must be reserved before graph capture (ops.reserve_workspace); "
+                                 f"need {nbytes} bytes, have {0 if buf is None else buf.numel()}")
         if buf is not None:
             _ws_keep.append(buf)
         buf = torch.empty(max(int(_ws_max * 1.25), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf.data_ptr(), buf.numel()
+
+
+def reserve_workspace(device, stream: "torch.cuda.Stream") -> None:
+    """Give `stream` its scratch buffer from the ordinary allocator, sized for the largest request seen so far
+    (eager warm-up).  Call before capturing a graph on that stream."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream.cuda_stream)
+    buf = _ws_cache.get(key)
+    need = max(int(_ws_max * 1.25), 1 << 20)
+    if buf is None or buf.numel() < need:
+        if buf is not None:
+            _ws_keep.append(buf)
+        _ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=dev)
 
 
 def _require_gpu(t: torch.Tensor):

@@ -16,6 +16,7 @@ from typing import Callable, Dict, Hashable
 import torch
 
 from crdr_amd.hip import functional as HF
+from crdr_amd.hip import ops
 
 
 class SegmentGraphs:
@@ -34,6 +35,7 @@ class SegmentGraphs:
         if g is None:
             HF.bump_weights_epoch()  # packs cached by earlier captures belong to those graphs; re-derive inside this one
             g = torch.cuda.CUDAGraph()
+            ops.reserve_workspace(torch.cuda.current_device(), self._stream)
             torch.cuda.synchronize()
             with torch.cuda.graph(g, pool=self._pool, stream=self._stream):
                 out = fn()
