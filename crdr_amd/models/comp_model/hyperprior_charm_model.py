@@ -73,9 +73,10 @@ class HyperpriorCharmModel(BaseModel):
         z_hat, z_lik, z_bits = self.entropy_model_z(z, is_train=is_train, noise=noise.get("z"), want_bits=True)
         hyper_out = self.hyperdecoder(z_hat)
         want_lik = self.return_likelihoods or not is_train
+        yb: Dict = {}
         y_hat, y_lik, y_qlik = self.context_model(y, hyper_out, self.entropy_model_y, is_train=is_train,
-                                                  calc_q_likelihood=True, noise=noise.get("y"), want_lik=want_lik)
-        y_bits, y_qbits = self.context_model.last_bits
+                                                  calc_q_likelihood=True, noise=noise.get("y"), want_lik=want_lik, bits_out=yb)
+        y_bits, y_qbits = yb["y"], yb["y_q"]
         fake = self._decode(y_hat, **cond)
         if not is_train:
             fake = torch.clamp(fake, min=-1.0, max=1.0)

@@ -65,9 +65,10 @@ class Minnen20CharmContextModel(BaseContextModel):
         return hats if self.max_support_slices < 0 else hats[: self.max_support_slices]
 
     def forward(self, y: Tensor, hyper_out: Tensor, entropy_model_y, is_train: bool, calc_q_likelihood: bool = True,
-                noise: Tensor = None, want_lik: bool = True):
+                noise: Tensor = None, want_lik: bool = True, bits_out: Dict = None):
         """-> (y_hat, y_likelihood, y_q_likelihood) like the reference; the per-image bit sums produced by the
-        fused kernel are left in `self.last_bits = (bits_noisy_or_quant[N], bits_quant[N])`."""
+        fused kernel are returned through `bits_out["y"], bits_out["y_q"]` when a dict is passed (nothing that carries
+        an autograd graph is kept on the module)."""
         ys = torch.chunk(y, self.num_slices, dim=1)
         h_mu, h_sc = torch.chunk(hyper_out, 2, dim=1)
         ns = None if noise is None else torch.chunk(noise, self.num_slices, dim=1)
@@ -90,7 +91,8 @@ class Minnen20CharmContextModel(BaseContextModel):
             qliks.append(lq)
             z = self.lrp_slice_transforms[i](torch.cat([mean_support, yh], dim=1))
             hats.append(HF.lrp(yh, z))
-        self.last_bits = (bits, bits_q)
+        if bits_out is not None:
+            bits_out["y"], bits_out["y_q"] = bits, bits_q
         y_hat = torch.cat(hats, dim=1)
         if not want_lik:
             return (y_hat, None, None) if calc_q_likelihood else (y_hat, None)

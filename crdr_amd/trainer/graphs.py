@@ -27,6 +27,16 @@ class SegmentGraphs:
         self._pool = None
         self._stream = torch.cuda.Stream() if self.enabled else None
 
+    @property
+    def stream(self):
+        return self._stream
+
+    def step_scope(self):
+        """Context manager for one training iteration: with graphs enabled ALL work of the trainer -- eager warm-up
+        and capture alike -- is issued on one dedicated stream, so autograd nodes that outlive an iteration (gradient
+        accumulators) never belong to a different stream than the capture."""
+        return _StepScope(self._stream) if self.enabled else _Null()
+
     def run(self, key: Hashable, fn: Callable[[], object]):
         """Run `fn` eagerly (graphs disabled) or through its captured graph (captured on first use)."""
         if not self.enabled:
@@ -47,3 +57,27 @@ class SegmentGraphs:
 
     def __len__(self):
         return len(self._graphs)
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _StepScope:
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self.ctx.__exit__(*a)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return False

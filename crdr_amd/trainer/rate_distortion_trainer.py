@@ -102,6 +102,10 @@ class RateDistortionTrainer(BaseTrainer):
         return {}, "rd"
 
     def optimize_parameters(self, current_iter: int, data_dict: Dict):
+        with self.graphs.step_scope():
+            return self._optimize_parameters(current_iter, data_dict)
+
+    def _optimize_parameters(self, current_iter: int, data_dict: Dict):
         data_dict = dict(data_dict)
         noise = data_dict.pop("noise", None)
         real = self._stage_input(data_dict["real_images"])
