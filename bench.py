@@ -37,7 +37,7 @@ def build_trainer(stage: int, bs: int, size: int, device: str, graphs: bool = Tr
     return _bt(ConfigDict(cfg))
 
 
-def cpu_baseline(stage: int, size: int, budget_s: float = 25.0):
+def _cpu_baseline_worker(stage: int, size: int, threads: int, budget_s: float) -> dict:
     """The oracle's training step (same losses, fwd + bwd for G and D) in stock torch on the host cores."""
     import torch
     from oracle import crdr_oracle as O
@@ -48,8 +48,7 @@ def cpu_baseline(stage: int, size: int, budget_s: float = 25.0):
     cfg, _, _ = BaseConfig._file2dict_yaml(os.path.join(ROOT, "config", f"crdr_stage_{stage}.yaml"))
     cfg["device"] = "cpu"
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     g = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in build_comp_model(ConfigDict(cfg)).state_dict().items() if v.numel() > 0}
     lp = {"lpips." + k: v.detach() for k, v in LpipsAlex().state_dict().items()}
     n = 1
@@ -71,12 +70,31 @@ def cpu_baseline(stage: int, size: int, budget_s: float = 25.0):
     step()  # warm-up (allocations, oneDNN primitive creation)
     warm = time.time() - t0
     t0, k = time.time(), 0
-    while k == 0 or (time.time() - t0 < budget_s - warm and k < 8):
+    while k == 0 or (time.time() - t0 + warm < budget_s and k < 8):
         step()
         k += 1
     dt = (time.time() - t0) / k
-    return {"value": round(n / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (stock torch fp32, oneDNN) stage-{stage} step at N={n}, {size}x{size}, q=2: {k} timed iteration(s) after 1 warm-up"}
+    return {"value": round(n / dt, 4), "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (stock torch fp32, oneDNN, {threads} threads) stage-{stage} step at N={n}, {size}x{size}, q=2: "
+                      f"{k} timed iteration(s) after 1 warm-up ({warm:.1f} s)"}
+
+
+def cpu_baseline(stage: int, size: int, budget_s: float = 25.0, hard_timeout_s: float = 240.0) -> dict:
+    """Runs the worker in a child process (bounded wall time; the GPU process is not disturbed by its threads)."""
+    import subprocess
+    threads = max(1, min(os.cpu_count() or 1, 32))
+    code = (f"import json,sys; sys.path.insert(0, {ROOT!r}); import bench; "
+            f"print('CPUBASE ' + json.dumps(bench._cpu_baseline_worker({stage}, {size}, {threads}, {budget_s})))")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=hard_timeout_s, env=env)
+        for line in r.stdout.splitlines():
+            if line.startswith("CPUBASE "):
+                return json.loads(line[8:])
+        return {"value": None, "unit": "img/s", "cores": threads, "kind": "port", "sample": "worker failed: " + r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "img/s", "cores": threads, "kind": "port",
+                "sample": f"one stage-{stage} oracle step at N=1 did not finish within {hard_timeout_s:.0f} s on {threads} threads"}
 
 
 def main():

@@ -44,6 +44,7 @@ struct IgemmArgs {
   int kchunks;
   int ws_ld;  // columns of a partial slab row (= gridDim.y * BN)
   int vec_epi;  // 1: y / res / gx / gt / sig rows are 16-byte aligned -> vector epilogue
+  int smallc;   // 1: Cin <= 4 and the weight pack is tap-major ([rows][taps*4]): a K-tile covers 8 taps x 4 channels
 };
 
 // Tap / phase tables travel as a second by-value kernel argument that is only ever indexed with wave-uniform
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int phase = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
   const int tb = tp.tap_begin[phase], te = tp.tap_begin[phase + 1];
-  const int KT = (te - tb) * p.kchunks;
+  const int KT = p.smallc ? p.kchunks : (te - tb) * p.kchunks;
   const int it0 = (int)((long long)KT * split / p.nsplit), it1 = (int)((long long)KT * (split + 1) / p.nsplit);
   const int poh = tp.poh[phase], pow_ = tp.pow[phase];
   const int H = p.H, W = p.W, ldx = p.ldx, Cin = p.Cin, kchunks = p.kchunks;
@@ -130,16 +131,31 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
   __syncthreads();  // sTap visible
 
   // K-iteration cursor of the NEXT tile to load: tap index (relative to tb) and channel chunk
-  int lt = it0 / kchunks, lc = it0 - lt * kchunks;
+  const bool smallc = p.smallc != 0;
+  int lt = smallc ? 0 : it0 / kchunks, lc = smallc ? it0 : it0 - lt * kchunks;
+  const int ntap = te - tb;
   f32x4 ra[AV], rb[BV];
   unsigned ra_mask = 0;
   auto load_tile = [&]() __attribute__((always_inline)) {
-    const int tp = __builtin_amdgcn_readfirstlane(sTap[lt]);
-    const int dh = (int)(signed char)(tp & 0xff), dw = (int)(signed char)((tp >> 8) & 0xff), wi = tp >> 16;
-    const int c0 = lc * 32 + chunk * 4;
-    const bool cok = c0 < Cin;
-    const int c0c = cok ? c0 : 0;
-    const size_t woff = (size_t)wi * p.wrows * p.wcols + (size_t)(lc * 32);
+    int dh, dw, c0c;
+    bool cok;
+    size_t woff;
+    if (smallc) {  // this thread's 16-byte chunk is tap (8 lc + chunk), channels 0..3
+      const int ti = lc * 8 + chunk;
+      cok = ti < ntap;
+      const int tp = sTap[cok ? ti : 0];
+      dh = (int)(signed char)(tp & 0xff); dw = (int)(signed char)((tp >> 8) & 0xff);
+      c0c = 0;
+      woff = (size_t)(lc * 32);
+    } else {
+      const int tp = __builtin_amdgcn_readfirstlane(sTap[lt]);
+      dh = (int)(signed char)(tp & 0xff); dw = (int)(signed char)((tp >> 8) & 0xff);
+      const int wi = tp >> 16;
+      const int c0 = lc * 32 + chunk * 4;
+      cok = c0 < Cin;
+      c0c = cok ? c0 : 0;
+      woff = (size_t)wi * p.wrows * p.wcols + (size_t)(lc * 32);
+    }
     unsigned mask = 0;
 #pragma unroll
     for (int j = 0; j < AV; ++j) {
@@ -152,7 +168,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
 #pragma unroll
     for (int j = 0; j < BV; ++j) rb[j] = *reinterpret_cast<const f32x4*>(b_ptr[j] + woff);
     ra_mask = mask;
-    if (++lc == kchunks) { lc = 0; ++lt; }
+    if (++lc == kchunks && !smallc) { lc = 0; ++lt; }
   };
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
     float* a = sA + buf * BM * 32;
@@ -389,7 +405,10 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
   a.OH = d->OH; a.OW = d->OW; a.ldy = d->ldy; a.Cout = d->OC;
   a.wrows = d->wrows; a.wcols = d->wcols;
   a.ldres = d->ldres; a.ldg = d->ldg; a.flags = d->flags;
-  a.kchunks = cdiv(d->C, 32);
+  a.smallc = d->wlayout == 1;
+  CRDR_REQUIRE(!a.smallc || (!d->transposed && d->C <= 4 && d->wcols >= 4 * d->kh * d->kw),
+               "conv2d: tap-major weight layout needs a non-transposed conv with C <= 4 and wcols >= 4*taps");
+  a.kchunks = a.smallc ? cdiv(d->kh * d->kw, 8) : cdiv(d->C, 32);
   const int S = d->stride, P = d->pad;
   int nt = 0;
   if (!d->transposed) {
@@ -423,7 +442,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
   // ---- choose tile config + split-K with a small cost model (MFMA cycles per block x waves of blocks)
   int maxtaps = 0;
   for (int ph = 0; ph < a.nphase; ++ph) maxtaps = std::max(maxtaps, (int)(tp.tap_begin[ph + 1] - tp.tap_begin[ph]));
-  const int KT = maxtaps * a.kchunks;
+  const int KT = a.smallc ? a.kchunks : maxtaps * a.kchunks;
   double best = 1e300; int bc = -1, bs = 1;
   for (int c = 0; c < kNumCfgs; ++c) {
     const TileCfg& t = kCfgs[c];

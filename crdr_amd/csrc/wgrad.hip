@@ -186,6 +186,17 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, floa
   }
 }
 
+// tap-major pack for C <= 4 inputs: dst[i][t*4 + j] <- src[i][j][t]   (one "tap" of rows x cols, cols >= 4*T)
+__global__ __launch_bounds__(256) void pack_weight_tapmajor_kernel(const float* src, float* dst, int I, int J, int T,
+                                                                   int rows, int cols) {
+  const long long total = (long long)rows * cols;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int c = (int)(e % cols), r = (int)(e / cols);
+    const int t = c >> 2, j = c & 3;
+    dst[e] = (r < I && j < J && t < T) ? src[((size_t)r * J + j) * T + t] : 0.f;
+  }
+}
+
 struct WCfg {
   int wm, wn, mb, nb;
   void (*kern)(const WgradArgs);
@@ -314,6 +325,14 @@ extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const
 extern "C" int crdr_pack_weight(const float* src, float* dst, int I, int J, int T, int rows, int cols, int transpose,
                                 crdr_stream_t s) {
   CRDR_REQUIRE(src && dst, "pack_weight: null pointer");
+  if (transpose == 2) {
+    CRDR_REQUIRE(J <= 4 && rows >= I && cols >= 4 * T, "pack_weight: tap-major pack needs J <= 4, rows >= I, cols >= 4*T");
+    const long long tot = (long long)rows * cols;
+    hipLaunchKernelGGL(pack_weight_tapmajor_kernel, dim3((int)std::min<long long>(cdiv64(tot, 256), 8192)), dim3(256), 0,
+                       as_stream(s), src, dst, I, J, T, rows, cols);
+    CRDR_CHECK_LAUNCH("pack_weight_tapmajor");
+    return 0;
+  }
   CRDR_REQUIRE(rows >= (transpose ? J : I) && cols >= (transpose ? I : J), "pack_weight: pack smaller than source");
   const long long total = (long long)T * rows * cols;
   const int blocks = (int)std::min<long long>(cdiv64(total, 256), 8192);

@@ -36,6 +36,7 @@ class ConvSpec:
         self.in_ch, self.out_ch, self.k = in_ch, out_ch, (k, k) if isinstance(k, int) else tuple(k)
         self.stride, self.pad, self.transposed, self.out_pad = stride, pad, transposed, out_pad
         self._packs = {}
+        self.smallc = (not transposed) and in_ch <= 4  # RGB-input convs use the tap-major forward pack
 
     def out_hw(self, h, w):
         return (ops.conv_out_size(h, self.k[0], self.stride, self.pad, self.transposed, self.out_pad),
@@ -49,7 +50,7 @@ class ConvSpec:
         if hit is not None and hit[0] == key:
             return hit[1]
         w4 = weight if weight.dim() == 4 else weight.reshape(weight.shape[0], weight.shape[1], 1, 1)
-        pk = ops.pack_weight(w4.detach(), transpose)
+        pk = ops.pack_weight_tapmajor(w4.detach()) if (self.smallc and not for_dgrad) else ops.pack_weight(w4.detach(), transpose)
         self._packs[transpose] = (key, pk)
         return pk
 
@@ -84,7 +85,7 @@ class _FusedConv(torch.autograd.Function):
         sig = ops.empty_nhwc(n, spec.out_ch, oh, ow, x.device) if gx is not None else None
         out = ops.conv2d_raw(x, spec.pack(weight, False), spec.out_ch, spec.k, spec.stride, spec.pad, spec.transposed,
                              (oh, ow), bias=bias, flags=flags, vec2=vec2, res=res, scale=scale, shift=shift,
-                             gate_x=gx, gate_t=gt, sig_out=sig)
+                             gate_x=gx, gate_t=gt, sig_out=sig, wlayout=1 if spec.smallc else 0)
         ctx.spec, ctx.flags, ctx.in_hw = spec, flags, (h, w)
         ctx.has = (bias is not None, vec2 is not None, res is not None, scale is not None, gx is not None)
         need_out = flags & (L.EPI_RELU | L.EPI_LRELU | L.EPI_AFFINE)

@@ -21,7 +21,7 @@ c_void_p = C.c_void_p
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "C", "OH", "OW", "OC", "kh", "kw", "stride", "pad", "transposed", "ldx", "ldy",
-        "wrows", "wcols", "flags", "ldres", "ldg", "reserved")]
+        "wrows", "wcols", "flags", "ldres", "ldg", "wlayout", "reserved")]
 
 
 class ConvIO(C.Structure):

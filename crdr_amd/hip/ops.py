@@ -161,6 +161,19 @@ def round32(v: int) -> int:
     return (v + 31) // 32 * 32
 
 
+def pack_weight_tapmajor(w: torch.Tensor) -> torch.Tensor:
+    """Conv2d weight [O][C<=4][kh][kw] -> [1][round32(O)][round32(4*kh*kw)] (crdr_conv_desc.wlayout = 1)."""
+    _require_gpu(w)
+    w = w.contiguous()
+    I, J = w.shape[0], w.shape[1]
+    T = w.shape[2] * w.shape[3]
+    rows, cols = round32(I), round32(4 * T)
+    dst = torch.empty((1, rows, cols), dtype=torch.float32, device=w.device)
+    lib = L.load()
+    L.check(lib.crdr_pack_weight(w.data_ptr(), dst.data_ptr(), I, J, T, rows, cols, 2, _stream()), "pack_weight")
+    return dst
+
+
 def pack_weight(w: torch.Tensor, transpose: bool) -> torch.Tensor:
     """[I][J][kh][kw] parameter -> [T][rows][cols] pack (rows/cols padded to 32)."""
     _require_gpu(w)
@@ -183,7 +196,7 @@ def conv_out_size(h, k, stride, pad, transposed, out_pad=0):
 def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int], stride: int, pad: int,
                transposed: bool, out_hw: Tuple[int, int], *, bias=None, flags: int = 0, vec2=None, res=None,
                scale=None, shift=None, gate_x=None, gate_t=None, sig_out=None, out: Optional[torch.Tensor] = None,
-               algo: int = 0):
+               algo: int = 0, wlayout: int = 0):
     """One fused implicit-GEMM launch. `out` may be a channel slice of a wider NHWC tensor (written in place)."""
     lib = L.load()
     x, ldx = nhwc(x)
@@ -194,7 +207,7 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
     out_t, ldy = out, (out.stride(3) if ow > 1 else (out.stride(2) if oh > 1 else (out.stride(0) if n > 1 else oc)))
     d = L.ConvDesc(N=n, H=h, W=w, C=(c + 3) // 4 * 4 if ldx >= (c + 3) // 4 * 4 else c, OH=oh, OW=ow, OC=oc, kh=k[0], kw=k[1],
                    stride=stride, pad=pad, transposed=int(transposed), ldx=ldx, ldy=ldy, wrows=wpack.shape[1],
-                   wcols=wpack.shape[2], flags=flags, ldres=0, ldg=0, reserved=0)
+                   wcols=wpack.shape[2], flags=flags, ldres=0, ldg=0, wlayout=wlayout, reserved=0)
     io = L.ConvIO(x=x.data_ptr(), w=wpack.data_ptr(), y=out_t.data_ptr(), bias=_p(bias), vec2=_p(vec2))
     if res is not None:
         res, d.ldres = nhwc(res)
@@ -213,7 +226,7 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
     if algo:
         d.reserved = algo
     elif AUTOTUNE and not (flags & L.EPI_ACCUM):
-        key = ("c", n, h, w, d.C, oh, ow, oc, k, stride, pad, int(transposed), ldx, ldy, flags, d.ldres, d.ldg)
+        key = ("c", n, h, w, d.C, oh, ow, oc, k, stride, pad, int(transposed), ldx, ldy, flags, d.ldres, d.ldg, wlayout)
         algo = _algo_cache.get(key)
         if algo is None:
             def run(a):

@@ -70,6 +70,8 @@ typedef struct crdr_conv_desc {
   int32_t flags;
   int32_t ldres; /* pixel stride of res                                    */
   int32_t ldg;   /* pixel stride of gx, gt and sig                          */
+  int32_t wlayout;  /* 0: weight pack [kh*kw][wrows][wcols] (below); 1: tap-major [wrows][wcols >= 4*kh*kw] for C <= 4
+                     * (RGB inputs): a K-tile then covers 8 taps x 4 channels instead of 1 tap x 32 mostly-zero channels */
   int32_t reserved; /* 0: built-in heuristic; else a forced algorithm = (config index + 1) | log2(split-K) << 8
                      * (what cudnn.benchmark=True does for the reference, base_trainer.py:20: time the candidates
                      * once per shape and keep the fastest; see crdr_amd/hip/ops.py) */
@@ -114,7 +116,8 @@ int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, 
                       crdr_stream_t s);
 
 /* src[I][J][T] (a Conv2d / ConvTranspose2d parameter, T = kh*kw) -> dst[T][rows][cols] zero padded.
- * transpose = 0: dst[t][i][j] = src[i][j][t] (rows >= I, cols >= J); transpose = 1: dst[t][j][i] = src[i][j][t]. */
+ * transpose = 0: dst[t][i][j] = src[i][j][t] (rows >= I, cols >= J); transpose = 1: dst[t][j][i] = src[i][j][t];
+ * transpose = 2 (J <= 4): tap-major dst[i][4 t + j] = src[i][j][t] (rows >= I, cols >= 4 T), see crdr_conv_desc.wlayout */
 int crdr_pack_weight(const float* src, float* dst, int I, int J, int T, int rows, int cols, int transpose,
                      crdr_stream_t s);
 

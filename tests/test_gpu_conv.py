@@ -69,6 +69,9 @@ def test_conv_fwd_dgrad_wgrad(case):
     out = ops.conv2d_raw(xd, wp, co, (k, k), s, p, False, (oh, ow), bias=bd, flags=1)
     torch.cuda.synchronize()
     _close(out, ref, name + " fwd")
+    if ci <= 4:  # RGB-input convs: tap-major pack, a K-tile = 8 taps x 4 channels
+        out2 = ops.conv2d_raw(xd, ops.pack_weight_tapmajor(wd), co, (k, k), s, p, False, (oh, ow), bias=bd, flags=1, wlayout=1)
+        _close(out2, ref, name + " fwd (tap-major)")
 
     wq = ops.pack_weight(wd, transpose=True)  # [T][Cin][Cout]
     dx = ops.conv2d_raw(dyd, wq, ci, (k, k), s, p, True, (h, w))
