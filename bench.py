@@ -119,7 +119,7 @@ def main():
     from crdr_amd.trainer import dist as D
     local = D.init_from_env()
     ws, rk = D.world_size(), D.rank()
-    assert ws == a.gpus or (a.gpus == 1 and ws == 1), f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+    assert ws == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
     tr = build_trainer(a.stage, a.bs, a.size, device, graphs=not a.no_graph)

@@ -10,8 +10,11 @@ import torch
 import torch.distributed as dist
 
 
+_FORCE = os.environ.get("CRDR_FORCE_DIST", "0") == "1"  # exercise the collective path with a single rank (tests)
+
+
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def world_size() -> int:
@@ -26,7 +29,10 @@ def init_from_env(backend: Optional[str] = None) -> int:
     """Initialise from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*). Returns the local rank."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if ws > 1 and not dist.is_initialized():
+    if (ws > 1 or _FORCE) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:

@@ -47,7 +47,11 @@ class SegmentGraphs:
             g = torch.cuda.CUDAGraph()
             ops.reserve_workspace(torch.cuda.current_device(), self._stream)
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, pool=self._pool, stream=self._stream):
+            # with a process group alive, its watchdog thread polls events while we capture: only this thread's
+            # unsafe calls should abort the capture
+            import torch.distributed as dist
+            mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            with torch.cuda.graph(g, pool=self._pool, stream=self._stream, capture_error_mode=mode):
                 out = fn()
             self._pool = g.pool()
             self._graphs[key] = g
