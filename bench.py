@@ -172,6 +172,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rk != 0:
+        if dist.is_initialized():
+            dist.destroy_process_group()
         return
     imgs = ws * a.bs * a.steps
     value = imgs / dt
@@ -220,6 +222,8 @@ def main():
     if ws == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.stage, a.size)
     print(json.dumps(line), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

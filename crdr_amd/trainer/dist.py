@@ -3,6 +3,7 @@ the CPU tests. The reference is single-GPU only (README.md:63); this is the MI35
 full replicas, one flat-buffer all-reduce per optimiser, and rank-consistent control decisions."""
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import List, Optional
 
@@ -43,21 +44,65 @@ def init_from_env(backend: Optional[str] = None) -> int:
     return local
 
 
-def all_reduce_mean_(buffers: List[torch.Tensor]) -> None:
-    """In-place average of each flat buffer across ranks (one collective per buffer)."""
+_DEBUG = os.environ.get("CRDR_DEBUG_DIST", "0") == "1"
+
+
+def _dbg(what: str) -> None:
+    if _DEBUG:
+        cap = torch.cuda.is_current_stream_capturing() if torch.cuda.is_available() else False
+        print(f"[dist] {what} stream={torch.cuda.current_stream().cuda_stream:#x} capturing={cap}", flush=True)
+
+
+_comm_streams = {}
+
+
+@contextlib.contextmanager
+def comm_scope(ref: torch.Tensor):
+    """Issue the enclosed collectives on a dedicated communication stream, ordered after / before the current one.
+
+    torch runs a blocking RCCL collective on the *current* stream and hands its completion event to the process-group
+    watchdog thread, which polls it with hipEventQuery.  The trainer's current stream is the one its HIP graphs are
+    captured on, and HIP refuses to query an event whose stream has since started capturing
+    (hipErrorCapturedEvent -> the watchdog aborts the process).  Collectives therefore never touch the capture stream:
+    they get a stream of their own that is never captured."""
+    if not ref.is_cuda:
+        yield
+        return
+    cur = torch.cuda.current_stream(ref.device)
+    comm = _comm_streams.get(ref.device)
+    if comm is None:
+        comm = _comm_streams[ref.device] = torch.cuda.Stream(ref.device)
+    comm.wait_stream(cur)
+    with torch.cuda.stream(comm):
+        yield
+    cur.wait_stream(comm)
+
+
+def all_reduce_(t: torch.Tensor, op=None) -> None:
     if not is_dist():
         return
+    _dbg(f"all_reduce {t.numel()}")
+    with comm_scope(t):
+        dist.all_reduce(t, op=op if op is not None else dist.ReduceOp.SUM)
+
+
+def all_reduce_mean_(buffers: List[torch.Tensor]) -> None:
+    """In-place average of each flat buffer across ranks (one collective per buffer)."""
+    if not is_dist() or not buffers:
+        return
     ws = dist.get_world_size()
-    for b in buffers:
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
-        b.div_(ws)
+    with comm_scope(buffers[0]):
+        for b in buffers:
+            _dbg(f"all_reduce {b.numel()}")
+            dist.all_reduce(b, op=dist.ReduceOp.SUM)
+            b.div_(ws)
 
 
 def all_reduce_scalars_mean(t: torch.Tensor) -> torch.Tensor:
     if not is_dist():
         return t
     t = t.clone()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    all_reduce_(t)
     return t / dist.get_world_size()
 
 
@@ -66,7 +111,7 @@ def any_rank_true(flag: bool, device) -> bool:
     if not is_dist():
         return flag
     t = torch.tensor([1.0 if flag else 0.0], device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    all_reduce_(t, op=dist.ReduceOp.MAX)
     return bool(t.item() > 0)
 
 

@@ -51,8 +51,14 @@ class SegmentGraphs:
             # unsafe calls should abort the capture
             import torch.distributed as dist
             mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            import os
+            dbg = os.environ.get("CRDR_DEBUG_DIST", "0") == "1"
+            if dbg:
+                print(f"[graphs] capture begin {key} stream={self._stream.cuda_stream:#x}", flush=True)
             with torch.cuda.graph(g, pool=self._pool, stream=self._stream, capture_error_mode=mode):
                 out = fn()
+            if dbg:
+                print(f"[graphs] capture end {key}", flush=True)
             self._pool = g.pool()
             self._graphs[key] = g
             self._outs[key] = out

@@ -86,7 +86,7 @@ class RateDistortionTrainer(BaseTrainer):
     def _sync_between_segments(self, ctx: Dict, optimizer) -> None:
         D.all_reduce_mean_(optimizer.flat_grads())
         if D.is_dist():
-            torch.distributed.all_reduce(ctx["bad"], op=torch.distributed.ReduceOp.MAX)
+            D.all_reduce_(ctx["bad"], op=torch.distributed.ReduceOp.MAX)
 
     def _conditions(self, data_dict: Dict) -> Tuple[Dict, object]:
         """-> (model conditioning kwargs, hashable graph key).  A multi-rate model (stage 2) gets its rate index drawn
