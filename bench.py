@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--shape-table", default=None, help="write per-shape conv timing of the timed region to this file")
     ap.add_argument("--no-autotune", action="store_true", help="use the library's built-in tile heuristic instead of timing candidates once per shape")
     ap.add_argument("--tune-log", default=None)
+    ap.add_argument("--tune-db", default=None, help="perf database to preload (default: the one shipped in crdr_amd/hip); shapes it lacks are tuned live")
+    ap.add_argument("--save-tune-db", default=None, help="write the tuner's choices after the run")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying captured HIP graphs")
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps after the timed region used for the per-kernel roofline")
     a = ap.parse_args()
@@ -125,6 +127,8 @@ def main():
     tr = build_trainer(a.stage, a.bs, a.size, device, graphs=not a.no_graph)
     loader = iter(tr.train_loader)
     ops.AUTOTUNE = not a.no_autotune  # the reference runs with cudnn.benchmark = True (base_trainer.py:20)
+    if ops.AUTOTUNE and a.tune_db != "none":
+        ops.load_tune_cache(a.tune_db or ops.DEFAULT_TUNE_DB)
     lib = __import__("crdr_amd.hip.lib", fromlist=["load"]).load()
 
     def barrier():
@@ -171,6 +175,8 @@ def main():
         t = torch.tensor([dt], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if rk == 0 and a.save_tune_db:
+        ops.save_tune_cache(a.save_tune_db)
     if rk != 0:
         if dist.is_initialized():
             dist.destroy_process_group()

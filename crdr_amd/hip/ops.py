@@ -55,6 +55,37 @@ def _autotune(key, ncfg: int, max_log2_split: int, run) -> int:
     return best
 
 
+DEFAULT_TUNE_DB = __import__("os").path.join(__import__("os").path.dirname(__file__), "tune_gfx950.json")
+
+
+def _tune_signature() -> str:
+    lib = L.load()
+    return f"v{lib.crdr_version()}-c{lib.crdr_conv2d_num_configs()}-w{lib.crdr_conv2d_wgrad_num_configs()}"
+
+
+def save_tune_cache(path: str) -> None:
+    """Persist the autotuner's choices (a perf database in the MIOpen sense): {repr(shape key): algo id}."""
+    import json
+    with open(path, "w") as f:
+        json.dump({"signature": _tune_signature(), "algos": {repr(k): v for k, v in _algo_cache.items()}}, f, indent=0)
+
+
+def load_tune_cache(path: str) -> int:
+    """Load choices saved by save_tune_cache; ignored (returns 0) if the library's configuration list has changed."""
+    import ast
+    import json
+    import os
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        db = json.load(f)
+    if db.get("signature") != _tune_signature():
+        return 0
+    for k, v in db["algos"].items():
+        _algo_cache.setdefault(ast.literal_eval(k), int(v))
+    return len(db["algos"])
+
+
 # Optional per-launch timing (bench.py): {"igemm": [(flops, ev0, ev1), ...], "wgrad": [...]} or None.
 # Events are recorded on the stream the kernels are launched on (torch's current stream).
 PROFILE = None

@@ -33,6 +33,12 @@ def main():
     if str(opt.device).startswith("cuda"):
         import torch
         torch.cuda.set_device(int(str(opt.device).split(":")[1]) if ":" in str(opt.device) else 0)
+    # the reference trains with cudnn.benchmark = True (base_trainer.py:20): per-shape algorithm selection, seeded from
+    # the shipped perf database; CRDR_AUTOTUNE=0 keeps the library's built-in cost model instead
+    if os.environ.get("CRDR_AUTOTUNE", "1") != "0":
+        from crdr_amd.hip import ops
+        ops.AUTOTUNE = True
+        ops.load_tune_cache(os.environ.get("CRDR_TUNE_DB", ops.DEFAULT_TUNE_DB))
     trainer = build_trainer(opt)
     trainer.train_loop()
 
