@@ -18,6 +18,13 @@
 
 #include "common.hpp"
 
+#ifndef CRDR_IGEMM_PREFETCH
+#define CRDR_IGEMM_PREFETCH 0
+#endif
+#ifndef CRDR_IGEMM_SETPRIO
+#define CRDR_IGEMM_SETPRIO 0
+#endif
+
 namespace crdr {
 
 struct IgemmArgs {
@@ -45,6 +52,7 @@ struct IgemmArgs {
   int ws_ld;  // columns of a partial slab row (= gridDim.y * BN)
   int vec_epi;  // 1: y / res / gx / gt / sig rows are 16-byte aligned -> vector epilogue
   int smallc;   // 1: Cin <= 4 and the weight pack is tap-major ([rows][taps*4]): a K-tile covers 8 taps x 4 channels
+  unsigned x_bytes, w_bytes;  // extents of the two buffer descriptors (range-checked loads)
 };
 
 // Tap / phase tables travel as a second by-value kernel argument that is only ever indexed with wave-uniform
@@ -76,114 +84,106 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, 
   *dst = v;
 }
 
-template <int WM, int WN, int MB, int NB>
+// Staging is LDS-DMA: `buffer_load_dwordx4 ... lds` moves 16 bytes per lane straight from global memory into LDS
+// (1 KiB = 8 tile rows per wave instruction, lane-linear destination), so the K loop carries no staging registers,
+// no ds_write pass and no zero-fill selects: rows / channel chunks / taps that fall outside the tensor get a byte
+// offset beyond the buffer descriptor's range and the hardware range check returns zeros for them.  The XOR swizzle
+// of the tile image (lds_off) is applied on the SOURCE side: the lane that fills slot s of row r fetches chunk
+// s ^ ((r >> 1) & 7).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+static constexpr unsigned kOobOffset = 0x80000000u;  // >= any descriptor size accepted by build_plan (< 2 GiB)
+
+template <int WM, int WN, int MB, int NB, bool SMALLC>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, const IgemmTaps tp) {
   constexpr int BM = 32 * WM * MB, BN = 32 * WN * NB, NT = 64 * WM * WN;
-  constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;  // float4 per thread per K-tile
+  constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;  // 16-byte pieces per thread per K-tile
   static_assert(AV * NT == BM * 8 && BV * NT == BN * 8, "tile/threads mismatch");
-  static_assert(AV <= 16 && BV <= 16, "mask bits");
-  constexpr int ROWS_PER_PASS = NT / 8;
+  constexpr int RPP = NT / 8;  // tile rows filled by one pass of the whole block
+  static_assert(RPP % 16 == 0, "the swizzle term must not depend on the pass");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                                        // [2][BM*32]
   float* sB = smem + 2 * BM * 32;                          // [2][BN*32]
-  int* sTap = reinterpret_cast<int*>(smem + 2 * (BM + BN) * 32);  // [<=128] packed (dh, dw, widx) of this phase
+  int* sTap = reinterpret_cast<int*>(smem + 2 * (BM + BN) * 32);  // [<=132] packed (dh, dw, widx) of this phase
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int phase = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
   const int tb = tp.tap_begin[phase], te = tp.tap_begin[phase + 1];
-  const int KT = p.smallc ? p.kchunks : (te - tb) * p.kchunks;
+  const int ntap = te - tb;
+  const int KT = SMALLC ? p.kchunks : ntap * p.kchunks;
   const int it0 = (int)((long long)KT * split / p.nsplit), it1 = (int)((long long)KT * (split + 1) / p.nsplit);
   const int poh = tp.poh[phase], pow_ = tp.pow[phase];
   const int H = p.H, W = p.W, ldx = p.ldx, Cin = p.Cin, kchunks = p.kchunks;
 
-  for (int t = 0; t < te - tb; ++t) {  // wave-uniform index: scalar loads from the kernarg segment
+  for (int t = 0; t < ntap; ++t) {  // wave-uniform index: scalar loads from the kernarg segment
     const int v = tp.packed[tb + t];
     if (tid == 0) sTap[t] = v;
   }
+  if (tid < 4) sTap[ntap + tid] = 0;  // the cursor may run one K-tile past the end (range-checked, never consumed)
 
-  // ---- staging assignment: thread owns chunk (tid&7) of rows (tid>>3) + j*ROWS_PER_PASS
-  const int chunk = tid & 7, srow = tid >> 3;
-  int a_pix[AV], a_ih[AV], a_iw[AV];
-  unsigned a_ok = 0;  // bit j: row j of this thread is a real output position
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  // ---- staging assignment: thread fills slot (tid & 7) of rows (tid >> 3) + j * RPP
+  const int srow = tid >> 3;
+  const int csrc = (tid & 7) ^ ((srow >> 1) & 7);  // source chunk landing in this thread's slot
+  unsigned a_off[AV];
+  int a_ih[AV], a_iw[AV];
 #pragma unroll
   for (int j = 0; j < AV; ++j) {
-    const int m = m0 + srow + j * ROWS_PER_PASS;
+    const int m = m0 + srow + j * RPP;
     const int hw = p.GH * p.GW;
     const int n = m / hw, rem = m - n * hw, a = rem / p.GW, b = rem - a * p.GW;
     const bool ok = (m < p.M) && (a * p.so + poh < p.OH) && (b * p.so + pow_ < p.OW);
-    a_ok |= (ok ? 1u : 0u) << j;
-    a_pix[j] = ok ? n * H * W : 0;
-    a_ih[j] = ok ? a * p.si : 0;
+    a_ih[j] = ok ? a * p.si : -(1 << 24);  // a dead row fails every bounds test below
     a_iw[j] = ok ? b * p.si : 0;
+    a_off[j] = ok ? (unsigned)(((n * H + a * p.si) * W + b * p.si) * ldx + (SMALLC ? 0 : csrc * 4)) * 4u : 0u;
   }
-  const float* b_ptr[BV];
-  unsigned b_okm = 0;
+  unsigned b_off[BV];
 #pragma unroll
   for (int j = 0; j < BV; ++j) {
-    const int oc = n0 + srow + j * ROWS_PER_PASS;
-    const bool ok = oc < p.wrows;
-    b_okm |= (ok ? 1u : 0u) << j;
-    b_ptr[j] = p.w + (size_t)(ok ? oc : 0) * p.wcols + chunk * 4;
+    const int oc = n0 + srow + j * RPP;
+    b_off[j] = oc < p.wrows ? (unsigned)(oc * p.wcols + csrc * 4) * 4u : kOobOffset;
   }
   __syncthreads();  // sTap visible
 
-  // K-iteration cursor of the NEXT tile to load: tap index (relative to tb) and channel chunk
-  const bool smallc = p.smallc != 0;
-  int lt = smallc ? 0 : it0 / kchunks, lc = smallc ? it0 : it0 - lt * kchunks;
-  const int ntap = te - tb;
-  f32x4 ra[AV], rb[BV];
-  unsigned ra_mask = 0;
-  auto load_tile = [&]() __attribute__((always_inline)) {
-    int dh, dw, c0c;
+  // K-iteration cursor of the NEXT tile to fetch: tap index (relative to tb) and channel chunk
+  int lt = SMALLC ? 0 : it0 / kchunks, lc = SMALLC ? it0 : it0 - lt * kchunks;
+  auto fetch = [&](int buf) __attribute__((always_inline)) {
+    float* a = sA + buf * BM * 32 + wave * 8 * 32;
+    float* b = sB + buf * BN * 32 + wave * 8 * 32;
+    int dh, dw;
+    unsigned toff, woff;
     bool cok;
-    size_t woff;
-    if (smallc) {  // this thread's 16-byte chunk is tap (8 lc + chunk), channels 0..3
-      const int ti = lc * 8 + chunk;
+    if constexpr (SMALLC) {  // this thread's piece is tap (8 lc + csrc), channels 0..3
+      const int ti = lc * 8 + csrc;
       cok = ti < ntap;
-      const int tp = sTap[cok ? ti : 0];
-      dh = (int)(signed char)(tp & 0xff); dw = (int)(signed char)((tp >> 8) & 0xff);
-      c0c = 0;
-      woff = (size_t)(lc * 32);
+      const int t = sTap[cok ? ti : 0];
+      dh = (int)(signed char)(t & 0xff); dw = (int)(signed char)((t >> 8) & 0xff);
+      toff = (unsigned)((dh * W + dw) * ldx) * 4u;
+      woff = (unsigned)(lc * 32) * 4u;
     } else {
-      const int tp = __builtin_amdgcn_readfirstlane(sTap[lt]);
-      dh = (int)(signed char)(tp & 0xff); dw = (int)(signed char)((tp >> 8) & 0xff);
-      const int wi = tp >> 16;
-      const int c0 = lc * 32 + chunk * 4;
-      cok = c0 < Cin;
-      c0c = cok ? c0 : 0;
-      woff = (size_t)wi * p.wrows * p.wcols + (size_t)(lc * 32);
+      const int t = __builtin_amdgcn_readfirstlane(sTap[lt]);
+      dh = (int)(signed char)(t & 0xff); dw = (int)(signed char)((t >> 8) & 0xff);
+      const int wi = t >> 16;
+      cok = lc * 32 + csrc * 4 < Cin;
+      toff = (unsigned)((dh * W + dw) * ldx + lc * 32) * 4u;
+      woff = (unsigned)(wi * p.wrows * p.wcols + lc * 32) * 4u;
     }
-    unsigned mask = 0;
 #pragma unroll
     for (int j = 0; j < AV; ++j) {
       const int ih = a_ih[j] + dh, iw = a_iw[j] + dw;
-      const bool ok = cok && ((a_ok >> j) & 1u) && ((unsigned)ih < (unsigned)H) && ((unsigned)iw < (unsigned)W);
-      mask |= (ok ? 1u : 0u) << j;
-      const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);  // always a legal address; masked at store
-      ra[j] = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_pix[j] + ihc * W + iwc) * ldx + c0c);
+      const bool ok = cok & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(a + j * RPP * 32), 16, (int)(ok ? a_off[j] + toff : kOobOffset),
+                                               0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < BV; ++j) rb[j] = *reinterpret_cast<const f32x4*>(b_ptr[j] + woff);
-    ra_mask = mask;
-    if (++lc == kchunks && !smallc) { lc = 0; ++lt; }
-  };
-  auto store_tile = [&](int buf) __attribute__((always_inline)) {
-    float* a = sA + buf * BM * 32;
-    float* b = sB + buf * BN * 32;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < AV; ++j) {
-      const int r = srow + j * ROWS_PER_PASS;
-      *reinterpret_cast<f32x4*>(a + lds_off(r, chunk)) = ((ra_mask >> j) & 1u) ? ra[j] : zero;
-    }
-#pragma unroll
-    for (int j = 0; j < BV; ++j) {
-      const int r = srow + j * ROWS_PER_PASS;
-      *reinterpret_cast<f32x4*>(b + lds_off(r, chunk)) = ((b_okm >> j) & 1u) ? rb[j] : zero;
-    }
+    for (int j = 0; j < BV; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(b + j * RPP * 32), 16, (int)(b_off[j] + woff), 0, 0, 0);
+    if (++lc == kchunks && !SMALLC) { lc = 0; ++lt; }
+    __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the MFMA stream that hides its latency
   };
 
   f32x16 acc[MB][NB];
@@ -195,23 +195,20 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frow = lane & 31, fh = lane >> 5;
-  if (it0 < it1) {
-    load_tile();
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int it = it0; it < it1; ++it) {
-    const int buf = (it - it0) & 1;
-    if (it + 1 < it1) load_tile();
-    const float* a = sA + buf * BM * 32 + (wm * MB * 32) * 32;
-    const float* b = sB + buf * BN * 32 + (wn * NB * 32) * 32;
+  const float* fa = sA + (wm * MB * 32) * 32;
+  const float* fb = sB + (wn * NB * 32) * 32;
+  int fo[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) fo[kk] = lds_off(frow, kk * 2 + fh);
+  auto compute = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       f32x4 af[MB], bf[NB];
 #pragma unroll
-      for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const f32x4*>(a + lds_off(i * 32 + frow, kk * 2 + fh));
+      for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const f32x4*>(fa + fo[kk] + (buf * BM * 32 + i * 1024));
 #pragma unroll
-      for (int j = 0; j < NB; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b + lds_off(j * 32 + frow, kk * 2 + fh));
+      for (int j = 0; j < NB; ++j) bf[j] = *reinterpret_cast<const f32x4*>(fb + fo[kk] + (buf * BN * 32 + j * 1024));
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -220,7 +217,22 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
           for (int j = 0; j < NB; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-    if (it + 1 < it1) store_tile(buf ^ 1);
+  };
+
+  using std::integral_constant;
+  if (it0 < it1) fetch(0);
+  __syncthreads();
+  int it = it0;
+  for (; it + 2 <= it1; it += 2) {
+    fetch(1);
+    compute(integral_constant<int, 0>{});
+    __syncthreads();
+    fetch(0);
+    compute(integral_constant<int, 1>{});
+    __syncthreads();
+  }
+  if (it < it1) {
+    compute(integral_constant<int, 0>{});
     __syncthreads();
   }
 
@@ -312,7 +324,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
     }
     __syncthreads();
   };
-  using std::integral_constant;
   pass(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
   if constexpr (NB > 4) pass(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
   if constexpr (MB > 1) {
@@ -344,16 +355,18 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p, 
 struct TileCfg {
   int wm, wn, mb, nb;
   void (*kern)(const IgemmArgs, const IgemmTaps);
+  void (*kern_smallc)(const IgemmArgs, const IgemmTaps);  // tap-major variant (Cin <= 4), nullptr where not built
 };
-#define CFG(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d>}
+#define CFG(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false>, nullptr}
+#define CFGS(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false>, igemm_kernel<a, b, c, d, true>}
 static const TileCfg kCfgs[] = {
     // BM=128 family (one 32-row strip per wave), BN = 32..224
-    CFG(4, 1, 1, 1), CFG(4, 1, 1, 2), CFG(4, 1, 1, 3), CFG(4, 1, 1, 4), CFG(4, 1, 1, 5), CFG(4, 1, 1, 6),
+    CFGS(4, 1, 1, 1), CFGS(4, 1, 1, 2), CFG(4, 1, 1, 3), CFG(4, 1, 1, 4), CFG(4, 1, 1, 5), CFG(4, 1, 1, 6),
     CFG(4, 1, 1, 7),
     // BM=256: two strips per wave
-    CFG(4, 1, 2, 2), CFG(4, 1, 2, 3), CFG(4, 1, 2, 4),
+    CFGS(4, 1, 2, 2), CFG(4, 1, 2, 3), CFG(4, 1, 2, 4),
     // 2x2 waves
-    CFG(2, 2, 2, 2),  // 128x128
+    CFGS(2, 2, 2, 2),  // 128x128
     CFG(2, 2, 1, 1),  // 64x64
     CFG(2, 2, 1, 2),  // 64x128
     CFG(2, 2, 1, 3),  // 64x192
@@ -362,18 +375,19 @@ static const TileCfg kCfgs[] = {
     CFG(1, 4, 1, 1),  // 32x128
     CFG(1, 4, 1, 2),  // 32x256
     // 8-wave blocks: two waves per SIMD share one staged tile (more MFMA work per staged byte, latency hiding)
-    CFG(4, 2, 1, 1),  // 128x64
-    CFG(4, 2, 1, 2),  // 128x128
+    CFGS(4, 2, 1, 1),  // 128x64
+    CFGS(4, 2, 1, 2),  // 128x128
     CFG(4, 2, 1, 3),  // 128x192
-    CFG(4, 2, 2, 1),  // 256x64
-    CFG(4, 2, 2, 2),  // 256x128
+    CFGS(4, 2, 2, 1),  // 256x64
+    CFGS(4, 2, 2, 2),  // 256x128
     CFG(2, 4, 1, 1),  // 64x128
-    CFG(2, 4, 2, 1),  // 128x128
+    CFGS(2, 4, 2, 1),  // 128x128
     CFG(2, 4, 1, 2),  // 64x256
     CFG(2, 2, 2, 1),  // 128x64 (4 waves)
     CFG(2, 2, 2, 3),  // 128x192 (4 waves)
 };
 #undef CFG
+#undef CFGS
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 struct Plan {
@@ -435,6 +449,14 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
       }
     tp.tap_begin[ph] = (short)nt;
   }
+  {  // extents of the range-checked buffer descriptors; byte offsets are 32 bit and 0x80000000 marks "outside"
+    const long long xb = (((long long)d->N * d->H * d->W - 1) * d->ldx + d->C) * 4;
+    const long long wb = (long long)(a.smallc ? 1 : d->kh * d->kw) * d->wrows * d->wcols * 4;
+    CRDR_REQUIRE(xb < (1ll << 31) && wb < (1ll << 31),
+                 "conv2d: input (%lld B) or weight pack (%lld B) reaches 2 GiB; split the batch / rows on the host", xb, wb);
+    a.x_bytes = (unsigned)xb;
+    a.w_bytes = (unsigned)wb;
+  }
   const long long M64 = (long long)d->N * a.GH * a.GW;
   CRDR_REQUIRE(M64 < (1ll << 31) && (long long)d->N * d->H * d->W < (1ll << 31), "conv2d: too many pixels");
   a.M = (int)M64;
@@ -446,6 +468,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
   double best = 1e300; int bc = -1, bs = 1;
   for (int c = 0; c < kNumCfgs; ++c) {
     const TileCfg& t = kCfgs[c];
+    if (a.smallc && !t.kern_smallc) continue;
     const int BM = 32 * t.wm * t.mb, BN = 32 * t.wn * t.nb;
     const long long tiles = (long long)cdiv(a.M, BM) * cdiv(d->OC, BN) * a.nphase;
     for (int ns = 1; ns <= 16; ns *= 2) {
@@ -462,6 +485,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
     bc = (d->reserved & 0xff) - 1;
     bs = 1 << ((d->reserved >> 8) & 0xf);
     CRDR_REQUIRE(bc >= 0 && bc < kNumCfgs, "conv2d: forced config %d out of range", bc);
+    CRDR_REQUIRE(!a.smallc || kCfgs[bc].kern_smallc, "conv2d: config %d has no tap-major variant", bc);
     CRDR_REQUIRE(bs == 1 || KT / bs >= 2, "conv2d: forced split %d too deep for %d K-iterations", bs, KT);
   }
   CRDR_REQUIRE(bc >= 0, "conv2d: no tile config");
@@ -472,7 +496,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
   pl->grid = dim3(cdiv(a.M, BM), cdiv(d->OC, BN), a.nphase * bs);
   a.ws_ld = pl->grid.y * BN;
   {
-    const size_t staging = (size_t)2 * (BM + BN) * 32 * sizeof(float) + 128 * sizeof(int);
+    const size_t staging = (size_t)2 * (BM + BN) * 32 * sizeof(float) + 132 * sizeof(int);
     const size_t epi = (size_t)t.wm * t.wn * 32 * 32 * std::min(t.nb, 4) * sizeof(float);
     pl->lds = std::max(staging, epi);
   }
@@ -522,13 +546,14 @@ extern "C" int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void
     a.vec_epi = v ? 1 : 0;
   }
   const TileCfg& t = kCfgs[pl.cfg];
-  static bool attr_done[64] = {false};
-  if (!attr_done[pl.cfg]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done[pl.cfg] = true;
+  auto kern = a.smallc ? t.kern_smallc : t.kern;
+  static bool attr_done[2][64] = {{false}};
+  if (!attr_done[a.smallc][pl.cfg]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done[a.smallc][pl.cfg] = true;
   }
   void* prof = profile_begin(as_stream(s));
-  hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, pl.t);
+  hipLaunchKernelGGL(kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, pl.t);
   CRDR_CHECK_LAUNCH("igemm_kernel");
   if (a.nsplit > 1) {
     dim3 g(cdiv(a.Cout, 64), std::min(cdiv(a.M, 4), 2048), a.nphase);

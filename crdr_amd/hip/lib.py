@@ -12,7 +12,8 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "_lib", "libcrdr_hip.so"))
+# CRDR_HIP_LIB selects another build of the same library (kernel experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("CRDR_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "_lib", "libcrdr_hip.so"))
 
 c_float_p = C.POINTER(C.c_float)
 c_void_p = C.c_void_p
