@@ -18,11 +18,8 @@
 
 #include "common.hpp"
 
-#ifndef CRDR_IGEMM_PREFETCH
-#define CRDR_IGEMM_PREFETCH 0
-#endif
-#ifndef CRDR_IGEMM_SETPRIO
-#define CRDR_IGEMM_SETPRIO 0
+#ifndef CRDR_IGEMM_FETCH_FIRST
+#define CRDR_IGEMM_FETCH_FIRST 1
 #endif
 
 namespace crdr {
@@ -200,10 +197,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
   int fo[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) fo[kk] = lds_off(frow, kk * 2 + fh);
-  auto compute = [&](auto bufc) __attribute__((always_inline)) {
-    constexpr int buf = decltype(bufc)::value;
+  // one K-tile: kk = [K0, K1) quarter steps of 8 K values each, out of LDS buffer `buf`
+  auto compute = [&](auto bufc, auto k0c, auto k1c) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value, K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = K0; kk < K1; ++kk) {
       f32x4 af[MB], bf[NB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const f32x4*>(fa + fo[kk] + (buf * BM * 32 + i * 1024));
@@ -220,19 +218,33 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
   };
 
   using std::integral_constant;
+  using I0 = integral_constant<int, 0>;
+  using I1 = integral_constant<int, 1>;
+  using I4 = integral_constant<int, 4>;
+  // a step = the MFMAs of one tile with the DMA of the next one issued behind the first quarter, so that its address
+  // arithmetic and issue slots run in the shadow of MFMAs already queued
+  auto step = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+#if CRDR_IGEMM_FETCH_FIRST
+    fetch(buf ^ 1);
+    compute(bufc, I0{}, I4{});
+#else
+    compute(bufc, I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(buf ^ 1);
+    compute(bufc, I1{}, I4{});
+#endif
+    __syncthreads();
+  };
   if (it0 < it1) fetch(0);
   __syncthreads();
   int it = it0;
   for (; it + 2 <= it1; it += 2) {
-    fetch(1);
-    compute(integral_constant<int, 0>{});
-    __syncthreads();
-    fetch(0);
-    compute(integral_constant<int, 1>{});
-    __syncthreads();
+    step(I0{});
+    step(I1{});
   }
   if (it < it1) {
-    compute(integral_constant<int, 0>{});
+    compute(I0{}, I0{}, I4{});
     __syncthreads();
   }
 

@@ -44,7 +44,11 @@ struct WgradArgs {
   int nsplit;
   int jtiles;
   FastDiv d_hw, d_w;
+  unsigned p_bytes, q_bytes;  // extents of the two buffer descriptors (range-checked loads)
 };
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+static constexpr unsigned kOob = 0x80000000u;  // >= any descriptor size accepted by build_wplan (< 2 GiB)
 
 template <int WM, int WN, int MB, int NB>
 __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) {
@@ -62,52 +66,47 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
   const int dh = tap / p.kw - p.pad, dw = tap % p.kw - p.pad;
   const int t0 = (int)((long long)p.ntiles * split / p.nsplit), t1 = (int)((long long)p.ntiles * (split + 1) / p.nsplit);
 
-  f32x4 rp[PV], rq[QV];
-  unsigned pmask = 0, qmask = 0;
-  const int Mlast = p.M - 1;
-  auto load_tile = [&](int t) __attribute__((always_inline)) {
+  // Staging is LDS-DMA (buffer_load ... lds, 16 B per lane, lane-linear destination = exactly the [32 px][channels]
+  // image): no staging registers, and pixels / channels / taps outside the tensors get an offset beyond the buffer
+  // descriptor's range, for which the hardware returns zeros.
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.p), 0, p.p_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.q), 0, p.q_bytes, 0x00020000);
+  unsigned p_off[PV], q_coff[QV];
+  int q_prow[QV];
+#pragma unroll
+  for (int k = 0; k < PV; ++k) {
+    const int e = tid + k * NT;
+    const int prow = e / (BI / 4), c = i0 + (e % (BI / 4)) * 4;
+    p_off[k] = (c < p.PC) ? (unsigned)(prow * p.ldp + c) * 4u : kOob;  // rows past M fall off the end by themselves
+  }
+#pragma unroll
+  for (int k = 0; k < QV; ++k) {
+    const int e = tid + k * NT;
+    const int c = j0 + (e % (BJ / 4)) * 4;
+    q_prow[k] = e / (BJ / 4);
+    q_coff[k] = (c < p.QC) ? (unsigned)c * 4u : kOob;
+  }
+  auto fetch = [&](int t, int buf) __attribute__((always_inline)) {
     const int mbase = t * 32;
-    unsigned pm = 0, qm = 0;
+    float* a = sP + buf * 32 * BI + wave * 256;
+    float* b = sQ + buf * 32 * BJ + wave * 256;
+    const unsigned pbase = (unsigned)(mbase * p.ldp) * 4u;
 #pragma unroll
-    for (int k = 0; k < PV; ++k) {
-      const int e = tid + k * NT;
-      const int prow = e / (BI / 4), ch = e % (BI / 4);
-      const int m = mbase + prow, c = i0 + ch * 4;
-      const bool ok = (e < 8 * BI) && (m < p.M) && (c < p.PC);
-      pm |= (ok ? 1u : 0u) << k;
-      rp[k] = *reinterpret_cast<const f32x4*>(p.p + (size_t)min(m, Mlast) * p.ldp + (c < p.PC ? c : 0));
-    }
+    for (int k = 0; k < PV; ++k)
+      if (tid + k * NT < 8 * BI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (lds_ptr_t)(a + k * NT * 4), 16, (int)(p_off[k] + pbase), 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < QV; ++k) {
-      const int e = tid + k * NT;
-      const int prow = e / (BJ / 4), ch = e % (BJ / 4);
-      const int m = min(mbase + prow, Mlast), c = j0 + ch * 4;
+      const int m = mbase + q_prow[k];
       const unsigned n = fdiv((unsigned)m, p.d_hw), rem = m - n * p.d_hw.d;
-      const unsigned a = fdiv(rem, p.d_w), b = rem - a * p.d_w.d;
-      const int ih = (int)a * p.stride + dh, iw = (int)b * p.stride + dw;
-      const bool ok = (e < 8 * BJ) && (mbase + prow < p.M) && (c < p.QC) && ((unsigned)ih < (unsigned)p.QH) &&
-                      ((unsigned)iw < (unsigned)p.QW);
-      qm |= (ok ? 1u : 0u) << k;
-      const int ihc = min(max(ih, 0), p.QH - 1), iwc = min(max(iw, 0), p.QW - 1);
-      rq[k] = *reinterpret_cast<const f32x4*>(p.q + ((size_t)(n * p.QH + ihc) * p.QW + iwc) * p.ldq + (c < p.QC ? c : 0));
+      const unsigned a_ = fdiv(rem, p.d_w), b_ = rem - a_ * p.d_w.d;
+      const int ih = (int)a_ * p.stride + dh, iw = (int)b_ * p.stride + dw;
+      const bool ok = (m < p.M) & ((unsigned)ih < (unsigned)p.QH) & ((unsigned)iw < (unsigned)p.QW);
+      const unsigned off = (unsigned)(((int)n * p.QH + ih) * p.QW + iw) * (unsigned)(p.ldq * 4) + q_coff[k];
+      if (tid + k * NT < 8 * BJ)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ, (lds_ptr_t)(b + k * NT * 4), 16, (int)(ok ? off : kOob), 0, 0, 0);
     }
-    pmask = pm;
-    qmask = qm;
-  };
-  auto store_tile = [&](int buf) __attribute__((always_inline)) {
-    float* a = sP + buf * 32 * BI;
-    float* b = sQ + buf * 32 * BJ;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < PV; ++k) {
-      const int e = tid + k * NT;
-      if (e < 8 * BI) *reinterpret_cast<f32x4*>(a + e * 4) = ((pmask >> k) & 1u) ? rp[k] : zero;  // [prow][ch*4] == e*4
-    }
-#pragma unroll
-    for (int k = 0; k < QV; ++k) {
-      const int e = tid + k * NT;
-      if (e < 8 * BJ) *reinterpret_cast<f32x4*>(b + e * 4) = ((qmask >> k) & 1u) ? rq[k] : zero;
-    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the MFMA stream that hides its latency
   };
 
   f32x16 acc[MB][NB];
@@ -119,26 +118,38 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int fcol = lane & 31, fh = lane >> 5;
-  if (t0 < t1) { load_tile(t0); store_tile(0); }
-  __syncthreads();
-  for (int t = t0; t < t1; ++t) {
-    const int buf = (t - t0) & 1;
-    if (t + 1 < t1) load_tile(t + 1);
-    const float* a = sP + buf * 32 * BI + wm * MB * 32 + fcol;
-    const float* b = sQ + buf * 32 * BJ + wn * NB * 32 + fcol;
+  const float* fa = sP + wm * MB * 32 + fcol + fh * BI;
+  const float* fb = sQ + wn * NB * 32 + fcol + fh * BJ;
+  auto compute = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       float af[MB], bf[NB];
 #pragma unroll
-      for (int i = 0; i < MB; ++i) af[i] = a[(2 * s + fh) * BI + i * 32];
+      for (int i = 0; i < MB; ++i) af[i] = fa[buf * 32 * BI + 2 * s * BI + i * 32];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) bf[j] = b[(2 * s + fh) * BJ + j * 32];
+      for (int j = 0; j < NB; ++j) bf[j] = fb[buf * 32 * BJ + 2 * s * BJ + j * 32];
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < t1) store_tile(buf ^ 1);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if (t0 < t1) fetch(t0, 0);
+  __syncthreads();
+  int t = t0;
+  for (; t + 2 <= t1; t += 2) {
+    fetch(t + 1, 1);  // t + 1 < t1 here
+    compute(I0{});
+    __syncthreads();
+    fetch(t + 2, 0);  // may be one tile past this block's range: fetched (range-checked), never consumed
+    compute(I1{});
+    __syncthreads();
+  }
+  if (t < t1) {
+    compute(I0{});
     __syncthreads();
   }
 
@@ -249,6 +260,12 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl) {
   const long long M64 = (long long)d->N * d->PH * d->PW;
   CRDR_REQUIRE(M64 < (1ll << 31) && (long long)d->N * d->QH * d->QW < (1ll << 31), "wgrad: too many pixels");
   a.M = (int)M64;
+  {
+    const long long pb = ((M64 - 1) * d->ldp + d->PC) * 4, qb = (((long long)d->N * d->QH * d->QW - 1) * d->ldq + d->QC) * 4;
+    CRDR_REQUIRE(pb < (1ll << 31) && qb < (1ll << 31), "wgrad: an operand (%lld / %lld B) reaches 2 GiB; split the batch on the host", pb, qb);
+    a.p_bytes = (unsigned)pb;
+    a.q_bytes = (unsigned)qb;
+  }
   a.ntiles = cdiv(a.M, 32);
   a.d_hw = make_fastdiv((unsigned)(d->PH * d->PW));
   a.d_w = make_fastdiv((unsigned)d->PW);
