@@ -175,6 +175,10 @@ def main():
         t = torch.tensor([dt], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    from crdr_amd.hip import functional as HF
+    if rk == 0 and HF.PACK_MISS_LOG is not None:
+        for k, v in sorted(HF.PACK_MISS_LOG.items(), key=lambda kv: -kv[1])[:40]:
+            print("[pack-miss]", k, v, file=sys.stderr)
     if rk == 0 and a.save_tune_db:
         ops.save_tune_cache(a.save_tune_db)
     if rk != 0:

@@ -208,6 +208,52 @@ __global__ __launch_bounds__(256) void pack_weight_tapmajor_kernel(const float* 
   }
 }
 
+// Every weight pack of one optimiser in a single launch.  Work unit = one tile of 8 pack rows x 32 pack columns x all
+// T taps, staged through LDS so that both sides are coalesced: the parameter is read in runs of 32 T (mode 0) or 8 T
+// (mode 1) contiguous floats, the pack is written in 128-byte row segments.
+constexpr int kPackMaxT = 32;
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const crdr_pack_item* items, const long long* prefix,
+                                                                   const long long* meta) {
+  __shared__ float tile[256 * kPackMaxT + 32];
+  const int n = (int)meta[0];
+  const long long total = meta[1];
+  const int tid = threadIdx.x;
+  for (long long g = blockIdx.x; g < total; g += gridDim.x) {
+    int lo = 0, hi = n - 1;  // last item with prefix[item] <= g  (block-uniform)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    const crdr_pack_item it = items[lo];
+    const int tl = (int)(g - prefix[lo]);
+    const int ctiles = it.cols >> 5;
+    const int r0 = (tl / ctiles) * 8, c0 = (tl % ctiles) * 32;
+    const int T = it.T;
+    if (it.mode == 0) {  // pack row = i, pack col = j : LDS [8 r][32 c][T]
+      const int run = 32 * T;
+      for (int e = tid; e < 8 * run; e += 256) {
+        const int r = e / run, rest = e - r * run;
+        const int i = r0 + r, j = c0 + rest / T;
+        tile[e] = (i < it.I && j < it.J) ? it.src[((size_t)i * it.J + c0) * T + rest] : 0.f;
+      }
+    } else {             // pack row = j, pack col = i : LDS [32 c][8 r][T], each c padded by one float
+      const int run = 8 * T;
+      for (int e = tid; e < 32 * run; e += 256) {
+        const int c = e / run, rest = e - c * run;
+        const int i = c0 + c, j = r0 + rest / T;
+        tile[c * (run + 1) + rest] = (i < it.I && j < it.J) ? it.src[((size_t)i * it.J + r0) * T + rest] : 0.f;
+      }
+    }
+    __syncthreads();
+    const int r = tid >> 5, c = tid & 31;
+    const float* sp = it.mode == 0 ? tile + (r * 32 + c) * T : tile + c * (8 * T + 1) + r * T;
+    float* dp = it.dst + ((size_t)(r0 + r)) * it.cols + c0 + c;
+    const size_t tstride = (size_t)it.rows * it.cols;
+    for (int t = 0; t < T; ++t) dp[t * tstride] = sp[t];
+    __syncthreads();
+  }
+}
+
 struct WCfg {
   int wm, wn, mb, nb;
   void (*kern)(const WgradArgs);
@@ -336,6 +382,15 @@ extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const
                      d->gJ, a.T, a.nsplit, d->accumulate);
   CRDR_CHECK_LAUNCH("wgrad_reduce");
   profile_end(1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
+  return 0;
+}
+
+extern "C" int crdr_pack_weights_batched(const crdr_pack_item* items, const int64_t* prefix, const int64_t* meta,
+                                         crdr_stream_t s) {
+  CRDR_REQUIRE(items && prefix && meta, "pack_weights_batched: null pointer");
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(2048), dim3(256), 0, as_stream(s), items,
+                     reinterpret_cast<const long long*>(prefix), reinterpret_cast<const long long*>(meta));
+  CRDR_CHECK_LAUNCH("pack_weights_batched_kernel");
   return 0;
 }
 

@@ -18,7 +18,8 @@ _weights_epoch = 0
 
 
 def bump_weights_epoch() -> None:
-    """Call after parameters were modified behind torch's back (the fused Adam kernel): invalidates weight packs."""
+    """Invalidate every weight pack (parameters were modified behind torch's back by something other than an optimiser
+    that owns a PackTable -- the fused Adam refills its packs itself, see PackTable)."""
     global _weights_epoch
     _weights_epoch += 1
 
@@ -29,8 +30,27 @@ def _grad_slot(p: torch.Tensor) -> torch.Tensor:
     return p.grad
 
 
+class _PackEntry:
+    """One persistent weight pack: destination buffer + how to refill it from its parameter."""
+    __slots__ = ("weight", "dst", "I", "J", "T", "rows", "cols", "mode", "key")
+
+    def fill(self) -> None:
+        lib = L.load()
+        L.check(lib.crdr_pack_weight(self.weight.data_ptr(), self.dst.data_ptr(), self.I, self.J, self.T, self.rows, self.cols,
+                                     self.mode, ops._stream()), "pack_weight")
+
+
+PACK_MISS_LOG = {} if __import__("os").environ.get("CRDR_DEBUG_PACK") == "1" else None  # {(I, J, T, mode, why): count}
+_pack_entries = []   # every pack ever made, in creation order (PackTable selects the ones of one optimiser)
+_pack_serial = 0     # bumped when _pack_entries grows
+
+
+def _current_key(w: torch.Tensor):
+    return (w.data_ptr(), w._version, _weights_epoch)
+
+
 class ConvSpec:
-    """Static description of one conv layer + cache of its two weight packs."""
+    """Static description of one conv layer + its two persistent weight packs (forward / input-gradient operand)."""
 
     def __init__(self, in_ch, out_ch, k, stride, pad, transposed=False, out_pad=0):
         self.in_ch, self.out_ch, self.k = in_ch, out_ch, (k, k) if isinstance(k, int) else tuple(k)
@@ -44,15 +64,94 @@ class ConvSpec:
 
     def pack(self, weight: torch.Tensor, for_dgrad: bool) -> torch.Tensor:
         # forward pack has rows = out channels: Conv2d weight [O][I] -> no transpose; ConvT weight [I][O] -> transpose
+        global _pack_serial
         transpose = (self.transposed != for_dgrad)
-        key = (weight.data_ptr(), weight._version, _weights_epoch)
-        hit = self._packs.get(transpose)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        w4 = weight if weight.dim() == 4 else weight.reshape(weight.shape[0], weight.shape[1], 1, 1)
-        pk = ops.pack_weight_tapmajor(w4.detach()) if (self.smallc and not for_dgrad) else ops.pack_weight(w4.detach(), transpose)
-        self._packs[transpose] = (key, pk)
-        return pk
+        ent = self._packs.get(transpose)
+        key = _current_key(weight)
+        if ent is not None and ent.key == key:
+            return ent.dst
+        if ent is None or ent.weight.data_ptr() != weight.data_ptr() or ent.weight.shape != weight.shape:
+            ops._require_gpu(weight)
+            assert weight.is_contiguous()
+            ent = _PackEntry()
+            ent.key = None
+            ent.weight = weight.detach()
+            ent.I, ent.J = weight.shape[0], weight.shape[1]
+            ent.T = weight.shape[2] * weight.shape[3] if weight.dim() == 4 else 1
+            if self.smallc and not for_dgrad:
+                ent.mode, ent.rows, ent.cols = 2, ops.round32(ent.I), ops.round32(4 * ent.T)
+                ent.dst = torch.empty((1, ent.rows, ent.cols), dtype=torch.float32, device=weight.device)
+            else:
+                ent.mode = int(transpose)
+                ent.rows, ent.cols = (ops.round32(ent.J), ops.round32(ent.I)) if transpose else (ops.round32(ent.I), ops.round32(ent.J))
+                ent.dst = torch.empty((ent.T, ent.rows, ent.cols), dtype=torch.float32, device=weight.device)
+            self._packs[transpose] = ent
+            _pack_entries.append(ent)
+            _pack_serial += 1
+        if PACK_MISS_LOG is not None:
+            why = "new" if ent.key is None else "ptr" if ent.key[0] != key[0] else "version" if ent.key[1] != key[1] else "epoch"
+            k = (ent.I, ent.J, ent.T, ent.mode, why)
+            PACK_MISS_LOG[k] = PACK_MISS_LOG.get(k, 0) + 1
+        ent.fill()
+        ent.key = key
+        return ent.dst
+
+
+class PackTable:
+    """The packs whose parameter lives in one address range (an optimiser's flat buffer, or a partition of it), refilled
+    by ONE launch right after that optimiser's update -- instead of one small launch per layer on next use.
+
+    The device-side table has a fixed capacity and is rewritten in place when new packs appear, so a HIP graph that
+    captured the launch keeps covering everything."""
+    CAP = 4096
+    ITEM = 40  # sizeof(crdr_pack_item)
+
+    def __init__(self, flat: torch.Tensor, lo: int = 0, hi: Optional[int] = None):
+        hi = flat.numel() if hi is None else hi
+        self.lo, self.hi = flat.data_ptr() + 4 * lo, flat.data_ptr() + 4 * hi
+        self.device = flat.device
+        self.items = torch.zeros(self.CAP * self.ITEM, dtype=torch.uint8, device=flat.device)
+        self.prefix = torch.zeros(self.CAP + 1, dtype=torch.int64, device=flat.device)
+        self.meta = torch.zeros(2, dtype=torch.int64, device=flat.device)
+        self.entries, self.singles = [], []
+        self._seen = -1
+
+    def _refresh(self) -> None:
+        import numpy as np
+        if self._seen == _pack_serial:
+            return
+        mine = [e for e in _pack_entries if self.lo <= e.weight.data_ptr() < self.hi and e.dst.device == self.device]
+        ents = [e for e in mine if e.mode in (0, 1) and e.T <= 32]   # what the batched kernel takes
+        self.singles = [e for e in mine if not (e.mode in (0, 1) and e.T <= 32)]
+        if [id(e) for e in ents] != [id(e) for e in self.entries]:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("PackTable: new weight packs appeared during graph capture (run eager warm-up iterations first)")
+            assert len(ents) <= self.CAP
+            rec = np.zeros(len(ents), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("I", "<i4"), ("J", "<i4"), ("T", "<i4"),
+                                                        ("rows", "<i4"), ("cols", "<i4"), ("mode", "<i4")]))
+            pre = np.zeros(len(ents) + 1, dtype=np.int64)
+            for k, e in enumerate(ents):
+                rec[k] = (e.weight.data_ptr(), e.dst.data_ptr(), e.I, e.J, e.T, e.rows, e.cols, e.mode)
+                pre[k + 1] = pre[k] + (e.rows // 8) * (e.cols // 32)
+            assert rec.dtype.itemsize == self.ITEM
+            if len(ents):
+                self.items[:len(ents) * self.ITEM].copy_(torch.from_numpy(rec.view(np.uint8).copy()))
+            self.prefix[:len(ents) + 1].copy_(torch.from_numpy(pre))
+            self.meta.copy_(torch.tensor([len(ents), int(pre[-1])], dtype=torch.int64))
+            self.entries = ents
+        self._seen = _pack_serial
+
+    def refill(self) -> None:
+        """Refill every pack of the range from the current parameter values and mark them fresh."""
+        self._refresh()
+        if self.entries:
+            lib = L.load()
+            L.check(lib.crdr_pack_weights_batched(self.items.data_ptr(), self.prefix.data_ptr(), self.meta.data_ptr(),
+                                                  ops._stream()), "pack_weights_batched")
+        for e in self.singles:
+            e.fill()
+        for e in self.entries + self.singles:
+            e.key = _current_key(e.weight)
 
 
 def _flags(bias, act, vec2, res, gate, affine) -> int:

@@ -70,6 +70,7 @@ SIGNATURES = {
     "crdr_conv2d_wgrad_workspace": (_SZ, [C.POINTER(WgradDesc)]),
     "crdr_conv2d_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _SZ, _P]),
     "crdr_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "crdr_pack_weights_batched": (_I, [_P, _P, _P, _P]),
     "crdr_epilogue_bwd_workspace": (_SZ, [C.POINTER(EbwdDesc)]),
     "crdr_epilogue_bwd": (_I, [C.POINTER(EbwdDesc), C.POINTER(EbwdIO), _P, _SZ, _P]),
     "crdr_affine": (_I, [_P, _I, _P, _P, _P, _I, _I64, _I, _P]),

@@ -34,6 +34,10 @@ class GANRateDistortionTrainer(RateDistortionTrainer):
         super()._set_optimizer_scheduler()
         oo = deepcopy(self.opt.optim)
         self.d_optimizer = build_optimizer(dict(self.discriminator.named_parameters()), oo.d_optimizer)
+        if hasattr(self.discriminator, "subD_list") and len(self.d_optimizer.param_groups) == 1:
+            # one partition per sub-discriminator: only the one a step ran is zeroed / all-reduced / updated, like
+            # torch.optim.Adam skipping the parameters whose .grad is None (module_list_discriminator.py:26-30)
+            self.d_optimizer.set_partitions(self.discriminator.subD_list)
         self.d_scheduler = build_scheduler(self.d_optimizer, oo.d_scheduler) if oo.get("d_scheduler") else None
 
     def _finish_step(self, current_iter: int, log):

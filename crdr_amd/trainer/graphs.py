@@ -43,7 +43,6 @@ class SegmentGraphs:
             return fn()
         g = self._graphs.get(key)
         if g is None:
-            HF.bump_weights_epoch()  # packs cached by earlier captures belong to those graphs; re-derive inside this one
             g = torch.cuda.CUDAGraph()
             ops.reserve_workspace(torch.cuda.current_device(), self._stream)
             torch.cuda.synchronize()

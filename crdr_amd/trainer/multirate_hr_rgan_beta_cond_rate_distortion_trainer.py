@@ -88,7 +88,7 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         out = super()._seg_update(ctx)
         q = ctx["q"]
         self.discriminator.requires_grad_(True)
-        self.d_optimizer.zero_grad()
+        self.d_optimizer.zero_grad(partitions=self._d_parts(q))
         fake_d = self.discriminator(ctx["fake"], rate_ind=q)
         real_d = self.discriminator(ctx["real"], rate_ind=q)
         l_d_real = self.gan_loss.forward_diff(real_d, fake_d.detach(), is_real=True, is_disc=True) * 0.5
@@ -98,8 +98,12 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
                     "out_d_real": real_d.detach().mean(), "out_d_fake": fake_d.detach().mean()})
         return out
 
+    def _d_parts(self, q):
+        """The optimiser partition of the sub-discriminator that rate level q trains (None = everything)."""
+        return [int(q)] if self.d_optimizer.param_groups[0].get("parts") and len(self.d_optimizer.param_groups[0]["parts"]) > 1 else None
+
     def _seg_dstep(self, ctx: Dict) -> Dict:
-        self.d_optimizer.step(skip=ctx["bad"])
+        self.d_optimizer.step(skip=ctx["bad"], partitions=self._d_parts(ctx["q"]))
         return {}
 
     def optimize_parameters(self, current_iter: int, data_dict: Dict):
@@ -118,7 +122,7 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         ctx = run("g", lambda: self._seg_generator(real, cond, noise, current_iter))
         self._sync_between_segments(ctx, self.g_optimizer)
         ctx2 = run("u", lambda: self._seg_update(ctx))
-        D.all_reduce_mean_(self.d_optimizer.flat_grads())
+        D.all_reduce_mean_(self.d_optimizer.flat_grads(partitions=self._d_parts(ctx["q"])))
         run("d", lambda: self._seg_dstep(ctx))
         log = {"qbpp": ctx["qbpp"] if ctx["qbpp"] is not None else -1, **ctx["losses"], **ctx2, "_bad": ctx["bad"]}
         return self._finish_step(current_iter, log)

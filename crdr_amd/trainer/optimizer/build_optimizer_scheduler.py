@@ -57,14 +57,53 @@ class Adam:
         grp["flat"], grp["grad"] = flat, grad
         grp["m"], grp["v"] = torch.zeros_like(flat), torch.zeros_like(flat)
 
-    # ---- gradient buffers
-    def flat_grads(self) -> List[torch.Tensor]:
-        return [g["grad"] for g in self.param_groups if g["grad"] is not None]
+    # ---- partitions: parameter subsets that are updated on their own (torch.optim.Adam skips parameters whose .grad is
+    # None -- e.g. the four sub-discriminators a step did not run, module_list_discriminator.py:26-30 -- leaving their
+    # moments and step counts untouched; a partition reproduces exactly that on the flat buffers)
+    def set_partitions(self, modules: Iterable[torch.nn.Module]) -> None:
+        """One partition per module (its parameters must be contiguous in the single param group, in order)."""
+        assert len(self.param_groups) == 1, "partitions are defined on a single param group"
+        g = self.param_groups[0]
+        offs, off = {}, 0
+        for p in g["params"]:
+            offs[id(p)] = off
+            off += p.numel()
+        parts, cursor = [], 0
+        for m in modules:
+            ps = [p for p in m.parameters() if p.requires_grad]
+            lo, hi = offs[id(ps[0])], offs[id(ps[-1])] + ps[-1].numel()
+            assert lo == cursor and sum(p.numel() for p in ps) == hi - lo, "partition parameters are not contiguous"
+            parts.append(_Group(lo=lo, hi=hi, step=g["step"]))
+            cursor = hi
+        assert cursor == g["flat"].numel(), "partitions must cover the group"
+        g["parts"] = parts
 
-    def zero_grad(self, set_to_none: bool = False) -> None:
+    @staticmethod
+    def _parts(g, which: Optional[Iterable[int]]):
+        if g.get("parts") is None:
+            g["parts"] = [_Group(lo=0, hi=g["flat"].numel(), step=g["step"])]
+        return g["parts"] if which is None else [g["parts"][i] for i in which]
+
+    # ---- gradient buffers
+    def flat_grads(self, partitions: Optional[Iterable[int]] = None) -> List[torch.Tensor]:
+        out = []
+        for g in self.param_groups:
+            if g["grad"] is None:
+                continue
+            if partitions is None:
+                out.append(g["grad"])
+            else:
+                out += [g["grad"][pt["lo"]:pt["hi"]] for pt in self._parts(g, partitions)]
+        return out
+
+    def zero_grad(self, set_to_none: bool = False, partitions: Optional[Iterable[int]] = None) -> None:
         for g in self.param_groups:
             if g["grad"] is not None:
-                g["grad"].zero_()
+                if partitions is None:
+                    g["grad"].zero_()
+                else:
+                    for pt in self._parts(g, partitions):
+                        g["grad"][pt["lo"]:pt["hi"]].zero_()
                 off = 0
                 for p in g["params"]:  # re-attach in case autograd replaced a .grad tensor
                     n = p.numel()
@@ -86,50 +125,63 @@ class Adam:
             return out
         return total
 
-    def _dyn(self, g) -> torch.Tensor:
-        """Device-resident [lr, step, skip] of a group (what the graph-capturable update reads)."""
-        if g.get("dyn") is None:
-            g["dyn"] = torch.tensor([float(g["lr"]), float(g["step"]), 0.0], dtype=torch.float32, device=g["flat"].device)
-            g["dyn_lr"] = float(g["lr"])
-        return g["dyn"]
+    def _dyn(self, g, pt) -> torch.Tensor:
+        """Device-resident [lr, step, skip] of a partition (what the graph-capturable update reads)."""
+        if pt.get("dyn") is None:
+            pt["dyn"] = torch.tensor([float(g["lr"]), float(pt["step"]), 0.0], dtype=torch.float32, device=g["flat"].device)
+            pt["dyn_lr"] = float(g["lr"])
+        return pt["dyn"]
 
     def sync_lr_to_device(self) -> None:
         """Push host-side lr changes (scheduler milestones) into the device scalars; call outside graph capture."""
         for g in self.param_groups:
-            if g.get("dyn") is not None and g["dyn_lr"] != float(g["lr"]):
-                g["dyn"][0:1].fill_(float(g["lr"]))
-                g["dyn_lr"] = float(g["lr"])
+            for pt in g.get("parts") or []:
+                if pt.get("dyn") is not None and pt["dyn_lr"] != float(g["lr"]):
+                    pt["dyn"][0:1].fill_(float(g["lr"]))
+                    pt["dyn_lr"] = float(g["lr"])
 
-    def step(self, sqnorm: Optional[torch.Tensor] = None, max_norm: float = 0.0, skip: Optional[torch.Tensor] = None) -> None:
-        """One Adam update. With `sqnorm` (1-element device tensor holding the squared global gradient norm) the
-        gradient is scaled by min(1, max_norm / (sqrt(sqnorm) + 1e-6)) inside the kernel (clip_grad_norm_).
-        With `skip` (1-element device tensor, 0 or 1) the step count, lr and the skip decision live on the device, so
-        the call sequence is identical every iteration and can be captured in a HIP graph."""
+    def step(self, sqnorm: Optional[torch.Tensor] = None, max_norm: float = 0.0, skip: Optional[torch.Tensor] = None,
+             partitions: Optional[Iterable[int]] = None) -> None:
+        """One Adam update (of the given partitions only). With `sqnorm` (1-element device tensor holding the squared
+        global gradient norm) the gradient is scaled by min(1, max_norm / (sqrt(sqnorm) + 1e-6)) inside the kernel
+        (clip_grad_norm_).  With `skip` (1-element device tensor, 0 or 1) the step count, lr and the skip decision live
+        on the device, so the call sequence is identical every iteration and can be captured in a HIP graph.
+        Every weight pack fed by the updated range is refilled by one batched launch right behind the update."""
         lib = L.load()
+        touched = []
         for g in self.param_groups:
             if g["flat"] is None:
                 continue
             b1, b2 = g["betas"]
             sq = None if sqnorm is None else sqnorm.data_ptr()
-            if skip is None:
-                g["step"] += 1
-                L.check(lib.crdr_adam_step(g["flat"].data_ptr(), g["grad"].data_ptr(), g["m"].data_ptr(), g["v"].data_ptr(),
-                                           g["flat"].numel(), float(g["lr"]), b1, b2, g["eps"], g["step"], sq, float(max_norm),
-                                           ops._stream()), "adam_step")
-            else:
-                dyn = self._dyn(g)
-                dyn[1:2].add_(1.0 - skip)   # the step count advances only when the update is applied
-                dyn[2:3].copy_(skip)
-                L.check(lib.crdr_adam_step_dyn(g["flat"].data_ptr(), g["grad"].data_ptr(), g["m"].data_ptr(), g["v"].data_ptr(),
-                                               g["flat"].numel(), b1, b2, g["eps"], dyn.data_ptr(), sq, float(max_norm),
-                                               ops._stream()), "adam_step_dyn")
-        HF.bump_weights_epoch()
+            for pt in self._parts(g, partitions):
+                lo, n = pt["lo"], pt["hi"] - pt["lo"]
+                ptrs = [g[k].data_ptr() + 4 * lo for k in ("flat", "grad", "m", "v")]
+                if skip is None:
+                    pt["step"] += 1
+                    L.check(lib.crdr_adam_step(*ptrs, n, float(g["lr"]), b1, b2, g["eps"], pt["step"], sq, float(max_norm),
+                                               ops._stream()), "adam_step")
+                else:
+                    dyn = self._dyn(g, pt)
+                    dyn[1:2].add_(1.0 - skip)   # the step count advances only when the update is applied
+                    dyn[2:3].copy_(skip)
+                    L.check(lib.crdr_adam_step_dyn(*ptrs, n, b1, b2, g["eps"], dyn.data_ptr(), sq, float(max_norm),
+                                                   ops._stream()), "adam_step_dyn")
+                touched.append((g, pt))
+            g["step"] = max(pt["step"] for pt in g["parts"])
+        for g, pt in touched:
+            if pt.get("packs") is None:
+                pt["packs"] = HF.PackTable(g["flat"], pt["lo"], pt["hi"])
+            pt["packs"].refill()
 
     def host_step_counts(self) -> None:
         """Refresh the host-side step counters from the device (for checkpoints); synchronises."""
         for g in self.param_groups:
-            if g.get("dyn") is not None:
-                g["step"] = int(round(float(g["dyn"][1])))
+            for pt in g.get("parts") or []:
+                if pt.get("dyn") is not None:
+                    pt["step"] = int(round(float(pt["dyn"][1])))
+            if g.get("parts"):
+                g["step"] = max(pt["step"] for pt in g["parts"])
 
     # ---- torch.optim-compatible checkpoint format
     def state_dict(self) -> Dict:
@@ -137,10 +189,12 @@ class Adam:
         state, groups, idx = {}, [], 0
         for g in self.param_groups:
             ids, off = [], 0
+            parts = self._parts(g, None) if g["flat"] is not None else []
             for p in g["params"]:
                 n = p.numel()
-                if g["step"] > 0:
-                    state[idx] = {"step": torch.tensor(float(g["step"])), "exp_avg": g["m"][off:off + n].view(p.shape).clone(),
+                step = next(pt["step"] for pt in parts if pt["lo"] <= off < pt["hi"])
+                if step > 0:  # torch keeps no state for a parameter that was never stepped
+                    state[idx] = {"step": torch.tensor(float(step)), "exp_avg": g["m"][off:off + n].view(p.shape).clone(),
                                   "exp_avg_sq": g["v"][off:off + n].view(p.shape).clone()}
                 ids.append(idx)
                 idx += 1
@@ -151,6 +205,11 @@ class Adam:
     def load_state_dict(self, sd: Dict) -> None:
         for g, sg in zip(self.param_groups, sd["param_groups"]):
             g["lr"], g["betas"], g["eps"] = sg["lr"], tuple(sg["betas"]), sg["eps"]
+            if g["flat"] is None:
+                continue
+            parts = self._parts(g, None)
+            for pt in parts:
+                pt["step"] = 0
             off = 0
             for p, pid in zip(g["params"], sg["params"]):
                 n = p.numel()
@@ -158,12 +217,16 @@ class Adam:
                 if st is not None:
                     g["m"][off:off + n].copy_(st["exp_avg"].reshape(-1))
                     g["v"][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
-                    g["step"] = int(st["step"])
+                    pt = next(pt for pt in parts if pt["lo"] <= off < pt["hi"])
+                    pt["step"] = max(pt["step"], int(st["step"]))
                 off += n
-            if g.get("dyn") is not None:
-                g["dyn"][1:2].fill_(float(g["step"]))
-                g["dyn"][0:1].fill_(float(g["lr"]))
-                g["dyn_lr"] = float(g["lr"])
+            g["step"] = max(pt["step"] for pt in parts)
+            for pt in parts:
+                if pt.get("dyn") is not None:
+                    pt["dyn"][1:2].fill_(float(pt["step"]))
+                    pt["dyn"][0:1].fill_(float(g["lr"]))
+                    pt["dyn_lr"] = float(g["lr"])
+            HF.bump_weights_epoch()
 
 
 class MultiStepLR:

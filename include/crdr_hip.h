@@ -121,6 +121,18 @@ int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, 
 int crdr_pack_weight(const float* src, float* dst, int I, int J, int T, int rows, int cols, int transpose,
                      crdr_stream_t s);
 
+/* All weight packs of an optimiser in one launch (they all go stale together, right after its fused Adam update).
+ * `items` and `prefix` are DEVICE arrays: item k packs like crdr_pack_weight(src, dst, I, J, T, rows, cols, mode) with
+ * mode 0 or 1, T <= 32, rows % 8 == 0, cols % 32 == 0, and owns the tiles (8 pack rows x 32 pack columns x T) numbered
+ * [prefix[k], prefix[k+1]); `meta` is a 2-element DEVICE array {number of items, prefix[number of items]} read by
+ * the kernel, so a table that is rewritten in place keeps working under a captured HIP graph. */
+typedef struct crdr_pack_item {
+  const float* src;
+  float* dst;
+  int32_t I, J, T, rows, cols, mode;
+} crdr_pack_item;
+int crdr_pack_weights_batched(const crdr_pack_item* items, const int64_t* prefix, const int64_t* meta, crdr_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* fused elementwise / reductions (HBM-bound)                                                        */
 /* ------------------------------------------------------------------------------------------------ */

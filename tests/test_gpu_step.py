@@ -73,16 +73,47 @@ def test_adam_matches_torch():
             opt.step(sqnorm=opt.grad_sqnorm(), max_norm=1.0, skip=torch.ones(1, device=dev()))
             assert all(torch.equal(a, p.detach()) for a, p in zip(before, ps)), "skip flag must leave parameters untouched"
             for g in opt.param_groups:  # host counter mirrors what the eager calls did so far
-                if g.get("dyn") is not None:
-                    g["dyn"][1:2].fill_(float(step))
+                for pt in g["parts"]:
+                    if pt.get("dyn") is not None:
+                        pt["dyn"][1:2].fill_(float(step))
             opt.step(sqnorm=opt.grad_sqnorm(), max_norm=1.0, skip=torch.zeros(1, device=dev()))
             for g in opt.param_groups:
-                g["step"] = step + 1
+                for pt in g["parts"]:
+                    pt["step"] = step + 1
         for p, r in zip(ps, ref):
             close(p, r, f"adam step {step}", 2e-6)
     sd = opt.state_dict()
     topt.load_state_dict(sd)  # format compatibility
     assert len(sd["state"]) == 3
+
+
+@pytest.mark.parametrize("device_counters", [False, True])
+def test_adam_partitions_skip_unused_modules_like_torch(device_counters):
+    """torch.optim.Adam leaves parameters whose .grad is None alone (moments, step count); a partitioned flat Adam must
+    do the same for the sub-discriminators a step did not run."""
+    from crdr_amd.trainer.optimizer import build_optimizer
+    torch.manual_seed(3)
+    mods = torch.nn.ModuleList(torch.nn.Linear(7, 5) for _ in range(3))
+    ref = torch.nn.ModuleList(torch.nn.Linear(7, 5) for _ in range(3))
+    ref.load_state_dict(mods.state_dict())
+    mods.to(dev())
+    opt = build_optimizer(dict(mods.named_parameters()), {"type": "Adam", "lr": 1e-2})
+    opt.set_partitions(mods)
+    topt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    for step, q in enumerate([1, 1, 0, 2, 1, 0]):
+        topt.zero_grad(set_to_none=True)
+        opt.zero_grad(partitions=[q])
+        for p, r in zip(mods[q].parameters(), ref[q].parameters()):
+            g = torch.randn(r.shape)
+            r.grad = g.clone()
+            p.grad.copy_(g.to(dev()))
+        topt.step()
+        opt.step(partitions=[q], skip=torch.zeros(1, device=dev()) if device_counters else None)
+        for (n, p), r in zip(mods.named_parameters(), ref.parameters()):
+            close(p, r, f"partitioned adam step {step} {n}", 2e-6)
+    sd = opt.state_dict()
+    assert [int(sd["state"][i]["step"]) for i in (0, 2, 4)] == [2, 3, 1]
+    topt.load_state_dict(sd)
 
 
 def test_stage3_step():

@@ -20,6 +20,9 @@ SHAPES = {
     "enc96k3@64": (96, 64, 96, 3, 1, 0, 3),
     "dec256k1": (256, 128, 128, 1, 1, 0, 3),
     "enc192k1@64": (192, 64, 96, 1, 1, 0, 3),
+    "enc96to192k1@64": (96, 64, 192, 1, 1, 0, 17),
+    "dec128to256k1@64": (128, 64, 256, 1, 1, 0, 17),
+    "enc96to192k1@128": (96, 128, 192, 1, 1, 0, 17),
     "up3T": (256, 64, 256, 5, 2, 1, 1),
     "enc5s2": (192, 128, 192, 5, 2, 0, 1),
     "charm480": (480, 16, 224, 5, 1, 0, 3),
@@ -62,19 +65,20 @@ def main():
         w = torch.randn(*((ci, co, k, k) if tr else (co, ci, k, k)), device=dev) * 0.02
         wf = ops.pack_weight(w, transpose=bool(tr))
         bias = torch.randn(co, device=dev)
+        resid = torch.randn(a.bs, co, oh, oh, device=dev).contiguous(memory_format=torch.channels_last) if flags & 16 else None
         flops = 2.0 * a.bs * (h * h if tr else oh * oh) * ci * co * k * k
         res = []
         for c in range(ncfg):
             for ls in range(5):
                 algo = (c + 1) | (ls << 8)
                 try:
-                    fn = lambda: ops.conv2d_raw(x, wf, co, (k, k), s, p, bool(tr), (oh, oh), bias=bias, flags=flags, algo=algo)  # noqa: E731
+                    fn = lambda: ops.conv2d_raw(x, wf, co, (k, k), s, p, bool(tr), (oh, oh), bias=bias, res=resid, flags=flags, algo=algo)  # noqa: E731
                     t = timeit(fn)
                 except L.CrdrHipError:
                     continue
                 res.append((t, c, 1 << ls))
         res.sort()
-        t0 = timeit(lambda: ops.conv2d_raw(x, wf, co, (k, k), s, p, bool(tr), (oh, oh), bias=bias, flags=flags))
+        t0 = timeit(lambda: ops.conv2d_raw(x, wf, co, (k, k), s, p, bool(tr), (oh, oh), bias=bias, res=resid, flags=flags))
         print(f"{name:14s} heuristic {t0 * 1e6:8.1f} us {flops / t0 / 1e12:6.1f} TF | " +
               "  ".join(f"cfg{c}/s{sp} {t * 1e6:.1f}us {flops / t / 1e12:.1f}TF" for t, c, sp in res[:a.top]), flush=True)
         if a.wgrad and not tr:
