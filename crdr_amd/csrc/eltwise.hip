@@ -484,6 +484,75 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(const float* f0, c
   }
 }
 
+
+// ---- linear layers on <= 16 row vectors (GEMV style) ---------------------------------------------------------
+constexpr int kLinMaxM = 16;
+// one wave per output feature: lanes stride over the input features, butterfly reduction at the end
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* x, int M, int I, int ldx, const float* w, const float* b,
+                                                         float* y, int O, int ldy, int relu) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= O) return;
+  float acc[kLinMaxM];
+#pragma unroll
+  for (int m = 0; m < kLinMaxM; ++m) acc[m] = 0.f;
+  for (int i = lane; i < I; i += 64) {
+    const float wv = w[(size_t)o * I + i];
+#pragma unroll
+    for (int m = 0; m < kLinMaxM; ++m)
+      if (m < M) acc[m] += wv * x[(size_t)m * ldx + i];
+  }
+#pragma unroll
+  for (int m = 0; m < kLinMaxM; ++m) {
+    float v = acc[m];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0 && m < M) {
+      v += b ? b[o] : 0.f;
+      y[(size_t)m * ldy + o] = relu ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+__device__ __forceinline__ float lin_g(const float* dy, int lddy, const float* y, int ldy, int m, int o) {
+  const float g = dy[(size_t)m * lddy + o];
+  return (y && !(y[(size_t)m * ldy + o] > 0.f)) ? 0.f : g;
+}
+// dw / db: one thread per (o, i)
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* x, int M, int I, int ldx, const float* dy, int lddy,
+                                                           const float* y, int ldy, int O, float* dw, float* db) {
+  const long long e = blockIdx.x * 256ll + threadIdx.x;
+  if (e >= (long long)O * I) return;
+  const int o = (int)(e / I), i = (int)(e % I);
+  float a = 0.f, s = 0.f;
+  for (int m = 0; m < M; ++m) {
+    const float g = lin_g(dy, lddy, y, ldy, m, o);
+    a += g * x[(size_t)m * ldx + i];
+    s += g;
+  }
+  if (dw) dw[e] += a;
+  if (db && i == 0) db[o] += s;
+}
+// dx: block = 64 input features, the 4 waves split the output features, LDS reduction in wave order
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* w, int M, int I, const float* dy, int lddy, const float* y,
+                                                           int ldy, int O, float* dx, int lddx) {
+  __shared__ float red[4][kLinMaxM][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = blockIdx.x * 64 + lane;
+  float acc[kLinMaxM];
+#pragma unroll
+  for (int m = 0; m < kLinMaxM; ++m) acc[m] = 0.f;
+  if (i < I)
+    for (int o = wave; o < O; o += 4) {
+      const float wv = w[(size_t)o * I + i];
+#pragma unroll
+      for (int m = 0; m < kLinMaxM; ++m)
+        if (m < M) acc[m] += wv * lin_g(dy, lddy, y, ldy, m, o);
+    }
+#pragma unroll
+  for (int m = 0; m < kLinMaxM; ++m) red[wave][m][lane] = acc[m];
+  __syncthreads();
+  if (wave == 0 && i < I)
+    for (int m = 0; m < M; ++m) dx[(size_t)m * lddx + i] = (red[0][m][lane] + red[1][m][lane]) + (red[2][m][lane] + red[3][m][lane]);
+}
+
 }  // namespace crdr
 
 using namespace crdr;
@@ -525,6 +594,32 @@ extern "C" int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io
   hipLaunchKernelGGL(colsum_final, dim3(cdiv(4 * d->C, 16)), dim3(256), 0, as_stream(s), (const float*)ws,
                      d->M > 0 ? nb : 0, 4, d->C, io->colsums, 0);
   CRDR_CHECK_LAUNCH("colsum_final");
+  return 0;
+}
+
+extern "C" int crdr_linear_fwd(const float* x, int M, int I, int ldx, const float* w, const float* b, float* y, int O,
+                               int ldy, int relu, crdr_stream_t s) {
+  CRDR_REQUIRE(x && w && y, "linear_fwd: null pointer");
+  CRDR_REQUIRE(M >= 1 && M <= kLinMaxM, "linear_fwd: M = %d rows (1..%d supported; use crdr_conv2d)", M, kLinMaxM);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(O, 4)), dim3(256), 0, as_stream(s), x, M, I, ldx, w, b, y, O, ldy, relu);
+  CRDR_CHECK_LAUNCH("linear_fwd_kernel");
+  return 0;
+}
+
+extern "C" int crdr_linear_bwd(const float* x, int M, int I, int ldx, const float* w, const float* dy, int lddy,
+                               const float* y, int ldy, int O, float* dx, int lddx, float* dw, float* db, crdr_stream_t s) {
+  CRDR_REQUIRE(x && w && dy, "linear_bwd: null pointer");
+  CRDR_REQUIRE(M >= 1 && M <= kLinMaxM, "linear_bwd: M = %d rows (1..%d supported)", M, kLinMaxM);
+  if (dw || db) {
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)cdiv64((long long)O * I, 256)), dim3(256), 0, as_stream(s), x, M, I,
+                       ldx, dy, lddy, y, ldy, O, dw, db);
+    CRDR_CHECK_LAUNCH("linear_bwd_w_kernel");
+  }
+  if (dx) {
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(I, 64)), dim3(256), 0, as_stream(s), w, M, I, dy, lddy, y, ldy, O, dx,
+                       lddx);
+    CRDR_CHECK_LAUNCH("linear_bwd_x_kernel");
+  }
   return 0;
 }
 

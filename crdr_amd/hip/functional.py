@@ -232,9 +232,45 @@ class _FusedConv(torch.autograd.Function):
                 dgt, None, None)
 
 
+class _SmallLinear(torch.autograd.Function):
+    """1x1 conv over <= 16 single-pixel rows (conditioning MLP / projections): GEMV kernels on the raw parameter."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu: bool):
+        lib = L.load()
+        ops._require_gpu(x)
+        m, i, o = x.shape[0], x.shape[1], weight.shape[0]
+        x2 = x.reshape(m, i).contiguous()
+        y = torch.empty((m, o), dtype=torch.float32, device=x.device)
+        L.check(lib.crdr_linear_fwd(x2.data_ptr(), m, i, i, weight.data_ptr(), None if bias is None else bias.data_ptr(),
+                                    y.data_ptr(), o, o, int(relu), ops._stream()), "linear_fwd")
+        ctx.relu = relu
+        ctx.save_for_backward(x2, weight, bias, y if relu else None)
+        return y.view(m, o, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias, y = ctx.saved_tensors
+        lib = L.load()
+        m, i, o = x2.shape[0], x2.shape[1], weight.shape[0]
+        dy2 = dy.reshape(m, o).contiguous()
+        needs = ctx.needs_input_grad
+        dx = torch.empty((m, i), dtype=torch.float32, device=dy.device) if needs[0] else None
+        dw = _grad_slot(weight) if needs[1] else None
+        db = _grad_slot(bias) if (bias is not None and needs[2]) else None
+        L.check(lib.crdr_linear_bwd(x2.data_ptr(), m, i, i, weight.data_ptr(), dy2.data_ptr(), o, None if y is None else y.data_ptr(),
+                                    o, o, None if dx is None else dx.data_ptr(), i, None if dw is None else dw.data_ptr(),
+                                    None if db is None else db.data_ptr(), ops._stream()), "linear_bwd")
+        return (None if dx is None else dx.view(m, i, 1, 1)), None, None, None
+
+
 def fused_conv(x, weight, bias, spec: ConvSpec, *, act: Optional[str] = None, vec2=None, res=None,
                affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                gate: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    if (spec.k == (1, 1) and spec.stride == 1 and spec.pad == 0 and not spec.transposed and x.dim() == 4 and x.shape[2] == 1
+            and x.shape[3] == 1 and x.shape[0] <= 16 and vec2 is None and res is None and affine is None and gate is None
+            and act in (None, "relu") and weight.is_contiguous()):
+        return _SmallLinear.apply(x, weight, bias, act == "relu")
     scale, shift = affine if affine is not None else (None, None)
     gx, gt = gate if gate is not None else (None, None)
     return _FusedConv.apply(x, weight, bias, vec2, res, scale, shift, gx, gt, spec, act)

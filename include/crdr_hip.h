@@ -164,6 +164,17 @@ typedef struct crdr_ebwd_io {
 size_t crdr_epilogue_bwd_workspace(const crdr_ebwd_desc* d);
 int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);
 
+/* Linear layer on a handful of row vectors (M <= 16: the beta-conditioning MLP and the per-block projections of the
+ * [1, 512] conditioning vector, elic_interpca_beta_cond_autoencoder.py:42-84, fourier_cond.py:12-37) -- a 1x1 conv
+ * over M pixels is launch-latency bound on the implicit-GEMM path, these run as GEMV-style kernels on the raw [O][I]
+ * parameter (no weight pack).   y[m][o] = act(sum_i x[m][i] w[o][i] + b[o]),  act = ReLU if relu != 0. */
+int crdr_linear_fwd(const float* x, int M, int I, int ldx, const float* w, const float* b, float* y, int O, int ldy,
+                    int relu, crdr_stream_t s);
+/* g = dy (masked by y > 0 when y is given: the ReLU of the forward);  dx[m][i] = sum_o g[m][o] w[o][i] (if dx);
+ * dw[o][i] += sum_m g[m][o] x[m][i] (if dw);  db[o] += sum_m g[m][o] (if db). */
+int crdr_linear_bwd(const float* x, int M, int I, int ldx, const float* w, const float* dy, int lddy, const float* y,
+                    int ldy, int O, float* dx, int lddx, float* dw, float* db, crdr_stream_t s);
+
 /* y[m][c] = x[m][c] * scale[c] + shift[c]   (stand-alone InterpChAtt apply) */
 int crdr_affine(const float* x, int ldx, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
                 crdr_stream_t s);

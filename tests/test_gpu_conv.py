@@ -240,3 +240,29 @@ def test_every_tile_config_and_split():
             g = torch.zeros_like(wt, device=dev)
             ops.conv2d_wgrad_raw(dyd, xd, g, (k, k), 1, 1, accumulate=False, algo=(c + 1) | (ls << 8))
             _close(g, wr.grad, f"wgrad cfg {c} split {1 << ls}")
+
+
+@pytest.mark.parametrize("m,i,o,relu", [(1, 512, 128, False), (1, 20, 512, True), (3, 512, 256, True), (16, 96, 40, False)])
+def test_small_linear_path(m, i, o, relu):
+    """1x1 conv over <= 16 single-pixel rows takes the GEMV kernels (crdr_linear_fwd / crdr_linear_bwd)."""
+    from crdr_amd.hip import functional as HF
+    dev = _dev()
+    x = _rand(m, i, 1, 1, seed=1)
+    wt = _rand(o, i, 1, 1, seed=2, scale=i ** -0.5)
+    b = _rand(o, seed=3)
+    xr, wr, br = x.double().requires_grad_(True), wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br)
+    ref = ref.relu() if relu else ref
+    gy = _rand(*ref.shape, seed=4)
+    ref.backward(gy.double())
+    spec = HF.ConvSpec(i, o, 1, 1, 0)
+    xg = x.to(dev).requires_grad_(True)
+    wg = torch.nn.Parameter(wt.to(dev))
+    bg = torch.nn.Parameter(b.to(dev))
+    out = HF.fused_conv(xg, wg, bg, spec, act="relu" if relu else None)
+    assert out.grad_fn is not None and "SmallLinear" in type(out.grad_fn).__name__
+    out.backward(gy.to(dev))
+    _close(out, ref, "small linear out")
+    _close(xg.grad, xr.grad, "small linear dx")
+    _close(wg.grad, wr.grad, "small linear dw")
+    _close(bg.grad, br.grad, "small linear db")
