@@ -553,6 +553,37 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* w, int M
     for (int m = 0; m < M; ++m) dx[(size_t)m * lddx + i] = (red[0][m][lane] + red[1][m][lane]) + (red[2][m][lane] + red[3][m][lane]);
 }
 
+
+// gather half of the GEMM + scatter formulation of RGB-output transposed ops (see crdr_col2im_rgb)
+__global__ __launch_bounds__(256) void col2im_rgb_kernel(const float* cols, int ldc, int N, int H, int W, int kh, int kw, int S,
+                                                         int P, const float* bias, float* out, int ldo, int OH, int OW, int C) {
+  const long long total = (long long)N * OH * OW;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int ow = (int)(e % OW);
+    const long long r2 = e / OW;
+    const int oh = (int)(r2 % OH), n = (int)(r2 / OH);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < kh; ++r) {
+      const int th = oh + P - r;
+      if (th < 0 || th % S) continue;
+      const int ih = th / S;
+      if (ih >= H) continue;
+      for (int s = 0; s < kw; ++s) {
+        const int tw = ow + P - s;
+        if (tw < 0 || tw % S) continue;
+        const int iw = tw / S;
+        if (iw >= W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(cols + ((size_t)(n * H + ih) * W + iw) * ldc + 4 * (r * kw + s));
+        acc += v;
+      }
+    }
+    float* o = out + (size_t)e * ldo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < C) o[c] = acc[c] + (bias ? bias[c] : 0.f);
+  }
+}
+
 }  // namespace crdr
 
 using namespace crdr;
@@ -594,6 +625,19 @@ extern "C" int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io
   hipLaunchKernelGGL(colsum_final, dim3(cdiv(4 * d->C, 16)), dim3(256), 0, as_stream(s), (const float*)ws,
                      d->M > 0 ? nb : 0, 4, d->C, io->colsums, 0);
   CRDR_CHECK_LAUNCH("colsum_final");
+  return 0;
+}
+
+extern "C" int crdr_col2im_rgb(const float* cols, int ldc, int N, int H, int W, int kh, int kw, int stride, int pad,
+                               const float* bias, float* out, int ldo, int OH, int OW, int C, crdr_stream_t s) {
+  CRDR_REQUIRE(cols && out, "col2im_rgb: null pointer");
+  CRDR_REQUIRE(C >= 1 && C <= 4 && ldc % 4 == 0 && ldc >= 4 * kh * kw && stride >= 1, "col2im_rgb: bad geometry (C=%d ldc=%d)", C, ldc);
+  CRDR_REQUIRE((reinterpret_cast<uintptr_t>(cols) & 15) == 0, "col2im_rgb: cols must be 16-byte aligned");
+  const long long total = (long long)N * OH * OW;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(col2im_rgb_kernel, dim3((unsigned)std::min<long long>(cdiv64(total, 256), 65535)), dim3(256), 0, as_stream(s),
+                     cols, ldc, N, H, W, kh, kw, stride, pad, bias, out, ldo, OH, OW, C);
+  CRDR_CHECK_LAUNCH("col2im_rgb_kernel");
   return 0;
 }
 

@@ -45,6 +45,8 @@ struct WgradArgs {
   int jtiles;
   FastDiv d_hw, d_w;
   unsigned p_bytes, q_bytes;  // extents of the two buffer descriptors (range-checked loads)
+  int smallj;  // 1: QC <= 4 (RGB operand): the taps are folded into the GEMM columns, column = 4 tap + channel, so one
+               // launch covers all taps instead of one 32-column (>= 87 % padding) GEMM per tap
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -62,8 +64,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
   const int wm = wave / WN, wn = wave % WN;
   const int it = blockIdx.x / p.jtiles, jt = blockIdx.x % p.jtiles;
   const int i0 = it * BI, j0 = jt * BJ;
-  const int tap = blockIdx.y, split = blockIdx.z;
-  const int dh = tap / p.kw - p.pad, dw = tap % p.kw - p.pad;
+  const int tap = p.smallj ? 0 : blockIdx.y, split = blockIdx.z;
+  const int ncols = p.smallj ? p.T * 4 : p.QC;  // GEMM columns = width of a slab row
   const int t0 = (int)((long long)p.ntiles * split / p.nsplit), t1 = (int)((long long)p.ntiles * (split + 1) / p.nsplit);
 
   // Staging is LDS-DMA (buffer_load ... lds, 16 B per lane, lane-linear destination = exactly the [32 px][channels]
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.p), 0, p.p_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.q), 0, p.q_bytes, 0x00020000);
   unsigned p_off[PV], q_coff[QV];
-  int q_prow[QV];
+  int q_prow[QV], q_dh[QV], q_dw[QV];
 #pragma unroll
   for (int k = 0; k < PV; ++k) {
     const int e = tid + k * NT;
@@ -84,7 +86,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
     const int e = tid + k * NT;
     const int c = j0 + (e % (BJ / 4)) * 4;
     q_prow[k] = e / (BJ / 4);
-    q_coff[k] = (c < p.QC) ? (unsigned)c * 4u : kOob;
+    const int tk = p.smallj ? (c >> 2) : (int)blockIdx.y;  // tap of this piece
+    q_dh[k] = tk / p.kw - p.pad;
+    q_dw[k] = tk % p.kw - p.pad;
+    q_coff[k] = p.smallj ? (tk < p.T ? 0u : kOob) : ((c < p.QC) ? (unsigned)c * 4u : kOob);
   }
   auto fetch = [&](int t, int buf) __attribute__((always_inline)) {
     const int mbase = t * 32;
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
       const int m = mbase + q_prow[k];
       const unsigned n = fdiv((unsigned)m, p.d_hw), rem = m - n * p.d_hw.d;
       const unsigned a_ = fdiv(rem, p.d_w), b_ = rem - a_ * p.d_w.d;
-      const int ih = (int)a_ * p.stride + dh, iw = (int)b_ * p.stride + dw;
+      const int ih = (int)a_ * p.stride + q_dh[k], iw = (int)b_ * p.stride + q_dw[k];
       const bool ok = (m < p.M) & ((unsigned)ih < (unsigned)p.QH) & ((unsigned)iw < (unsigned)p.QW);
       const unsigned off = (unsigned)(((int)n * p.QH + ih) * p.QW + iw) * (unsigned)(p.ldq * 4) + q_coff[k];
       if (tid + k * NT < 8 * BJ)
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
   }
 
   // partial tile -> slab ws[split][tap][PC][QC]
-  float* dst = p.ws + ((size_t)split * p.T + tap) * p.PC * p.QC;
+  float* dst = p.ws + ((size_t)split * (p.smallj ? 1 : p.T) + tap) * p.PC * ncols;
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -164,21 +169,25 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int col = j0 + (wn * NB + j) * 32 + fcol;
-        if (col < p.QC) dst[(size_t)row * p.QC + col] = acc[i][j][r];
+        if (col < ncols) dst[(size_t)row * ncols + col] = acc[i][j][r];
       }
     }
 }
 
 // g[(i*gJ + j)*T + t] (+)= sum_s ws[((s*T + t)*PC + i)*QC + j]
+// (smallj: the slab row is [T][4] instead: ws[(s*PC + i)*4T + 4t + j])
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* ws, float* g, int PC, int QC, int gI, int gJ, int T,
-                                                    int nsplit, int accumulate) {
+                                                    int nsplit, int accumulate, int smallj) {
   const long long total = (long long)gI * gJ * T;
   for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
     const int j = (int)(e % gJ);
     const long long r = e / gJ;
     const int i = (int)(r % gI), t = (int)(r / gI);
     float v = 0.f;
-    for (int s = 0; s < nsplit; ++s) v += ws[((size_t)(s * T + t) * PC + i) * QC + j];
+    if (smallj)
+      for (int s = 0; s < nsplit; ++s) v += ws[((size_t)s * PC + i) * (4 * T) + 4 * t + j];
+    else
+      for (int s = 0; s < nsplit; ++s) v += ws[((size_t)(s * T + t) * PC + i) * QC + j];
     float* d = g + ((size_t)i * gJ + j) * T + t;
     *d = accumulate ? *d + v : v;
   }
@@ -254,6 +263,17 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const crdr_pa
   }
 }
 
+// scatter pack for RGB-output transposed ops: dst[4 t + j][i] <- src[i][j][t]   (rows >= 4*T, cols >= I, J <= 4)
+__global__ __launch_bounds__(256) void pack_weight_scatter_kernel(const float* src, float* dst, int I, int J, int T, int rows,
+                                                                  int cols) {
+  const long long total = (long long)rows * cols;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int i = (int)(e % cols), r = (int)(e / cols);
+    const int t = r >> 2, j = r & 3;
+    dst[e] = (i < I && j < J && t < T) ? src[((size_t)i * J + j) * T + t] : 0.f;
+  }
+}
+
 struct WCfg {
   int wm, wn, mb, nb;
   void (*kern)(const WgradArgs);
@@ -313,13 +333,16 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl) {
     a.q_bytes = (unsigned)qb;
   }
   a.ntiles = cdiv(a.M, 32);
+  a.smallj = (d->QC <= 4 && a.T > 1) ? 1 : 0;
+  const int ncols = a.smallj ? a.T * 4 : d->QC;   // GEMM columns per launch
+  const int ntapg = a.smallj ? 1 : a.T;           // tap groups = grid.y = slabs per split
   a.d_hw = make_fastdiv((unsigned)(d->PH * d->PW));
   a.d_w = make_fastdiv((unsigned)d->PW);
   double best = 1e300; int bc = -1, bs = 1;
   for (int c = 0; c < kNumWCfgs; ++c) {
     const WCfg& t = kWCfgs[c];
     const int BI = 32 * t.wm * t.mb, BJ = 32 * t.wn * t.nb;
-    const long long tiles = (long long)cdiv(d->PC, BI) * cdiv(d->QC, BJ) * a.T;
+    const long long tiles = (long long)cdiv(d->PC, BI) * cdiv(ncols, BJ) * ntapg;
     const int waves_per_block = t.wm * t.wn;
     for (int ns = 1; ns <= 256; ns *= 2) {
       if (ns > 1 && a.ntiles / ns < 4) break;
@@ -327,7 +350,7 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl) {
       const double slots = 256.0 * std::max(1, 4 / waves_per_block);  // blocks that run at full MFMA rate at once
       const double per_tile = 16.0 * t.mb * t.nb * 64.0 + 400.0;
       double cost = std::ceil(blocks / slots) * ((double)cdiv(a.ntiles, ns) * per_tile + 4000.0);
-      cost += (double)ns * a.T * d->PC * d->QC * 4.0 / 1500.0;  // slab write + read
+      cost += (double)ns * ntapg * d->PC * ncols * 4.0 / 1500.0;  // slab write + read
       if (cost < best) { best = cost; bc = c; bs = ns; }
     }
   }
@@ -340,10 +363,10 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl) {
   CRDR_REQUIRE(bc >= 0, "wgrad: no tile config");
   const WCfg& t = kWCfgs[bc];
   const int BI = 32 * t.wm * t.mb, BJ = 32 * t.wn * t.nb;
-  pl->cfg = bc; a.nsplit = bs; a.jtiles = cdiv(d->QC, BJ);
-  pl->grid = dim3(cdiv(d->PC, BI) * a.jtiles, a.T, bs);
+  pl->cfg = bc; a.nsplit = bs; a.jtiles = cdiv(ncols, BJ);
+  pl->grid = dim3(cdiv(d->PC, BI) * a.jtiles, ntapg, bs);
   pl->lds = (size_t)2 * 32 * (BI + BJ) * sizeof(float);
-  pl->ws_bytes = (size_t)bs * a.T * d->PC * d->QC * sizeof(float);
+  pl->ws_bytes = (size_t)bs * ntapg * d->PC * ncols * sizeof(float);
   return 0;
 }
 
@@ -379,7 +402,7 @@ extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const
   const long long total = (long long)d->gI * d->gJ * a.T;
   const int blocks = (int)std::min<long long>(cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(wgrad_reduce, dim3(blocks), dim3(256), 0, as_stream(s), (const float*)ws, g, d->PC, d->QC, d->gI,
-                     d->gJ, a.T, a.nsplit, d->accumulate);
+                     d->gJ, a.T, a.nsplit, d->accumulate, a.smallj);
   CRDR_CHECK_LAUNCH("wgrad_reduce");
   profile_end(1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
   return 0;
@@ -403,6 +426,14 @@ extern "C" int crdr_pack_weight(const float* src, float* dst, int I, int J, int 
     hipLaunchKernelGGL(pack_weight_tapmajor_kernel, dim3((int)std::min<long long>(cdiv64(tot, 256), 8192)), dim3(256), 0,
                        as_stream(s), src, dst, I, J, T, rows, cols);
     CRDR_CHECK_LAUNCH("pack_weight_tapmajor");
+    return 0;
+  }
+  if (transpose == 3) {
+    CRDR_REQUIRE(J <= 4 && rows >= 4 * T && cols >= I, "pack_weight: scatter pack needs J <= 4, rows >= 4*T, cols >= I");
+    const long long tot = (long long)rows * cols;
+    hipLaunchKernelGGL(pack_weight_scatter_kernel, dim3((int)std::min<long long>(cdiv64(tot, 256), 8192)), dim3(256), 0,
+                       as_stream(s), src, dst, I, J, T, rows, cols);
+    CRDR_CHECK_LAUNCH("pack_weight_scatter");
     return 0;
   }
   CRDR_REQUIRE(rows >= (transpose ? J : I) && cols >= (transpose ? I : J), "pack_weight: pack smaller than source");

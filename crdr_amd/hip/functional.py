@@ -57,6 +57,8 @@ class ConvSpec:
         self.stride, self.pad, self.transposed, self.out_pad = stride, pad, transposed, out_pad
         self._packs = {}
         self.smallc = (not transposed) and in_ch <= 4  # RGB-input convs use the tap-major forward pack
+        # ... and so does the input-gradient of an RGB-output ConvTranspose2d (a regular conv that reduces over <= 4 channels)
+        self.smallc_dgrad = transposed and out_ch <= 4
 
     def out_hw(self, h, w):
         return (ops.conv_out_size(h, self.k[0], self.stride, self.pad, self.transposed, self.out_pad),
@@ -64,9 +66,17 @@ class ConvSpec:
 
     def pack(self, weight: torch.Tensor, for_dgrad: bool) -> torch.Tensor:
         # forward pack has rows = out channels: Conv2d weight [O][I] -> no transpose; ConvT weight [I][O] -> transpose
-        global _pack_serial
         transpose = (self.transposed != for_dgrad)
-        ent = self._packs.get(transpose)
+        tapmajor = (self.smallc and not for_dgrad) or (self.smallc_dgrad and for_dgrad)
+        return self._pack(weight, transpose, 2 if tapmajor else int(transpose))
+
+    def pack_scatter(self, weight: torch.Tensor) -> torch.Tensor:
+        """[4 T][first weight dim] pack of an RGB-output transposed op done as GEMM + col2im (crdr_col2im_rgb)."""
+        return self._pack(weight, "scatter", 3)
+
+    def _pack(self, weight: torch.Tensor, slot, mode: int) -> torch.Tensor:
+        global _pack_serial
+        ent = self._packs.get(slot)
         key = _current_key(weight)
         if ent is not None and ent.key == key:
             return ent.dst
@@ -78,14 +88,16 @@ class ConvSpec:
             ent.weight = weight.detach()
             ent.I, ent.J = weight.shape[0], weight.shape[1]
             ent.T = weight.shape[2] * weight.shape[3] if weight.dim() == 4 else 1
-            if self.smallc and not for_dgrad:
-                ent.mode, ent.rows, ent.cols = 2, ops.round32(ent.I), ops.round32(4 * ent.T)
-                ent.dst = torch.empty((1, ent.rows, ent.cols), dtype=torch.float32, device=weight.device)
+            ent.mode = mode
+            if mode == 2:
+                shape = (1, ops.round32(ent.I), ops.round32(4 * ent.T))
+            elif mode == 3:
+                shape = (1, ops.round32(4 * ent.T), ops.round32(ent.I))
             else:
-                ent.mode = int(transpose)
-                ent.rows, ent.cols = (ops.round32(ent.J), ops.round32(ent.I)) if transpose else (ops.round32(ent.I), ops.round32(ent.J))
-                ent.dst = torch.empty((ent.T, ent.rows, ent.cols), dtype=torch.float32, device=weight.device)
-            self._packs[transpose] = ent
+                shape = (ent.T, ops.round32(ent.J), ops.round32(ent.I)) if mode else (ent.T, ops.round32(ent.I), ops.round32(ent.J))
+            ent.rows, ent.cols = shape[1], shape[2]
+            ent.dst = torch.empty(shape, dtype=torch.float32, device=weight.device)
+            self._packs[slot] = ent
             _pack_entries.append(ent)
             _pack_serial += 1
         if PACK_MISS_LOG is not None:
@@ -95,6 +107,22 @@ class ConvSpec:
         ent.fill()
         ent.key = key
         return ent.dst
+
+
+def scatter_conv(u: torch.Tensor, weight: torch.Tensor, bias, spec: "ConvSpec", out_hw) -> torch.Tensor:
+    """RGB-output transposed op (ConvTranspose2d C -> <=4, or the input gradient of a Conv2d <=4 -> C) as ONE 1x1 GEMM
+    with 4 T output columns + a gather, instead of per-tap / per-phase GEMMs padded from 3 to 32 output columns."""
+    lib = L.load()
+    n, _, h, w = u.shape
+    T = spec.k[0] * spec.k[1]
+    pk = spec.pack_scatter(weight)
+    cols = ops.conv2d_raw(u, pk, 4 * T, (1, 1), 1, 0, False, (h, w))
+    c = weight.shape[1]
+    out = ops.empty_nhwc(n, c, out_hw[0], out_hw[1], u.device)
+    L.check(lib.crdr_col2im_rgb(cols.data_ptr(), 4 * T, n, h, w, spec.k[0], spec.k[1], spec.stride, spec.pad,
+                                None if bias is None else bias.data_ptr(), out.data_ptr(), ops.ld_for(c), out_hw[0], out_hw[1], c,
+                                ops._stream()), "col2im_rgb")
+    return out
 
 
 class PackTable:
@@ -182,9 +210,12 @@ class _FusedConv(torch.autograd.Function):
         n, _, h, w = x.shape
         oh, ow = spec.out_hw(h, w)
         sig = ops.empty_nhwc(n, spec.out_ch, oh, ow, x.device) if gx is not None else None
-        out = ops.conv2d_raw(x, spec.pack(weight, False), spec.out_ch, spec.k, spec.stride, spec.pad, spec.transposed,
-                             (oh, ow), bias=bias, flags=flags, vec2=vec2, res=res, scale=scale, shift=shift,
-                             gate_x=gx, gate_t=gt, sig_out=sig, wlayout=1 if spec.smallc else 0)
+        if spec.transposed and spec.out_ch <= 4 and not (flags & ~L.EPI_BIAS) and spec.k[0] * spec.k[1] > 1:
+            out = scatter_conv(x, weight, bias, spec, (oh, ow))
+        else:
+            out = ops.conv2d_raw(x, spec.pack(weight, False), spec.out_ch, spec.k, spec.stride, spec.pad, spec.transposed,
+                                 (oh, ow), bias=bias, flags=flags, vec2=vec2, res=res, scale=scale, shift=shift,
+                                 gate_x=gx, gate_t=gt, sig_out=sig, wlayout=1 if spec.smallc else 0)
         ctx.spec, ctx.flags, ctx.in_hw = spec, flags, (h, w)
         ctx.has = (bias is not None, vec2 is not None, res is not None, scale is not None, gx is not None)
         need_out = flags & (L.EPI_RELU | L.EPI_LRELU | L.EPI_AFFINE)
@@ -219,8 +250,11 @@ class _FusedConv(torch.autograd.Function):
             gres = dout  # no affine in front: the residual branch sees dout itself
         dx = None
         if needs[0]:
-            dx = ops.conv2d_raw(dz, spec.pack(weight, True), x.shape[1], spec.k, spec.stride, spec.pad,
-                                not spec.transposed, ctx.in_hw)
+            if (not spec.transposed) and spec.in_ch <= 4 and spec.k[0] * spec.k[1] > 1:
+                dx = scatter_conv(dz, weight, None, spec, ctx.in_hw)  # RGB image gradient: one GEMM + gather
+            else:
+                dx = ops.conv2d_raw(dz, spec.pack(weight, True), x.shape[1], spec.k, spec.stride, spec.pad,
+                                    not spec.transposed, ctx.in_hw, wlayout=1 if spec.smallc_dgrad else 0)
         if needs[1]:
             g = _grad_slot(weight)
             g4 = g if g.dim() == 4 else g.view(g.shape[0], g.shape[1], 1, 1)

@@ -117,9 +117,19 @@ int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, 
 
 /* src[I][J][T] (a Conv2d / ConvTranspose2d parameter, T = kh*kw) -> dst[T][rows][cols] zero padded.
  * transpose = 0: dst[t][i][j] = src[i][j][t] (rows >= I, cols >= J); transpose = 1: dst[t][j][i] = src[i][j][t];
- * transpose = 2 (J <= 4): tap-major dst[i][4 t + j] = src[i][j][t] (rows >= I, cols >= 4 T), see crdr_conv_desc.wlayout */
+ * transpose = 2 (J <= 4): tap-major dst[i][4 t + j] = src[i][j][t] (rows >= I, cols >= 4 T), see crdr_conv_desc.wlayout;
+ * transpose = 3 (J <= 4): scatter pack dst[4 t + j][i] = src[i][j][t] (rows >= 4 T, cols >= I), see crdr_col2im_rgb */
 int crdr_pack_weight(const float* src, float* dst, int I, int J, int T, int rows, int cols, int transpose,
                      crdr_stream_t s);
+
+/* Second half of an RGB-output transposed op done as GEMM + scatter (ConvTranspose2d C -> 3, or the input gradient of
+ * a Conv2d 3 -> C): a 1x1 conv with the scatter pack above first produces cols[n][ih][iw][4 t + c] = sum_i u[n][ih][iw][i]
+ * w[i][c][t] (4 T columns instead of T GEMMs padded from 3 to 32 columns); this kernel then gathers, per output pixel,
+ *   out[n][oh][ow][c] = bias[c] + sum_{t=(r,s): (oh+pad-r) % stride == 0, (ow+pad-s) % stride == 0}
+ *                                  cols[n][(oh+pad-r)/stride][(ow+pad-s)/stride][4 t + c],          c < C <= 4.
+ * H, W: the grid of `cols`; OH, OW: the output; ldc / ldo: pixel strides in floats (multiples of 4). */
+int crdr_col2im_rgb(const float* cols, int ldc, int N, int H, int W, int kh, int kw, int stride, int pad, const float* bias,
+                    float* out, int ldo, int OH, int OW, int C, crdr_stream_t s);
 
 /* All weight packs of an optimiser in one launch (they all go stale together, right after its fused Adam update).
  * `items` and `prefix` are DEVICE arrays: item k packs like crdr_pack_weight(src, dst, I, J, T, rows, cols, mode) with

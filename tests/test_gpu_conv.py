@@ -266,3 +266,38 @@ def test_small_linear_path(m, i, o, relu):
     _close(xg.grad, xr.grad, "small linear dx")
     _close(wg.grad, wr.grad, "small linear dw")
     _close(bg.grad, br.grad, "small linear db")
+
+
+RGB_CASES = [
+    # name, transposed, Cin, Cout, k, stride, pad, out_pad, H
+    ("up4_T256_3_k5s2", True, 256, 3, 5, 2, 2, 1, 12),
+    ("T64_3_k3s1", True, 64, 3, 3, 1, 1, 0, 10),
+    ("D_3_64_k3", False, 3, 64, 3, 1, 1, 0, 20),
+    ("stem_3_192_k5s2", False, 3, 192, 5, 2, 2, 0, 22),
+    ("alex_3_64_k11s4", False, 3, 64, 11, 4, 2, 0, 63),
+]
+
+
+@pytest.mark.parametrize("case", RGB_CASES, ids=[c[0] for c in RGB_CASES])
+def test_rgb_layers_through_fused_conv(case):
+    """3-channel ends of the networks: tap-major forward / input-gradient packs, GEMM + col2im for RGB-output transposed
+    ops, tap-folded weight gradient -- all behind fused_conv, against fp64 torch."""
+    from crdr_amd.hip import functional as HF
+    name, tr, ci, co, k, s, p, op, h = case
+    dev = _dev()
+    x = _rand(2, ci, h, h + 3, seed=1)
+    wt = _rand(*((ci, co, k, k) if tr else (co, ci, k, k)), seed=2, scale=(ci * k * k) ** -0.5)
+    b = _rand(co, seed=3)
+    xr, wr, br = x.double().requires_grad_(True), wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, br, stride=s, padding=p, output_padding=op) if tr else F.conv2d(xr, wr, br, stride=s, padding=p)
+    gy = _rand(*ref.shape, seed=4)
+    ref.backward(gy.double())
+    spec = HF.ConvSpec(ci, co, k, s, p, transposed=tr, out_pad=op)
+    xg = x.to(dev).requires_grad_(True)
+    wg, bg = torch.nn.Parameter(wt.to(dev)), torch.nn.Parameter(b.to(dev))
+    out = HF.fused_conv(xg, wg, bg, spec)
+    out.backward(gy.to(dev))
+    _close(out, ref, name + " out")
+    _close(xg.grad, xr.grad, name + " dx")
+    _close(wg.grad, wr.grad, name + " dw")
+    _close(bg.grad, br.grad, name + " db")

@@ -23,6 +23,8 @@ SHAPES = {
     "enc96to192k1@64": (96, 64, 192, 1, 1, 0, 17),
     "dec128to256k1@64": (128, 64, 256, 1, 1, 0, 17),
     "enc96to192k1@128": (96, 128, 192, 1, 1, 0, 17),
+    "D3to64": (3, 256, 64, 3, 1, 0, 5),
+    "stem3": (3, 256, 192, 5, 2, 0, 1),
     "up3T": (256, 64, 256, 5, 2, 1, 1),
     "enc5s2": (192, 128, 192, 5, 2, 0, 1),
     "charm480": (480, 16, 224, 5, 1, 0, 3),
@@ -62,6 +64,7 @@ def main():
         p = k // 2
         oh = ops.conv_out_size(h, k, s, p, bool(tr), out_pad=(1 if (tr and s == 2) else 0))
         x = torch.randn(a.bs, ci, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+        x, _ = ops.nhwc(x)
         w = torch.randn(*((ci, co, k, k) if tr else (co, ci, k, k)), device=dev) * 0.02
         wf = ops.pack_weight(w, transpose=bool(tr))
         bias = torch.randn(co, device=dev)
