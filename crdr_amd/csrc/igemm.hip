@@ -105,8 +105,21 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int phase = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
+  // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs (each with its own L2) in linear
+  // block-id order; remap so that every XCD walks a CONTIGUOUS range of tiles ordered (M tile, phase/split, N tile):
+  // the N tiles, phases and K splits that read the same activation rows then run back to back on one L2.
+  int tile_m, tile_n, tile_z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int nwg = gx * gy * gz, bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int cpx = nwg >> 3;
+    const int t = bid < cpx * 8 ? (bid & 7) * cpx + (bid >> 3) : bid;
+    tile_n = t % gy;
+    tile_z = (t / gy) % gz;
+    tile_m = t / (gy * gz);
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int phase = tile_z / p.nsplit, split = tile_z % p.nsplit;
   const int tb = tp.tap_begin[phase], te = tp.tap_begin[phase + 1];
   const int ntap = te - tb;
   const int KT = SMALLC ? p.kchunks : ntap * p.kchunks;

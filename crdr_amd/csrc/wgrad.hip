@@ -62,9 +62,21 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int it = blockIdx.x / p.jtiles, jt = blockIdx.x % p.jtiles;
+  // XCD-aware order (see igemm.hip): every XCD walks a contiguous range of (pixel split, tap, channel tile) so that the
+  // workgroups re-reading one pixel range -- all taps and channel tiles of a split -- share an L2.
+  int bx, by, bz;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int nwg = gx * gy * gz, bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int cpx = nwg >> 3;
+    const int t = bid < cpx * 8 ? (bid & 7) * cpx + (bid >> 3) : bid;
+    bx = t % gx;
+    by = (t / gx) % gy;
+    bz = t / (gx * gy);
+  }
+  const int it = bx / p.jtiles, jt = bx % p.jtiles;
   const int i0 = it * BI, j0 = jt * BJ;
-  const int tap = p.smallj ? 0 : blockIdx.y, split = blockIdx.z;
+  const int tap = p.smallj ? 0 : by, split = bz;
   const int ncols = p.smallj ? p.T * 4 : p.QC;  // GEMM columns = width of a slab row
   const int t0 = (int)((long long)p.ntiles * split / p.nsplit), t1 = (int)((long long)p.ntiles * (split + 1) / p.nsplit);
 
@@ -86,7 +98,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
     const int e = tid + k * NT;
     const int c = j0 + (e % (BJ / 4)) * 4;
     q_prow[k] = e / (BJ / 4);
-    const int tk = p.smallj ? (c >> 2) : (int)blockIdx.y;  // tap of this piece
+    const int tk = p.smallj ? (c >> 2) : by;  // tap of this piece
     q_dh[k] = tk / p.kw - p.pad;
     q_dw[k] = tk % p.kw - p.pad;
     q_coff[k] = p.smallj ? (tk < p.T ? 0u : kOob) : ((c < p.QC) ? (unsigned)c * 4u : kOob);
