@@ -214,8 +214,16 @@ def main():
         with open(a.shape_table, "w") as f:
             for (kind, label), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"{ms / max(a.profile_steps, 1):8.3f} ms/step  {cnt / max(a.profile_steps, 1):6.1f} calls/step  {fl / (ms * 1e-3) / 1e12:6.1f} TF  {kind:5s} {label}\n")
+    # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over one step (counters cannot
+    # be read inside this process): tools/pmc_step.py + tools/pmc_traffic.py, result committed under profiles/
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "r1_e_hbm_traffic_pmc.json")
+    if a.stage == 3 and a.bs == 16 and a.size == 256 and os.path.exists(tp):
+        with open(tp) as f:
+            traffic = round(json.load(f)["igemm"]["hbm_bytes_per_launch"])
+        traffic_src = "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step (profiles/r1_e_hbm_traffic_pmc.json)"
     roof = {"bound": "mfma", "achieved": ig["tflops"] if ig else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None, "traffic": None,
+            "frac": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "igemm_kernel<*> (conv / convT forward + input-gradient launches, v_mfma_f32_32x32x2_f32)",
             "measured_over": f"{a.profile_steps} eager steps after the timed region (HIP events around each launch, on its stream)",
             "detail": ig, "wgrad_kernel": wg,

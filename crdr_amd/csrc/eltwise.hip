@@ -130,8 +130,9 @@ __global__ __launch_bounds__(256) void ebwd_kernel_v4(const EbwdArgs p) {
 }
 
 // out[e] (+)= sum_b partial[b][e], e over K*C columns; 16 columns x 16 block-groups per workgroup, fixed order
+// (acc0, optional: columns of the first of the K rows are also added into acc0[0..C))
 __global__ __launch_bounds__(256) void colsum_final(const float* partial, int nblocks, int K, int C, float* out,
-                                                    int accumulate) {
+                                                    int accumulate, float* acc0) {
   __shared__ float red[16][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int e = blockIdx.x * 16 + tx;
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void colsum_final(const float* partial, int nb
 #pragma unroll
     for (int r = 1; r < 16; ++r) t += red[r][tx];
     out[e] = accumulate ? out[e] + t : t;
+    if (acc0 && e < C) acc0[e] += t;
   }
 }
 
@@ -531,16 +533,16 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* x, int M
   if (dw) dw[e] += a;
   if (db && i == 0) db[o] += s;
 }
-// dx: block = 64 input features, the 4 waves split the output features, LDS reduction in wave order
-__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* w, int M, int I, const float* dy, int lddy, const float* y,
-                                                           int ldy, int O, float* dx, int lddx) {
-  __shared__ float red[4][kLinMaxM][64];
+// dx: block = 64 input features, the 16 waves split the output features, LDS reduction in wave order
+__global__ __launch_bounds__(1024) void linear_bwd_x_kernel(const float* w, int M, int I, const float* dy, int lddy, const float* y,
+                                                            int ldy, int O, float* dx, int lddx) {
+  __shared__ float red[16][kLinMaxM][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = blockIdx.x * 64 + lane;
   float acc[kLinMaxM];
 #pragma unroll
   for (int m = 0; m < kLinMaxM; ++m) acc[m] = 0.f;
   if (i < I)
-    for (int o = wave; o < O; o += 4) {
+    for (int o = wave; o < O; o += 16) {
       const float wv = w[(size_t)o * I + i];
 #pragma unroll
       for (int m = 0; m < kLinMaxM; ++m)
@@ -550,9 +552,13 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* w, int M
   for (int m = 0; m < kLinMaxM; ++m) red[wave][m][lane] = acc[m];
   __syncthreads();
   if (wave == 0 && i < I)
-    for (int m = 0; m < M; ++m) dx[(size_t)m * lddx + i] = (red[0][m][lane] + red[1][m][lane]) + (red[2][m][lane] + red[3][m][lane]);
+    for (int m = 0; m < M; ++m) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r][m][lane];
+      dx[(size_t)m * lddx + i] = t;
+    }
 }
-
 
 // gather half of the GEMM + scatter formulation of RGB-output transposed ops (see crdr_col2im_rgb)
 __global__ __launch_bounds__(256) void col2im_rgb_kernel(const float* cols, int ldc, int N, int H, int W, int kh, int kw, int S,
@@ -623,7 +629,7 @@ extern "C" int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io
     CRDR_CHECK_LAUNCH("ebwd_kernel");
   }
   hipLaunchKernelGGL(colsum_final, dim3(cdiv(4 * d->C, 16)), dim3(256), 0, as_stream(s), (const float*)ws,
-                     d->M > 0 ? nb : 0, 4, d->C, io->colsums, 0);
+                     d->M > 0 ? nb : 0, 4, d->C, io->colsums, 0, io->dbias_accum);
   CRDR_CHECK_LAUNCH("colsum_final");
   return 0;
 }
@@ -660,7 +666,7 @@ extern "C" int crdr_linear_bwd(const float* x, int M, int I, int ldx, const floa
     CRDR_CHECK_LAUNCH("linear_bwd_w_kernel");
   }
   if (dx) {
-    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(I, 64)), dim3(256), 0, as_stream(s), w, M, I, dy, lddy, y, ldy, O, dx,
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(I, 64)), dim3(1024), 0, as_stream(s), w, M, I, dy, lddy, y, ldy, O, dx,
                        lddx);
     CRDR_CHECK_LAUNCH("linear_bwd_x_kernel");
   }
@@ -693,7 +699,7 @@ extern "C" int crdr_colsum(const float* x, int ldx, int64_t M, int C, float* out
     CRDR_CHECK_LAUNCH("colsum");
   }
   hipLaunchKernelGGL(colsum_final, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(s), (const float*)ws, M > 0 ? nb : 0, 1,
-                     C, out, accumulate);
+                     C, out, accumulate, (float*)nullptr);
   CRDR_CHECK_LAUNCH("colsum_final");
   return 0;
 }

@@ -205,6 +205,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* ws, float* g, i
   }
 }
 
+// all pending reductions of a backward pass in one launch; block = 256 consecutive outputs (j fastest) of one job
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const crdr_wgrad_job* jobs, const long long* prefix,
+                                                                   const long long* meta) {
+  const int n = (int)meta[0];
+  const long long total = meta[1];
+  for (long long tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    int lo = 0, hi = n - 1;  // last job with prefix[job] <= tl  (block-uniform)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= tl) lo = mid; else hi = mid - 1;
+    }
+    const crdr_wgrad_job jb = jobs[lo];
+    const long long e = (tl - prefix[lo]) * 256 + threadIdx.x;
+    if (e >= (long long)jb.gI * jb.gJ * jb.T) continue;
+    const int j = (int)(e % jb.gJ);
+    const long long r = e / jb.gJ;
+    const int i = (int)(r % jb.gI), t = (int)(r / jb.gI);
+    // slab element of split s = base + s * stride; four independent chains keep loads in flight (fixed order)
+    const float* base = jb.smallj ? jb.slab + (size_t)i * (4 * jb.T) + 4 * t + j : jb.slab + ((size_t)t * jb.PC + i) * jb.QC + j;
+    const size_t stride = jb.smallj ? (size_t)jb.PC * 4 * jb.T : (size_t)jb.T * jb.PC * jb.QC;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= jb.nsplit; s += 4) {
+      v0 += base[(size_t)s * stride];
+      v1 += base[(size_t)(s + 1) * stride];
+      v2 += base[(size_t)(s + 2) * stride];
+      v3 += base[(size_t)(s + 3) * stride];
+    }
+    for (; s < jb.nsplit; ++s) v0 += base[(size_t)s * stride];
+    const float v = (v0 + v1) + (v2 + v3);
+    float* d = jb.g + ((size_t)i * jb.gJ + j) * jb.T + t;
+    *d = jb.accumulate ? *d + v : v;
+  }
+}
+
 // dst[t][rows][cols] <- src[I][J][T]
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, float* dst, int I, int J, int T, int rows,
                                                           int cols, int transpose) {
@@ -394,11 +429,10 @@ extern "C" size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d) {
   return pl.ws_bytes;
 }
 
-extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* ws,
-                                 size_t ws_bytes, crdr_stream_t s) {
-  WPlan pl;
+static int launch_wgrad_slabs(const crdr_wgrad_desc* d, const float* p, const float* q, void* ws, size_t ws_bytes, WPlan& pl,
+                              crdr_stream_t s) {
   if (int rc = build_wplan(d, &pl)) return rc;
-  CRDR_REQUIRE(p && q && g && ws, "wgrad: null pointer");
+  CRDR_REQUIRE(p && q && ws, "wgrad: null pointer");
   CRDR_REQUIRE(pl.ws_bytes <= ws_bytes, "wgrad: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
   WgradArgs& a = pl.a;
   a.p = p; a.q = q; a.ws = (float*)ws;
@@ -408,15 +442,47 @@ extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[pl.cfg] = true;
   }
-  void* prof = profile_begin(as_stream(s));
   hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a);
   CRDR_CHECK_LAUNCH("wgrad_kernel");
+  return 0;
+}
+
+extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* ws,
+                                 size_t ws_bytes, crdr_stream_t s) {
+  CRDR_REQUIRE(g, "wgrad: null pointer");
+  WPlan pl;
+  void* prof = profile_begin(as_stream(s));
+  if (int rc = launch_wgrad_slabs(d, p, q, ws, ws_bytes, pl, s)) return rc;
+  const WgradArgs& a = pl.a;
   const long long total = (long long)d->gI * d->gJ * a.T;
   const int blocks = (int)std::min<long long>(cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(wgrad_reduce, dim3(blocks), dim3(256), 0, as_stream(s), (const float*)ws, g, d->PC, d->QC, d->gI,
                      d->gJ, a.T, a.nsplit, d->accumulate, a.smallj);
   CRDR_CHECK_LAUNCH("wgrad_reduce");
   profile_end(1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
+  return 0;
+}
+
+extern "C" int crdr_conv2d_wgrad_partial(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* slab,
+                                         size_t slab_bytes, crdr_wgrad_job* job, crdr_stream_t s) {
+  CRDR_REQUIRE(g && job, "wgrad_partial: null pointer");
+  WPlan pl;
+  void* prof = profile_begin(as_stream(s));
+  if (int rc = launch_wgrad_slabs(d, p, q, slab, slab_bytes, pl, s)) return rc;
+  const WgradArgs& a = pl.a;
+  job->slab = (const float*)slab; job->g = g;
+  job->PC = d->PC; job->QC = d->QC; job->gI = d->gI; job->gJ = d->gJ; job->T = a.T; job->nsplit = a.nsplit;
+  job->smallj = a.smallj; job->accumulate = d->accumulate;
+  profile_end(1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
+  return 0;
+}
+
+extern "C" int crdr_wgrad_reduce_batched(const crdr_wgrad_job* jobs, const int64_t* prefix, const int64_t* meta,
+                                         crdr_stream_t s) {
+  CRDR_REQUIRE(jobs && prefix && meta, "wgrad_reduce_batched: null pointer");
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(16384), dim3(256), 0, as_stream(s), jobs,
+                     reinterpret_cast<const long long*>(prefix), reinterpret_cast<const long long*>(meta));
+  CRDR_CHECK_LAUNCH("wgrad_reduce_batched_kernel");
   return 0;
 }
 

@@ -233,11 +233,10 @@ class _FusedConv(torch.autograd.Function):
         gres = dgt = dscale = dshift = dvec2 = None
         if heavy or has_vec2:
             dz, gres, dgt, cs = ops.epilogue_bwd(dout, out, flags, vec2=vec2, scale=scale, shift=shift, gate_t=gt, sig=sig,
-                                                 need_dz=bool(heavy))
+                                                 need_dz=bool(heavy),
+                                                 dbias_accum=_grad_slot(bias) if (has_bias and needs[2]) else None)
             if dz is None:
                 dz = dout
-            if has_bias and needs[2]:
-                _grad_slot(bias).add_(cs[0])
             if has_vec2:
                 dvec2 = cs[1]
             if has_aff:

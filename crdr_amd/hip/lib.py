@@ -41,9 +41,14 @@ class EbwdDesc(C.Structure):
         "C", "flags", "lddout", "ldout", "lddz", "ldgres", "ldg")]
 
 
+class WgradJob(C.Structure):
+    _fields_ = [("slab", c_void_p), ("g", c_void_p)] + [(n, C.c_int32) for n in (
+        "PC", "QC", "gI", "gJ", "T", "nsplit", "smallj", "accumulate")]
+
+
 class EbwdIO(C.Structure):
     _fields_ = [(n, c_void_p) for n in (
-        "dout", "out", "vec2", "scale", "shift", "gt", "sig", "dz", "gres", "dgt", "colsums")]
+        "dout", "out", "vec2", "scale", "shift", "gt", "sig", "dz", "gres", "dgt", "colsums", "dbias_accum")]
 
 
 class GcDesc(C.Structure):
@@ -69,6 +74,8 @@ SIGNATURES = {
     "crdr_conv2d_flops": (_D, [C.POINTER(ConvDesc)]),
     "crdr_conv2d_wgrad_workspace": (_SZ, [C.POINTER(WgradDesc)]),
     "crdr_conv2d_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _SZ, _P]),
+    "crdr_conv2d_wgrad_partial": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _SZ, C.POINTER(WgradJob), _P]),
+    "crdr_wgrad_reduce_batched": (_I, [_P, _P, _P, _P]),
     "crdr_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "crdr_pack_weights_batched": (_I, [_P, _P, _P, _P]),
     "crdr_epilogue_bwd_workspace": (_SZ, [C.POINTER(EbwdDesc)]),

@@ -307,12 +307,102 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
             d.accumulate = int(accumulate)
         d.algo = algo
     nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
-    ws, ws_n = workspace(nbytes, p.device)
     e0 = _prof_begin()
-    L.check(lib.crdr_conv2d_wgrad(C.byref(d), p.data_ptr(), q.data_ptr(), g.data_ptr(), ws, ws_n, _stream()), "conv2d_wgrad")
+    if WGRAD_DEFER is not None and WGRAD_DEFER.device == p.device:
+        job = L.WgradJob()
+        L.check(lib.crdr_conv2d_wgrad_partial(C.byref(d), p.data_ptr(), q.data_ptr(), g.data_ptr(), WGRAD_DEFER.alloc(nbytes),
+                                              nbytes, C.byref(job), _stream()), "conv2d_wgrad_partial")
+        WGRAD_DEFER.jobs.append(job)
+    else:
+        ws, ws_n = workspace(nbytes, p.device)
+        L.check(lib.crdr_conv2d_wgrad(C.byref(d), p.data_ptr(), q.data_ptr(), g.data_ptr(), ws, ws_n, _stream()), "conv2d_wgrad")
     _prof_end("wgrad", 2.0 * n * ph * pw * g.shape[0] * g.shape[1] * k[0] * k[1], e0,
               f"W {g.shape[0]}x{g.shape[1]} k{k[0]}s{stride} p{ph}x{pw}")
     return g
+
+
+class DeferredWgrad:
+    """Weight-gradient reductions of a whole backward pass finished by ONE launch (crdr_wgrad_reduce_batched) instead of
+    one small launch per layer.  Slabs are bump-allocated from an arena that is recycled at every flush; the device-side
+    job tables are kept per flush site and rewritten only when their content changes, so a site captured in a HIP graph
+    (same layers, same buffers every iteration) replays without host work."""
+    CAP = 4096
+
+    def __init__(self, device, arena_bytes: int = 1 << 30):
+        self.device = torch.device(device)
+        self.arena = torch.empty(arena_bytes, dtype=torch.uint8, device=self.device)
+        self._keep = []
+        self.off = 0
+        self.jobs = []
+        self.tables = {}
+
+    def alloc(self, nbytes: int) -> int:
+        nbytes = (nbytes + 255) // 256 * 256
+        if self.off + nbytes > self.arena.numel():
+            if torch.cuda.is_current_stream_capturing():
+                raise L.CrdrHipError("DeferredWgrad: arena too small during graph capture (run eager warm-up iterations first)")
+            self._keep.append(self.arena)  # pending jobs still point into it
+            self.arena = torch.empty(max(2 * self.arena.numel(), self.off + nbytes), dtype=torch.uint8, device=self.device)
+            self.off = 0
+        p = self.arena.data_ptr() + self.off
+        self.off += nbytes
+        return p
+
+    def pending(self) -> int:
+        return len(self.jobs)
+
+    def flush(self, key=None) -> None:
+        if not self.jobs:
+            return
+        import numpy as np
+        lib = L.load()
+        rounds = []  # no two jobs of one launch may write the same gradient (a weight used twice in one backward)
+        for jb in self.jobs:
+            for r in rounds:
+                if jb.g not in r[1]:
+                    r[0].append(jb); r[1].add(jb.g)
+                    break
+            else:
+                rounds.append(([jb], {jb.g}))
+        for ri, (js, _) in enumerate(rounds):
+            assert len(js) <= self.CAP
+            host = b"".join(bytes(j) for j in js)
+            pre = np.zeros(len(js) + 1, dtype=np.int64)
+            for k, j in enumerate(js):
+                pre[k + 1] = pre[k] + (j.gI * j.gJ * j.T + 255) // 256
+            tb = self.tables.get((key, ri))
+            if tb is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise L.CrdrHipError("DeferredWgrad: first flush of this site happened during graph capture")
+                tb = self.tables[(key, ri)] = {
+                    "jobs": torch.zeros(self.CAP * C.sizeof(L.WgradJob), dtype=torch.uint8, device=self.device),
+                    "prefix": torch.zeros(self.CAP + 1, dtype=torch.int64, device=self.device),
+                    "meta": torch.zeros(2, dtype=torch.int64, device=self.device), "host": None}
+            if tb["host"] != host:
+                if torch.cuda.is_current_stream_capturing():
+                    raise L.CrdrHipError("DeferredWgrad: the job table of a captured site changed")
+                tb["jobs"][:len(host)].copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
+                tb["prefix"][:len(js) + 1].copy_(torch.from_numpy(pre))
+                tb["meta"].copy_(torch.tensor([len(js), int(pre[-1])], dtype=torch.int64))
+                tb["host"] = host
+            L.check(lib.crdr_wgrad_reduce_batched(tb["jobs"].data_ptr(), tb["prefix"].data_ptr(), tb["meta"].data_ptr(),
+                                                  _stream()), "wgrad_reduce_batched")
+        self.jobs = []
+        self.off = 0
+        if not torch.cuda.is_current_stream_capturing():
+            self._keep = []
+
+
+WGRAD_DEFER: Optional[DeferredWgrad] = None  # set by a trainer; every backward must then be followed by flush_wgrads()
+
+
+def flush_wgrads(key=None) -> None:
+    if WGRAD_DEFER is not None:
+        WGRAD_DEFER.flush(key)
+
+
+def pending_wgrads() -> int:
+    return WGRAD_DEFER.pending() if WGRAD_DEFER is not None else 0
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool):
@@ -326,8 +416,9 @@ def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool):
     return out
 
 
-def epilogue_bwd(dout, out, flags, *, vec2=None, scale=None, shift=None, gate_t=None, sig=None, need_dz=True):
-    """Returns (dz, gres, dgt, colsums[4][C])."""
+def epilogue_bwd(dout, out, flags, *, vec2=None, scale=None, shift=None, gate_t=None, sig=None, need_dz=True,
+                 dbias_accum: Optional[torch.Tensor] = None):
+    """Returns (dz, gres, dgt, colsums[4][C]); `dbias_accum` [C] additionally receives += sum dz inside the same launch."""
     lib = L.load()
     dout, lddout = nhwc(dout)
     n, c, h, w = dout.shape
@@ -354,6 +445,9 @@ def epilogue_bwd(dout, out, flags, *, vec2=None, scale=None, shift=None, gate_t=
         io.gres = gres.data_ptr()
     colsums = torch.empty((4, c), dtype=torch.float32, device=dout.device)
     io.colsums = colsums.data_ptr()
+    if dbias_accum is not None:
+        assert dbias_accum.is_contiguous() and dbias_accum.numel() == c
+        io.dbias_accum = dbias_accum.data_ptr()
     nbytes = lib.crdr_epilogue_bwd_workspace(C.byref(d))
     ws, ws_n = workspace(nbytes, dout.device)
     L.check(lib.crdr_epilogue_bwd(C.byref(d), C.byref(io), ws, ws_n, _stream()), "epilogue_bwd")

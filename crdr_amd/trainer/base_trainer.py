@@ -33,6 +33,15 @@ class BaseTrainer:
         # HIP-graph execution of the step (crdr_amd/trainer/graphs.py): `hip_graphs: true` in the config / CLI overlay
         from .graphs import SegmentGraphs
         self.graphs = SegmentGraphs(bool(opt.get("hip_graphs", False)))
+        # weight-gradient reductions of a backward pass are finished by one batched launch (ops.DeferredWgrad); every
+        # backward of the trainers is followed by self._flush_wgrads(site)
+        self._flush_key = None
+        self._deferred = None
+        if str(self.device).startswith("cuda") and opt.get("defer_wgrad", True):
+            from crdr_amd.hip import ops as _ops
+            dev = torch.device(self.device)
+            dev = torch.device("cuda", torch.cuda.current_device()) if dev.index is None else dev
+            self._deferred = _ops.DeferredWgrad(dev)
         self.graph_warmup = int(opt.get("hip_graph_warmup", 2))  # eager iterations per graph key before capturing
         self._warm = {}
         self._real_static = None
@@ -151,7 +160,17 @@ class BaseTrainer:
         t = l_total.detach().reshape(1)
         return (~torch.isfinite(t) | (t > self.loss_huge_threshold)).float()
 
+    def _flush_wgrads(self, site: str) -> None:
+        from crdr_amd.hip import ops as _ops
+        _ops.flush_wgrads((site, self._flush_key))
+
+    def _step_scope(self):
+        """Context of one optimize_parameters call: the trainer's stream (graphs.step_scope) + deferred weight-gradient
+        reductions switched on for exactly this call."""
+        return _TrainerStepScope(self)
+
     def _runner(self, key, allow_graph: bool):
+        self._flush_key = key
         """-> callable(name, fn): eager for the first `graph_warmup` iterations of a key (also fills the autotune cache)."""
         n = self._warm.get(key, 0)
         self._warm[key] = n + 1
@@ -197,3 +216,25 @@ class BaseTrainer:
         if v > 10000:
             return "huge"
         return False
+
+
+class _TrainerStepScope:
+    def __init__(self, tr):
+        self.tr = tr
+        self.inner = tr.graphs.step_scope()
+
+    def __enter__(self):
+        from crdr_amd.hip import ops as _ops
+        self.prev = _ops.WGRAD_DEFER
+        _ops.WGRAD_DEFER = self.tr._deferred
+        self.inner.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        from crdr_amd.hip import ops as _ops
+        try:
+            return self.inner.__exit__(*a)
+        finally:
+            if a[0] is not None and _ops.WGRAD_DEFER is not None:
+                _ops.WGRAD_DEFER.jobs, _ops.WGRAD_DEFER.off = [], 0  # an exception left reductions behind: drop them
+            _ops.WGRAD_DEFER = self.prev

@@ -80,6 +80,7 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
                + self.gan_loss.forward_diff(fake_g, real_d, is_real=True, is_disc=False)) / 2
         l_total = dist_loss + rate_loss + beta_t * (percep + adv)
         l_total.backward()
+        self._flush_wgrads("g")
         return {"losses": {"distortion": dist_loss, "rate": rate_loss, "perceptual": percep, "adv": adv},
                 "bad": self._bad_flag(l_total), "qbpp": other.get("qbpp", None), "real": real_p, "fake": fake.detach(), "q": q}
 
@@ -94,6 +95,7 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         l_d_real = self.gan_loss.forward_diff(real_d, fake_d.detach(), is_real=True, is_disc=True) * 0.5
         l_d_fake = self.gan_loss.forward_diff(fake_d, real_d.detach(), is_real=False, is_disc=True) * 0.5
         (l_d_real + l_d_fake).backward()
+        self._flush_wgrads("d")
         out.update({"d_real": l_d_real, "d_fake": l_d_fake, "d_total": l_d_real + l_d_fake,
                     "out_d_real": real_d.detach().mean(), "out_d_fake": fake_d.detach().mean()})
         return out
@@ -107,7 +109,7 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         return {}
 
     def optimize_parameters(self, current_iter: int, data_dict: Dict):
-        with self.graphs.step_scope():
+        with self._step_scope():
             return self._optimize_parameters(current_iter, data_dict)
 
     def _optimize_parameters(self, current_iter: int, data_dict: Dict):

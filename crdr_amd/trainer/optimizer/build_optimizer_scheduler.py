@@ -148,6 +148,8 @@ class Adam:
         on the device, so the call sequence is identical every iteration and can be captured in a HIP graph.
         Every weight pack fed by the updated range is refilled by one batched launch right behind the update."""
         lib = L.load()
+        if ops.pending_wgrads():
+            raise RuntimeError("Adam.step with weight-gradient reductions still pending: call ops.flush_wgrads() after backward")
         touched = []
         for g in self.param_groups:
             if g["flat"] is None:

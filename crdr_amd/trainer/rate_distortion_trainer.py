@@ -77,6 +77,7 @@ class RateDistortionTrainer(BaseTrainer):
             g["perceptual"] = self.perceptual_loss(real_p, fake)
         l_total = sum(g.values())
         l_total.backward()
+        self._flush_wgrads("g")
         return {"losses": g, "bad": self._bad_flag(l_total), "qbpp": other.get("qbpp", None)}
 
     def _seg_update(self, ctx: Dict) -> Dict:
@@ -102,7 +103,7 @@ class RateDistortionTrainer(BaseTrainer):
         return {}, "rd"
 
     def optimize_parameters(self, current_iter: int, data_dict: Dict):
-        with self.graphs.step_scope():
+        with self._step_scope():
             return self._optimize_parameters(current_iter, data_dict)
 
     def _optimize_parameters(self, current_iter: int, data_dict: Dict):

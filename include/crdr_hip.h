@@ -115,6 +115,20 @@ size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d);
 int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* ws, size_t ws_bytes,
                       crdr_stream_t s);
 
+/* Deferred reduction.  crdr_conv2d_wgrad = partial-slab kernel + a small reduce launch per layer; a backward pass makes
+ * hundreds of those.  crdr_conv2d_wgrad_partial runs only the slab kernel (into `slab`, crdr_conv2d_wgrad_workspace bytes,
+ * which must stay untouched until the reduce) and describes the pending reduction in *job; crdr_wgrad_reduce_batched
+ * then finishes ALL pending layers in one launch.  `jobs`, `prefix` (first 256-element output tile of each job) and
+ * `meta` = {number of jobs, total tiles} are DEVICE arrays.  No two jobs of one batch may write the same g. */
+typedef struct crdr_wgrad_job {
+  const float* slab;
+  float* g;
+  int32_t PC, QC, gI, gJ, T, nsplit, smallj, accumulate;
+} crdr_wgrad_job;
+int crdr_conv2d_wgrad_partial(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* slab,
+                              size_t slab_bytes, crdr_wgrad_job* job, crdr_stream_t s);
+int crdr_wgrad_reduce_batched(const crdr_wgrad_job* jobs, const int64_t* prefix, const int64_t* meta, crdr_stream_t s);
+
 /* src[I][J][T] (a Conv2d / ConvTranspose2d parameter, T = kh*kw) -> dst[T][rows][cols] zero padded.
  * transpose = 0: dst[t][i][j] = src[i][j][t] (rows >= I, cols >= J); transpose = 1: dst[t][j][i] = src[i][j][t];
  * transpose = 2 (J <= 4): tap-major dst[i][4 t + j] = src[i][j][t] (rows >= I, cols >= 4 T), see crdr_conv_desc.wlayout;
@@ -170,6 +184,7 @@ typedef struct crdr_ebwd_io {
   float* gres; /* grad to res / gx */
   float* dgt;  /* grad to trunk    */
   float* colsums; /* [4][C] */
+  float* dbias_accum; /* optional [C]: += sum dz, i.e. the bias gradient goes straight into its (flat) gradient slot */
 } crdr_ebwd_io;
 size_t crdr_epilogue_bwd_workspace(const crdr_ebwd_desc* d);
 int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);
