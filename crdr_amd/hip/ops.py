@@ -328,11 +328,12 @@ class DeferredWgrad:
     (same layers, same buffers every iteration) replays without host work."""
     CAP = 4096
 
-    def __init__(self, device, arena_bytes: int = 1 << 30):
+    def __init__(self, device, arena_bytes: int = 2 << 30):
         self.device = torch.device(device)
         self.arena = torch.empty(arena_bytes, dtype=torch.uint8, device=self.device)
         self._keep = []
         self.off = 0
+        self.cycle = 0  # bytes handed out since the last flush (over all arenas)
         self.jobs = []
         self.tables = {}
 
@@ -342,10 +343,12 @@ class DeferredWgrad:
             if torch.cuda.is_current_stream_capturing():
                 raise L.CrdrHipError("DeferredWgrad: arena too small during graph capture (run eager warm-up iterations first)")
             self._keep.append(self.arena)  # pending jobs still point into it
-            self.arena = torch.empty(max(2 * self.arena.numel(), self.off + nbytes), dtype=torch.uint8, device=self.device)
+            # big enough for a whole cycle like this one, so that the next iteration never grows again
+            self.arena = torch.empty(max(2 * self.arena.numel(), 2 * (self.cycle + nbytes)), dtype=torch.uint8, device=self.device)
             self.off = 0
         p = self.arena.data_ptr() + self.off
         self.off += nbytes
+        self.cycle += nbytes
         return p
 
     def pending(self) -> int:
@@ -390,7 +393,12 @@ class DeferredWgrad:
         self.jobs = []
         self.off = 0
         if not torch.cuda.is_current_stream_capturing():
-            self._keep = []
+            if self.arena.numel() < self.cycle:  # the cycle spilled over several arenas: make the next one fit in one
+                self._keep.append(self.arena)    # (the reduce just launched may still be reading it: freed next flush)
+                self.arena = torch.empty(2 * self.cycle, dtype=torch.uint8, device=self.device)
+            else:
+                self._keep = []
+        self.cycle = 0
 
 
 WGRAD_DEFER: Optional[DeferredWgrad] = None  # set by a trainer; every backward must then be followed by flush_wgrads()
