@@ -98,6 +98,46 @@ def all_reduce_mean_(buffers: List[torch.Tensor]) -> None:
             b.div_(ws)
 
 
+class AsyncGradSync:
+    """Mean all-reduce of flat gradient buffers (+ MAX all-reduce of flags) issued on the communication stream WITHOUT
+    making the caller's stream wait: independent work (the discriminator's forward/backward while the generator's
+    510 MB of gradients travel over xGMI) overlaps the collective; wait() orders the caller's stream behind it."""
+
+    def __init__(self, mean_buffers: List[torch.Tensor], max_flags: Optional[List[torch.Tensor]] = None):
+        ts = list(mean_buffers) + list(max_flags or [])
+        self._comm = None
+        if not is_dist() or not ts:
+            return
+        ws = dist.get_world_size()
+
+        def issue():
+            for b in mean_buffers:
+                _dbg(f"all_reduce {b.numel()}")
+                dist.all_reduce(b, op=dist.ReduceOp.SUM)
+                b.div_(ws)
+            for f in max_flags or []:
+                _dbg("all_reduce flag")
+                dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        if ts[0].is_cuda:
+            cur = torch.cuda.current_stream(ts[0].device)
+            comm = _comm_streams.get(ts[0].device)
+            if comm is None:
+                comm = _comm_streams[ts[0].device] = torch.cuda.Stream(ts[0].device)
+            comm.wait_stream(cur)
+            with torch.cuda.stream(comm):
+                issue()
+                self._done = torch.cuda.Event()
+                self._done.record(comm)  # later collectives queued on the same stream are not waited for
+            self._comm = comm
+        else:
+            issue()
+
+    def wait(self) -> None:
+        if self._comm is not None:
+            torch.cuda.current_stream(self._comm.device).wait_event(self._done)
+            self._comm = None
+
+
 def all_reduce_scalars_mean(t: torch.Tensor) -> torch.Tensor:
     if not is_dist():
         return t

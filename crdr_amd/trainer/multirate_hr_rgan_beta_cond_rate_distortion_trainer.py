@@ -84,9 +84,11 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         return {"losses": {"distortion": dist_loss, "rate": rate_loss, "perceptual": percep, "adv": adv},
                 "bad": self._bad_flag(l_total), "qbpp": other.get("qbpp", None), "real": real_p, "fake": fake.detach(), "q": q}
 
-    # ------------------------------------------------------------------ G / aux update, then D forward + backward
-    def _seg_update(self, ctx: Dict) -> Dict:
-        out = super()._seg_update(ctx)
+    # ------------------------------------------------------------------ D forward + backward (needs only x and x̂)
+    def _seg_dfwdbwd(self, ctx: Dict) -> Dict:
+        """The reference steps G before it runs D on (x, x̂.detach()) (…beta_cond_…trainer.py:70-100); D's forward and
+        backward do not read G's parameters, so running them BEFORE the G update is the same computation -- and lets
+        them overlap the all-reduce of G's gradients."""
         q = ctx["q"]
         self.discriminator.requires_grad_(True)
         self.d_optimizer.zero_grad(partitions=self._d_parts(q))
@@ -96,9 +98,8 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         l_d_fake = self.gan_loss.forward_diff(fake_d, real_d.detach(), is_real=False, is_disc=True) * 0.5
         (l_d_real + l_d_fake).backward()
         self._flush_wgrads("d")
-        out.update({"d_real": l_d_real, "d_fake": l_d_fake, "d_total": l_d_real + l_d_fake,
-                    "out_d_real": real_d.detach().mean(), "out_d_fake": fake_d.detach().mean()})
-        return out
+        return {"d_real": l_d_real, "d_fake": l_d_fake, "d_total": l_d_real + l_d_fake,
+                "out_d_real": real_d.detach().mean(), "out_d_fake": fake_d.detach().mean()}
 
     def _d_parts(self, q):
         """The optimiser partition of the sub-discriminator that rate level q trains (None = everything)."""
@@ -122,9 +123,12 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         self.g_optimizer.sync_lr_to_device()
         self.d_optimizer.sync_lr_to_device()
         ctx = run("g", lambda: self._seg_generator(real, cond, noise, current_iter))
-        self._sync_between_segments(ctx, self.g_optimizer)
+        g_sync = D.AsyncGradSync(self.g_optimizer.flat_grads(), [ctx["bad"]])       # overlaps the D forward/backward
+        ctx_d = run("dfb", lambda: self._seg_dfwdbwd(ctx))
+        d_sync = D.AsyncGradSync(self.d_optimizer.flat_grads(partitions=self._d_parts(ctx["q"])))  # overlaps the G update
+        g_sync.wait()
         ctx2 = run("u", lambda: self._seg_update(ctx))
-        D.all_reduce_mean_(self.d_optimizer.flat_grads(partitions=self._d_parts(ctx["q"])))
+        d_sync.wait()
         run("d", lambda: self._seg_dstep(ctx))
-        log = {"qbpp": ctx["qbpp"] if ctx["qbpp"] is not None else -1, **ctx["losses"], **ctx2, "_bad": ctx["bad"]}
+        log = {"qbpp": ctx["qbpp"] if ctx["qbpp"] is not None else -1, **ctx["losses"], **ctx2, **ctx_d, "_bad": ctx["bad"]}
         return self._finish_step(current_iter, log)

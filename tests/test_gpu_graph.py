@@ -40,7 +40,7 @@ def test_graph_replay_equals_eager(stage):
                 data.update(rate_ind=1, beta=2.56 + 0.01 * it)  # beta changes every step: must flow through device buffers
             out.append(tr.optimize_parameters(it, data))
         if mode:
-            assert len(tr.graphs) == (3 if stage == 3 else 2), "segments were not captured"
+            assert len(tr.graphs) == (4 if stage == 3 else 2), "segments were not captured"  # g, dfb, u, d
         logs[mode] = out
         params[mode] = {k: p.detach().clone() for k, p in tr.comp_model.named_parameters()}
         if stage == 3:
