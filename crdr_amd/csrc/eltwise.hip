@@ -590,6 +590,29 @@ __global__ __launch_bounds__(256) void col2im_rgb_kernel(const float* cols, int 
   }
 }
 
+
+// batch of random crops (+ horizontal flip, normalisation to [-1, 1]) out of a uint8 RGB image pool
+__global__ __launch_bounds__(256) void crop_flip_normalize_kernel(const uint8_t* pool, const long long* items, int N, int ch, int cw,
+                                                                  float* out, int ldo) {
+  const long long total = (long long)N * ch * cw;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int c = (int)(e % cw);
+    const long long r2 = e / cw;
+    const int r = (int)(r2 % ch), n = (int)(r2 / ch);
+    const long long* it = items + (size_t)n * 6;
+    const int H = (int)it[1], W = (int)it[2];
+    int y = (int)it[3] + r, x = (int)it[4] + (it[5] ? cw - 1 - c : c);
+    y = y < 0 ? -y : y; y = y >= H ? 2 * (H - 1) - y : y;
+    x = x < 0 ? -x : x; x = x >= W ? 2 * (W - 1) - x : x;
+    const uint8_t* px = pool + it[0] + ((size_t)y * W + x) * 3;
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = ((float)px[k] / 255.0f - 0.5f) / 0.5f;
+    v[3] = 0.f;
+    *reinterpret_cast<f32x4*>(out + (size_t)e * ldo) = v;
+  }
+}
+
 }  // namespace crdr
 
 using namespace crdr;
@@ -644,6 +667,18 @@ extern "C" int crdr_col2im_rgb(const float* cols, int ldc, int N, int H, int W, 
   hipLaunchKernelGGL(col2im_rgb_kernel, dim3((unsigned)std::min<long long>(cdiv64(total, 256), 65535)), dim3(256), 0, as_stream(s),
                      cols, ldc, N, H, W, kh, kw, stride, pad, bias, out, ldo, OH, OW, C);
   CRDR_CHECK_LAUNCH("col2im_rgb_kernel");
+  return 0;
+}
+
+extern "C" int crdr_crop_flip_normalize(const uint8_t* pool, const int64_t* items, int N, int crop_h, int crop_w, float* out,
+                                        int ldo, crdr_stream_t s) {
+  CRDR_REQUIRE(pool && items && out, "crop_flip_normalize: null pointer");
+  CRDR_REQUIRE(ldo >= 4 && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "crop_flip_normalize: out must be 16-byte aligned rows");
+  const long long total = (long long)N * crop_h * crop_w;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(crop_flip_normalize_kernel, dim3((unsigned)std::min<long long>(cdiv64(total, 256), 65535)), dim3(256), 0,
+                     as_stream(s), pool, reinterpret_cast<const long long*>(items), N, crop_h, crop_w, out, ldo);
+  CRDR_CHECK_LAUNCH("crop_flip_normalize_kernel");
   return 0;
 }
 

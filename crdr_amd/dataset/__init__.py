@@ -101,7 +101,16 @@ def build_loaders(opt, device) -> Tuple[object, Optional[DataLoader]]:
     if tr is None or tr.get("type") == "SyntheticDataset" or not os.path.isdir(str(tr.get("root_dir", ""))):
         size = tr.get("image_size", 256) if tr else 256
         return SyntheticLoader(bs, size, device, seed=opt.get("data_seed", 0)), None
-    train = DataLoader(build_dataset(tr, True), batch_size=bs, drop_last=True, shuffle=True, num_workers=opt.get("num_workers", 8))
+    if tr.get("device_pool", False) and str(device).startswith("cuda"):
+        # decode the training set once into HBM and cut every batch with one launch (crdr_amd/dataset/device_pipeline.py)
+        from .device_pipeline import DeviceCropLoader, DeviceImagePool
+        from crdr_amd.trainer import dist as _D
+        o = {k: v for k, v in dict(tr).items() if k != "device_pool"}
+        paths = build_dataset(o, True).paths
+        train = DeviceCropLoader(DeviceImagePool.from_paths(paths, device), bs, int(o.get("image_size", 256)),
+                                 seed=int(opt.get("data_seed", 0)), rank=_D.rank(), world_size=_D.world_size())
+    else:
+        train = DataLoader(build_dataset(tr, True), batch_size=bs, drop_last=True, shuffle=True, num_workers=opt.get("num_workers", 8))
     ev = ds.get("eval_dataset", None)
     evl = DataLoader(build_dataset(ev, False), batch_size=1, shuffle=False, num_workers=1) if ev and os.path.isdir(str(ev.get("root_dir", ""))) else None
     return train, evl

@@ -81,6 +81,7 @@ SIGNATURES = {
     "crdr_epilogue_bwd_workspace": (_SZ, [C.POINTER(EbwdDesc)]),
     "crdr_epilogue_bwd": (_I, [C.POINTER(EbwdDesc), C.POINTER(EbwdIO), _P, _SZ, _P]),
     "crdr_col2im_rgb": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "crdr_crop_flip_normalize": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
     "crdr_linear_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "crdr_linear_bwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
     "crdr_affine": (_I, [_P, _I, _P, _P, _P, _I, _I64, _I, _P]),

@@ -189,6 +189,14 @@ typedef struct crdr_ebwd_io {
 size_t crdr_epilogue_bwd_workspace(const crdr_ebwd_desc* d);
 int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);
 
+/* Device-side input pipeline (data_transform.py:19-45: RandomCrop(size, pad_if_needed, reflect) -> HFlip -> ToTensor ->
+ * (x - 0.5) / 0.5) over a pool of decoded uint8 RGB images that lives in HBM: one launch cuts a whole batch.
+ * items: DEVICE array [N][6] of int64 {byte offset of the image in pool, H, W, sy0, sx0, flip}; (sy0, sx0) is the crop
+ * origin in image coordinates and may be negative / reach past the image, where torchvision's reflect padding
+ * (no edge repeat) applies.  out: NHWC fp32, pixel stride ldo >= 4, channel 3 zeroed. */
+int crdr_crop_flip_normalize(const uint8_t* pool, const int64_t* items, int N, int crop_h, int crop_w, float* out, int ldo,
+                             crdr_stream_t s);
+
 /* Linear layer on a handful of row vectors (M <= 16: the beta-conditioning MLP and the per-block projections of the
  * [1, 512] conditioning vector, elic_interpca_beta_cond_autoencoder.py:42-84, fourier_cond.py:12-37) -- a 1x1 conv
  * over M pixels is launch-latency bound on the implicit-GEMM path, these run as GEMV-style kernels on the raw [O][I]

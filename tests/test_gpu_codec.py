@@ -48,3 +48,25 @@ def test_training_forward_is_deterministic():
     b = model.run_model(x, rate_ind=1.0, beta=2.0, noise=noise)
     for k in ("fake_images", "y_hat", "bpp", "qbpp"):
         assert torch.equal(a[k], b[k]), k
+
+
+def test_device_input_pipeline_matches_torchvision_semantics():
+    """crdr_crop_flip_normalize vs the numpy statement of RandomCrop(pad_if_needed, reflect) -> HFlip -> ToTensor ->
+    Normalize (data_transform.py:34-39): bit-exact, including images smaller than the crop (reflect padding on both
+    sides) and flips."""
+    from crdr_amd.dataset.device_pipeline import DeviceCropLoader, DeviceImagePool, crop_reference, draw_crops
+    rng = np.random.default_rng(7)
+    shapes = [(300, 400), (256, 256), (200, 310), (257, 180), (513, 129)]
+    imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in shapes]
+    pool = DeviceImagePool(imgs, dev())
+    loader = DeviceCropLoader(pool, batch_size=16, size=256, seed=3)
+    idx = np.asarray([0, 1, 2, 3, 4, 2, 3, 4, 0, 1, 2, 3, 4, 4, 3, 2])
+    draws = draw_crops(pool.shapes, idx, 256, np.random.default_rng(11))
+    assert (draws[:, 4] == 1).any() and (draws[:, 4] == 0).any()
+    out = loader.cut(idx, draws)
+    assert out.shape == (16, 3, 256, 256)
+    for k, i in enumerate(idx):
+        ref = crop_reference(imgs[i], 256, int(draws[k, 2]), int(draws[k, 3]), int(draws[k, 4]))
+        assert np.array_equal(out[k].cpu().numpy(), ref), f"sample {k} (image {i}, draw {draws[k]})"
+    batch = next(loader)["real_images"]
+    assert batch.shape == (16, 3, 256, 256) and float(batch.min()) >= -1.0 and float(batch.max()) <= 1.0
