@@ -1,0 +1,79 @@
+"""End-to-end drop-in check of the two entry points on the GPU (scripts/train.py:16-27, scripts/compress.py:35-47):
+train stage 3 for a few iterations on a tiny PNG folder (host DataLoader and the device-pool pipeline), with HIP graphs,
+logging, validation and checkpoints; resume from the checkpoint; then compress / decompress an image folder with the
+trained weights and check the container accounting."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _png_dir(path, n, h, w, seed):
+    from PIL import Image
+    os.makedirs(path, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        base = rng.integers(0, 256, size=(h // 8 + 1, w // 8 + 1, 3), dtype=np.uint8)
+        img = np.kron(base, np.ones((8, 8, 1), dtype=np.uint8))[:h, :w]  # blocky, compressible
+        Image.fromarray(img).save(os.path.join(path, f"im{i:02d}.png"))
+
+
+def _run(args, cwd, timeout=900):
+    env = dict(os.environ, CRDR_AUTOTUNE="0", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable] + args, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-4000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("device_pool", [False, True])
+def test_train_resume_compress(tmp_path, device_pool):
+    train_dir, eval_dir = str(tmp_path / "train" / "0"), str(tmp_path / "kodak")
+    _png_dir(train_dir, 6, 96, 120, 1)
+    _png_dir(eval_dir, 2, 64, 128, 2)
+    os.makedirs(tmp_path / "checkpoint")  # like the reference, ckpt_root must exist (options.py:174-177)
+    cfg = tmp_path / "tiny_stage3.yaml"
+    cfg.write_text(f"""_base_: [{os.path.relpath(os.path.join(ROOT, 'config', 'crdr_stage_3.yaml'), str(tmp_path))}]
+pretrained_weight_path: null
+ckpt_root: {tmp_path}/checkpoint
+hip_graphs: true
+keep_training_state: true
+keep_discriminator: true
+dataset:
+  batch_size: 2
+  train_dataset:
+    root_dir: {tmp_path}/train
+    name: openimage
+    type: ImageDataset
+    image_size: 64
+    subset_list: [0]
+    device_pool: {'true' if device_pool else 'false'}
+  eval_dataset:
+    root_dir: {eval_dir}
+    name: Kodak
+    type: ImageDataset
+""")
+    train = os.path.join(ROOT, "scripts", "train.py")
+    _run([train, str(cfg), "-d", "cuda:0", "-b", "2", "-ti", "6", "-s", "3", "-l", "2", "-e", "3", "-nw", "0"], cwd=str(tmp_path))
+    model_dir = tmp_path / "checkpoint" / "tiny_stage3" / "model"
+    names = sorted(os.listdir(model_dir))
+    assert "comp_model_iter6.pth.tar" in names and any(n.startswith("training_state_iter6") for n in names), names
+    # resume: two more iterations from the iteration-6 checkpoint
+    _run([train, str(cfg), "-d", "cuda:0", "-b", "2", "-si", "6", "-ti", "8", "-s", "2", "-l", "1", "-e", "100", "-nw", "0"], cwd=str(tmp_path))
+    assert "comp_model_iter8.pth.tar" in os.listdir(model_dir)
+    # compress / decompress with the trained generator
+    out_dir = tmp_path / "out"
+    _run([os.path.join(ROOT, "scripts", "compress.py"), "--config_path", os.path.join(ROOT, "config", "crdr.yaml"), "--model_path",
+          str(model_dir / "comp_model_iter8.pth.tar"), "--img_dir", eval_dir, "--save_dir", str(out_dir), "-q", "1.5", "-b", "2.56",
+          "--decompress", "-d", "cuda:0"], cwd=ROOT)
+    files = sorted(os.listdir(out_dir))
+    assert "im00.bin" in files and "im00.png" in files and "_avg_bitrate.json" in files, files
+    avg = json.load(open(out_dir / "_avg_bitrate.json"))
+    assert 0 < list(avg.values())[0] < 24
+    from PIL import Image
+    assert Image.open(out_dir / "im00.png").size == (128, 64)
