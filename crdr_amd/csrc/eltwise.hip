@@ -278,7 +278,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return r;
 }
 
-enum { RED_SQDIFF = 0, RED_BCE = 1, RED_SQNORM = 2 };
+enum { RED_SQDIFF = 0, RED_BCE = 1, RED_SQNORM = 2, RED_DOT = 3 };
 template <int OP>
 __global__ __launch_bounds__(256) void reduce_kernel(const float* a, const float* b, int64_t n, float target,
                                                      float* partial) {
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* a, const float
   for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += gridDim.x * 256ll) {
     if (OP == RED_SQDIFF) { const float d = a[e] - b[e]; s += d * d; }
     if (OP == RED_SQNORM) { const float d = a[e]; s += d * d; }
+    if (OP == RED_DOT) s += a[e] * b[e];
     if (OP == RED_BCE) {  // BCEWithLogits(x, t) = max(x,0) - x t + log(1 + exp(-|x|))
       const float x = a[e] - b[e];
       s += fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
@@ -613,6 +614,66 @@ __global__ __launch_bounds__(256) void crop_flip_normalize_kernel(const uint8_t*
   }
 }
 
+
+// ---- spectral norm (power iteration on w[O][K]) --------------------------------------------------------------
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* w, const float* u, int O, int K, float* t) {  // t[k] = sum_o w[o][k] u[o]
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float a = 0.f;
+  for (int o = 0; o < O; ++o) a += w[(size_t)o * K + k] * u[o];
+  t[k] = a;
+}
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* w, const float* v, int O, int K, float* t) {  // t[o] = sum_k w[o][k] v[k]
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= O) return;
+  float a = 0.f;
+  for (int k = lane; k < K; k += 64) a += w[(size_t)o * K + k] * v[k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+  if (lane == 0) t[o] = a;
+}
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < 16; ++i) t += red[i];
+  return t;
+}
+// one block: x <- t / max(||t||, eps)  (normalize != 0), and *dot_out = sum x[i] t[i] (dot_with_t) -- fixed order
+__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* t, int n, float eps, float* x, int normalize, float* dot_out) {
+  __shared__ float red[16];
+  float a = 0.f;
+  if (normalize) {
+    for (int i = threadIdx.x; i < n; i += 1024) a += t[i] * t[i];
+    const float nrm = fmaxf(sqrtf(block_sum_1024(a, red)), eps);
+    for (int i = threadIdx.x; i < n; i += 1024) x[i] = t[i] / nrm;
+    __syncthreads();
+  }
+  if (dot_out) {
+    float d = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) d += x[i] * t[i];
+    d = block_sum_1024(d, red);
+    if (threadIdx.x == 0) *dot_out = d;
+  }
+}
+__global__ __launch_bounds__(256) void sn_scale_kernel(const float* w, const float* sigma, long long n, float* out) {
+  const float s = *sigma;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) out[i] = w[i] / s;
+}
+__global__ __launch_bounds__(256) void sn_bwd_kernel(const float* dw_sn, const float* u, const float* v, const float* sigma,
+                                                     const float* dot, int O, int K, float* dw) {
+  const float s = *sigma, c = *dot / (s * s);
+  const long long n = (long long)O * K;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+    const int o = (int)(i / K), k = (int)(i % K);
+    dw[i] += dw_sn[i] / s - c * u[o] * v[k];
+  }
+}
+
 }  // namespace crdr
 
 using namespace crdr;
@@ -786,6 +847,40 @@ static int run_reduce(const float* a, const float* b, int64_t n, float target, f
   CRDR_CHECK_LAUNCH(what);
   return 0;
 }
+extern "C" int crdr_spectral_norm_fwd(const float* w, int O, int K, float* u, float* v, int power_iter, float eps, float* w_out,
+                                      float* sigma_out, void* ws, size_t ws_bytes, crdr_stream_t s) {
+  CRDR_REQUIRE(w && u && v && w_out && sigma_out && ws, "spectral_norm_fwd: null pointer");
+  CRDR_REQUIRE(ws_bytes >= (size_t)(O + K + 2) * sizeof(float), "spectral_norm_fwd: workspace too small");
+  float* tv = (float*)ws;       // [K]
+  float* tu = tv + K;           // [O]
+  hipStream_t st = as_stream(s);
+  if (power_iter) {
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, w, u, O, K, tv);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, tv, K, eps, v, 1, (float*)nullptr);
+  }
+  hipLaunchKernelGGL(sn_w_v_kernel, dim3(cdiv(O, 4)), dim3(256), 0, st, w, v, O, K, tu);
+  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, tu, O, eps, u, power_iter ? 1 : 0, sigma_out);  // sigma = u . (w v)
+  hipLaunchKernelGGL(sn_scale_kernel, dim3(grid_for((int64_t)O * K)), dim3(256), 0, st, w, sigma_out, (long long)O * K, w_out);
+  CRDR_CHECK_LAUNCH("spectral_norm_fwd");
+  return 0;
+}
+
+extern "C" int crdr_spectral_norm_bwd(const float* dw_sn, const float* w, const float* u, const float* v, const float* sigma,
+                                      int O, int K, float* dw, void* ws, size_t ws_bytes, crdr_stream_t s) {
+  CRDR_REQUIRE(dw_sn && w && u && v && sigma && dw && ws, "spectral_norm_bwd: null pointer");
+  const int64_t n = (int64_t)O * K;
+  const int nb = reduce_blocks(n);
+  CRDR_REQUIRE(ws_bytes >= (size_t)(nb + 1) * sizeof(float), "spectral_norm_bwd: workspace too small");
+  float* part = (float*)ws;
+  float* dot = part + nb;
+  hipStream_t st = as_stream(s);
+  hipLaunchKernelGGL(reduce_kernel<RED_DOT>, dim3(nb), dim3(256), 0, st, dw_sn, w, n, 0.f, part);
+  hipLaunchKernelGGL(reduce_final, dim3(1), dim3(256), 0, st, (const float*)part, nb, dot);
+  hipLaunchKernelGGL(sn_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dw_sn, u, v, sigma, (const float*)dot, O, K, dw);
+  CRDR_CHECK_LAUNCH("spectral_norm_bwd");
+  return 0;
+}
+
 extern "C" int crdr_sqdiff_sum(const float* a, const float* b, int64_t n, float* out, void* ws, size_t ws_bytes,
                                crdr_stream_t s) {
   CRDR_REQUIRE(b, "sqdiff_sum: null pointer");

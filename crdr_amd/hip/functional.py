@@ -70,6 +70,11 @@ class ConvSpec:
         tapmajor = (self.smallc and not for_dgrad) or (self.smallc_dgrad and for_dgrad)
         return self._pack(weight, transpose, 2 if tapmajor else int(transpose))
 
+    def mark_stale(self) -> None:
+        """The weight buffer was rewritten in place by a kernel (spectral norm): refill the packs on next use."""
+        for ent in self._packs.values():
+            ent.key = None
+
     def pack_scatter(self, weight: torch.Tensor) -> torch.Tensor:
         """[4 T][first weight dim] pack of an RGB-output transposed op done as GEMM + col2im (crdr_col2im_rgb)."""
         return self._pack(weight, "scatter", 3)
@@ -205,7 +210,8 @@ def _flags(bias, act, vec2, res, gate, affine) -> int:
 
 class _FusedConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, vec2, res, scale, shift, gx, gt, spec: ConvSpec, act):
+    def forward(ctx, x, weight, bias, vec2, res, scale, shift, gx, gt, spec: ConvSpec, act, return_wgrad=False):
+        ctx.return_wgrad = return_wgrad
         flags = _flags(bias, act, vec2, res, gx is not None, scale is not None)
         n, _, h, w = x.shape
         oh, ow = spec.out_hw(h, w)
@@ -254,15 +260,20 @@ class _FusedConv(torch.autograd.Function):
             else:
                 dx = ops.conv2d_raw(dz, spec.pack(weight, True), x.shape[1], spec.k, spec.stride, spec.pad,
                                     not spec.transposed, ctx.in_hw, wlayout=1 if spec.smallc_dgrad else 0)
+        dw = None
         if needs[1]:
-            g = _grad_slot(weight)
+            # a parameter's gradient is accumulated straight into its (flat) slot; a derived weight (spectral norm) gets
+            # its gradient returned through autograd instead, reduced immediately
+            g = torch.empty_like(weight) if ctx.return_wgrad else _grad_slot(weight)
             g4 = g if g.dim() == 4 else g.view(g.shape[0], g.shape[1], 1, 1)
+            kw = dict(accumulate=not ctx.return_wgrad, defer=not ctx.return_wgrad)
             if spec.transposed:
-                ops.conv2d_wgrad_raw(x, dz, g4, spec.k, spec.stride, spec.pad, accumulate=True)
+                ops.conv2d_wgrad_raw(x, dz, g4, spec.k, spec.stride, spec.pad, **kw)
             else:
-                ops.conv2d_wgrad_raw(dz, x, g4, spec.k, spec.stride, spec.pad, accumulate=True)
-        return (dx, None, None, dvec2, gres if has_res else None, dscale, dshift, gres if has_gate else None,
-                dgt, None, None)
+                ops.conv2d_wgrad_raw(dz, x, g4, spec.k, spec.stride, spec.pad, **kw)
+            dw = g if ctx.return_wgrad else None
+        return (dx, dw, None, dvec2, gres if has_res else None, dscale, dshift, gres if has_gate else None,
+                dgt, None, None, None)
 
 
 class _SmallLinear(torch.autograd.Function):
@@ -299,14 +310,47 @@ class _SmallLinear(torch.autograd.Function):
 
 def fused_conv(x, weight, bias, spec: ConvSpec, *, act: Optional[str] = None, vec2=None, res=None,
                affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-               gate: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
-    if (spec.k == (1, 1) and spec.stride == 1 and spec.pad == 0 and not spec.transposed and x.dim() == 4 and x.shape[2] == 1
+               gate: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, return_wgrad: bool = False):
+    if (not return_wgrad and spec.k == (1, 1) and spec.stride == 1 and spec.pad == 0 and not spec.transposed and x.dim() == 4 and x.shape[2] == 1
             and x.shape[3] == 1 and x.shape[0] <= 16 and vec2 is None and res is None and affine is None and gate is None
             and act in (None, "relu") and weight.is_contiguous()):
         return _SmallLinear.apply(x, weight, bias, act == "relu")
     scale, shift = affine if affine is not None else (None, None)
     gx, gt = gate if gate is not None else (None, None)
-    return _FusedConv.apply(x, weight, bias, vec2, res, scale, shift, gx, gt, spec, act)
+    return _FusedConv.apply(x, weight, bias, vec2, res, scale, shift, gx, gt, spec, act, return_wgrad)
+
+
+class _SpectralNorm(torch.autograd.Function):
+    """weight_orig -> weight_orig / sigma with torch.nn.utils.spectral_norm's semantics (one power iteration per
+    training-mode call, u / v updated in place and treated as constants by the backward)."""
+
+    @staticmethod
+    def forward(ctx, w_orig, u, v, training: bool, out_buf: torch.Tensor, eps: float):
+        lib = L.load()
+        ops._require_gpu(w_orig)
+        o, k = w_orig.shape[0], w_orig.numel() // w_orig.shape[0]
+        sigma = torch.empty(1, dtype=torch.float32, device=w_orig.device)
+        ws, wsn = ops.workspace((o + k + 2) * 4, w_orig.device)
+        L.check(lib.crdr_spectral_norm_fwd(w_orig.data_ptr(), o, k, u.data_ptr(), v.data_ptr(), int(training), float(eps),
+                                           out_buf.data_ptr(), sigma.data_ptr(), ws, wsn, ops._stream()), "spectral_norm_fwd")
+        ctx.save_for_backward(w_orig, u.clone() if training else u, v.clone() if training else v, sigma)
+        return out_buf.detach()  # a fresh alias of the persistent buffer (stable address for the weight packs)
+
+    @staticmethod
+    def backward(ctx, dw_sn):
+        w_orig, u, v, sigma = ctx.saved_tensors
+        lib = L.load()
+        o, k = w_orig.shape[0], w_orig.numel() // w_orig.shape[0]
+        g = _grad_slot(w_orig)
+        nb = lib.crdr_reduce_workspace(o * k) + 16
+        ws, wsn = ops.workspace(nb, w_orig.device)
+        L.check(lib.crdr_spectral_norm_bwd(dw_sn.contiguous().data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(),
+                                           sigma.data_ptr(), o, k, g.data_ptr(), ws, wsn, ops._stream()), "spectral_norm_bwd")
+        return None, None, None, None, None, None
+
+
+def spectral_norm_weight(w_orig, u, v, training: bool, out_buf: torch.Tensor, eps: float = 1e-12):
+    return _SpectralNorm.apply(w_orig, u, v, training, out_buf, eps)
 
 
 class _InterpCaVectors(torch.autograd.Function):

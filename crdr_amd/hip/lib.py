@@ -81,6 +81,8 @@ SIGNATURES = {
     "crdr_epilogue_bwd_workspace": (_SZ, [C.POINTER(EbwdDesc)]),
     "crdr_epilogue_bwd": (_I, [C.POINTER(EbwdDesc), C.POINTER(EbwdIO), _P, _SZ, _P]),
     "crdr_col2im_rgb": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "crdr_spectral_norm_fwd": (_I, [_P, _I, _I, _P, _P, _I, C.c_float, _P, _P, _P, _SZ, _P]),
+    "crdr_spectral_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
     "crdr_crop_flip_normalize": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
     "crdr_linear_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "crdr_linear_bwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P]),

@@ -276,7 +276,8 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
     return out
 
 
-def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, stride, pad, accumulate: bool, algo: int = 0):
+def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, stride, pad, accumulate: bool, algo: int = 0,
+                      defer: bool = True):
     """g[I][J][kh][kw] (+)= sum P[., i] * Q[gathered, j]; P is the dense operand (see crdr_hip.h)."""
     lib = L.load()
     p, ldp = nhwc(p)
@@ -308,7 +309,7 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
         d.algo = algo
     nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
     e0 = _prof_begin()
-    if WGRAD_DEFER is not None and WGRAD_DEFER.device == p.device:
+    if defer and WGRAD_DEFER is not None and WGRAD_DEFER.device == p.device:
         job = L.WgradJob()
         L.check(lib.crdr_conv2d_wgrad_partial(C.byref(d), p.data_ptr(), q.data_ptr(), g.data_ptr(), WGRAD_DEFER.alloc(nbytes),
                                               nbytes, C.byref(job), _stream()), "conv2d_wgrad_partial")

@@ -189,6 +189,15 @@ typedef struct crdr_ebwd_io {
 size_t crdr_epilogue_bwd_workspace(const crdr_ebwd_desc* d);
 int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);
 
+/* torch.nn.utils.spectral_norm on a conv weight viewed as w[O][K] (hific_discriminator.py:10-13; n_power_iterations = 1,
+ * eps = 1e-12).  power_iter != 0 (training-mode forward): v <- normalize(w^T u), u <- normalize(w v), both updated in
+ * place; then sigma = u . (w v) and w_out = w / sigma.  ws: (O + K + 2) floats.  The backward treats u, v as constants:
+ * dw[o][k] += dw_sn[o][k] / sigma - (sum(dw_sn * w) / sigma^2) u[o] v[k];  ws: crdr_reduce_workspace(O*K) + 4 bytes. */
+int crdr_spectral_norm_fwd(const float* w, int O, int K, float* u, float* v, int power_iter, float eps, float* w_out,
+                           float* sigma_out, void* ws, size_t ws_bytes, crdr_stream_t s);
+int crdr_spectral_norm_bwd(const float* dw_sn, const float* w, const float* u, const float* v, const float* sigma, int O, int K,
+                           float* dw, void* ws, size_t ws_bytes, crdr_stream_t s);
+
 /* Device-side input pipeline (data_transform.py:19-45: RandomCrop(size, pad_if_needed, reflect) -> HFlip -> ToTensor ->
  * (x - 0.5) / 0.5) over a pool of decoded uint8 RGB images that lives in HBM: one launch cuts a whole batch.
  * items: DEVICE array [N][6] of int64 {byte offset of the image in pool, H, W, sy0, sx0, flip}; (sy0, sx0) is the crop

@@ -383,6 +383,39 @@ def discriminator(sd: SD, x, rate_ind, p: str = "subD_list"):
     return clic21_discriminator(sd, x, f"{p}.{int(rate_ind)}")  # module_list_discriminator.py:25-30
 
 
+def spectral_norm_weight(sd: SD, name: str, training: bool, eps: float = 1e-12):
+    """torch.nn.utils.spectral_norm as the reference applies it (hific_discriminator.py:10-13; one power iteration per
+    training-mode forward, none in eval): returns (weight_orig / sigma, new u, new v); u, v enter sigma as constants."""
+    w, u, v = sd[name + ".weight_orig"], sd[name + ".weight_u"], sd[name + ".weight_v"]
+    wm = w.reshape(w.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps)
+            u = F.normalize(torch.mv(wm, v), dim=0, eps=eps)
+    sigma = torch.dot(u, torch.mv(wm, v))
+    return w / sigma, u, v
+
+
+def hific_discriminator(sd: SD, x, p: str = "", training: bool = False, y_hat=None, use_sn: bool = True, uv_out: Optional[dict] = None):
+    """HiFiCDiscriminator / HiFiCConditionalDiscriminator (hific_discriminator.py:24-58): 4x4 convs with padding
+    ceil(3/2) = 2 and strides 2, 2, 2, 1, LeakyReLU(0.2), 1x1 head; the conditional variant prepends a 1x1 conv +
+    LeakyReLU of the detached latent, nearest-upsampled x16, concatenated to the image."""
+    def w_of(i):
+        name = f"{p}model.{i}"
+        if not use_sn:
+            return sd[name + ".weight"]
+        w, u, v = spectral_norm_weight(sd, name, training)
+        if uv_out is not None:
+            uv_out[name + ".weight_u"], uv_out[name + ".weight_v"] = u, v
+        return w
+    if y_hat is not None:
+        c = F.leaky_relu(F.conv2d(y_hat.detach(), sd[p + "latent_conv.0.weight"], sd[p + "latent_conv.0.bias"]), 0.2)
+        x = torch.cat((x, F.interpolate(c, scale_factor=16, mode="nearest")), 1)
+    for i, stride in zip((0, 2, 4, 6), (2, 2, 2, 1)):
+        x = F.leaky_relu(F.conv2d(x, w_of(i), sd[f"{p}model.{i}.bias"], stride=stride, padding=2), 0.2)
+    return F.conv2d(x, w_of(8), sd[p + "model.8.bias"])
+
+
 def mse_loss(real, fake, weight=150.0):
     return weight * F.mse_loss((real + 1) / 2, (fake + 1) / 2)  # distortion_loss.py:41-46
 

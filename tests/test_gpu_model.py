@@ -234,3 +234,42 @@ def test_discriminator_fwd_bwd():
     (out * r.to(dev())).sum().backward()
     assert rel(xd.grad, xg.grad) < 2e-3
     check_grads(D, "", sdg, "discriminator")
+
+
+@pytest.mark.parametrize("name", ["plain", "nosn", "cond"])
+def test_hific_discriminator_fwd_bwd(name):
+    """HiFiC discriminators (spectral norm with its power iteration on the device) against the oracle,
+    which is itself pinned to vectors from the reference (tests/test_oracle_golden.py)."""
+    from oracle import crdr_oracle as O
+    from crdr_amd.models.discriminator.hific_discriminator import HiFiCConditionalDiscriminator, HiFiCDiscriminator
+    torch.manual_seed(0)
+    if name == "cond":
+        D = HiFiCConditionalDiscriminator(in_ch=3, out_ch=1, main_ch=16, y_ch=24, latent_nc=4, use_sn=True)
+    else:
+        D = HiFiCDiscriminator(in_ch=3, out_ch=1, main_ch=16, use_sn=name != "nosn")
+    from tests.golden.seeded_weights import fill_module_
+    sd = fill_module_(D, f"hific.{name}.")
+    D.to(dev())
+    x = seeded_input("hific.x", (2, 3, 32, 48))
+    y = seeded_input("hific.y", (2, 24, 2, 3))
+    pre = f"hific.{name}."
+    osd = {k: v.clone().requires_grad_(not k.endswith(("_u", "_v"))) for k, v in sd.items()}
+    kw_o = {"y_hat": y} if name == "cond" else {}
+    kw_g = {"y_hat": y.to(dev())} if name == "cond" else {}
+    D.eval()
+    close(D(x.to(dev()), **kw_g), O.hific_discriminator(osd, x, pre, training=False, use_sn=name != "nosn", **kw_o), "hific eval", 2e-5)
+    D.train()
+    xo = x.clone().requires_grad_(True)
+    uv = {}
+    ref = O.hific_discriminator(osd, xo, pre, training=True, use_sn=name != "nosn", uv_out=uv, **kw_o)
+    gy = seeded_input(f"hific.{name}.gy", tuple(ref.shape))
+    ref.backward(gy)
+    xg = x.to(dev()).requires_grad_(True)
+    out = D(xg, **kw_g)
+    out.backward(gy.to(dev()))
+    close(out, ref, "hific train", 2e-5)
+    close(xg.grad, xo.grad, "hific dx", 2e-4)
+    got = D.state_dict()
+    for k, v in uv.items():
+        close(got[k[len(pre):]], v, k, 2e-5)
+    check_grads(D, pre, osd, f"hific {name}")

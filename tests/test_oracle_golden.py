@@ -170,3 +170,45 @@ def test_config_merge():
         cfg, _, loaded = BaseConfig._file2dict_yaml(os.path.join(root, name))
         assert cfg == ref["cfg"], name
         assert len(loaded) == ref["n_loaded"]
+
+
+@pytest.mark.parametrize("name", ["plain", "nosn", "cond"])
+def test_hific_discriminator_oracle_matches_reference(name):
+    """oracle.hific_discriminator (incl. torch's spectral-norm power iteration) against vectors
+    recorded from the reference's HiFiC discriminators (tests/golden/gen_golden_hific.py)."""
+    import numpy as np
+    from oracle import crdr_oracle as O
+    from tests.golden.seeded_weights import seeded_input, seeded_tensor
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_hific.npz"))
+    keys = [str(k) for k in g[f"{name}.keys"]]
+    main_ch, y_ch, lat = 16, 24, 4
+    shapes = {}
+    cin = 3 + (lat if name == "cond" else 0)
+    for i, (ci, co, k) in zip((0, 2, 4, 6, 8), ((cin, main_ch, 4), (main_ch, 2 * main_ch, 4), (2 * main_ch, 4 * main_ch, 4),
+                                                 (4 * main_ch, 8 * main_ch, 4), (8 * main_ch, 1, 1))):
+        if name == "nosn":
+            shapes[f"model.{i}.weight"] = (co, ci, k, k)
+        else:
+            shapes[f"model.{i}.weight_orig"] = (co, ci, k, k)
+            shapes[f"model.{i}.weight_u"] = (co,)
+            shapes[f"model.{i}.weight_v"] = (ci * k * k,)
+        shapes[f"model.{i}.bias"] = (co,)
+    if name == "cond":
+        shapes["latent_conv.0.weight"], shapes["latent_conv.0.bias"] = (lat, y_ch, 1, 1), (lat,)
+    assert sorted(shapes) == keys, "state-dict schema differs from the reference"
+    sd = {k: seeded_tensor(f"hific.{name}." + k, s).requires_grad_(not k.endswith(("_u", "_v"))) for k, s in shapes.items()}
+    x = torch.from_numpy(g["in.x"]).requires_grad_(True)
+    kw = {"y_hat": torch.from_numpy(g["in.y"])} if name == "cond" else {}
+    ev = O.hific_discriminator(sd, x, "", training=False, use_sn=name != "nosn", **kw)
+    np.testing.assert_allclose(ev.detach().numpy(), g[f"{name}.eval"], rtol=2e-5, atol=2e-6)
+    uv = {}
+    tr = O.hific_discriminator(sd, x, "", training=True, use_sn=name != "nosn", uv_out=uv, **kw)
+    np.testing.assert_allclose(tr.detach().numpy(), g[f"{name}.train"], rtol=2e-5, atol=2e-6)
+    tr.backward(seeded_input(f"hific.{name}.gy", tuple(tr.shape)))
+    np.testing.assert_allclose(x.grad.numpy(), g[f"{name}.train.dx"], rtol=2e-4, atol=2e-6)
+    for k, v in uv.items():
+        np.testing.assert_allclose(v.numpy(), g[f"{name}.after.{k}"], rtol=2e-5, atol=2e-6)
+    for gk in [k for k in g.files if k.startswith(f"{name}.grad.")]:
+        got = sd[gk[len(name) + 6:]].grad
+        got = got[:, :8] if got.numel() > 20000 else got
+        np.testing.assert_allclose(got.numpy(), g[gk], rtol=2e-4, atol=2e-6)
