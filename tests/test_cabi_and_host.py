@@ -206,3 +206,29 @@ def test_multistep_lr_and_rate_loss_host_logic():
     assert abs(HificRateLoss(0.05, 0.015625, 1.5)(bpp, qbpp=qbpp, current_iter=1).item() - 0.015625 * 0.415) < 1e-7
     with pytest.raises(AssertionError):
         HificVariableRateLoss(lambda_A=[1.0, 2.0], lambda_B=0.1, target_rate=[0.1, 0.2])
+
+
+def test_calc_metrics_psnr_semantics(tmp_path):
+    """scripts/calc_metrics.py PSNR: uint8 read-back, float32 squared error, per-image PSNR then mean
+    (reference scripts/calc_metrics.py:146,168) -- not the PSNR of the pooled MSE."""
+    import importlib.util
+    import numpy as np
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("calc_metrics", os.path.join(ROOT, "scripts", "calc_metrics.py"))
+    cm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cm)
+    rng = np.random.default_rng(0)
+    rd, fd = tmp_path / "real", tmp_path / "fake"
+    rd.mkdir(), fd.mkdir()
+    expect = []
+    for i, noise in enumerate((2, 20)):
+        a = rng.integers(0, 256, size=(16, 24, 3), dtype=np.uint8)
+        b = np.clip(a.astype(np.int32) + rng.integers(-noise, noise + 1, size=a.shape), 0, 255).astype(np.uint8)
+        Image.fromarray(a).save(rd / f"im{i}.png")
+        Image.fromarray(b).save(fd / f"im{i}.png")
+        mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+        expect.append(10 * np.log10(255.0 ** 2 / mse))
+    res = cm.main(["--real_dir", str(rd), "--fake_dir", str(fd), "--metrics", "psnr"])
+    assert res["num_images"] == 2 and abs(res["PSNR"] - float(np.mean(expect))) < 1e-3
+    pooled = 10 * np.log10(255.0 ** 2 / np.mean([255.0 ** 2 / 10 ** (e / 10) for e in expect]))
+    assert abs(res["PSNR"] - pooled) > 1.0  # averaging per-image PSNRs is a different number
