@@ -217,11 +217,11 @@ def main():
     # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over one step (counters cannot
     # be read inside this process): tools/pmc_step.py + tools/pmc_traffic.py, result committed under profiles/
     traffic, traffic_src = None, None
-    tp = os.path.join(ROOT, "profiles", "r1_e_hbm_traffic_pmc.json")
+    tp = os.path.join(ROOT, "profiles", "r1_h_hbm_traffic_pmc_xcd.json")
     if a.stage == 3 and a.bs == 16 and a.size == 256 and os.path.exists(tp):
         with open(tp) as f:
             traffic = round(json.load(f)["igemm"]["hbm_bytes_per_launch"])
-        traffic_src = "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step (profiles/r1_e_hbm_traffic_pmc.json)"
+        traffic_src = "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step (profiles/r1_h_hbm_traffic_pmc_xcd.json)"
     roof = {"bound": "mfma", "achieved": ig["tflops"] if ig else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "igemm_kernel<*> (conv / convT forward + input-gradient launches, v_mfma_f32_32x32x2_f32)",
