@@ -92,8 +92,10 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         q = ctx["q"]
         self.discriminator.requires_grad_(True)
         self.d_optimizer.zero_grad(partitions=self._d_parts(q))
-        fake_d = self.discriminator(ctx["fake"], rate_ind=q)
-        real_d = self.discriminator(ctx["real"], rate_ind=q)
+        # one pass over [x̂; x] (the discriminator has no batch statistics -- norm_type none -- so this equals the
+        # reference's two separate calls per sample) halves the launches and doubles the rows of every GEMM
+        both = self.discriminator(torch.cat([ctx["fake"], ctx["real"]], dim=0), rate_ind=q)
+        fake_d, real_d = both[: both.shape[0] // 2], both[both.shape[0] // 2:]
         l_d_real = self.gan_loss.forward_diff(real_d, fake_d.detach(), is_real=True, is_disc=True) * 0.5
         l_d_fake = self.gan_loss.forward_diff(fake_d, real_d.detach(), is_real=False, is_disc=True) * 0.5
         (l_d_real + l_d_fake).backward()

@@ -185,7 +185,8 @@ def test_stage3_step():
                 continue
             r = ref_sd[n].grad
             if r is None or r.abs().max() == 0:
-                assert g is None or g.abs().max().item() == 0, f"{what}: unexpected gradient for {n}"
+                # analytically zero (e.g. the D head bias cancels in D(x) - D(x̂)): allow summation-order noise
+                assert g is None or g.abs().max().item() <= 1e-7, f"{what}: unexpected gradient for {n}"
                 continue
             e = rel(g, r)
             if e > tol:
