@@ -24,15 +24,21 @@ _algo_cache = {}
 TUNE_LOG = []
 
 
+TUNE_ROUNDS = int(__import__("os").environ.get("CRDR_TUNE_ROUNDS", "1"))  # >1: best of several timings (perf-database builds)
+
+
 def _time_call(fn, reps: int = 2) -> float:
     fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / reps
+    best = float("inf")
+    for _ in range(max(1, TUNE_ROUNDS)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best
 
 
 def _autotune(key, ncfg: int, max_log2_split: int, run) -> int:
