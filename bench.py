@@ -19,7 +19,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-GFLOP_PER_IMG_STAGE3 = 644.6    # 3.8 F_G + 7.8 F_D + LPIPS, 2 FLOP per MAC
+# 3.8 F_G + 7.8 F_D + LPIPS (2 FLOP per MAC) = 644.6 GFLOP/img "as written"; the no-grad high-rate
+# pass (0.8 of the steps) does not evaluate the Charm's scale transforms (8.12 GMAC) nor the hyper-decoder's scale branch
+# (0.28 GMAC), whose results the reference discards: 644.6 - 0.8 * 2 * 8.40 = 631.2 GFLOP/img are actually required
+GFLOP_PER_IMG_STAGE3 = 631.2
 GFLOP_PER_IMG_STAGE1 = 434.0
 
 

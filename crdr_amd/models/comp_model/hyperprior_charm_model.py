@@ -52,6 +52,22 @@ class HyperpriorCharmModel(BaseModel):
         return dict(real_images=real, fake_images=fake, y_hat=out["quantized_code"]["y"], z_hat=out["quantized_code"]["z"],
                     **self._extra_outputs(**cond), **rate, **out.get("others", {}))
 
+    @torch.no_grad()
+    def reconstruct(self, real_images, **cond) -> Dict[str, Tensor]:
+        """Training-mode reconstruction WITHOUT the rate terms: same x̂, y_hat, z_hat as run_model(is_train=True) (STE
+        rounding does not depend on the noise draws or on the scale branch), minus the scale transforms of the Charm, the
+        scale branch of the hyper-decoder and every likelihood.  Used for the no-grad high-rate pass of stage 3
+        (multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:42-47 only keeps `fake_images` of that pass)."""
+        N, _, H, W = real_images.size()
+        x = self.data_preprocess(real_images, is_train=True)
+        y = self._encode(x, **cond)
+        z = self.hyperencoder(y)
+        z_hat = self.entropy_model_z(z, is_train=True, want_bits=True)[0]
+        y_hat = self.context_model.reconstruct_latent(y, self.hyperdecoder.hd_mu(z_hat), self.entropy_model_y)
+        fake = self._decode(y_hat, **cond)
+        real, fake = self.data_postprocess(x, fake, size=(H, W), is_train=True)
+        return dict(real_images=real, fake_images=fake, y_hat=y_hat, z_hat=z_hat)
+
     def get_rate_summary_dict(self, out_dict: Dict, num_pixel: int) -> Dict[str, Tensor]:
         """bpp[n] = (bits_y[n] + bits_z[n]) / (H*W): noisy (`bpp`) and quantised (`qbpp`) (hyperprior_model.py:60-85).
         The bit sums come straight out of the fused entropy kernels."""

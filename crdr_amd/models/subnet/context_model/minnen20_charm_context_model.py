@@ -64,6 +64,26 @@ class Minnen20CharmContextModel(BaseContextModel):
     def _support(self, hats: List[Tensor]) -> List[Tensor]:
         return hats if self.max_support_slices < 0 else hats[: self.max_support_slices]
 
+    @torch.no_grad()
+    def reconstruct_latent(self, y: Tensor, h_mu: Tensor, entropy_model_y) -> Tensor:
+        """y_hat only (the no-grad high-rate pass of stage 3 needs nothing else): y_hat_i = round(y_i - mu_i) + mu_i, then
+        the LRP correction, do not depend on the scale transforms or on any likelihood, so those are not evaluated.
+        Bit-identical to the y_hat of forward()."""
+        ys = torch.chunk(y, self.num_slices, dim=1)
+        hats: List[Tensor] = []
+        ones = None
+        for i, ysl in enumerate(ys):
+            mean_support = torch.cat([h_mu] + self._support(hats), dim=1)
+            mu = self.mean_slice_transforms[i](mean_support)
+            if ones is None:
+                ones = torch.ones_like(mu)
+            yh = entropy_model_y.forward_split(ysl, mu, ones, is_train=False, want_bits=False, want_lik=False)[0]
+            if getattr(self, "record_symbols", None) is not None:
+                self.record_symbols.append(torch.round(yh.detach() - mu.detach()))
+            z = self.lrp_slice_transforms[i](torch.cat([mean_support, yh], dim=1))
+            hats.append(HF.lrp(yh, z))
+        return torch.cat(hats, dim=1)
+
     def forward(self, y: Tensor, hyper_out: Tensor, entropy_model_y, is_train: bool, calc_q_likelihood: bool = True,
                 noise: Tensor = None, want_lik: bool = True, bits_out: Dict = None):
         """-> (y_hat, y_likelihood, y_q_likelihood) like the reference; the per-image bit sums produced by the

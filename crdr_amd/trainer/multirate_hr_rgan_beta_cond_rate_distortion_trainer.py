@@ -65,10 +65,11 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         if q + self.relative_score_rate_delta > self.rate_level - 1:
             relative = real_p
         else:
-            hr = dict(data)
+            # high-rate reconstruction at q + delta (reference :42-47 runs the full model under no_grad and keeps only
+            # fake_images): the rate terms of that pass are dead code, reconstruct() does not evaluate them
+            hr = {k: v for k, v in data.items() if k != "noise"}
             hr["rate_ind"] = float(q + self.relative_score_rate_delta)
-            with torch.no_grad():
-                _, relative, _, _ = self.run_comp_model(hr)
+            relative = self.comp_model.reconstruct(**hr)["fake_images"]
         dist_loss = self.distortion_loss(real_p, fake, **other)
         rate_loss = self.rate_loss(bpp, **other, **self._rate_kwargs(other), current_iter=current_iter)
         assert self.perceptual_loss

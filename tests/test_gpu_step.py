@@ -154,6 +154,13 @@ def test_stage3_step():
         z_hats.append(o["z_hat"].detach().cpu())
         return o
     tr.comp_model.run_model = spy
+    reconstruct = tr.comp_model.reconstruct
+
+    def spy_hr(*a, **k):  # the no-grad high-rate pass
+        o = reconstruct(*a, **k)
+        z_hats.append(o["z_hat"].detach().cpu())
+        return o
+    tr.comp_model.reconstruct = spy_hr
     log = tr.optimize_parameters(1, data)
     assert log is not None
     syms = [t.cpu() for t in tr.comp_model.context_model.record_symbols]
