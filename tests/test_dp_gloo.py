@@ -34,6 +34,11 @@ def _worker(rank, world, port, q):
         bufs = [torch.full((5,), float(rank + 1)), torch.arange(3.0) * (rank + 1)]
         D.all_reduce_mean_(bufs)
         assert torch.allclose(bufs[0], torch.full((5,), 1.5)) and torch.allclose(bufs[1], torch.arange(3.0) * 1.5)
+        # 1b) the asynchronous form the stage-3 trainer uses (gradient buffers mean-reduced, skip flag max-reduced)
+        gb, flag = torch.full((7,), float(2 * rank)), torch.tensor([float(rank)])
+        sync = D.AsyncGradSync([gb], [flag])
+        sync.wait()
+        assert torch.allclose(gb, torch.full((7,), 1.0)) and float(flag) == 1.0
         # 2) skip decision is an OR over ranks; scalar mean
         assert D.any_rank_true(rank == 1, torch.device("cpu")) is True
         assert D.any_rank_true(False, torch.device("cpu")) is False
