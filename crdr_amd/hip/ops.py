@@ -224,6 +224,9 @@ def pack_weight(w: torch.Tensor, transpose: bool) -> torch.Tensor:
     return dst
 
 
+_SPAN_LIMIT = (1 << 31) - (1 << 20)  # operand byte span the conv kernels address with one buffer descriptor
+
+
 def conv_out_size(h, k, stride, pad, transposed, out_pad=0):
     if transposed:
         return (h - 1) * stride - 2 * pad + k + out_pad
@@ -234,13 +237,22 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
                transposed: bool, out_hw: Tuple[int, int], *, bias=None, flags: int = 0, vec2=None, res=None,
                scale=None, shift=None, gate_x=None, gate_t=None, sig_out=None, out: Optional[torch.Tensor] = None,
                algo: int = 0, wlayout: int = 0):
-    """One fused implicit-GEMM launch. `out` may be a channel slice of a wider NHWC tensor (written in place)."""
+    """One fused implicit-GEMM launch. `out` may be a channel slice of a wider NHWC tensor (written in place).
+    An input that reaches the 2 GiB span of the kernel's 32-bit buffer offsets is processed in batch halves."""
     lib = L.load()
     x, ldx = nhwc(x)
     n, c, h, w = x.shape
     oh, ow = out_hw
     if out is None:
         out = empty_nhwc(n, oc, oh, ow, x.device)
+    if n > 1 and n * h * w * ldx * 4 >= _SPAN_LIMIT:
+        n1 = n // 2
+        for sl in (slice(0, n1), slice(n1, n)):
+            conv2d_raw(x[sl], wpack, oc, k, stride, pad, transposed, out_hw, bias=bias, flags=flags, vec2=vec2,
+                       res=None if res is None else res[sl], scale=scale, shift=shift,
+                       gate_x=None if gate_x is None else gate_x[sl], gate_t=None if gate_t is None else gate_t[sl],
+                       sig_out=None if sig_out is None else sig_out[sl], out=out[sl], algo=algo, wlayout=wlayout)
+        return out
     out_t, ldy = out, (out.stride(3) if ow > 1 else (out.stride(2) if oh > 1 else (out.stride(0) if n > 1 else oc)))
     d = L.ConvDesc(N=n, H=h, W=w, C=(c + 3) // 4 * 4 if ldx >= (c + 3) // 4 * 4 else c, OH=oh, OW=ow, OC=oc, kh=k[0], kw=k[1],
                    stride=stride, pad=pad, transposed=int(transposed), ldx=ldx, ldy=ldy, wrows=wpack.shape[1],
@@ -284,12 +296,18 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
 
 def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, stride, pad, accumulate: bool, algo: int = 0,
                       defer: bool = True):
-    """g[I][J][kh][kw] (+)= sum P[., i] * Q[gathered, j]; P is the dense operand (see crdr_hip.h)."""
+    """g[I][J][kh][kw] (+)= sum P[., i] * Q[gathered, j]; P is the dense operand (see crdr_hip.h).
+    Operands that reach the 2 GiB span of the kernel's 32-bit buffer offsets are processed in batch halves."""
     lib = L.load()
     p, ldp = nhwc(p)
     q, ldq = nhwc(q)
     n, pc, ph, pw = p.shape
     _, qc, qh, qw = q.shape
+    if n > 1 and max(n * ph * pw * ldp, n * qh * qw * ldq) * 4 >= _SPAN_LIMIT:
+        n1 = n // 2
+        conv2d_wgrad_raw(p[:n1], q[:n1], g, k, stride, pad, accumulate, algo=algo, defer=False)
+        conv2d_wgrad_raw(p[n1:], q[n1:], g, k, stride, pad, True, algo=algo, defer=False)
+        return g
     pc4 = min((pc + 3) // 4 * 4, ldp)
     qc4 = min((qc + 3) // 4 * 4, ldq)
     assert g.is_contiguous() and g.shape[0] <= pc4 and g.shape[1] <= qc4

@@ -301,3 +301,20 @@ def test_rgb_layers_through_fused_conv(case):
     _close(xg.grad, xr.grad, name + " dx")
     _close(wg.grad, wr.grad, name + " dw")
     _close(bg.grad, br.grad, name + " db")
+
+
+def test_batch_split_for_operands_over_2gib(monkeypatch):
+    """The kernels address an operand through one buffer descriptor with 32-bit offsets; ops splits larger batches."""
+    from crdr_amd.hip import ops
+    dev = _dev()
+    x = _rand(4, 32, 12, 12, seed=1).to(dev).contiguous(memory_format=torch.channels_last)
+    wt = _rand(16, 32, 3, 3, seed=2, scale=0.1).to(dev)
+    dy = _rand(4, 16, 12, 12, seed=3).to(dev).contiguous(memory_format=torch.channels_last)
+    pk = ops.pack_weight(wt, False)
+    ref = ops.conv2d_raw(x, pk, 16, (3, 3), 1, 1, False, (12, 12))
+    gref = ops.conv2d_wgrad_raw(dy, x, torch.empty(16, 32, 3, 3, device=dev), (3, 3), 1, 1, False)
+    monkeypatch.setattr(ops, "_SPAN_LIMIT", 4 * 12 * 12 * 32 * 4 - 1)  # pretend the 4-image batch is too large
+    got = ops.conv2d_raw(x, pk, 16, (3, 3), 1, 1, False, (12, 12))
+    ggot = ops.conv2d_wgrad_raw(dy, x, torch.empty(16, 32, 3, 3, device=dev), (3, 3), 1, 1, False)
+    assert torch.equal(got, ref)
+    _close(ggot, gref, "split wgrad", 1e-5)
