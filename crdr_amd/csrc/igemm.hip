@@ -49,7 +49,8 @@ struct IgemmArgs {
   int ws_ld;  // columns of a partial slab row (= gridDim.y * BN)
   int vec_epi;  // 1: y / res / gx / gt / sig rows are 16-byte aligned -> vector epilogue
   int smallc;   // 1: Cin <= 4 and the weight pack is tap-major ([rows][taps*4]): a K-tile covers 8 taps x 4 channels
-  unsigned x_bytes, w_bytes;  // extents of the two buffer descriptors (range-checked loads)
+  unsigned long long x_bytes;  // extent of the input tensor (the descriptor is re-based per workgroup, see kernel)
+  unsigned w_bytes;            // extent of the weight pack's buffer descriptor
 };
 
 // Tap / phase tables travel as a second by-value kernel argument that is only ever indexed with wave-uniform
@@ -127,13 +128,27 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
   const int poh = tp.poh[phase], pow_ = tp.pow[phase];
   const int H = p.H, W = p.W, ldx = p.ldx, Cin = p.Cin, kchunks = p.kchunks;
 
+  int mintap = 0;  // most negative pixel offset any tap of this phase reaches (wave-uniform)
   for (int t = 0; t < ntap; ++t) {  // wave-uniform index: scalar loads from the kernarg segment
     const int v = tp.packed[tb + t];
     if (tid == 0) sTap[t] = v;
+    mintap = min(mintap, (int)(signed char)(v & 0xff) * W + (int)(signed char)((v >> 8) & 0xff));
   }
   if (tid < 4) sTap[ntap + tid] = 0;  // the cursor may run one K-tile past the end (range-checked, never consumed)
 
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  // The input descriptor is re-based at the first pixel this workgroup can touch, so the 32-bit byte offsets below only
+  // have to span one tile (+ halo) and the tensor itself may be of any size.
+  long long base_pix;
+  {
+    const int hw0 = p.GH * p.GW;
+    const int nn = m0 / hw0, rem0 = m0 - nn * hw0, a0 = rem0 / p.GW, b0 = rem0 - a0 * p.GW;
+    base_pix = (long long)(nn * H + a0 * p.si) * W + b0 * p.si + mintap;
+    base_pix = base_pix < 0 ? 0 : base_pix;
+  }
+  const unsigned long long base_bytes = (unsigned long long)base_pix * ldx * 4ull;
+  const unsigned long long left = p.x_bytes - base_bytes;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x) + base_pix * ldx, 0, (unsigned)(left < 0x7fffffffull ? left : 0x7fffffffull), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
   // ---- staging assignment: thread fills slot (tid & 7) of rows (tid >> 3) + j * RPP
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
     const bool ok = (m < p.M) && (a * p.so + poh < p.OH) && (b * p.so + pow_ < p.OW);
     a_ih[j] = ok ? a * p.si : -(1 << 24);  // a dead row fails every bounds test below
     a_iw[j] = ok ? b * p.si : 0;
-    a_off[j] = ok ? (unsigned)(((n * H + a * p.si) * W + b * p.si) * ldx + (SMALLC ? 0 : csrc * 4)) * 4u : 0u;
+    a_off[j] = ok ? (unsigned)(((long long)(n * H + a * p.si) * W + b * p.si - base_pix) * ldx + (SMALLC ? 0 : csrc * 4)) * 4u : 0u;
   }
   unsigned b_off[BV];
 #pragma unroll
@@ -474,12 +489,12 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
       }
     tp.tap_begin[ph] = (short)nt;
   }
-  {  // extents of the range-checked buffer descriptors; byte offsets are 32 bit and 0x80000000 marks "outside"
+  {  // extents of the range-checked buffer descriptors (the input's is re-based per workgroup: any size)
     const long long xb = (((long long)d->N * d->H * d->W - 1) * d->ldx + d->C) * 4;
     const long long wb = (long long)(a.smallc ? 1 : d->kh * d->kw) * d->wrows * d->wcols * 4;
-    CRDR_REQUIRE(xb < (1ll << 31) && wb < (1ll << 31),
-                 "conv2d: input (%lld B) or weight pack (%lld B) reaches 2 GiB; split the batch / rows on the host", xb, wb);
-    a.x_bytes = (unsigned)xb;
+    CRDR_REQUIRE(wb < (1ll << 31), "conv2d: weight pack (%lld B) reaches 2 GiB", wb);
+    CRDR_REQUIRE((long long)d->W * d->ldx * 4 * (d->kh + 2) < (1ll << 30), "conv2d: an image row (%d px x %d floats) is too wide", d->W, d->ldx);
+    a.x_bytes = (unsigned long long)xb;
     a.w_bytes = (unsigned)wb;
   }
   const long long M64 = (long long)d->N * a.GH * a.GW;

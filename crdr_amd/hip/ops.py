@@ -238,21 +238,13 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
                scale=None, shift=None, gate_x=None, gate_t=None, sig_out=None, out: Optional[torch.Tensor] = None,
                algo: int = 0, wlayout: int = 0):
     """One fused implicit-GEMM launch. `out` may be a channel slice of a wider NHWC tensor (written in place).
-    An input that reaches the 2 GiB span of the kernel's 32-bit buffer offsets is processed in batch halves."""
+    The input may be of any size (the kernel re-bases its buffer descriptor per workgroup)."""
     lib = L.load()
     x, ldx = nhwc(x)
     n, c, h, w = x.shape
     oh, ow = out_hw
     if out is None:
         out = empty_nhwc(n, oc, oh, ow, x.device)
-    if n > 1 and n * h * w * ldx * 4 >= _SPAN_LIMIT:
-        n1 = n // 2
-        for sl in (slice(0, n1), slice(n1, n)):
-            conv2d_raw(x[sl], wpack, oc, k, stride, pad, transposed, out_hw, bias=bias, flags=flags, vec2=vec2,
-                       res=None if res is None else res[sl], scale=scale, shift=shift,
-                       gate_x=None if gate_x is None else gate_x[sl], gate_t=None if gate_t is None else gate_t[sl],
-                       sig_out=None if sig_out is None else sig_out[sl], out=out[sl], algo=algo, wlayout=wlayout)
-        return out
     out_t, ldy = out, (out.stride(3) if ow > 1 else (out.stride(2) if oh > 1 else (out.stride(0) if n > 1 else oc)))
     d = L.ConvDesc(N=n, H=h, W=w, C=(c + 3) // 4 * 4 if ldx >= (c + 3) // 4 * 4 else c, OH=oh, OW=ow, OC=oc, kh=k[0], kw=k[1],
                    stride=stride, pad=pad, transposed=int(transposed), ldx=ldx, ldy=ldy, wrows=wpack.shape[1],

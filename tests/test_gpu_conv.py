@@ -303,18 +303,30 @@ def test_rgb_layers_through_fused_conv(case):
     _close(bg.grad, br.grad, name + " db")
 
 
-def test_batch_split_for_operands_over_2gib(monkeypatch):
-    """The kernels address an operand through one buffer descriptor with 32-bit offsets; ops splits larger batches."""
+def test_operands_beyond_2gib(monkeypatch):
+    """Forward convs address the input through a buffer descriptor that is re-based per workgroup, so byte offsets past
+    2 GiB work (here: a 32-channel slice of a 4096-float pixel stride, 2.6 GB span); the weight-gradient kernel keeps one
+    descriptor per operand and ops splits the batch instead."""
     from crdr_amd.hip import ops
     dev = _dev()
-    x = _rand(4, 32, 12, 12, seed=1).to(dev).contiguous(memory_format=torch.channels_last)
-    wt = _rand(16, 32, 3, 3, seed=2, scale=0.1).to(dev)
+    h = w = 400
+    base = torch.zeros(1, h, w, 4096, device=dev)
+    xs = _rand(1, 32, h, w, seed=1)
+    x = base[..., :32].permute(0, 3, 1, 2)
+    x.copy_(xs.to(dev))
+    assert x.stride(1) == 1 and x.stride(3) == 4096 and h * w * 4096 * 4 > (1 << 31)
+    wt = _rand(16, 32, 3, 3, seed=2, scale=0.1)
+    b = _rand(16, seed=3)
+    out = ops.conv2d_raw(x, ops.pack_weight(wt.to(dev), False), 16, (3, 3), 1, 1, False, (h, w), bias=b.to(dev), flags=1)
+    _close(out, F.conv2d(xs.double(), wt.double(), b.double(), padding=1), "conv on a >2 GiB span")
+    outT = ops.conv2d_raw(x, ops.pack_weight(_rand(32, 16, 5, 5, seed=4, scale=0.1).to(dev), True), 16, (5, 5), 2, 2, True, (2 * h, 2 * w))
+    _close(outT, F.conv_transpose2d(xs.double(), _rand(32, 16, 5, 5, seed=4, scale=0.1).double(), stride=2, padding=2, output_padding=1),
+           "convT on a >2 GiB span")
+    del base, x, out, outT
+    # weight gradient: batch halves
+    x4 = _rand(4, 32, 12, 12, seed=1).to(dev).contiguous(memory_format=torch.channels_last)
     dy = _rand(4, 16, 12, 12, seed=3).to(dev).contiguous(memory_format=torch.channels_last)
-    pk = ops.pack_weight(wt, False)
-    ref = ops.conv2d_raw(x, pk, 16, (3, 3), 1, 1, False, (12, 12))
-    gref = ops.conv2d_wgrad_raw(dy, x, torch.empty(16, 32, 3, 3, device=dev), (3, 3), 1, 1, False)
+    gref = ops.conv2d_wgrad_raw(dy, x4, torch.empty(16, 32, 3, 3, device=dev), (3, 3), 1, 1, False)
     monkeypatch.setattr(ops, "_SPAN_LIMIT", 4 * 12 * 12 * 32 * 4 - 1)  # pretend the 4-image batch is too large
-    got = ops.conv2d_raw(x, pk, 16, (3, 3), 1, 1, False, (12, 12))
-    ggot = ops.conv2d_wgrad_raw(dy, x, torch.empty(16, 32, 3, 3, device=dev), (3, 3), 1, 1, False)
-    assert torch.equal(got, ref)
+    ggot = ops.conv2d_wgrad_raw(dy, x4, torch.empty(16, 32, 3, 3, device=dev), (3, 3), 1, 1, False)
     _close(ggot, gref, "split wgrad", 1e-5)
