@@ -570,6 +570,7 @@ extern "C" int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void
   a.x = io->x; a.w = io->w; a.y = io->y; a.ws = (float*)ws;
   a.bias = io->bias; a.vec2 = io->vec2; a.res = io->res; a.scale = io->scale; a.shift = io->shift;
   a.gx = io->gx; a.gt = io->gt; a.sig = io->sig;
+  if (a.M == 0) return 0;  // empty batch: nothing to compute (tensors may legitimately be null)
   CRDR_REQUIRE(a.x && a.w && a.y, "conv2d: null tensor");
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_BIAS) || a.bias, "conv2d: BIAS flag without bias");
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_VEC2) || a.vec2, "conv2d: VEC2 flag without vec2");

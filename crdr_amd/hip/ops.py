@@ -295,6 +295,10 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
     q, ldq = nhwc(q)
     n, pc, ph, pw = p.shape
     _, qc, qh, qw = q.shape
+    if n * ph * pw == 0:  # empty batch: the gradient contribution is zero
+        if not accumulate:
+            g.zero_()
+        return g
     if n > 1 and max(n * ph * pw * ldp, n * qh * qw * ldq) * 4 >= _SPAN_LIMIT:
         n1 = n // 2
         conv2d_wgrad_raw(p[:n1], q[:n1], g, k, stride, pad, accumulate, algo=algo, defer=False)

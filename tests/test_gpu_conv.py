@@ -330,3 +330,30 @@ def test_operands_beyond_2gib(monkeypatch):
     monkeypatch.setattr(ops, "_SPAN_LIMIT", 4 * 12 * 12 * 32 * 4 - 1)  # pretend the 4-image batch is too large
     ggot = ops.conv2d_wgrad_raw(dy, x4, torch.empty(16, 32, 3, 3, device=dev), (3, 3), 1, 1, False)
     _close(ggot, gref, "split wgrad", 1e-5)
+
+
+def test_degenerate_shapes():
+    """Empty batch, single pixel, single channel in / out, spatial sizes smaller than the kernel: every entry point
+    returns well-formed (possibly empty) results instead of launching on nothing."""
+    from crdr_amd.hip import functional as HF
+    dev = _dev()
+    spec = HF.ConvSpec(8, 12, 3, 1, 1)
+    w = torch.nn.Parameter(_rand(12, 8, 3, 3, seed=2).to(dev))
+    b = torch.nn.Parameter(_rand(12, seed=3).to(dev))
+    empty = torch.zeros(0, 8, 5, 5, device=dev)
+    y = HF.fused_conv(empty, w, b, spec, act="relu")
+    assert y.shape == (0, 12, 5, 5)
+    for h, wd in ((1, 1), (2, 1), (1, 7)):  # smaller than the 3x3 kernel: padding supplies the rest
+        x = _rand(2, 8, h, wd, seed=h * 10 + wd)
+        xr = x.double().requires_grad_(True)
+        ref = F.conv2d(xr, w.detach().cpu().double(), b.detach().cpu().double(), padding=1).relu()
+        ref.sum().backward()
+        xg = x.to(dev).requires_grad_(True)
+        out = HF.fused_conv(xg, w, b, spec, act="relu")
+        out.sum().backward()
+        _close(out, ref, f"{h}x{wd} out")
+        _close(xg.grad, xr.grad, f"{h}x{wd} dx")
+    spec1 = HF.ConvSpec(1, 1, 5, 2, 2)  # one channel in and out, strided
+    w1 = torch.nn.Parameter(_rand(1, 1, 5, 5, seed=5).to(dev))
+    x = _rand(1, 1, 9, 11, seed=6)
+    _close(HF.fused_conv(x.to(dev), w1, None, spec1), F.conv2d(x.double(), w1.detach().cpu().double(), stride=2, padding=2), "1->1 k5s2")
