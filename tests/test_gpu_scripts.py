@@ -77,3 +77,37 @@ dataset:
     assert 0 < list(avg.values())[0] < 24
     from PIL import Image
     assert Image.open(out_dir / "im00.png").size == (128, 64)
+
+
+def test_three_stage_recipe(tmp_path):
+    """The reference's training recipe end to end at toy scale: stage 1 (single rate) -> stage 2 (multi-rate InterpCA,
+    initialised from stage 1 through `pretrained_weight_path`, non-strict like the reference) -> stage 3 (GAN, initialised
+    from stage 2); every hand-over goes through the checkpoint files scripts/train.py writes."""
+    train_dir, eval_dir = str(tmp_path / "train" / "0"), str(tmp_path / "kodak")
+    _png_dir(train_dir, 4, 80, 96, 3)
+    _png_dir(eval_dir, 1, 64, 64, 4)
+    os.makedirs(tmp_path / "checkpoint")
+    train = os.path.join(ROOT, "scripts", "train.py")
+    prev = None
+    for stage in (1, 2, 3):
+        cfg = tmp_path / f"toy_stage{stage}.yaml"
+        cfg.write_text(f"""_base_: [{os.path.relpath(os.path.join(ROOT, 'config', f'crdr_stage_{stage}.yaml'), str(tmp_path))}]
+pretrained_weight_path: {prev if prev else 'null'}
+ckpt_root: {tmp_path}/checkpoint
+hip_graphs: true
+dataset:
+  batch_size: 2
+  train_dataset:
+    root_dir: {tmp_path}/train
+    name: openimage
+    type: ImageDataset
+    image_size: 64
+    subset_list: [0]
+  eval_dataset:
+    root_dir: {eval_dir}
+    name: Kodak
+    type: ImageDataset
+""")
+        _run([train, str(cfg), "-d", "cuda:0", "-b", "2", "-ti", "4", "-s", "4", "-l", "2", "-e", "4", "-nw", "0"], cwd=str(tmp_path))
+        prev = str(tmp_path / "checkpoint" / f"toy_stage{stage}" / "model" / "comp_model_iter4.pth.tar")
+        assert os.path.exists(prev), os.listdir(os.path.dirname(prev))
