@@ -111,3 +111,27 @@ dataset:
         _run([train, str(cfg), "-d", "cuda:0", "-b", "2", "-ti", "4", "-s", "4", "-l", "2", "-e", "4", "-nw", "0"], cwd=str(tmp_path))
         prev = str(tmp_path / "checkpoint" / f"toy_stage{stage}" / "model" / "comp_model_iter4.pth.tar")
         assert os.path.exists(prev), os.listdir(os.path.dirname(prev))
+
+
+def test_compress_demo_images(tmp_path):
+    """BASELINE config #1 (plumbing): scripts/compress.py over ./demo_images (three Kodak images, public data) at q = 0,
+    beta = 3.84 -- here on the GPU and with random-init weights (the reference's checkpoint is a Google-Drive download), so
+    the check is the container: one .bin + one 768x512 .png per image, per-image accounting, average bpp file."""
+    import pandas as pd
+    from PIL import Image
+    out_dir = tmp_path / "out"
+    _run([os.path.join(ROOT, "scripts", "compress.py"), "--config_path", os.path.join(ROOT, "config", "crdr.yaml"), "--img_dir",
+          os.path.join(ROOT, "demo_images"), "--save_dir", str(out_dir), "-q", "0.0", "-b", "3.84", "--decompress", "-d", "cuda:0"],
+         cwd=ROOT)
+    names = ["kodim03", "kodim15", "kodim23"]
+    for n in names:
+        assert os.path.exists(out_dir / f"{n}.bin")
+        assert Image.open(out_dir / f"{n}.png").size == (768, 512)
+    df = pd.read_csv(out_dir / "_bitrates.csv")
+    assert sorted(df["img_name"]) == [n + ".png" for n in names]
+    for _, r in df.iterrows():
+        nbytes = os.path.getsize(out_dir / r["img_name"].replace(".png", ".bin"))
+        assert r["real_bit"] == 8 * nbytes == r["header_bit"] + r["z_bit"] + r["y_bit"] + 96  # 3 x u32 length prefixes
+        assert abs(r["real_bpp"] - 8 * nbytes / (768 * 512)) < 1e-12 and r["header_bit"] == 48
+    avg = json.load(open(out_dir / "_avg_bitrate.json"))
+    assert abs(list(avg.values())[0] - df["real_bpp"].mean()) < 1e-9
