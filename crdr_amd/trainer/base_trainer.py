@@ -162,7 +162,9 @@ class BaseTrainer:
 
     def _flush_wgrads(self, site: str) -> None:
         from crdr_amd.hip import ops as _ops
-        _ops.flush_wgrads((site, self._flush_key))
+        # captured and eager executions of a site keep separate job tables: an eager iteration after the capture (e.g. the
+        # profiling steps of bench.py) must not rewrite the table a graph replays with
+        _ops.flush_wgrads((site, self._flush_key, torch.cuda.is_current_stream_capturing()))
 
     def _step_scope(self):
         """Context of one optimize_parameters call: the trainer's stream (graphs.step_scope) + deferred weight-gradient
