@@ -375,7 +375,9 @@ class DeferredWgrad:
     def pending(self) -> int:
         return len(self.jobs)
 
-    def flush(self, key=None) -> None:
+    def flush(self, key=None, twin=None) -> None:
+        """Reduce everything pending.  `twin` (eager calls only): a second table key that receives the same content, so
+        that a later graph capture of the same site -- which cannot upload -- finds its own, identical table."""
         if not self.jobs:
             return
         import numpy as np
@@ -394,21 +396,9 @@ class DeferredWgrad:
             pre = np.zeros(len(js) + 1, dtype=np.int64)
             for k, j in enumerate(js):
                 pre[k + 1] = pre[k] + (j.gI * j.gJ * j.T + 255) // 256
-            tb = self.tables.get((key, ri))
-            if tb is None:
-                if torch.cuda.is_current_stream_capturing():
-                    raise L.CrdrHipError("DeferredWgrad: first flush of this site happened during graph capture")
-                tb = self.tables[(key, ri)] = {
-                    "jobs": torch.zeros(self.CAP * C.sizeof(L.WgradJob), dtype=torch.uint8, device=self.device),
-                    "prefix": torch.zeros(self.CAP + 1, dtype=torch.int64, device=self.device),
-                    "meta": torch.zeros(2, dtype=torch.int64, device=self.device), "host": None}
-            if tb["host"] != host:
-                if torch.cuda.is_current_stream_capturing():
-                    raise L.CrdrHipError("DeferredWgrad: the job table of a captured site changed")
-                tb["jobs"][:len(host)].copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
-                tb["prefix"][:len(js) + 1].copy_(torch.from_numpy(pre))
-                tb["meta"].copy_(torch.tensor([len(js), int(pre[-1])], dtype=torch.int64))
-                tb["host"] = host
+            for tk in ([twin] if twin is not None and not torch.cuda.is_current_stream_capturing() else []):
+                self._table((tk, ri), host, pre, len(js))
+            tb = self._table((key, ri), host, pre, len(js))
             L.check(lib.crdr_wgrad_reduce_batched(tb["jobs"].data_ptr(), tb["prefix"].data_ptr(), tb["meta"].data_ptr(),
                                                   _stream()), "wgrad_reduce_batched")
         self.jobs = []
@@ -421,13 +411,32 @@ class DeferredWgrad:
                 self._keep = []
         self.cycle = 0
 
+    def _table(self, tkey, host: bytes, pre, njobs: int):
+        """Device-side job table `tkey` holding `host` (uploaded only when the content changed)."""
+        tb = self.tables.get(tkey)
+        if tb is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.CrdrHipError("DeferredWgrad: first flush of this site happened during graph capture")
+            tb = self.tables[tkey] = {
+                "jobs": torch.zeros(self.CAP * C.sizeof(L.WgradJob), dtype=torch.uint8, device=self.device),
+                "prefix": torch.zeros(self.CAP + 1, dtype=torch.int64, device=self.device),
+                "meta": torch.zeros(2, dtype=torch.int64, device=self.device), "host": None}
+        if tb["host"] != host:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.CrdrHipError("DeferredWgrad: the job table of a captured site changed")
+            tb["jobs"][:len(host)].copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
+            tb["prefix"][:njobs + 1].copy_(torch.from_numpy(pre))
+            tb["meta"].copy_(torch.tensor([njobs, int(pre[-1])], dtype=torch.int64))
+            tb["host"] = host
+        return tb
+
 
 WGRAD_DEFER: Optional[DeferredWgrad] = None  # set by a trainer; every backward must then be followed by flush_wgrads()
 
 
-def flush_wgrads(key=None) -> None:
+def flush_wgrads(key=None, twin=None) -> None:
     if WGRAD_DEFER is not None:
-        WGRAD_DEFER.flush(key)
+        WGRAD_DEFER.flush(key, twin)
 
 
 def pending_wgrads() -> int:

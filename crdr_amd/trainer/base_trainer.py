@@ -164,7 +164,8 @@ class BaseTrainer:
         from crdr_amd.hip import ops as _ops
         # captured and eager executions of a site keep separate job tables: an eager iteration after the capture (e.g. the
         # profiling steps of bench.py) must not rewrite the table a graph replays with
-        _ops.flush_wgrads((site, self._flush_key, torch.cuda.is_current_stream_capturing()))
+        cap = torch.cuda.is_current_stream_capturing()
+        _ops.flush_wgrads((site, self._flush_key, cap), twin=None if cap else (site, self._flush_key, True))
 
     def _step_scope(self):
         """Context of one optimize_parameters call: the trainer's stream (graphs.step_scope) + deferred weight-gradient
