@@ -251,3 +251,21 @@ def test_stage1_step():
         if e > 5e-3:
             bad.append((n, e))
     assert not bad, bad[:8]
+
+
+def test_stage1_training_reduces_the_loss():
+    """Not a parity statement, a liveness one: 150 stage-1 iterations on one fixed batch (graph-replayed) must drive the
+    R-D objective down by a wide margin -- gradients, clipping, the fused Adam, the batched weight-pack refill and the
+    deferred weight-gradient reduction all have to cooperate for that."""
+    import bench
+    tr = bench.build_trainer(1, 4, 64, "cuda:0", graphs=True)
+    x = (torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(0)) * 2 - 1).to("cuda:0")
+    x = torch.nn.functional.avg_pool2d(x, 4).repeat_interleave(4, 2).repeat_interleave(4, 3)  # blocky, learnable
+    first, last = [], []
+    for it in range(1, 151):
+        log = tr.optimize_parameters(it, {"real_images": x})
+        assert log is not None, f"iteration {it} was skipped"
+        tot = log["distortion"] + log["rate"] + log["perceptual"]
+        (first if it <= 5 else last if it > 145 else []).append(tot)
+    a, b = sum(first) / len(first), sum(last) / len(last)
+    assert b < 0.6 * a, (a, b)
