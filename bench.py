@@ -203,7 +203,10 @@ def main():
         return {"launches_per_step": n.value / ps, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                 "avg_gflop_per_launch": round(fl.value / n.value / 1e9, 3), "tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
                 "ms_per_step": round(ms.value / ps, 2)}
-    ig, wg = fam(0), fam(1)
+    ig, wg, sk = fam(0), fam(1), fam(2)
+    if ig is not None and sk is not None:
+        ig["splitk_epilogue"] = {"launches_per_step": sk["launches_per_step"], "avg_launch_us": sk["avg_launch_us"],
+                                 "ms_per_step": sk["ms_per_step"]}
     if a.tune_log:
         with open(a.tune_log, "w") as f:
             for key, best, t0, t1 in ops.TUNE_LOG:
@@ -227,7 +230,7 @@ def main():
         traffic_src = "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step (profiles/r1_h_hbm_traffic_pmc_xcd.json)"
     roof = {"bound": "mfma", "achieved": ig["tflops"] if ig else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "igemm_kernel<*> (conv / convT forward + input-gradient launches, v_mfma_f32_32x32x2_f32)",
+            "kernel": "igemm_kernel<*> (conv / convT forward + input-gradient launches, v_mfma_f32_32x32x2_f32; split-K epilogue launches timed separately under detail.splitk_epilogue)",
             "measured_over": f"{a.profile_steps} eager steps after the timed region (HIP events around each launch, on its stream)",
             "detail": ig, "wgrad_kernel": wg,
             "whole_step": {"algorithmic_gflop_per_img": gflop, "achieved": round(value / ws * gflop / 1e3, 2),
