@@ -135,3 +135,48 @@ def test_compress_demo_images(tmp_path):
         assert abs(r["real_bpp"] - 8 * nbytes / (768 * 512)) < 1e-12 and r["header_bit"] == 48
     avg = json.load(open(out_dir / "_avg_bitrate.json"))
     assert abs(list(avg.values())[0] - df["real_bpp"].mean()) < 1e-9
+
+
+def test_stage3_with_hific_discriminator(tmp_path):
+    """Registry / YAML surface: swapping the discriminator type in the config is all it takes to train stage 3 against the
+    spectrally normalised HiFiC discriminator (graphs, deferred reductions and the power iteration included)."""
+    train_dir, eval_dir = str(tmp_path / "train" / "0"), str(tmp_path / "kodak")
+    _png_dir(train_dir, 4, 80, 96, 5)
+    _png_dir(eval_dir, 1, 64, 64, 6)
+    os.makedirs(tmp_path / "checkpoint")
+    cfg = tmp_path / "hific_d.yaml"
+    cfg.write_text(f"""_base_: [{os.path.relpath(os.path.join(ROOT, 'config', 'crdr_stage_3.yaml'), str(tmp_path))}]
+pretrained_weight_path: null
+ckpt_root: {tmp_path}/checkpoint
+hip_graphs: true
+keep_discriminator: true
+discriminator:
+  _delete_: true
+  type: HiFiCDiscriminator
+  in_ch: 3
+  out_ch: 1
+  main_ch: 16
+  use_sn: true
+dataset:
+  batch_size: 2
+  train_dataset:
+    root_dir: {tmp_path}/train
+    name: openimage
+    type: ImageDataset
+    image_size: 64
+    subset_list: [0]
+  eval_dataset:
+    root_dir: {eval_dir}
+    name: Kodak
+    type: ImageDataset
+""")
+    out = _run([os.path.join(ROOT, "scripts", "train.py"), str(cfg), "-d", "cuda:0", "-b", "2", "-ti", "8", "-s", "8", "-l", "2", "-e", "100",
+                "-nw", "0"], cwd=str(tmp_path))
+    model_dir = tmp_path / "checkpoint" / "hific_d" / "model"
+    assert "comp_model_iter8.pth.tar" in os.listdir(model_dir), os.listdir(model_dir)
+    import torch
+    names = [n for n in os.listdir(model_dir) if n.startswith("discriminator")]
+    assert names, os.listdir(model_dir)
+    sd = torch.load(model_dir / names[0], map_location="cpu")
+    keys = list(next(v for k, v in sd.items() if isinstance(v, dict)).keys())
+    assert "model.0.weight_orig" in keys and "model.0.weight_u" in keys and "model.8.weight_v" in keys, keys[:8]
