@@ -239,6 +239,7 @@ def main():
             "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
             "autotune": bool(ops.AUTOTUNE), "hip_graphs": bool(graphs_on),
+            "peak_device_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             "config": {"workload": f"config/crdr_stage_{a.stage}.yaml -b {a.bs}: full GAN step (G + 5x CLIC21GVAE D + LPIPS-Alex, random-init weights)"
                                    if a.stage == 3 else f"config/crdr_stage_1.yaml -b {a.bs}: R-D step (+LPIPS-Alex, random-init weights)",
                        "global_batch": ws * a.bs, "crop": a.size, "parallelism": f"dp{ws}"},
