@@ -36,6 +36,8 @@ def build_trainer(stage: int, bs: int, size: int, device: str, graphs: bool = Tr
     cfg["dataset"] = {"batch_size": bs, "train_dataset": {"type": "SyntheticDataset", "image_size": size}}
     cfg["path"] = None
     cfg["hip_graphs"] = graphs
+    if cfg.get("loss", {}).get("perceptual_loss"):  # throughput is weight-independent; stated in config.workload
+        cfg["loss"]["perceptual_loss"]["allow_random_weights"] = True
     torch.manual_seed(0)
     return _bt(ConfigDict(cfg))
 

@@ -151,6 +151,29 @@ __global__ __launch_bounds__(256) void colsum_final(const float* partial, int nb
   }
 }
 
+// the same second stage writing through a pointer table: column e goes to outs[e / block][e % block]
+__global__ __launch_bounds__(256) void colsum_final_scatter(const float* partial, int nblocks, int C, int block,
+                                                            float* const* outs, int accumulate) {
+  __shared__ float red[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + tx;
+  float v = 0.f;
+  if (e < C)
+    for (int b = ty; b < nblocks; b += 16) v += partial[(size_t)b * C + e];
+  red[ty][tx] = v;
+  __syncthreads();
+  if (ty == 0 && e < C) {
+    float t = red[0][tx];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) t += red[r][tx];
+    float* o = outs[e / block];
+    if (o) {
+      o += e % block;
+      *o = accumulate ? *o + t : t;
+    }
+  }
+}
+
 // rows per strip: large enough that the second stage sums <= 512 partials per column
 static int ebwd_blocks(int64_t M, int* rpb) {
   int r = 64;
@@ -797,6 +820,24 @@ extern "C" int crdr_colsum(const float* x, int ldx, int64_t M, int C, float* out
   hipLaunchKernelGGL(colsum_final, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(s), (const float*)ws, M > 0 ? nb : 0, 1,
                      C, out, accumulate, (float*)nullptr);
   CRDR_CHECK_LAUNCH("colsum_final");
+  return 0;
+}
+
+extern "C" int crdr_colsum_scatter(const float* x, int ldx, int64_t M, int C, int block, float* const* outs, int accumulate,
+                                   void* ws, size_t ws_bytes, crdr_stream_t s) {
+  int rpb;
+  const int nb = ebwd_blocks(M, &rpb);
+  CRDR_REQUIRE(x && outs && block > 0 && ws_bytes >= (size_t)nb * C * sizeof(float), "colsum_scatter: bad arguments");
+  if (M > 0) {
+    if ((C % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0))
+      hipLaunchKernelGGL(colsum_kernel_v4, dim3(nb, cdiv(C, 64)), dim3(256), 0, as_stream(s), x, ldx, M, C, (float*)ws, rpb);
+    else
+      hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, as_stream(s), x, ldx, M, C, (float*)ws, rpb);
+    CRDR_CHECK_LAUNCH("colsum");
+  }
+  hipLaunchKernelGGL(colsum_final_scatter, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(s), (const float*)ws, M > 0 ? nb : 0, C,
+                     block, outs, accumulate);
+  CRDR_CHECK_LAUNCH("colsum_final_scatter");
   return 0;
 }
 

@@ -29,13 +29,37 @@ __device__ __forceinline__ float block_sum(float v, float* red) {  // any block 
 }
 
 struct GcArgs {
-  crdr_gc_desc d;
-  const float *y, *mu, *sigma, *noise;
-  float *yhat, *lik_noisy, *lik_quant, *bits_noisy, *bits_quant;
-  const float *gbits, *dyhat;
-  int lddyhat;
-  float *dy, *dmu, *dsigma;
+  crdr_gc_desc2 d;
+  crdr_gc_io io;
 };
+
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so the backward pass regenerates the forward's samples from
+// (seed, offset, element index) instead of storing 4 B per latent element.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// U(-1/2, 1/2) sample of global element `idx` (24 random bits, like torch.rand's fp32 path: [0, 1) - 1/2)
+__device__ __forceinline__ float philox_uniform(const uint64_t* ph, unsigned long long idx) {
+  const unsigned long long seed = ph[0], ctr = ph[1] + (idx >> 2);
+  unsigned o[4];
+  philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+  const unsigned r = o[idx & 3];
+  return (float)(r >> 8) * (1.0f / 16777216.0f) - 0.5f;
+}
+
+__device__ __forceinline__ float gc_noise(const GcArgs& p, size_t pix, int c) {
+  if (p.io.noise) return p.io.noise[pix * p.d.ldnoise + c];
+  return philox_uniform(p.io.philox, (unsigned long long)pix * p.d.Ctot + p.d.c0 + c);
+}
 
 // grid (B, N): block b of image n strides over that image's HW*C elements
 __global__ __launch_bounds__(1024) void gauss_cond_fwd_kernel(const GcArgs p) {
@@ -43,26 +67,28 @@ __global__ __launch_bounds__(1024) void gauss_cond_fwd_kernel(const GcArgs p) {
   const int n = blockIdx.y, C = p.d.C;
   const int per_img = p.d.HW * C;
   const float inv_ln2 = 1.4426950408889634f;
+  const bool noisy = p.io.noise || p.io.philox;
   float sn = 0.f, sq = 0.f;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < per_img; e += gridDim.x * blockDim.x) {
     const int px = e / C, c = e - px * C;
     const size_t pix = (size_t)n * p.d.HW + px;
-    const float yv = p.y[pix * p.d.ldy + c], m = p.mu[pix * p.d.ldmu + c];
-    const float sg = fmaxf(p.sigma[pix * p.d.ldsigma + c], p.d.scale_bound);
+    const float yv = p.io.y[pix * p.d.ldy + c], m = p.io.mu[pix * p.d.ldmu + c];
+    const float sg = fmaxf(p.io.sigma[pix * p.d.ldsigma + c], p.d.scale_bound);
     const float q = rintf(yv - m);  // torch.round: half to even
-    if (p.yhat) p.yhat[pix * p.d.ldyhat + c] = q + m;
-    {
+    if (p.io.yhat) p.io.yhat[pix * p.d.ldyhat + c] = q + m;
+    if (p.io.yhat2) p.io.yhat2[pix * p.d.ldyhat2 + c] = q + m;
+    if (p.io.lik_quant || p.io.bits_quant) {
       const float a = fabsf(q);  // |round(y - mu) + mu - mu|
       float l = std_cdf((0.5f - a) / sg) - std_cdf((-0.5f - a) / sg);
       l = fmaxf(l, p.d.likelihood_bound);
-      if (p.lik_quant) p.lik_quant[pix * C + c] = l;
+      if (p.io.lik_quant) p.io.lik_quant[pix * p.d.ldlik + c] = l;
       sq -= logf(l) * inv_ln2;
     }
-    if (p.noise) {
-      const float a = fabsf(yv + p.noise[pix * C + c] - m);
+    if (noisy) {
+      const float a = fabsf(yv + gc_noise(p, pix, c) - m);
       float l = std_cdf((0.5f - a) / sg) - std_cdf((-0.5f - a) / sg);
       l = fmaxf(l, p.d.likelihood_bound);
-      if (p.lik_noisy) p.lik_noisy[pix * C + c] = l;
+      if (p.io.lik_noisy) p.io.lik_noisy[pix * p.d.ldlik + c] = l;
       sn -= logf(l) * inv_ln2;
     }
   }
@@ -70,11 +96,11 @@ __global__ __launch_bounds__(1024) void gauss_cond_fwd_kernel(const GcArgs p) {
   sq = block_sum(sq, red);
   if (threadIdx.x == 0) {
     if (gridDim.x == 1) {  // the training shapes: deterministic
-      if (p.bits_noisy && p.noise) p.bits_noisy[n] += sn;
-      if (p.bits_quant) p.bits_quant[n] += sq;
+      if (p.io.bits_noisy && noisy) p.io.bits_noisy[n] += sn;
+      if (p.io.bits_quant) p.io.bits_quant[n] += sq;
     } else {
-      if (p.bits_noisy && p.noise) atomicAdd(p.bits_noisy + n, sn);
-      if (p.bits_quant) atomicAdd(p.bits_quant + n, sq);
+      if (p.io.bits_noisy && noisy) atomicAdd(p.io.bits_noisy + n, sn);
+      if (p.io.bits_quant) atomicAdd(p.io.bits_quant + n, sq);
     }
   }
 }
@@ -88,15 +114,15 @@ __global__ __launch_bounds__(256) void gauss_cond_bwd_kernel(const GcArgs p) {
     const int n = (int)(e / per_img);
     const size_t pix = (size_t)(e / C);
     const int c = (int)(e - (int64_t)pix * C);
-    const float yv = p.y[pix * p.d.ldy + c], m = p.mu[pix * p.d.ldmu + c];
-    const float sraw = p.sigma[pix * p.d.ldsigma + c];
+    const float yv = p.io.y[pix * p.d.ldy + c], m = p.io.mu[pix * p.d.ldmu + c];
+    const float sraw = p.io.sigma[pix * p.d.ldsigma + c];
     const float sg = fmaxf(sraw, p.d.scale_bound);
-    const float dlt = yv + p.noise[pix * C + c] - m;
+    const float dlt = yv + gc_noise(p, pix, c) - m;
     const float a = fabsf(dlt), sgn = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
     const float zu = (0.5f - a) / sg, zl = (-0.5f - a) / sg;
     const float lraw = std_cdf(zu) - std_cdf(zl);
     const float l = fmaxf(lraw, p.d.likelihood_bound);
-    const float glik = p.gbits[n] * (-inv_ln2 / l);                      // d(-log2 l)/dl scaled
+    const float glik = p.io.gbits[n] * (-inv_ln2 / l);                      // d(-log2 l)/dl scaled
     const float graw = (lraw >= p.d.likelihood_bound || glik < 0.f) ? glik : 0.f;  // LowerBound backward
     const float pu = std_pdf(zu), pl = std_pdf(zl);
     const float dl_da = (pl - pu) / sg;
@@ -104,10 +130,19 @@ __global__ __launch_bounds__(256) void gauss_cond_bwd_kernel(const GcArgs p) {
     const float gy = graw * dl_da * sgn;
     const float gsg = graw * dl_dsg;
     const float gsig = (sraw >= p.d.scale_bound || gsg < 0.f) ? gsg : 0.f;
-    const float ste = p.dyhat ? p.dyhat[pix * p.lddyhat + c] : 0.f;
-    p.dy[pix * C + c] = gy + ste;   // yhat = ste_round(y - mu) + mu: d/dy = 1, d/dmu = 0
-    p.dmu[pix * C + c] = -gy;
-    p.dsigma[pix * C + c] = gsig;
+    const float ste = p.io.dyhat ? p.io.dyhat[pix * p.d.lddyhat + c] : 0.f;
+    p.io.dy[pix * p.d.ldgrad + c] = gy + ste;   // yhat = ste_round(y - mu) + mu: d/dy = 1, d/dmu = 0
+    p.io.dmu[pix * p.d.ldgrad + c] = -gy;
+    p.io.dsigma[pix * p.d.ldgrad + c] = gsig;
+  }
+}
+
+__global__ __launch_bounds__(256) void philox_uniform_kernel(const uint64_t* ph, int64_t M, int C, int Ctot, int c0, float* out, int ld) {
+  const int64_t total = M * C;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int64_t pix = e / C;
+    const int c = (int)(e - pix * C);
+    out[pix * ld + c] = philox_uniform(ph, (unsigned long long)pix * Ctot + c0 + c);
   }
 }
 
@@ -322,36 +357,92 @@ extern "C" int crdr_eb_quantile_loss(const float* quantiles, const float* params
   return 0;
 }
 
-extern "C" int crdr_gauss_cond_fwd(const crdr_gc_desc* d, const float* y, const float* mu, const float* sigma,
-                                   const float* noise, float* yhat, float* lik_noisy, float* lik_quant,
-                                   float* bits_noisy, float* bits_quant, crdr_stream_t s) {
-  CRDR_REQUIRE(y && mu && sigma, "gauss_cond_fwd: null input");
+static void gc_fill_defaults(crdr_gc_desc2& d) {
+  if (!d.ldnoise) d.ldnoise = d.C;
+  if (!d.ldlik) d.ldlik = d.C;
+  if (!d.ldgrad) d.ldgrad = d.C;
+  if (!d.Ctot) d.Ctot = d.C;
+}
+
+extern "C" int crdr_gauss_cond_fwd2(const crdr_gc_desc2* d, const crdr_gc_io* io, crdr_stream_t s) {
+  CRDR_REQUIRE(d && io && io->y && io->mu && io->sigma, "gauss_cond_fwd: null input");
   GcArgs a;
-  memset(&a, 0, sizeof(a));
-  a.d = *d; a.y = y; a.mu = mu; a.sigma = sigma; a.noise = noise;
-  a.yhat = yhat; a.lik_noisy = lik_noisy; a.lik_quant = lik_quant; a.bits_noisy = bits_noisy; a.bits_quant = bits_quant;
+  a.d = *d; a.io = *io;
+  gc_fill_defaults(a.d);
   const int per_img = d->HW * d->C;
   if (per_img == 0 || d->N == 0) return 0;
-  const int B = std::max(1, std::min(cdiv(per_img, 16384), 128));
+  // one block per image up to 64 Ki elements (every training shape): the per-image bit sums are then plain stores in a
+  // fixed order, bit-reproducible run to run; larger images (codec / validation) split and combine with atomics
+  const int B = std::max(1, std::min(cdiv(per_img, 65536), 128));
   hipLaunchKernelGGL(gauss_cond_fwd_kernel, dim3(B, d->N), dim3(1024), 0, as_stream(s), a);
   CRDR_CHECK_LAUNCH("gauss_cond_fwd");
   return 0;
 }
 
-extern "C" int crdr_gauss_cond_bwd(const crdr_gc_desc* d, const float* y, const float* mu, const float* sigma,
-                                   const float* noise, const float* gbits, const float* dyhat, int lddyhat, float* dy,
-                                   float* dmu, float* dsigma, crdr_stream_t s) {
-  CRDR_REQUIRE(y && mu && sigma && noise && gbits && dy && dmu && dsigma, "gauss_cond_bwd: null pointer");
+extern "C" int crdr_gauss_cond_bwd2(const crdr_gc_desc2* d, const crdr_gc_io* io, crdr_stream_t s) {
+  CRDR_REQUIRE(d && io && io->y && io->mu && io->sigma && (io->noise || io->philox) && io->gbits && io->dy && io->dmu && io->dsigma,
+               "gauss_cond_bwd: null pointer");
   GcArgs a;
-  memset(&a, 0, sizeof(a));
-  a.d = *d; a.y = y; a.mu = mu; a.sigma = sigma; a.noise = noise;
-  a.gbits = gbits; a.dyhat = dyhat; a.lddyhat = lddyhat; a.dy = dy; a.dmu = dmu; a.dsigma = dsigma;
+  a.d = *d; a.io = *io;
+  gc_fill_defaults(a.d);
   const int64_t total = (int64_t)d->N * d->HW * d->C;
   if (total == 0) return 0;
   const int nb = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(gauss_cond_bwd_kernel, dim3(nb), dim3(256), 0, as_stream(s), a);
   CRDR_CHECK_LAUNCH("gauss_cond_bwd");
   return 0;
+}
+
+__global__ void philox_fork_kernel(uint64_t* state, uint64_t* call, unsigned long long inc) {
+  call[0] = state[0];
+  call[1] = state[1];
+  state[1] += inc;
+}
+
+extern "C" int crdr_philox_fork(uint64_t* state, uint64_t* call, uint64_t inc, crdr_stream_t s) {
+  CRDR_REQUIRE(state && call, "philox_fork: null pointer");
+  hipLaunchKernelGGL(philox_fork_kernel, dim3(1), dim3(1), 0, as_stream(s), state, call, (unsigned long long)inc);
+  CRDR_CHECK_LAUNCH("philox_fork");
+  return 0;
+}
+
+extern "C" int crdr_philox_uniform(const uint64_t* philox, int N, int HW, int C, int Ctot, int c0, float* out, int ld,
+                                   crdr_stream_t s) {
+  CRDR_REQUIRE(philox && out, "philox_uniform: null pointer");
+  const int64_t M = (int64_t)N * HW, total = M * C;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(philox_uniform_kernel, dim3((int)std::min<int64_t>(cdiv64(total, 256), 4096)), dim3(256), 0, as_stream(s),
+                     philox, M, C, Ctot, c0, out, ld);
+  CRDR_CHECK_LAUNCH("philox_uniform");
+  return 0;
+}
+
+extern "C" int crdr_gauss_cond_fwd(const crdr_gc_desc* d, const float* y, const float* mu, const float* sigma,
+                                   const float* noise, float* yhat, float* lik_noisy, float* lik_quant,
+                                   float* bits_noisy, float* bits_quant, crdr_stream_t s) {
+  crdr_gc_desc2 d2;
+  memset(&d2, 0, sizeof(d2));
+  d2.N = d->N; d2.HW = d->HW; d2.C = d->C; d2.ldy = d->ldy; d2.ldmu = d->ldmu; d2.ldsigma = d->ldsigma; d2.ldyhat = d->ldyhat;
+  d2.scale_bound = d->scale_bound; d2.likelihood_bound = d->likelihood_bound;
+  crdr_gc_io io;
+  memset(&io, 0, sizeof(io));
+  io.y = y; io.mu = mu; io.sigma = sigma; io.noise = noise; io.yhat = yhat; io.lik_noisy = lik_noisy; io.lik_quant = lik_quant;
+  io.bits_noisy = bits_noisy; io.bits_quant = bits_quant;
+  return crdr_gauss_cond_fwd2(&d2, &io, s);
+}
+
+extern "C" int crdr_gauss_cond_bwd(const crdr_gc_desc* d, const float* y, const float* mu, const float* sigma,
+                                   const float* noise, const float* gbits, const float* dyhat, int lddyhat, float* dy,
+                                   float* dmu, float* dsigma, crdr_stream_t s) {
+  crdr_gc_desc2 d2;
+  memset(&d2, 0, sizeof(d2));
+  d2.N = d->N; d2.HW = d->HW; d2.C = d->C; d2.ldy = d->ldy; d2.ldmu = d->ldmu; d2.ldsigma = d->ldsigma; d2.ldyhat = d->ldyhat;
+  d2.lddyhat = lddyhat; d2.scale_bound = d->scale_bound; d2.likelihood_bound = d->likelihood_bound;
+  crdr_gc_io io;
+  memset(&io, 0, sizeof(io));
+  io.y = y; io.mu = mu; io.sigma = sigma; io.noise = noise; io.gbits = gbits; io.dyhat = dyhat; io.dy = dy; io.dmu = dmu;
+  io.dsigma = dsigma;
+  return crdr_gauss_cond_bwd2(&d2, &io, s);
 }
 
 extern "C" int crdr_entropy_bottleneck_fwd(const float* z, const float* noise, const float* params,

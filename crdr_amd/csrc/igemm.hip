@@ -14,6 +14,7 @@
 // Split-K (blockIdx.z) writes raw partial slabs; igemm_splitk_epilogue reduces them in a fixed order.
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #include "common.hpp"
@@ -37,6 +38,10 @@ struct IgemmArgs {
   const float* gx;
   const float* gt;
   float* sig;
+  const float* pre;
+  const float* mask;
+  int ldpre, ldmask;
+  int ngroup;
   int N, H, W, Cin, ldx;
   int GH, GW, so, OH, OW, ldy, Cout;
   int si;
@@ -61,11 +66,23 @@ struct IgemmTaps {
   int8_t poh[16], pow[16];
 };
 
+// Per-problem pointers of a grouped launch (crdr_conv2d_grouped); a plain launch is a group of one.  Only ever indexed
+// with the workgroup-uniform problem index.
+struct IgemmGroup {
+  const float* x[CRDR_MAX_GROUP];
+  const float* w[CRDR_MAX_GROUP];
+  float* y[CRDR_MAX_GROUP];
+  const float* bias[CRDR_MAX_GROUP];
+  const float* pre[CRDR_MAX_GROUP];
+  const float* mask[CRDR_MAX_GROUP];
+};
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 // epilogue on one element; opix = output pixel index, oc = channel
 __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, int oc, float v) {
   const int f = p.flags;
+  if (f & CRDR_EPI_PREADD) v += p.pre[opix * p.ldpre + oc];
   if (f & CRDR_EPI_BIAS) v += p.bias[oc];
   if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
   if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
@@ -77,6 +94,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, 
     v = p.gx[opix * p.ldg + oc] + p.gt[opix * p.ldg + oc] * s;
   }
   if (f & CRDR_EPI_AFFINE) v = v * p.scale[oc] + p.shift[oc];
+  if (f & CRDR_EPI_RELUMASK) v = p.mask[opix * p.ldmask + oc] > 0.0f ? v : 0.0f;
   float* dst = p.y + opix * p.ldy + oc;
   if (f & CRDR_EPI_ACCUM) v += *dst;
   *dst = v;
@@ -92,7 +110,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 static constexpr unsigned kOobOffset = 0x80000000u;  // >= any descriptor size accepted by build_plan (< 2 GiB)
 
 template <int WM, int WN, int MB, int NB, bool SMALLC>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, const IgemmTaps tp) {
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
   constexpr int BM = 32 * WM * MB, BN = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;  // 16-byte pieces per thread per K-tile
   static_assert(AV * NT == BM * 8 && BV * NT == BN * 8, "tile/threads mismatch");
@@ -120,6 +138,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
     tile_m = t / (gy * gz);
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // problem of a grouped launch (workgroup-uniform): its pointers replace the ones in the argument block
+  IgemmArgs p = p_;
+  const int zper = p.nphase * p.nsplit;
+  const int gidx = tile_z / zper;
+  tile_z -= gidx * zper;
+  if (p.ngroup > 1) {
+    p.x = grp.x[gidx]; p.w = grp.w[gidx]; p.y = grp.y[gidx];
+    p.bias = grp.bias[gidx]; p.pre = grp.pre[gidx]; p.mask = grp.mask[gidx];
+  }
   const int phase = tile_z / p.nsplit, split = tile_z % p.nsplit;
   const int tb = tp.tap_begin[phase], te = tp.tap_begin[phase + 1];
   const int ntap = te - tb;
@@ -305,7 +332,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
       bool live_row = m < p.M;
       if (p.nsplit > 1) {
         if (live_row)
-          *reinterpret_cast<f32x4*>(p.ws + ((size_t)(phase * p.nsplit + split) * p.M + m) * p.ws_ld + oc0) = a4;
+          *reinterpret_cast<f32x4*>(p.ws + ((size_t)((gidx * p.nphase + phase) * p.nsplit + split) * p.M + m) * p.ws_ld + oc0) = a4;
       } else {
         size_t opix = (size_t)m;
         if (!direct) {
@@ -317,8 +344,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
         }
         if (live_row && oc0 < p.Cout) {
           const bool full = vec && (oc0 + 3 < p.Cout);
-          f32x4 res4 = {0.f, 0.f, 0.f, 0.f}, gx4 = res4, gt4 = res4, old4 = res4;
+          f32x4 res4 = {0.f, 0.f, 0.f, 0.f}, gx4 = res4, gt4 = res4, old4 = res4, pre4 = res4, msk4 = res4;
           if (full) {
+            if (f & CRDR_EPI_PREADD) pre4 = *reinterpret_cast<const f32x4*>(p.pre + opix * p.ldpre + oc0);
+            if (f & CRDR_EPI_RELUMASK) msk4 = *reinterpret_cast<const f32x4*>(p.mask + opix * p.ldmask + oc0);
             if (f & CRDR_EPI_RES) res4 = *reinterpret_cast<const f32x4*>(p.res + opix * p.ldres + oc0);
             if (f & CRDR_EPI_GATE) {
               gx4 = *reinterpret_cast<const f32x4*>(p.gx + opix * p.ldg + oc0);
@@ -332,6 +361,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
             const int oc = oc0 + e;
             const bool live = oc < p.Cout;
             float v = a4[e];
+            if (f & CRDR_EPI_PREADD) v += full ? pre4[e] : (live ? p.pre[opix * p.ldpre + oc] : 0.f);
             if (f & CRDR_EPI_BIAS) v += live ? p.bias[oc] : 0.f;
             if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
             if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
@@ -345,6 +375,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
               v = gxv + gtv * sgm;
             }
             if (f & CRDR_EPI_AFFINE) v = live ? v * p.scale[oc] + p.shift[oc] : v;
+            if (f & CRDR_EPI_RELUMASK) v = (full ? msk4[e] : (live ? p.mask[opix * p.ldmask + oc] : 0.f)) > 0.0f ? v : 0.0f;
             if (f & CRDR_EPI_ACCUM) v += full ? old4[e] : (live ? p.y[opix * p.ldy + oc] : 0.f);
             o4[e] = v;
           }
@@ -374,14 +405,19 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p, 
 }
 
 // reduce split-K slabs in split order, then the same epilogue. grid: (ceil(Cout/64), M rows chunked, nphase)
-__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p, const IgemmTaps tp) {
-  const int phase = blockIdx.z;
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
+  IgemmArgs p = p_;
+  const int gidx = blockIdx.z / p.nphase;
+  const int phase = blockIdx.z - gidx * p.nphase;
+  if (p.ngroup > 1) {
+    p.y = grp.y[gidx]; p.bias = grp.bias[gidx]; p.pre = grp.pre[gidx]; p.mask = grp.mask[gidx];
+  }
   const int oc = blockIdx.x * 64 + (threadIdx.x & 63);
   const int hw = p.GH * p.GW;
   for (int m = blockIdx.y * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.y * 4) {
     if (oc >= p.Cout) continue;
     float v = 0.f;
-    for (int s = 0; s < p.nsplit; ++s) v += p.ws[((size_t)(phase * p.nsplit + s) * p.M + m) * p.ws_ld + oc];
+    for (int s = 0; s < p.nsplit; ++s) v += p.ws[((size_t)((gidx * p.nphase + phase) * p.nsplit + s) * p.M + m) * p.ws_ld + oc];
     const int n = m / hw, rem = m - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
     const int oh = ga * p.so + tp.poh[phase], ow = gb * p.so + tp.pow[phase];
     if (oh >= p.OH || ow >= p.OW) continue;
@@ -394,8 +430,8 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p, 
 // ------------------------------------------------------------------------------------------------------------
 struct TileCfg {
   int wm, wn, mb, nb;
-  void (*kern)(const IgemmArgs, const IgemmTaps);
-  void (*kern_smallc)(const IgemmArgs, const IgemmTaps);  // tap-major variant (Cin <= 4), nullptr where not built
+  void (*kern)(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+  void (*kern_smallc)(const IgemmArgs, const IgemmTaps, const IgemmGroup);  // tap-major variant (Cin <= 4), nullptr where not built
 };
 #define CFG(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false>, nullptr}
 #define CFGS(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false>, igemm_kernel<a, b, c, d, true>}
@@ -444,7 +480,7 @@ static int floordiv(int a, int b) {
   return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
 }
 
-static int build_plan(const crdr_conv_desc* d, Plan* pl) {
+static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
   IgemmArgs& a = pl->a;
   IgemmTaps& tp = pl->t;
   memset(&a, 0, sizeof(a));
@@ -459,6 +495,8 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
   a.OH = d->OH; a.OW = d->OW; a.ldy = d->ldy; a.Cout = d->OC;
   a.wrows = d->wrows; a.wcols = d->wcols;
   a.ldres = d->ldres; a.ldg = d->ldg; a.flags = d->flags;
+  a.ldpre = d->ldpre; a.ldmask = d->ldmask; a.ngroup = G;
+  CRDR_REQUIRE(G >= 1 && G <= CRDR_MAX_GROUP, "conv2d: group of %d problems (max %d)", G, CRDR_MAX_GROUP);
   a.smallc = d->wlayout == 1;
   CRDR_REQUIRE(!a.smallc || (!d->transposed && d->C <= 4 && d->wcols >= 4 * d->kh * d->kw),
                "conv2d: tap-major weight layout needs a non-transposed conv with C <= 4 and wcols >= 4*taps");
@@ -513,7 +551,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
     const long long tiles = (long long)cdiv(a.M, BM) * cdiv(d->OC, BN) * a.nphase;
     for (int ns = 1; ns <= 16; ns *= 2) {
       if (ns > 1 && KT / ns < 8) break;
-      const long long blocks = tiles * ns;
+      const long long blocks = tiles * ns * G;
       const double per_iter = 16.0 * t.mb * t.nb * 64.0 + 350.0 + 24.0 * (t.mb + t.nb);  // cycles
       const double waves = (double)cdiv64(blocks, 256);
       double cost = waves * ((double)cdiv(KT, ns) * per_iter + 3000.0);
@@ -533,14 +571,14 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl) {
   const int BM = 32 * t.wm * t.mb, BN = 32 * t.wn * t.nb;
   pl->cfg = bc;
   a.nsplit = bs;
-  pl->grid = dim3(cdiv(a.M, BM), cdiv(d->OC, BN), a.nphase * bs);
+  pl->grid = dim3(cdiv(a.M, BM), cdiv(d->OC, BN), a.nphase * bs * G);
   a.ws_ld = pl->grid.y * BN;
   {
     const size_t staging = (size_t)2 * (BM + BN) * 32 * sizeof(float) + 132 * sizeof(int);
     const size_t epi = (size_t)t.wm * t.wn * 32 * 32 * std::min(t.nb, 4) * sizeof(float);
     pl->lds = std::max(staging, epi);
   }
-  pl->ws_bytes = bs > 1 ? (size_t)a.nphase * bs * a.M * a.ws_ld * sizeof(float) : 0;
+  pl->ws_bytes = bs > 1 ? (size_t)G * a.nphase * bs * a.M * a.ws_ld * sizeof(float) : 0;
   return 0;
 }
 
@@ -556,53 +594,84 @@ extern "C" size_t crdr_conv2d_workspace(const crdr_conv_desc* d) {
   return pl.ws_bytes;
 }
 
+extern "C" size_t crdr_conv2d_grouped_workspace(const crdr_conv_desc* d, int G) {
+  Plan pl;
+  if (build_plan(d, &pl, G)) return 0;
+  return pl.ws_bytes;
+}
+
 extern "C" double crdr_conv2d_flops(const crdr_conv_desc* d) {
   // exact count of in-bounds multiply-accumulates is shape dependent only at the borders; report the dense count
   if (!d->transposed) return 2.0 * d->N * d->OH * d->OW * (double)d->OC * d->C * d->kh * d->kw;
   return 2.0 * d->N * d->H * d->W * (double)d->OC * d->C * d->kh * d->kw;
 }
 
-extern "C" int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void* ws, size_t ws_bytes,
-                           crdr_stream_t s) {
+static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, void* ws, size_t ws_bytes, crdr_stream_t s) {
   Plan pl;
-  if (int rc = build_plan(d, &pl)) return rc;
+  if (int rc = build_plan(d, &pl, G)) return rc;
   IgemmArgs& a = pl.a;
+  const crdr_conv_io* io = ios;
   a.x = io->x; a.w = io->w; a.y = io->y; a.ws = (float*)ws;
   a.bias = io->bias; a.vec2 = io->vec2; a.res = io->res; a.scale = io->scale; a.shift = io->shift;
-  a.gx = io->gx; a.gt = io->gt; a.sig = io->sig;
+  a.gx = io->gx; a.gt = io->gt; a.sig = io->sig; a.pre = io->pre; a.mask = io->mask;
   if (a.M == 0) return 0;  // empty batch: nothing to compute (tensors may legitimately be null)
-  CRDR_REQUIRE(a.x && a.w && a.y, "conv2d: null tensor");
-  CRDR_REQUIRE(!(a.flags & CRDR_EPI_BIAS) || a.bias, "conv2d: BIAS flag without bias");
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_VEC2) || a.vec2, "conv2d: VEC2 flag without vec2");
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_RES) || a.res, "conv2d: RES flag without res");
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_AFFINE) || (a.scale && a.shift), "conv2d: AFFINE flag without scale/shift");
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_GATE) || (a.gx && a.gt && a.sig), "conv2d: GATE flag without gx/gt/sig");
+  CRDR_REQUIRE(G == 1 || !(a.flags & (CRDR_EPI_VEC2 | CRDR_EPI_RES | CRDR_EPI_AFFINE | CRDR_EPI_GATE)),
+               "conv2d_grouped: epilogue flags %d not supported in a grouped launch", a.flags);
   CRDR_REQUIRE(pl.ws_bytes <= ws_bytes, "conv2d: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
-  if (a.M == 0) return 0;
-  {
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    bool v = (a.ldy % 4 == 0) && al16(a.y);
-    if (a.flags & CRDR_EPI_RES) v = v && (a.ldres % 4 == 0) && al16(a.res);
-    if (a.flags & CRDR_EPI_GATE) v = v && (a.ldg % 4 == 0) && al16(a.gx) && al16(a.gt) && al16(a.sig);
-    a.vec_epi = v ? 1 : 0;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  IgemmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  bool v = (a.ldy % 4 == 0);
+  if (a.flags & CRDR_EPI_RES) v = v && (a.ldres % 4 == 0) && al16(a.res);
+  if (a.flags & CRDR_EPI_GATE) v = v && (a.ldg % 4 == 0) && al16(a.gx) && al16(a.gt) && al16(a.sig);
+  if (a.flags & CRDR_EPI_PREADD) v = v && (a.ldpre % 4 == 0);
+  if (a.flags & CRDR_EPI_RELUMASK) v = v && (a.ldmask % 4 == 0);
+  for (int g = 0; g < G; ++g) {
+    const crdr_conv_io& q = ios[g];
+    CRDR_REQUIRE(q.x && q.w && q.y, "conv2d: null tensor (problem %d)", g);
+    CRDR_REQUIRE(!(a.flags & CRDR_EPI_BIAS) || q.bias, "conv2d: BIAS flag without bias (problem %d)", g);
+    CRDR_REQUIRE(!(a.flags & CRDR_EPI_PREADD) || q.pre, "conv2d: PREADD flag without pre (problem %d)", g);
+    CRDR_REQUIRE(!(a.flags & CRDR_EPI_RELUMASK) || q.mask, "conv2d: RELUMASK flag without mask (problem %d)", g);
+    grp.x[g] = q.x; grp.w[g] = q.w; grp.y[g] = q.y; grp.bias[g] = q.bias; grp.pre[g] = q.pre; grp.mask[g] = q.mask;
+    v = v && al16(q.y);
+    if (a.flags & CRDR_EPI_PREADD) v = v && al16(q.pre);
+    if (a.flags & CRDR_EPI_RELUMASK) v = v && al16(q.mask);
   }
+  a.vec_epi = v ? 1 : 0;
   const TileCfg& t = kCfgs[pl.cfg];
   auto kern = a.smallc ? t.kern_smallc : t.kern;
-  static bool attr_done[2][64] = {{false}};
-  if (!attr_done[a.smallc][pl.cfg]) {
+  static std::atomic<bool> attr_done[2][64];
+  if (!attr_done[a.smallc][pl.cfg].load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done[a.smallc][pl.cfg] = true;
+    attr_done[a.smallc][pl.cfg].store(true, std::memory_order_release);
   }
   void* prof = profile_begin(as_stream(s));
-  hipLaunchKernelGGL(kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, pl.t);
+  hipLaunchKernelGGL(kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, pl.t, grp);
   CRDR_CHECK_LAUNCH("igemm_kernel");
-  profile_end(0, crdr_conv2d_flops(d), prof, as_stream(s));  // kind 0 = the igemm kernel alone (what rocprofv3 lists)
+  profile_end(0, G * crdr_conv2d_flops(d), prof, as_stream(s));  // kind 0 = the igemm kernel alone (what rocprofv3 lists)
   if (a.nsplit > 1) {
     void* prof2 = profile_begin(as_stream(s));
-    dim3 g(cdiv(a.Cout, 64), std::min(cdiv(a.M, 4), 2048), a.nphase);
-    hipLaunchKernelGGL(igemm_splitk_epilogue, g, dim3(256), 0, as_stream(s), a, pl.t);
+    dim3 g(cdiv(a.Cout, 64), std::min(cdiv(a.M, 4), 2048), a.nphase * G);
+    hipLaunchKernelGGL(igemm_splitk_epilogue, g, dim3(256), 0, as_stream(s), a, pl.t, grp);
     CRDR_CHECK_LAUNCH("igemm_splitk_epilogue");
     profile_end(2, 0.0, prof2, as_stream(s));  // kind 2 = split-K epilogue launches
   }
   return 0;
+}
+
+extern "C" int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void* ws, size_t ws_bytes,
+                           crdr_stream_t s) {
+  CRDR_REQUIRE(d && io, "conv2d: null descriptor");
+  return launch_conv(d, io, 1, ws, ws_bytes, s);
+}
+
+extern "C" int crdr_conv2d_grouped(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, void* ws, size_t ws_bytes,
+                                   crdr_stream_t s) {
+  CRDR_REQUIRE(d && ios, "conv2d_grouped: null descriptor");
+  CRDR_REQUIRE(G >= 1 && G <= CRDR_MAX_GROUP, "conv2d_grouped: %d problems (1..%d)", G, CRDR_MAX_GROUP);
+  return launch_conv(d, ios, G, ws, ws_bytes, s);
 }

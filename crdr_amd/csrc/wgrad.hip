@@ -10,6 +10,7 @@
 // into the parameter layout [I][J][T].
 
 #include <algorithm>
+#include <atomic>
 
 #include "common.hpp"
 
@@ -32,10 +33,17 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
   return (t + ((n - t) >> 1)) >> (f.sh - 1);
 }
 
+struct WgradGroup {  // per-problem operands of a grouped launch; indexed with the workgroup-uniform problem index only
+  const float* p[CRDR_MAX_GROUP];
+  const float* q[CRDR_MAX_GROUP];
+};
+
 struct WgradArgs {
   const float* p;
   const float* q;
   float* ws;
+  int ngroup;
+  long long slab_elems;  // floats of one problem's slab
   int N, PH, PW, PC, ldp;
   int QH, QW, QC, ldq;
   int kw, stride, pad, T;
@@ -53,7 +61,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 static constexpr unsigned kOob = 0x80000000u;  // >= any descriptor size accepted by build_wplan (< 2 GiB)
 
 template <int WM, int WN, int MB, int NB>
-__global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p_, const WgradGroup grp) {
   constexpr int BI = 32 * WM * MB, BJ = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int PV = (8 * BI + NT - 1) / NT, QV = (8 * BJ + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -73,6 +81,13 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p) 
     bx = t % gx;
     by = (t / gx) % gy;
     bz = t / (gx * gy);
+  }
+  WgradArgs p = p_;
+  const int gidx = bz / p.nsplit;
+  bz -= gidx * p.nsplit;
+  if (p.ngroup > 1) {
+    p.p = grp.p[gidx]; p.q = grp.q[gidx];
+    p.ws += (size_t)gidx * p.slab_elems;
   }
   const int it = bx / p.jtiles, jt = bx % p.jtiles;
   const int i0 = it * BI, j0 = jt * BJ;
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const crdr_wg
     }
     for (; s < jb.nsplit; ++s) v0 += base[(size_t)s * stride];
     const float v = (v0 + v1) + (v2 + v3);
-    float* d = jb.g + ((size_t)i * jb.gJ + j) * jb.T + t;
+    float* d = jb.g + ((size_t)i * (jb.gJtot ? jb.gJtot : jb.gJ) + j) * jb.T + t;
     *d = jb.accumulate ? *d + v : v;
   }
 }
@@ -250,6 +265,20 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, floa
     const int r = (int)(r2 % rows), t = (int)(r2 / rows);
     const int i = transpose ? c : r, j = transpose ? r : c;
     dst[e] = (i < I && j < J) ? src[((size_t)i * J + j) * T + t] : 0.f;
+  }
+}
+
+// one pack item with sub-block strides (crdr_pack_item), modes 0 / 1, any T
+__global__ __launch_bounds__(256) void pack_weight_item_kernel(const crdr_pack_item it) {
+  const long long total = (long long)it.T * it.rows * it.cols;
+  const int sJ = it.srcJ ? it.srcJ : it.J;
+  const long long dld = it.dld ? it.dld : it.cols, ts = it.tstride ? it.tstride : (long long)it.rows * it.cols;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int c = (int)(e % it.cols);
+    const long long r2 = e / it.cols;
+    const int r = (int)(r2 % it.rows), t = (int)(r2 / it.rows);
+    const int i = it.mode ? c : r, j = it.mode ? r : c;
+    it.dst[t * ts + r * dld + c] = (i < it.I && j < it.J) ? it.src[((size_t)i * sJ + j) * it.T + t] : 0.f;
   }
 }
 
@@ -285,26 +314,27 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const crdr_pa
     const int ctiles = it.cols >> 5;
     const int r0 = (tl / ctiles) * 8, c0 = (tl % ctiles) * 32;
     const int T = it.T;
+    const int sJ = it.srcJ ? it.srcJ : it.J;
     if (it.mode == 0) {  // pack row = i, pack col = j : LDS [8 r][32 c][T]
       const int run = 32 * T;
       for (int e = tid; e < 8 * run; e += 256) {
         const int r = e / run, rest = e - r * run;
         const int i = r0 + r, j = c0 + rest / T;
-        tile[e] = (i < it.I && j < it.J) ? it.src[((size_t)i * it.J + c0) * T + rest] : 0.f;
+        tile[e] = (i < it.I && j < it.J) ? it.src[((size_t)i * sJ + c0) * T + rest] : 0.f;
       }
     } else {             // pack row = j, pack col = i : LDS [32 c][8 r][T], each c padded by one float
       const int run = 8 * T;
       for (int e = tid; e < 32 * run; e += 256) {
         const int c = e / run, rest = e - c * run;
         const int i = c0 + c, j = r0 + rest / T;
-        tile[c * (run + 1) + rest] = (i < it.I && j < it.J) ? it.src[((size_t)i * it.J + r0) * T + rest] : 0.f;
+        tile[c * (run + 1) + rest] = (i < it.I && j < it.J) ? it.src[((size_t)i * sJ + r0) * T + rest] : 0.f;
       }
     }
     __syncthreads();
     const int r = tid >> 5, c = tid & 31;
     const float* sp = it.mode == 0 ? tile + (r * 32 + c) * T : tile + c * (8 * T + 1) + r * T;
-    float* dp = it.dst + ((size_t)(r0 + r)) * it.cols + c0 + c;
-    const size_t tstride = (size_t)it.rows * it.cols;
+    float* dp = it.dst + ((size_t)(r0 + r)) * (it.dld ? it.dld : it.cols) + c0 + c;
+    const size_t tstride = it.tstride ? (size_t)it.tstride : (size_t)it.rows * it.cols;
     for (int t = 0; t < T; ++t) dp[t * tstride] = sp[t];
     __syncthreads();
   }
@@ -323,7 +353,7 @@ __global__ __launch_bounds__(256) void pack_weight_scatter_kernel(const float* s
 
 struct WCfg {
   int wm, wn, mb, nb;
-  void (*kern)(const WgradArgs);
+  void (*kern)(const WgradArgs, const WgradGroup);
 };
 #define CFG(a, b, c, d) {a, b, c, d, wgrad_kernel<a, b, c, d>}
 static const WCfg kWCfgs[] = {
@@ -361,7 +391,7 @@ struct WPlan {
   size_t lds, ws_bytes;
 };
 
-static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl) {
+static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl, int G = 1) {
   WgradArgs& a = pl->a;
   memset(&a, 0, sizeof(a));
   CRDR_REQUIRE(d->PC % 4 == 0 && d->QC % 4 == 0 && d->ldp % 4 == 0 && d->ldq % 4 == 0,
@@ -393,7 +423,7 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl) {
     const int waves_per_block = t.wm * t.wn;
     for (int ns = 1; ns <= 256; ns *= 2) {
       if (ns > 1 && a.ntiles / ns < 4) break;
-      const long long blocks = tiles * ns;
+      const long long blocks = tiles * ns * G;
       const double slots = 256.0 * std::max(1, 4 / waves_per_block);  // blocks that run at full MFMA rate at once
       const double per_tile = 16.0 * t.mb * t.nb * 64.0 + 400.0;
       double cost = std::ceil(blocks / slots) * ((double)cdiv(a.ntiles, ns) * per_tile + 4000.0);
@@ -411,9 +441,11 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl) {
   const WCfg& t = kWCfgs[bc];
   const int BI = 32 * t.wm * t.mb, BJ = 32 * t.wn * t.nb;
   pl->cfg = bc; a.nsplit = bs; a.jtiles = cdiv(ncols, BJ);
-  pl->grid = dim3(cdiv(d->PC, BI) * a.jtiles, ntapg, bs);
+  pl->grid = dim3(cdiv(d->PC, BI) * a.jtiles, ntapg, bs * G);
   pl->lds = (size_t)2 * 32 * (BI + BJ) * sizeof(float);
-  pl->ws_bytes = (size_t)bs * ntapg * d->PC * ncols * sizeof(float);
+  a.ngroup = G;
+  a.slab_elems = (long long)bs * ntapg * d->PC * ncols;
+  pl->ws_bytes = (size_t)G * bs * ntapg * d->PC * ncols * sizeof(float);
   return 0;
 }
 
@@ -429,20 +461,26 @@ extern "C" size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d) {
   return pl.ws_bytes;
 }
 
-static int launch_wgrad_slabs(const crdr_wgrad_desc* d, const float* p, const float* q, void* ws, size_t ws_bytes, WPlan& pl,
-                              crdr_stream_t s) {
-  if (int rc = build_wplan(d, &pl)) return rc;
-  CRDR_REQUIRE(p && q && ws, "wgrad: null pointer");
+static int launch_wgrad_slabs(const crdr_wgrad_desc* d, const float* const* ps, const float* const* qs, int G, void* ws,
+                              size_t ws_bytes, WPlan& pl, crdr_stream_t s) {
+  if (int rc = build_wplan(d, &pl, G)) return rc;
+  CRDR_REQUIRE(ws, "wgrad: null pointer");
   CRDR_REQUIRE(pl.ws_bytes <= ws_bytes, "wgrad: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
   WgradArgs& a = pl.a;
-  a.p = p; a.q = q; a.ws = (float*)ws;
-  const WCfg& t = kWCfgs[pl.cfg];
-  static bool attr_done[64] = {false};
-  if (!attr_done[pl.cfg]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done[pl.cfg] = true;
+  WgradGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  for (int g = 0; g < G; ++g) {
+    CRDR_REQUIRE(ps[g] && qs[g], "wgrad: null operand (problem %d)", g);
+    grp.p[g] = ps[g]; grp.q[g] = qs[g];
   }
-  hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a);
+  a.p = ps[0]; a.q = qs[0]; a.ws = (float*)ws;
+  const WCfg& t = kWCfgs[pl.cfg];
+  static std::atomic<bool> attr_done[64];
+  if (!attr_done[pl.cfg].load(std::memory_order_acquire)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done[pl.cfg].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, grp);
   CRDR_CHECK_LAUNCH("wgrad_kernel");
   return 0;
 }
@@ -452,7 +490,7 @@ extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const
   CRDR_REQUIRE(g, "wgrad: null pointer");
   WPlan pl;
   void* prof = profile_begin(as_stream(s));
-  if (int rc = launch_wgrad_slabs(d, p, q, ws, ws_bytes, pl, s)) return rc;
+  if (int rc = launch_wgrad_slabs(d, &p, &q, 1, ws, ws_bytes, pl, s)) return rc;
   const WgradArgs& a = pl.a;
   const long long total = (long long)d->gI * d->gJ * a.T;
   const int blocks = (int)std::min<long long>(cdiv64(total, 256), 4096);
@@ -468,12 +506,38 @@ extern "C" int crdr_conv2d_wgrad_partial(const crdr_wgrad_desc* d, const float* 
   CRDR_REQUIRE(g && job, "wgrad_partial: null pointer");
   WPlan pl;
   void* prof = profile_begin(as_stream(s));
-  if (int rc = launch_wgrad_slabs(d, p, q, slab, slab_bytes, pl, s)) return rc;
+  if (int rc = launch_wgrad_slabs(d, &p, &q, 1, slab, slab_bytes, pl, s)) return rc;
   const WgradArgs& a = pl.a;
   job->slab = (const float*)slab; job->g = g;
   job->PC = d->PC; job->QC = d->QC; job->gI = d->gI; job->gJ = d->gJ; job->T = a.T; job->nsplit = a.nsplit;
-  job->smallj = a.smallj; job->accumulate = d->accumulate;
+  job->smallj = a.smallj; job->accumulate = d->accumulate; job->gJtot = 0; job->reserved = 0;
   profile_end(1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
+  return 0;
+}
+
+extern "C" size_t crdr_conv2d_wgrad_grouped_workspace(const crdr_wgrad_desc* d, int G) {
+  WPlan pl;
+  if (G < 1 || G > CRDR_MAX_GROUP || build_wplan(d, &pl, G)) return 0;
+  return pl.ws_bytes;
+}
+
+extern "C" int crdr_conv2d_wgrad_partial_grouped(const crdr_wgrad_desc* d, const float* const* ps, const float* const* qs,
+                                                 float* const* gs, int G, void* slab, size_t slab_bytes, crdr_wgrad_job* jobs,
+                                                 crdr_stream_t s) {
+  CRDR_REQUIRE(ps && qs && gs && jobs, "wgrad_partial_grouped: null pointer");
+  CRDR_REQUIRE(G >= 1 && G <= CRDR_MAX_GROUP, "wgrad_partial_grouped: %d problems (1..%d)", G, CRDR_MAX_GROUP);
+  WPlan pl;
+  void* prof = profile_begin(as_stream(s));
+  if (int rc = launch_wgrad_slabs(d, ps, qs, G, slab, slab_bytes, pl, s)) return rc;
+  const WgradArgs& a = pl.a;
+  for (int g = 0; g < G; ++g) {
+    crdr_wgrad_job* job = jobs + g;
+    CRDR_REQUIRE(gs[g], "wgrad_partial_grouped: null gradient (problem %d)", g);
+    job->slab = (const float*)slab + (size_t)g * a.slab_elems; job->g = gs[g];
+    job->PC = d->PC; job->QC = d->QC; job->gI = d->gI; job->gJ = d->gJ; job->T = a.T; job->nsplit = a.nsplit;
+    job->smallj = a.smallj; job->accumulate = d->accumulate; job->gJtot = 0; job->reserved = 0;
+  }
+  profile_end(1, 2.0 * (double)G * a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
   return 0;
 }
 
@@ -492,6 +556,18 @@ extern "C" int crdr_pack_weights_batched(const crdr_pack_item* items, const int6
   hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(2048), dim3(256), 0, as_stream(s), items,
                      reinterpret_cast<const long long*>(prefix), reinterpret_cast<const long long*>(meta));
   CRDR_CHECK_LAUNCH("pack_weights_batched_kernel");
+  return 0;
+}
+
+extern "C" int crdr_pack_weight_item(const crdr_pack_item* item, crdr_stream_t s) {
+  CRDR_REQUIRE(item && item->src && item->dst, "pack_weight_item: null pointer");
+  CRDR_REQUIRE(item->mode == 0 || item->mode == 1, "pack_weight_item: mode %d", item->mode);
+  CRDR_REQUIRE(item->rows >= (item->mode ? item->J : item->I) && item->cols >= (item->mode ? item->I : item->J),
+               "pack_weight_item: pack smaller than source");
+  const long long total = (long long)item->T * item->rows * item->cols;
+  hipLaunchKernelGGL(pack_weight_item_kernel, dim3((int)std::min<long long>(cdiv64(total, 256), 8192)), dim3(256), 0,
+                     as_stream(s), *item);
+  CRDR_CHECK_LAUNCH("pack_weight_item");
   return 0;
 }
 

@@ -31,13 +31,59 @@ def _grad_slot(p: torch.Tensor) -> torch.Tensor:
 
 
 class _PackEntry:
-    """One persistent weight pack: destination buffer + how to refill it from its parameter."""
-    __slots__ = ("weight", "dst", "I", "J", "T", "rows", "cols", "mode", "key")
+    """One persistent weight pack: destination buffer + how to refill it from its parameter.  A *sub-block* entry
+    (`src_off` / `srcJ` / `dst_off` / `dld` / `tstride`, see crdr_pack_item) packs an input-channel range of the parameter
+    into a row / column range of a wider pack shared with other parameters (the Charm's hoisted first-layer convs)."""
+    __slots__ = ("weight", "dst", "I", "J", "T", "rows", "cols", "mode", "key", "src_off", "srcJ", "dst_off", "dld", "tstride")
+
+    def __init__(self):
+        self.src_off = self.srcJ = self.dst_off = self.dld = self.tstride = 0
+
+    def item(self) -> "L.PackItem":
+        return L.PackItem(src=self.weight.data_ptr() + self.src_off, dst=self.dst.data_ptr() + self.dst_off, I=self.I, J=self.J,
+                          T=self.T, rows=self.rows, cols=self.cols, mode=self.mode, srcJ=self.srcJ, dld=self.dld,
+                          tstride=self.tstride)
 
     def fill(self) -> None:
         lib = L.load()
-        L.check(lib.crdr_pack_weight(self.weight.data_ptr(), self.dst.data_ptr(), self.I, self.J, self.T, self.rows, self.cols,
-                                     self.mode, ops._stream()), "pack_weight")
+        if self.mode in (0, 1):
+            it = self.item()
+            L.check(lib.crdr_pack_weight_item(C.byref(it), ops._stream()), "pack_weight_item")
+        else:
+            L.check(lib.crdr_pack_weight(self.weight.data_ptr(), self.dst.data_ptr(), self.I, self.J, self.T, self.rows, self.cols,
+                                         self.mode, ops._stream()), "pack_weight")
+
+
+def sub_pack(weight: torch.Tensor, j0: int, j1: int, dst: torch.Tensor, dst_off: int, rows: int, cols: int, transposed: bool,
+             dld: int = 0, tstride: int = 0) -> _PackEntry:
+    """Register a sub-block pack: input channels [j0, j1) of `weight` [I][J][kh][kw] -> the [T][rows][cols] block that
+    starts `dst_off` floats into `dst` (row stride `dld`, tap stride `tstride`; 0 = dense).  transposed=False: pack row =
+    output channel i, column = input channel j (forward operand); True: row = j, column = i (input-gradient operand)."""
+    global _pack_serial
+    ops._require_gpu(weight)
+    assert weight.is_contiguous() and weight.dim() == 4
+    e = _PackEntry()
+    e.key = None
+    e.weight = weight.detach()
+    e.I, e.J, e.T = weight.shape[0], j1 - j0, weight.shape[2] * weight.shape[3]
+    e.src_off, e.srcJ = 4 * j0 * e.T, weight.shape[1]
+    e.mode = 1 if transposed else 0
+    e.rows, e.cols = rows, cols
+    assert rows % 8 == 0 and cols % 32 == 0 and rows >= (e.J if transposed else e.I) and cols >= (e.I if transposed else e.J)
+    e.dst, e.dst_off, e.dld, e.tstride = dst, 4 * dst_off, dld, tstride
+    _pack_entries.append(e)
+    _pack_serial += 1
+    return e
+
+
+def ensure_fresh(entries) -> None:
+    """Refill the entries whose parameter changed since their last fill (first use, load_state_dict, a foreign optimiser);
+    the fused Adam keeps them fresh through its PackTable."""
+    for e in entries:
+        k = _current_key(e.weight)
+        if e.key != k:
+            e.fill()
+            e.key = k
 
 
 PACK_MISS_LOG = {} if __import__("os").environ.get("CRDR_DEBUG_PACK") == "1" else None  # {(I, J, T, mode, why): count}
@@ -137,7 +183,7 @@ class PackTable:
     The device-side table has a fixed capacity and is rewritten in place when new packs appear, so a HIP graph that
     captured the launch keeps covering everything."""
     CAP = 4096
-    ITEM = 40  # sizeof(crdr_pack_item)
+    ITEM = 56  # sizeof(crdr_pack_item)
 
     def __init__(self, flat: torch.Tensor, lo: int = 0, hi: Optional[int] = None):
         hi = flat.numel() if hi is None else hi
@@ -161,10 +207,12 @@ class PackTable:
                 raise RuntimeError("PackTable: new weight packs appeared during graph capture (run eager warm-up iterations first)")
             assert len(ents) <= self.CAP
             rec = np.zeros(len(ents), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("I", "<i4"), ("J", "<i4"), ("T", "<i4"),
-                                                        ("rows", "<i4"), ("cols", "<i4"), ("mode", "<i4")]))
+                                                        ("rows", "<i4"), ("cols", "<i4"), ("mode", "<i4"), ("srcJ", "<i4"),
+                                                        ("dld", "<i4"), ("tstride", "<i8")]))
             pre = np.zeros(len(ents) + 1, dtype=np.int64)
             for k, e in enumerate(ents):
-                rec[k] = (e.weight.data_ptr(), e.dst.data_ptr(), e.I, e.J, e.T, e.rows, e.cols, e.mode)
+                rec[k] = (e.weight.data_ptr() + e.src_off, e.dst.data_ptr() + e.dst_off, e.I, e.J, e.T, e.rows, e.cols, e.mode,
+                          e.srcJ, e.dld, e.tstride)
                 pre[k + 1] = pre[k] + (e.rows // 8) * (e.cols // 32)
             assert rec.dtype.itemsize == self.ITEM
             if len(ents):

@@ -22,12 +22,12 @@ c_void_p = C.c_void_p
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "C", "OH", "OW", "OC", "kh", "kw", "stride", "pad", "transposed", "ldx", "ldy",
-        "wrows", "wcols", "flags", "ldres", "ldg", "wlayout", "reserved")]
+        "wrows", "wcols", "flags", "ldres", "ldg", "wlayout", "reserved", "ldpre", "ldmask")]
 
 
 class ConvIO(C.Structure):
     _fields_ = [(n, c_void_p) for n in (
-        "x", "w", "y", "bias", "vec2", "res", "scale", "shift", "gx", "gt", "sig")]
+        "x", "w", "y", "bias", "vec2", "res", "scale", "shift", "gx", "gt", "sig", "pre", "mask")]
 
 
 class WgradDesc(C.Structure):
@@ -43,7 +43,23 @@ class EbwdDesc(C.Structure):
 
 class WgradJob(C.Structure):
     _fields_ = [("slab", c_void_p), ("g", c_void_p)] + [(n, C.c_int32) for n in (
-        "PC", "QC", "gI", "gJ", "T", "nsplit", "smallj", "accumulate")]
+        "PC", "QC", "gI", "gJ", "T", "nsplit", "smallj", "accumulate", "gJtot", "reserved")]
+
+
+class PackItem(C.Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p)] + [(n, C.c_int32) for n in (
+        "I", "J", "T", "rows", "cols", "mode", "srcJ", "dld")] + [("tstride", C.c_int64)]
+
+
+class GcDesc2(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "HW", "C", "ldy", "ldmu", "ldsigma", "ldyhat", "ldyhat2", "ldnoise", "ldlik",
+                                         "ldgrad", "lddyhat", "Ctot", "c0")] + [
+        ("scale_bound", C.c_float), ("likelihood_bound", C.c_float)]
+
+
+class GcIO(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("y", "mu", "sigma", "noise", "philox", "yhat", "yhat2", "lik_noisy", "lik_quant",
+                                        "bits_noisy", "bits_quant", "gbits", "dyhat", "dy", "dmu", "dsigma")]
 
 
 class EbwdIO(C.Structure):
@@ -57,6 +73,8 @@ class GcDesc(C.Structure):
 
 
 EPI_BIAS, EPI_RELU, EPI_LRELU, EPI_VEC2, EPI_RES, EPI_GATE, EPI_AFFINE, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64, 128
+EPI_PREADD, EPI_RELUMASK = 256, 512
+MAX_GROUP = 16
 EB_PARAMS = 58
 
 # name -> (restype, argtypes); every symbol include/crdr_hip.h declares
@@ -72,6 +90,16 @@ SIGNATURES = {
     "crdr_conv2d_workspace": (_SZ, [C.POINTER(ConvDesc)]),
     "crdr_conv2d": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvIO), _P, _SZ, _P]),
     "crdr_conv2d_flops": (_D, [C.POINTER(ConvDesc)]),
+    "crdr_conv2d_grouped_workspace": (_SZ, [C.POINTER(ConvDesc), _I]),
+    "crdr_conv2d_grouped": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _SZ, _P]),
+    "crdr_conv2d_wgrad_grouped_workspace": (_SZ, [C.POINTER(WgradDesc), _I]),
+    "crdr_conv2d_wgrad_partial_grouped": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _I, _P, _SZ, _P, _P]),
+    "crdr_pack_weight_item": (_I, [C.POINTER(PackItem), _P]),
+    "crdr_colsum_scatter": (_I, [_P, _I, _I64, _I, _I, _P, _I, _P, _SZ, _P]),
+    "crdr_gauss_cond_fwd2": (_I, [C.POINTER(GcDesc2), C.POINTER(GcIO), _P]),
+    "crdr_gauss_cond_bwd2": (_I, [C.POINTER(GcDesc2), C.POINTER(GcIO), _P]),
+    "crdr_philox_fork": (_I, [_P, _P, C.c_uint64, _P]),
+    "crdr_philox_uniform": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "crdr_conv2d_wgrad_workspace": (_SZ, [C.POINTER(WgradDesc)]),
     "crdr_conv2d_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _SZ, _P]),
     "crdr_conv2d_wgrad_partial": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _SZ, C.POINTER(WgradJob), _P]),

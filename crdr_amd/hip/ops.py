@@ -490,3 +490,169 @@ def epilogue_bwd(dout, out, flags, *, vec2=None, scale=None, shift=None, gate_t=
     ws, ws_n = workspace(nbytes, dout.device)
     L.check(lib.crdr_epilogue_bwd(C.byref(d), C.byref(io), ws, ws_n, _stream()), "epilogue_bwd")
     return dz, gres, dgt, colsums
+
+
+# ---------------------------------------------------------------------------------------------------------
+# pointer-level launchers (used by the fused Charm engine, crdr_amd/hip/charm.py): operands are (address, pixel stride)
+# pairs into wide NHWC buffers owned by the caller -- no layout checks, no allocation, no autograd.
+# ---------------------------------------------------------------------------------------------------------
+class V:
+    """A channel range of a wide NHWC buffer: address of channel 0 of pixel 0, pixel stride, channel count."""
+    __slots__ = ("ptr", "ld", "c")
+
+    def __init__(self, ptr: int, ld: int, c: int):
+        self.ptr, self.ld, self.c = ptr, ld, c
+
+
+def view(buf: torch.Tensor, c0: int, c: int) -> V:
+    """Channels [c0, c0 + c) of a dense [pixels..., ld] buffer (last dim = pixel stride)."""
+    return V(buf.data_ptr() + 4 * c0, buf.shape[-1], c)
+
+
+def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, int], pad: int, transposed: bool, *,
+               wrows: int, wcols: int, biases=None, pres=None, masks=None, flags: int = 0, device=None, label: str = ""):
+    """G stride-1 'same' convolutions of one geometry in one launch (crdr_conv2d_grouped; G = 1: crdr_conv2d).
+    xs / ys / pres / masks: lists of V (equal ld and c within each list); wpacks / biases: lists of addresses."""
+    lib = L.load()
+    G = len(xs)
+    x0, y0 = xs[0], ys[0]
+    if biases is not None:
+        flags |= L.EPI_BIAS
+    if pres is not None:
+        flags |= L.EPI_PREADD
+    if masks is not None:
+        flags |= L.EPI_RELUMASK
+    d = L.ConvDesc(N=n, H=h, W=w, C=x0.c, OH=h, OW=w, OC=oc, kh=k[0], kw=k[1], stride=1, pad=pad, transposed=int(transposed),
+                   ldx=x0.ld, ldy=y0.ld, wrows=wrows, wcols=wcols, flags=flags, ldres=0, ldg=0, wlayout=0, reserved=0,
+                   ldpre=pres[0].ld if pres is not None else 0, ldmask=masks[0].ld if masks is not None else 0)
+    ios = (L.ConvIO * G)()
+    for g in range(G):
+        io = ios[g]
+        io.x, io.w, io.y = xs[g].ptr, wpacks[g], ys[g].ptr
+        if biases is not None:
+            io.bias = biases[g]
+        if pres is not None:
+            io.pre = pres[g].ptr
+        if masks is not None:
+            io.mask = masks[g].ptr
+    if AUTOTUNE:
+        key = ("g", G, n, h, w, d.C, oc, k, pad, int(transposed), d.ldx, d.ldy, flags, d.ldpre, d.ldmask, wrows, wcols)
+        algo = _algo_cache.get(key)
+        if algo is None:
+            if flags & (L.EPI_ACCUM | L.EPI_PREADD):
+                # timing runs would accumulate into live data: tune on scratch outputs with the same strides
+                span = (n * h * w - 1) * y0.ld + oc
+                scratch = torch.empty(G * span + 64, dtype=torch.float32, device=device)
+                tio = (L.ConvIO * G)()
+                for g in range(G):
+                    for f_, _ in L.ConvIO._fields_:
+                        setattr(tio[g], f_, getattr(ios[g], f_))
+                    tio[g].y = scratch.data_ptr() + 4 * g * span
+                    if pres is not None and pres[g].ptr == ys[g].ptr:
+                        tio[g].pre = tio[g].y
+            else:
+                tio = ios
+
+            def run(a):
+                d.reserved = a
+                nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
+                w_, wn_ = workspace(nb, device) if nb else (None, 0)
+                return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
+            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run)
+        d.reserved = algo
+    nbytes = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
+    ws, ws_n = workspace(nbytes, device) if nbytes else (None, 0)
+    e0 = _prof_begin()
+    L.check(lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream()), "conv2d_grouped")
+    _prof_end("igemm", 2.0 * G * n * h * w * x0.c * oc * k[0] * k[1], e0,
+              f"{'T' if transposed else 'C'} {G}x {x0.c}->{oc} k{k[0]} in{h}x{w} f{flags} {label}")
+
+
+def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[int, int], pad: int, *, device, accumulate=True,
+                label: str = ""):
+    """G stride-1 weight gradients of one geometry in one slab launch, reductions deferred (WGRAD_DEFER must be active).
+    ps / qs: lists of V (dense operand = output gradient, gathered operand = layer input); gs: list of
+    (address of g[0][j0][0], gJtot) -- the job writes g[i][j0 + j][t], i < gi, j < gj, of a parameter whose second dim is
+    gJtot.  Returns nothing; the jobs are queued on WGRAD_DEFER."""
+    lib = L.load()
+    G = len(ps)
+    p0, q0 = ps[0], qs[0]
+    d = L.WgradDesc(N=n, PH=h, PW=w, PC=p0.c, ldp=p0.ld, QH=h, QW=w, QC=q0.c, ldq=q0.ld, kh=k[0], kw=k[1], stride=1, pad=pad,
+                    gI=gi, gJ=gj, accumulate=int(accumulate), algo=0)
+    pa, qa, ga = (C.c_void_p * G)(*[v.ptr for v in ps]), (C.c_void_p * G)(*[v.ptr for v in qs]), (C.c_void_p * G)(*[g[0] for g in gs])
+    if AUTOTUNE:
+        key = ("wg", G, n, h, w, p0.c, p0.ld, q0.c, q0.ld, k, pad, gi, gj)
+        algo = _algo_cache.get(key)
+        if algo is None:
+            tmp = torch.empty(G * gi * gj * k[0] * k[1] + 64, dtype=torch.float32, device=device)
+            ta = (C.c_void_p * G)(*[tmp.data_ptr() + 4 * g * gi * gj * k[0] * k[1] for g in range(G)])
+            jobs_t = (L.WgradJob * G)()
+
+            def run(a):
+                d.algo = a
+                nb = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
+                if nb == 0 or nb > (8 << 30):
+                    return False
+                w_, wn_ = workspace(nb, device)
+                return lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ta, G, w_, wn_, jobs_t, _stream()) == 0
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run)
+        d.algo = algo
+    nbytes = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
+    jobs = (L.WgradJob * G)()
+    e0 = _prof_begin()
+    assert WGRAD_DEFER is not None, "wgrad_group needs deferred weight-gradient reductions (ops.WGRAD_DEFER)"
+    L.check(lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ga, G, WGRAD_DEFER.alloc(nbytes), nbytes, jobs, _stream()),
+            "conv2d_wgrad_partial_grouped")
+    for g in range(G):
+        jb = L.WgradJob()
+        C.memmove(C.byref(jb), C.byref(jobs[g]), C.sizeof(L.WgradJob))
+        jb.gJtot = gs[g][1]
+        WGRAD_DEFER.jobs.append(jb)
+    _prof_end("wgrad", 2.0 * G * n * h * w * gi * gj * k[0] * k[1], e0, f"W {G}x {gi}x{gj} k{k[0]} p{h}x{w} {label}")
+
+
+def wgrad_split(n: int, h: int, w: int, p: V, q: V, parts, k: Tuple[int, int], pad: int, *, device, label: str = ""):
+    """ONE slab launch whose rows feed several parameters: P = a wide output-gradient range (p.c channels = the
+    concatenated outputs of several convs that read the same input q), parts = [(row0, rows, address of g[0][j0][0],
+    gJtot)]: rows [row0, row0 + rows) of the slab reduce into g[i][j0 + j][t], j < q.c."""
+    lib = L.load()
+    d = L.WgradDesc(N=n, PH=h, PW=w, PC=p.c, ldp=p.ld, QH=h, QW=w, QC=q.c, ldq=q.ld, kh=k[0], kw=k[1], stride=1, pad=pad,
+                    gI=p.c, gJ=q.c, accumulate=1, algo=0)
+    if AUTOTUNE:
+        key = ("ws", n, h, w, p.c, p.ld, q.c, q.ld, k, pad)
+        algo = _algo_cache.get(key)
+        if algo is None:
+            tmp = torch.empty(p.c * q.c * k[0] * k[1], dtype=torch.float32, device=device)
+
+            def run(a):
+                d.algo, d.accumulate = a, 0
+                nb = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
+                if nb == 0 or nb > (8 << 30):
+                    return False
+                w_, wn_ = workspace(nb, device)
+                return lib.crdr_conv2d_wgrad(C.byref(d), p.ptr, q.ptr, tmp.data_ptr(), w_, wn_, _stream()) == 0
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run)
+            d.accumulate = 1
+        d.algo = algo
+    nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
+    job = L.WgradJob()
+    e0 = _prof_begin()
+    assert WGRAD_DEFER is not None
+    L.check(lib.crdr_conv2d_wgrad_partial(C.byref(d), p.ptr, q.ptr, parts[0][2], WGRAD_DEFER.alloc(nbytes), nbytes, C.byref(job),
+                                          _stream()), "conv2d_wgrad_partial")
+    for row0, rows, gptr, gjtot in parts:
+        jb = L.WgradJob()
+        C.memmove(C.byref(jb), C.byref(job), C.sizeof(L.WgradJob))
+        jb.slab = job.slab + 4 * row0 * q.c
+        jb.g, jb.gI, jb.gJtot = gptr, rows, gjtot
+        WGRAD_DEFER.jobs.append(jb)
+    _prof_end("wgrad", 2.0 * n * h * w * p.c * q.c * k[0] * k[1], e0, f"W {p.c}x{q.c} k{k[0]} p{h}x{w} {label}")
+
+
+def colsum_scatter(x: V, m: int, block: int, outs_table: torch.Tensor, device, accumulate: bool = True):
+    """outs_table: device int64 tensor of ceil(x.c / block) addresses (0 = skip)."""
+    lib = L.load()
+    nbytes = lib.crdr_colsum_workspace(m, x.c)
+    ws, ws_n = workspace(nbytes, device)
+    L.check(lib.crdr_colsum_scatter(x.ptr, x.ld, m, x.c, block, outs_table.data_ptr(), int(accumulate), ws, ws_n, _stream()),
+            "colsum_scatter")

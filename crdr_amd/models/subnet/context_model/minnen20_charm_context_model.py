@@ -64,108 +64,104 @@ class Minnen20CharmContextModel(BaseContextModel):
     def _support(self, hats: List[Tensor]) -> List[Tensor]:
         return hats if self.max_support_slices < 0 else hats[: self.max_support_slices]
 
+    # ---- noise: Philox state (seed, offset) on the device; the fused kernels draw U(-1/2, 1/2) from it and the backward
+    # regenerates the same samples (crdr_gauss_cond_fwd2).  Seeded per rank by the trainer (seed_noise).
+    def _philox(self, device) -> Tensor:
+        st = getattr(self, "_philox_state", None)
+        if st is None or st.device != device:
+            seed = int(getattr(self, "_noise_seed", torch.initial_seed() & 0x7FFFFFFFFFFFFFFF))
+            st = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+            self._philox_state = st
+        return st
+
+    def seed_noise(self, seed: int) -> None:
+        self._noise_seed = int(seed) & 0x7FFFFFFFFFFFFFFF
+        self._philox_state = None
+
+    def _record(self, run) -> None:
+        """parity tests read the rounding decisions (round(y_hat_pre - mu) per slice)"""
+        if getattr(self, "record_symbols", None) is not None:
+            yp, mu = run.as_nchw(run.Ypre), run.as_nchw(run.MSL, 0, run.Cy)
+            for i in range(self.num_slices):
+                a, b = i * self.slice_ch, (i + 1) * self.slice_ch
+                self.record_symbols.append(torch.round(yp[:, a:b] - mu[:, a:b]))
+
     @torch.no_grad()
     def reconstruct_latent(self, y: Tensor, h_mu: Tensor, entropy_model_y) -> Tensor:
         """y_hat only (the no-grad high-rate pass of stage 3 needs nothing else): y_hat_i = round(y_i - mu_i) + mu_i, then
         the LRP correction, do not depend on the scale transforms or on any likelihood, so those are not evaluated.
         Bit-identical to the y_hat of forward()."""
-        ys = torch.chunk(y, self.num_slices, dim=1)
-        hats: List[Tensor] = []
-        ones = None
-        for i, ysl in enumerate(ys):
-            mean_support = torch.cat([h_mu] + self._support(hats), dim=1)
-            mu = self.mean_slice_transforms[i](mean_support)
-            if ones is None:
-                ones = torch.ones_like(mu)
-            yh = entropy_model_y.forward_split(ysl, mu, ones, is_train=False, want_bits=False, want_lik=False)[0]
-            if getattr(self, "record_symbols", None) is not None:
-                self.record_symbols.append(torch.round(yh.detach() - mu.detach()))
-            z = self.lrp_slice_transforms[i](torch.cat([mean_support, yh], dim=1))
-            hats.append(HF.lrp(yh, z))
-        return torch.cat(hats, dim=1)
+        from crdr_amd.hip import charm
+        run = charm.charm_reconstruct(self, y, h_mu, entropy_model_y.scale_bound, entropy_model_y.likelihood_bound)
+        self._record(run)
+        return run.as_nchw(run.Yh)
 
     def forward(self, y: Tensor, hyper_out: Tensor, entropy_model_y, is_train: bool, calc_q_likelihood: bool = True,
                 noise: Tensor = None, want_lik: bool = True, bits_out: Dict = None):
-        """-> (y_hat, y_likelihood, y_q_likelihood) like the reference; the per-image bit sums produced by the
-        fused kernel are returned through `bits_out["y"], bits_out["y_q"]` when a dict is passed (nothing that carries
-        an autograd graph is kept on the module)."""
-        ys = torch.chunk(y, self.num_slices, dim=1)
-        h_mu, h_sc = torch.chunk(hyper_out, 2, dim=1)
-        ns = None if noise is None else torch.chunk(noise, self.num_slices, dim=1)
-        hats, liks, qliks = [], [], []
-        bits = bits_q = None
-        for i, ysl in enumerate(ys):
-            sup = self._support(hats)
-            mean_support = torch.cat([h_mu] + sup, dim=1)
-            scale_support = torch.cat([h_sc] + sup, dim=1)
-            mu = self.mean_slice_transforms[i](mean_support)
-            sigma = self.scale_slice_transforms[i](scale_support)
-            yh, lik, b, bq, lq = entropy_model_y.forward_split(ysl, mu, sigma, is_train=is_train,
-                                                              noise=None if ns is None else ns[i], want_bits=True,
-                                                              want_lik=want_lik)
-            if getattr(self, "record_symbols", None) is not None:  # parity tests read the rounding decisions
-                self.record_symbols.append(torch.round(yh.detach() - mu.detach()))
-            bits = b if bits is None else bits + b
-            bits_q = bq if bits_q is None else bits_q + bq
-            liks.append(lik)
-            qliks.append(lq)
-            z = self.lrp_slice_transforms[i](torch.cat([mean_support, yh], dim=1))
-            hats.append(HF.lrp(yh, z))
+        """-> (y_hat, y_likelihood, y_q_likelihood) like the reference (:88-141); the per-image bit sums produced by the
+        fused kernels are returned through `bits_out["y"], bits_out["y_q"]` when a dict is passed.  The whole slice loop runs
+        in crdr_amd.hip.charm (hoisted hyper-prior convs, grouped launches, hand-written backward)."""
+        from crdr_amd.hip import charm
+        yh, bn, bq, lik_n, lik_q, mu, sigma = charm.charm_forward(
+            self, y, hyper_out, noise, self._philox(y.device) if (is_train and noise is None) else None,
+            entropy_model_y.scale_bound, entropy_model_y.likelihood_bound, want_lik, is_train)
+        if getattr(self, "record_symbols", None) is not None:
+            for i in range(self.num_slices):
+                a, b = i * self.slice_ch, (i + 1) * self.slice_ch
+                # y_hat before the LRP correction = round(y - mu) + mu
+                self.record_symbols.append(torch.round(y.detach()[:, a:b] - mu[:, a:b]))
         if bits_out is not None:
-            bits_out["y"], bits_out["y_q"] = bits, bits_q
-        y_hat = torch.cat(hats, dim=1)
+            bits_out["y"], bits_out["y_q"] = (bn if is_train else bq), bq
         if not want_lik:
-            return (y_hat, None, None) if calc_q_likelihood else (y_hat, None)
-        y_lik = torch.cat(liks, dim=1)
+            return (yh, None, None) if calc_q_likelihood else (yh, None)
+        lik = lik_n if is_train else lik_q
         if calc_q_likelihood:
-            return y_hat, y_lik, torch.cat(qliks, dim=1)
-        return y_hat, y_lik
+            return yh, lik, lik_q
+        return yh, lik
 
     # ---- codec paths (GPU transforms, host rANS)
     @torch.no_grad()
     def forward_compress(self, y: Tensor, hyper_out: Tensor, entropy_model_y) -> Tuple[List[bytes], Tensor, Tensor]:
-        ys = torch.chunk(y, self.num_slices, dim=1)
-        h_mu, h_sc = torch.chunk(hyper_out, 2, dim=1)
-        hats, liks, mus, sigmas = [], [], [], []
-        for i, ysl in enumerate(ys):
-            sup = self._support(hats)
-            mean_support = torch.cat([h_mu] + sup, dim=1)
-            scale_support = torch.cat([h_sc] + sup, dim=1)
-            mu = self.mean_slice_transforms[i](mean_support)
-            sigma = self.scale_slice_transforms[i](scale_support)
-            mus.append(mu)
-            sigmas.append(sigma)
-            yh, lik = entropy_model_y.forward_split(ysl, mu, sigma, is_train=False)
-            z = self.lrp_slice_transforms[i](torch.cat([mean_support, yh], dim=1))
-            hats.append(HF.lrp(yh, z))
-            liks.append(lik)
-        y_hat, y_lik = torch.cat(hats, 1), torch.cat(liks, 1)
-        y_mean, y_scale = torch.cat(mus, 1), torch.cat(sigmas, 1)
-        indexes = entropy_model_y.build_indexes(y_scale)
-        y_str = entropy_model_y.compress(y, indexes=indexes, means=y_mean)
-        return y_str, y_hat, y_lik
+        yh, _, _, _, lik_q, mu, sigma = self.forward_raw_eval(y, hyper_out, entropy_model_y)
+        indexes = entropy_model_y.build_indexes(sigma)
+        y_str = entropy_model_y.compress(y, indexes=indexes, means=mu)
+        return y_str, yh, lik_q
+
+    @torch.no_grad()
+    def forward_raw_eval(self, y, hyper_out, entropy_model_y):
+        from crdr_amd.hip import charm
+        return charm.charm_forward(self, y, hyper_out, None, None, entropy_model_y.scale_bound, entropy_model_y.likelihood_bound,
+                                   True, False)
 
     @torch.no_grad()
     def forward_decompress(self, y_str: bytes, hyper_out: Tensor, entropy_model_y) -> Tuple[Tensor, Tensor]:
+        """Decoder side (:189-240): the serial rANS decoder on the host alternates with the GPU transforms -- ms + 1 round
+        trips (one per sequential slice, one for the whole tail) instead of one per slice."""
         from crdr_amd.codec import rans
+        from crdr_amd.hip import charm
         cdf = entropy_model_y._quantized_cdf.cpu().numpy()
         sizes = entropy_model_y._cdf_length.cpu().numpy()
         offs = entropy_model_y._offset.cpu().numpy()
         dec = rans.RansDecoder()
         dec.set_stream(y_str)
         h_mu, h_sc = torch.chunk(hyper_out, 2, dim=1)
-        hats, syms = [], []
-        for i in range(self.num_slices):
-            sup = self._support(hats)
-            mean_support = torch.cat([h_mu] + sup, dim=1)
-            scale_support = torch.cat([h_sc] + sup, dim=1)
-            mu = self.mean_slice_transforms[i](mean_support)
-            sigma = self.scale_slice_transforms[i](scale_support)
-            idx = entropy_model_y.build_indexes(sigma)
+        run = charm.CharmRun(charm.plan_for(self), h_mu, h_sc)
+        run.scale_bound, run.lik_bound = entropy_model_y.scale_bound, entropy_model_y.likelihood_bound
+        run.hoist()
+        sc = self.slice_ch
+        mu_all, sg_all = run.as_nchw(run.MSL, 0, run.Cy), run.as_nchw(run.MSL, run.Cy, run.Cy)
+        yh_all, yp_all = run.as_nchw(run.Yh), run.as_nchw(run.Ypre)
+        syms = torch.empty((run.n, run.Cy, run.h, run.w), dtype=torch.int32, device=hyper_out.device)
+        for st in run.stages():
+            run.mean_scale(st)
+            # the stream holds the symbols in (channel, row, column) order: the channels of a stage are consecutive in it
+            a, b = st[0] * sc, (st[-1] + 1) * sc
+            idx = entropy_model_y.build_indexes(sg_all[:, a:b])
             vals = dec.decode_stream(idx.cpu().reshape(-1).int().numpy(), cdf, sizes, offs)
-            sym = torch.from_numpy(vals).view(sigma.shape).to(sigma.device)
-            yh = entropy_model_y.dequantize(sym, mu)
-            z = self.lrp_slice_transforms[i](torch.cat([mean_support, yh], dim=1))
-            hats.append(HF.lrp(yh, z))
-            syms.append(sym)
-        return torch.cat(hats, 1), torch.cat(syms, 1).int()
+            sym = torch.from_numpy(vals).view(run.n, b - a, run.h, run.w).to(hyper_out.device)
+            syms[:, a:b] = sym
+            v = entropy_model_y.dequantize(sym, mu_all[:, a:b])
+            yh_all[:, a:b] = v
+            yp_all[:, a:b] = v
+            run.lrp(st)
+        return yh_all, syms

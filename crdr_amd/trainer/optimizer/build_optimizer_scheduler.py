@@ -232,19 +232,23 @@ class Adam:
 
 
 class MultiStepLR:
+    """torch.optim.lr_scheduler.MultiStepLR semantics (build_optimizer_scheduler.py:60-77 builds the torch class): the
+    schedule is *chainable* -- step() multiplies the optimiser's current lr by gamma when a milestone is reached and
+    leaves it alone otherwise, so an lr set from outside (load_checkpoint's new_g_lr / new_d_lr,
+    base_trainer.py:update_learning_rate) survives until the next milestone, and load_state_dict restores the counters
+    only (the lr itself travels in the optimiser's state dict)."""
+
     def __init__(self, optimizer, milestones: Iterable[int], gamma: float = 0.1):
         self.optimizer, self.milestones, self.gamma = optimizer, sorted(milestones), gamma
         self.base_lrs = [g["lr"] for g in optimizer.param_groups]
         self.last_epoch = 0
 
-    def _apply(self) -> None:
-        k = sum(1 for m in self.milestones if m <= self.last_epoch)
-        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
-            g["lr"] = base * self.gamma ** k
-
     def step(self) -> None:
         self.last_epoch += 1
-        self._apply()
+        k = sum(1 for m in self.milestones if m == self.last_epoch)  # a milestone listed twice decays twice
+        if k:
+            for g in self.optimizer.param_groups:
+                g["lr"] = g["lr"] * self.gamma ** k
 
     def state_dict(self) -> Dict:
         return {"milestones": list(self.milestones), "gamma": self.gamma, "base_lrs": self.base_lrs, "last_epoch": self.last_epoch}
@@ -252,7 +256,8 @@ class MultiStepLR:
     def load_state_dict(self, sd: Dict) -> None:
         self.last_epoch = sd["last_epoch"]
         self.base_lrs = sd.get("base_lrs", self.base_lrs)
-        self._apply()
+        self.milestones = sorted(sd.get("milestones", self.milestones))
+        self.gamma = sd.get("gamma", self.gamma)
 
 
 OPTIMIZER_REGISTRY.register()(Adam)

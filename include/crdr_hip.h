@@ -55,6 +55,13 @@ int crdr_profile_read(int kind, double* flops, double* ms, long long* launches);
 #define CRDR_EPI_GATE 32   /* s = sigmoid(v); sig[pix][oc] = s; v = gx + gt * s (cheng_nlam.py:23-29) */
 #define CRDR_EPI_AFFINE 64 /* v = v * scale[oc] + shift[oc] (InterpChAtt, interp_channel_attention.py:68-72) */
 #define CRDR_EPI_ACCUM 128 /* y[pix][oc] += v  instead of  = v (gradient accumulation)              */
+/* v = acc + pre[pix][oc] BEFORE the bias: the K range of a conv may be split over several launches (the Charm's
+ * first-layer convs: the hyper-prior channels of all 28 slice transforms are computed up front as two wide convs,
+ * the support channels follow inside the slice loop, minnen20_charm_context_model.py:88-141); pre may alias y */
+#define CRDR_EPI_PREADD 256
+/* v = mask[pix][oc] > 0 ? v : 0, applied last (before ACCUM): the ReLU backward of the layer below, fused into the
+ * input-gradient conv that produces its output gradient (mask = that layer's saved post-ReLU activation) */
+#define CRDR_EPI_RELUMASK 512
 
 typedef struct crdr_conv_desc {
   /* "in" tensor [N][H][W][C] (NHWC, pixel stride ldx) and "out" tensor [N][OH][OW][OC] (pixel stride ldy) */
@@ -76,6 +83,8 @@ typedef struct crdr_conv_desc {
   int32_t reserved; /* 0: built-in heuristic; else a forced algorithm = (config index + 1) | log2(split-K) << 8
                      * (what cudnn.benchmark=True does for the reference, base_trainer.py:20: time the candidates
                      * once per shape and keep the fastest; see crdr_amd/hip/ops.py) */
+  int32_t ldpre;    /* pixel stride of pre  (CRDR_EPI_PREADD)   */
+  int32_t ldmask;   /* pixel stride of mask (CRDR_EPI_RELUMASK) */
 } crdr_conv_desc;
 
 typedef struct crdr_conv_io {
@@ -90,6 +99,8 @@ typedef struct crdr_conv_io {
   const float* gx;
   const float* gt;
   float* sig;
+  const float* pre;
+  const float* mask;
 } crdr_conv_io;
 
 /* number of tile configurations a forced algorithm may name */
@@ -97,6 +108,15 @@ int crdr_conv2d_num_configs(void);
 /* bytes of workspace crdr_conv2d needs for this problem (split-K partial slabs; may be 0) */
 size_t crdr_conv2d_workspace(const crdr_conv_desc* d);
 int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);
+/* G <= CRDR_MAX_GROUP independent convolutions of ONE geometry (same desc) in one launch; problem g reads
+ * ios[g].{x, w, bias, pre, mask} and writes ios[g].y (the other io fields must be unused: flags limited to BIAS, RELU,
+ * LRELU, PREADD, RELUMASK, ACCUM).  The mean and scale transforms of a Charm slice -- and, from slice 5 on, those of
+ * all remaining slices, whose support no longer grows (minnen20_charm_context_model.py:104-105) -- are independent
+ * and identically shaped: one launch fills the chip where 2..15 small ones each pay their own ramp.
+ * Workspace: crdr_conv2d_grouped_workspace(d, G).  No two problems may write overlapping outputs. */
+#define CRDR_MAX_GROUP 16
+size_t crdr_conv2d_grouped_workspace(const crdr_conv_desc* d, int G);
+int crdr_conv2d_grouped(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, void* ws, size_t ws_bytes, crdr_stream_t s);
 /* algorithmic FLOPs of the call (2 * MACs actually needed, padding taps excluded approx.) for roofline maths */
 double crdr_conv2d_flops(const crdr_conv_desc* d);
 
@@ -125,10 +145,20 @@ typedef struct crdr_wgrad_job {
   const float* slab;
   float* g;
   int32_t PC, QC, gI, gJ, T, nsplit, smallj, accumulate;
+  int32_t gJtot;   /* second dim of the parameter g points into (0 = gJ): g[(i * gJtot + j) * T + t]; with `g` offset by
+                    * j0 * T the job fills the input-channel range [j0, j0 + gJ) of a wider weight, and with `slab` offset
+                    * by i0 * QC it takes rows [i0, i0 + gI) of the slab: one slab launch may feed several parameters */
+  int32_t reserved;
 } crdr_wgrad_job;
 int crdr_conv2d_wgrad_partial(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* slab,
                               size_t slab_bytes, crdr_wgrad_job* job, crdr_stream_t s);
 int crdr_wgrad_reduce_batched(const crdr_wgrad_job* jobs, const int64_t* prefix, const int64_t* meta, crdr_stream_t s);
+/* G <= CRDR_MAX_GROUP weight gradients of one geometry in one slab launch: problem g = (ps[g], qs[g]) -> gs[g]; `slab`
+ * holds G x crdr_conv2d_wgrad_workspace(d) bytes, jobs[g] describes the pending reduction of problem g. */
+size_t crdr_conv2d_wgrad_grouped_workspace(const crdr_wgrad_desc* d, int G);
+int crdr_conv2d_wgrad_partial_grouped(const crdr_wgrad_desc* d, const float* const* ps, const float* const* qs,
+                                      float* const* gs, int G, void* slab, size_t slab_bytes, crdr_wgrad_job* jobs,
+                                      crdr_stream_t s);
 
 /* src[I][J][T] (a Conv2d / ConvTranspose2d parameter, T = kh*kw) -> dst[T][rows][cols] zero padded.
  * transpose = 0: dst[t][i][j] = src[i][j][t] (rows >= I, cols >= J); transpose = 1: dst[t][j][i] = src[i][j][t];
@@ -155,8 +185,15 @@ typedef struct crdr_pack_item {
   const float* src;
   float* dst;
   int32_t I, J, T, rows, cols, mode;
+  /* sub-blocks: element (i, j, t) of the source block is src[(i * srcJ + j) * T + t] (srcJ = 0: J), i.e. `src` may point
+   * at input-channel j0 of a wider parameter; pack element (t, r, c) is dst[t * tstride + r * dld + c] (0: rows * cols
+   * resp. cols), i.e. `dst` may point at a row / column offset inside a wider pack shared by several parameters */
+  int32_t srcJ, dld;
+  int64_t tstride;
 } crdr_pack_item;
 int crdr_pack_weights_batched(const crdr_pack_item* items, const int64_t* prefix, const int64_t* meta, crdr_stream_t s);
+/* one item (a HOST struct, modes 0 / 1, any T) */
+int crdr_pack_weight_item(const crdr_pack_item* item, crdr_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* fused elementwise / reductions (HBM-bound)                                                        */
@@ -225,6 +262,11 @@ int crdr_affine(const float* x, int ldx, const float* scale, const float* shift,
 size_t crdr_colsum_workspace(int64_t M, int C);
 int crdr_colsum(const float* x, int ldx, int64_t M, int C, float* out, int accumulate, void* ws, size_t ws_bytes,
                 crdr_stream_t s);
+/* the same sums scattered block-wise: outs[c / block][c % block] (+)= sum_m x[m][c]; `outs` is a DEVICE array of
+ * ceil(C / block) pointers (NULL = skip that block).  One pass over a wide activation-gradient buffer yields the bias
+ * gradients of every conv whose output lives in it. */
+int crdr_colsum_scatter(const float* x, int ldx, int64_t M, int C, int block, float* const* outs, int accumulate, void* ws,
+                        size_t ws_bytes, crdr_stream_t s);
 
 /* InterpChAtt parameters -> per-channel scale/shift (interp_channel_attention.py:39-73):
  *   l = floor(q), r = min(l+1, L-1), a = r - q; scale = softplus(a W[l] + (1-a) W[r]); shift = a B[l] + (1-a) B[r] */
@@ -266,6 +308,37 @@ int crdr_gauss_cond_fwd(const crdr_gc_desc* d, const float* y, const float* mu, 
 int crdr_gauss_cond_bwd(const crdr_gc_desc* d, const float* y, const float* mu, const float* sigma, const float* noise,
                         const float* gbits, const float* dyhat, int lddyhat, float* dy, float* dmu, float* dsigma,
                         crdr_stream_t s);
+
+/* The same two entries over channel slices of wider tensors and with in-kernel noise.
+ *   io.noise != NULL : explicit U(-1/2,1/2) samples (pixel stride ldnoise) -- the parity tests' path;
+ *   io.noise == NULL && io.philox != NULL : noise drawn in the kernel, Philox4x32-10 keyed by philox[0] (seed) with
+ *     counter (philox[1] + global element index / 4), element index = (n * HW + px) * Ctot + c0 + c; philox is a DEVICE
+ *     array of two uint64 (a captured HIP graph replays with fresh noise when the host bumps philox[1]); the backward
+ *     regenerates the same samples, nothing is stored;
+ *   both NULL : quantised outputs only (eval).
+ * yhat2 (optional) receives a second copy of yhat (pixel stride ldyhat2). lik_* / dy, dmu, dsigma use pixel strides ldlik /
+ * ldgrad (0 = C, dense). */
+typedef struct crdr_gc_desc2 {
+  int32_t N, HW, C;
+  int32_t ldy, ldmu, ldsigma, ldyhat, ldyhat2, ldnoise, ldlik, ldgrad, lddyhat;
+  int32_t Ctot, c0; /* width of the full latent and first channel of this slice (Philox indexing) */
+  float scale_bound, likelihood_bound;
+} crdr_gc_desc2;
+typedef struct crdr_gc_io {
+  const float *y, *mu, *sigma, *noise;
+  const uint64_t* philox;
+  float *yhat, *yhat2, *lik_noisy, *lik_quant, *bits_noisy, *bits_quant;
+  const float *gbits, *dyhat;
+  float *dy, *dmu, *dsigma;
+} crdr_gc_io;
+int crdr_gauss_cond_fwd2(const crdr_gc_desc2* d, const crdr_gc_io* io, crdr_stream_t s);
+int crdr_gauss_cond_bwd2(const crdr_gc_desc2* d, const crdr_gc_io* io, crdr_stream_t s);
+/* U(-1/2, 1/2) samples of the generator above written out: out[(n * HW + px) * ld + c] for c < C (tests, and the noisy
+ * latent the reference's non-STE GaussianConditional returns) */
+/* call[0..1] = state[0..1]; state[1] += inc -- one launch hands a forward pass its own (seed, offset) pair (kept for the
+ * backward) and moves the generator on, so a captured HIP graph draws fresh noise at every replay */
+int crdr_philox_fork(uint64_t* state, uint64_t* call, uint64_t inc, crdr_stream_t s);
+int crdr_philox_uniform(const uint64_t* philox, int N, int HW, int C, int Ctot, int c0, float* out, int ld, crdr_stream_t s);
 
 /* factorised prior (EntropyBottleneck, filters (3,3,3,3)); parameters are passed as one packed block per
  * channel made by the host: see crdr_amd/models/subnet/entropy_model. Replaces SteEntropyBottleneck.forward

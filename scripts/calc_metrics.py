@@ -47,7 +47,7 @@ def avg_lpips(real_paths, fake_paths, device: str, weights=None) -> float:
     from crdr_amd.losses.perceptual_loss import LpipsAlex
     net = LpipsAlex().to(device)
     if weights:
-        net.load_lpips_weights(weights)
+        net.load_lpips_file(weights)  # {"alexnet_features": sd, "lpips_lin": sd}, see crdr_amd/losses/perceptual_loss.py
     else:
         print("warning: no --lpips_weights given, LPIPS runs on randomly initialised weights", file=sys.stderr)
     net.eval()

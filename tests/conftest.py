@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the tests exercise the LPIPS arithmetic on seeded / random weights on purpose (no pretrained file exists offline)
+os.environ.setdefault("CRDR_ALLOW_RANDOM_LPIPS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -232,3 +232,63 @@ def test_calc_metrics_psnr_semantics(tmp_path):
     assert res["num_images"] == 2 and abs(res["PSNR"] - float(np.mean(expect))) < 1e-3
     pooled = 10 * np.log10(255.0 ** 2 / np.mean([255.0 ** 2 / 10 ** (e / 10) for e in expect]))
     assert abs(res["PSNR"] - pooled) > 1.0  # averaging per-image PSNRs is a different number
+
+
+def test_multistep_lr_is_chainable_like_torch():
+    """an lr set from outside (load_checkpoint new_g_lr) must survive scheduler.step() until the next
+    milestone, exactly like torch.optim.lr_scheduler.MultiStepLR (the class the reference builds)."""
+    import torch
+    from crdr_amd.trainer.optimizer.build_optimizer_scheduler import MultiStepLR
+
+    class _Opt:
+        def __init__(self, lr):
+            self.param_groups = [{"lr": lr}]
+    ours = _Opt(1e-4)
+    sch = MultiStepLR(ours, milestones=[3, 6], gamma=0.1)
+    p = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.Adam([p], lr=1e-4)
+    ref = torch.optim.lr_scheduler.MultiStepLR(ref_opt, milestones=[3, 6], gamma=0.1)
+    for it in range(1, 9):
+        if it == 2:  # resume-style override
+            ours.param_groups[0]["lr"] = 5e-5
+            ref_opt.param_groups[0]["lr"] = 5e-5
+        ref_opt.step()
+        sch.step()
+        ref.step()
+        assert abs(ours.param_groups[0]["lr"] - ref_opt.param_groups[0]["lr"]) < 1e-12, it
+    # state round trip keeps counters, not the lr
+    sd = sch.state_dict()
+    o2 = _Opt(7e-6)
+    s2 = MultiStepLR(o2, milestones=[1], gamma=0.5)
+    s2.load_state_dict(sd)
+    assert s2.last_epoch == 8 and s2.milestones == [3, 6] and o2.param_groups[0]["lr"] == 7e-6
+
+
+def test_lpips_loss_refuses_random_weights_unless_allowed(tmp_path, monkeypatch):
+    import torch
+    from crdr_amd.losses.perceptual_loss import ALEX_CFG, LPIPSLoss, _TV_IDX
+    monkeypatch.delenv("CRDR_ALLOW_RANDOM_LPIPS", raising=False)
+    monkeypatch.delenv("CRDR_LPIPS_WEIGHTS", raising=False)
+    with pytest.raises(RuntimeError, match="pretrained"):
+        LPIPSLoss(loss_weight=1.0)
+    assert LPIPSLoss(loss_weight=1.0, allow_random_weights=True).pretrained is False
+    feats, lin = {}, {}
+    for i, (ci, co, k, _, _) in enumerate(ALEX_CFG):
+        feats[f"{_TV_IDX[i]}.weight"] = torch.full((co, ci, k, k), 0.01 * (i + 1))
+        feats[f"{_TV_IDX[i]}.bias"] = torch.full((co,), 0.1 * (i + 1))
+        lin[f"lin{i}.model.1.weight"] = torch.full((1, co, 1, 1), float(i + 2))
+    f = tmp_path / "lpips_alex.pth"
+    torch.save({"alexnet_features": feats, "lpips_lin": lin}, f)
+    m = LPIPSLoss(loss_weight=1.0, weights=str(f))
+    assert m.pretrained and float(m.lpips.net[2].bias[0]) == pytest.approx(0.3) and float(m.lpips.lin[4][7]) == 6.0
+    monkeypatch.setenv("CRDR_LPIPS_WEIGHTS", str(f))
+    assert LPIPSLoss(loss_weight=1.0).pretrained
+    # scripts/calc_metrics.py reads the same file layout
+    from crdr_amd.losses.perceptual_loss import LpipsAlex
+    n = LpipsAlex()
+    n.load_lpips_file(str(f))
+    assert float(n.net[0].weight[0, 0, 0, 0]) == pytest.approx(0.01)
+    bad = tmp_path / "bad.pth"
+    torch.save({"x": 1}, bad)
+    with pytest.raises(ValueError):
+        n.load_lpips_file(str(bad))
