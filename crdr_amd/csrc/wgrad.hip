@@ -220,11 +220,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* ws, float* g, i
   }
 }
 
-// all pending reductions of a backward pass in one launch; block = 256 consecutive outputs (j fastest) of one job
+// All pending reductions of a backward pass in one launch.  Work unit ("tile") of a regular job = one output row i x 64
+// input channels j x ALL T taps: the slab is read in 256-byte row segments (j contiguous), the sums go through LDS and
+// leave as ONE contiguous run of 64 T floats of the parameter gradient g[i][j0 .. j0+63][0 .. T) -- both sides fully
+// coalesced (a direct j-fastest mapping writes 4-byte pieces T floats apart and re-touches every output line T times).
+// RGB jobs (smallj: slab rows are [T][4]) keep 256 consecutive outputs per tile.  Tile count per job (host side):
+// smallj ? ceil(gI gJ T / 256) : gI * ceil(gJ / 64).  Splits are summed in a fixed order (deterministic).
+constexpr int kRedMaxT = 32;
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const crdr_wgrad_job* jobs, const long long* prefix,
                                                                    const long long* meta) {
+  __shared__ float tile[64 * kRedMaxT + 64];
   const int n = (int)meta[0];
   const long long total = meta[1];
+  const int tid = threadIdx.x;
   for (long long tl = blockIdx.x; tl < total; tl += gridDim.x) {
     int lo = 0, hi = n - 1;  // last job with prefix[job] <= tl  (block-uniform)
     while (lo < hi) {
@@ -232,26 +240,55 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const crdr_wg
       if (prefix[mid] <= tl) lo = mid; else hi = mid - 1;
     }
     const crdr_wgrad_job jb = jobs[lo];
-    const long long e = (tl - prefix[lo]) * 256 + threadIdx.x;
-    if (e >= (long long)jb.gI * jb.gJ * jb.T) continue;
-    const int j = (int)(e % jb.gJ);
-    const long long r = e / jb.gJ;
-    const int i = (int)(r % jb.gI), t = (int)(r / jb.gI);
-    // slab element of split s = base + s * stride; four independent chains keep loads in flight (fixed order)
-    const float* base = jb.smallj ? jb.slab + (size_t)i * (4 * jb.T) + 4 * t + j : jb.slab + ((size_t)t * jb.PC + i) * jb.QC + j;
-    const size_t stride = jb.smallj ? (size_t)jb.PC * 4 * jb.T : (size_t)jb.T * jb.PC * jb.QC;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= jb.nsplit; s += 4) {
-      v0 += base[(size_t)s * stride];
-      v1 += base[(size_t)(s + 1) * stride];
-      v2 += base[(size_t)(s + 2) * stride];
-      v3 += base[(size_t)(s + 3) * stride];
+    const long long rel = tl - prefix[lo];
+    const int gJt = jb.gJtot ? jb.gJtot : jb.gJ;
+    if (jb.smallj || jb.T > kRedMaxT) {
+      const long long e = rel * 256 + tid;
+      if (e >= (long long)jb.gI * jb.gJ * jb.T) continue;
+      const int j = (int)(e % jb.gJ);
+      const long long r = e / jb.gJ;
+      const int i = (int)(r % jb.gI), t = (int)(r / jb.gI);
+      const float* base = jb.smallj ? jb.slab + (size_t)i * (4 * jb.T) + 4 * t + j : jb.slab + ((size_t)t * jb.PC + i) * jb.QC + j;
+      const size_t stride = jb.smallj ? (size_t)jb.PC * 4 * jb.T : (size_t)jb.T * jb.PC * jb.QC;
+      float v = 0.f;
+      for (int s = 0; s < jb.nsplit; ++s) v += base[(size_t)s * stride];
+      float* d = jb.g + ((size_t)i * gJt + j) * jb.T + t;
+      *d = jb.accumulate ? *d + v : v;
+      continue;
     }
-    for (; s < jb.nsplit; ++s) v0 += base[(size_t)s * stride];
-    const float v = (v0 + v1) + (v2 + v3);
-    float* d = jb.g + ((size_t)i * (jb.gJtot ? jb.gJtot : jb.gJ) + j) * jb.T + t;
-    *d = jb.accumulate ? *d + v : v;
+    const int jt = (jb.gJ + 63) >> 6;
+    const int i = (int)(rel / jt), j0 = (int)(rel % jt) * 64;
+    const int T = jb.T, jn = min(64, jb.gJ - j0);
+    const size_t stride = (size_t)T * jb.PC * jb.QC;
+    // phase 1: thread -> (tap group tid >> 6, channel tid & 63); sums over splits in split order, four loads in flight
+    const int jl = tid & 63;
+    for (int t = tid >> 6; t < T; t += 4) {
+      float v = 0.f;
+      if (jl < jn) {
+        const float* base = jb.slab + ((size_t)t * jb.PC + i) * jb.QC + j0 + jl;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= jb.nsplit; s += 4) {
+          v0 += base[(size_t)s * stride];
+          v1 += base[(size_t)(s + 1) * stride];
+          v2 += base[(size_t)(s + 2) * stride];
+          v3 += base[(size_t)(s + 3) * stride];
+        }
+        for (; s < jb.nsplit; ++s) v0 += base[(size_t)s * stride];
+        v = (v0 + v1) + (v2 + v3);
+      }
+      tile[jl * (T + 1) + t] = v;  // (T + 1): the transposed read below walks T-strided rows
+    }
+    __syncthreads();
+    // phase 2: the jn * T outputs of this tile are contiguous in g
+    float* d = jb.g + ((size_t)i * gJt + j0) * T;
+    const int cnt = jn * T;
+    for (int e = tid; e < cnt; e += 256) {
+      const int j = e / T, t = e - j * T;
+      const float v = tile[j * (T + 1) + t];
+      d[e] = jb.accumulate ? d[e] + v : v;
+    }
+    __syncthreads();
   }
 }
 

@@ -320,7 +320,7 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
             def run(a):
                 d.algo, d.accumulate = a, 0
                 nb = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
-                if nb > (8 << 30):
+                if nb > (2 << 30):
                     return False
                 w_, wn_ = workspace(nb, p.device)
                 return lib.crdr_conv2d_wgrad(C.byref(d), p.data_ptr(), q.data_ptr(), tmp.data_ptr(), w_, wn_, _stream()) == 0
@@ -395,7 +395,8 @@ class DeferredWgrad:
             host = b"".join(bytes(j) for j in js)
             pre = np.zeros(len(js) + 1, dtype=np.int64)
             for k, j in enumerate(js):
-                pre[k + 1] = pre[k] + (j.gI * j.gJ * j.T + 255) // 256
+                # tiles of crdr_wgrad_reduce_batched: one output row x 64 input channels x all taps (RGB / many-tap jobs: 256 outputs)
+                pre[k + 1] = pre[k] + ((j.gI * j.gJ * j.T + 255) // 256 if (j.smallj or j.T > 32) else j.gI * ((j.gJ + 63) // 64))
             for tk in ([twin] if twin is not None and not torch.cuda.is_current_stream_capturing() else []):
                 self._table((tk, ri), host, pre, len(js))
             tb = self._table((key, ri), host, pre, len(js))
@@ -591,7 +592,7 @@ def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[i
             def run(a):
                 d.algo = a
                 nb = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
-                if nb == 0 or nb > (8 << 30):
+                if nb == 0 or nb > (2 << 30):
                     return False
                 w_, wn_ = workspace(nb, device)
                 return lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ta, G, w_, wn_, jobs_t, _stream()) == 0
@@ -627,7 +628,7 @@ def wgrad_split(n: int, h: int, w: int, p: V, q: V, parts, k: Tuple[int, int], p
             def run(a):
                 d.algo, d.accumulate = a, 0
                 nb = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
-                if nb == 0 or nb > (8 << 30):
+                if nb == 0 or nb > (2 << 30):
                     return False
                 w_, wn_ = workspace(nb, device)
                 return lib.crdr_conv2d_wgrad(C.byref(d), p.ptr, q.ptr, tmp.data_ptr(), w_, wn_, _stream()) == 0

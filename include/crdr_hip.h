@@ -139,7 +139,8 @@ int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, 
 /* Deferred reduction.  crdr_conv2d_wgrad = partial-slab kernel + a small reduce launch per layer; a backward pass makes
  * hundreds of those.  crdr_conv2d_wgrad_partial runs only the slab kernel (into `slab`, crdr_conv2d_wgrad_workspace bytes,
  * which must stay untouched until the reduce) and describes the pending reduction in *job; crdr_wgrad_reduce_batched
- * then finishes ALL pending layers in one launch.  `jobs`, `prefix` (first 256-element output tile of each job) and
+ * then finishes ALL pending layers in one launch.  `jobs`, `prefix` (first tile of each job; a job has gI * ceil(gJ / 64) tiles --
+ * one output row x 64 input channels x all taps -- or ceil(gI gJ T / 256) when smallj is set or T > 32) and
  * `meta` = {number of jobs, total tiles} are DEVICE arrays.  No two jobs of one batch may write the same g. */
 typedef struct crdr_wgrad_job {
   const float* slab;
