@@ -110,7 +110,16 @@ def build_loaders(opt, device) -> Tuple[object, Optional[DataLoader]]:
         train = DeviceCropLoader(DeviceImagePool.from_paths(paths, device), bs, int(o.get("image_size", 256)),
                                  seed=int(opt.get("data_seed", 0)), rank=_D.rank(), world_size=_D.world_size())
     else:
-        train = DataLoader(build_dataset(tr, True), batch_size=bs, drop_last=True, shuffle=True, num_workers=opt.get("num_workers", 8))
+        from crdr_amd.trainer import dist as _D
+        dset = build_dataset(tr, True)
+        gen = torch.Generator().manual_seed(int(opt.get("data_seed", 0)))
+        if _D.world_size() > 1:  # disjoint, reproducible shards per rank (same permutation everywhere, strided by rank)
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(dset, num_replicas=_D.world_size(), rank=_D.rank(), shuffle=True, seed=int(opt.get("data_seed", 0)),
+                                         drop_last=True)
+            train = DataLoader(dset, batch_size=bs, drop_last=True, sampler=sampler, num_workers=opt.get("num_workers", 8))
+        else:
+            train = DataLoader(dset, batch_size=bs, drop_last=True, shuffle=True, generator=gen, num_workers=opt.get("num_workers", 8))
     ev = ds.get("eval_dataset", None)
     evl = DataLoader(build_dataset(ev, False), batch_size=1, shuffle=False, num_workers=1) if ev and os.path.isdir(str(ev.get("root_dir", ""))) else None
     return train, evl

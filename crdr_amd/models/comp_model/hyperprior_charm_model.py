@@ -111,6 +111,20 @@ class HyperpriorCharmModel(BaseModel):
         }
 
     # ---- codec
+    codec_profile: Optional[Dict[str, float]] = None  # set to {} to collect the wall-time split of compress / decompress
+
+    def _tick(self, key: Optional[str], t0: Optional[float] = None) -> float:
+        """Wall-time accounting of the codec (BASELINE config #5 reports {transforms, Charm, rANS}); active only when
+        `codec_profile` is a dict -- each tick synchronises the device, so it is off in normal use."""
+        import time
+        if self.codec_profile is None:
+            return 0.0
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        if key is not None:
+            self.codec_profile[key] = self.codec_profile.get(key, 0.0) + (t - t0)
+        return t
+
     def _make_header_handler(self):
         return HeaderHandler(use_non_zero_ind=False)
 
@@ -136,12 +150,17 @@ class HyperpriorCharmModel(BaseModel):
     def compress(self, real_images: Tensor, **cond) -> Dict:
         N, _, H, W = real_images.shape
         assert N == 1, f"In compress mode, batchsize must be 1, but {N}"
+        t = self._tick(None)
         x = self.data_preprocess(real_images, is_train=False)
         y = self._encode(x, **cond)
         z = self.hyperencoder(y)
         z_hat, z_lik = self.entropy_model_z(z, is_train=False)
+        t = self._tick("transforms", t)
         z_str = self.entropy_model_z.compress(z)
+        t = self._tick("rans", t)
         hyper_out = self.hyperdecoder(z_hat)
+        t = self._tick("transforms", t)
+        self.context_model.codec_profile = self.codec_profile
         y_str, y_hat, y_lik = self.context_model.forward_compress(y, hyper_out, self.entropy_model_y)
         header = self._header_encode((H, W), y_hat, **cond)
         y_bit, y_bpp = self.likelihood_to_bit(y_lik, H * W)
@@ -157,12 +176,18 @@ class HyperpriorCharmModel(BaseModel):
         H, W = header["img_size"]
         s = self.model_stride
         zH, zW = int(np.ceil(H / s)), int(np.ceil(W / s))
+        t = self._tick(None)
         z_symbol = self.entropy_model_z.decompress([string_list[1]], (zH, zW)).to(self.device)
         z_hat = self.entropy_model_z.dequantize(z_symbol)
+        t = self._tick("rans", t)
         hyper_out = self.hyperdecoder(z_hat)
+        t = self._tick("transforms", t)
+        self.context_model.codec_profile = self.codec_profile
         y_hat, _ = self.context_model.forward_decompress(string_list[2], hyper_out, self.entropy_model_y)
+        t = self._tick(None)
         fake = self._decode(y_hat, **self._header_cond(header), **cond)
         fake = self.data_postprocess(fake, size=(H, W), is_train=False)
+        self._tick("transforms", t)
         return fake, z_hat, y_hat
 
     # ---- validation (bpp / PSNR over a loader)

@@ -120,11 +120,26 @@ class Minnen20CharmContextModel(BaseContextModel):
         return yh, lik
 
     # ---- codec paths (GPU transforms, host rANS)
+    codec_profile = None  # shared with the model's compress / decompress (wall-time split {charm, rans})
+
+    def _tick(self, key, t0=None):
+        import time
+        if self.codec_profile is None:
+            return 0.0
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        if key is not None:
+            self.codec_profile[key] = self.codec_profile.get(key, 0.0) + (t - t0)
+        return t
+
     @torch.no_grad()
     def forward_compress(self, y: Tensor, hyper_out: Tensor, entropy_model_y) -> Tuple[List[bytes], Tensor, Tensor]:
+        t = self._tick(None)
         yh, _, _, _, lik_q, mu, sigma = self.forward_raw_eval(y, hyper_out, entropy_model_y)
+        t = self._tick("charm", t)
         indexes = entropy_model_y.build_indexes(sigma)
         y_str = entropy_model_y.compress(y, indexes=indexes, means=mu)
+        self._tick("rans", t)
         return y_str, yh, lik_q
 
     @torch.no_grad()
@@ -152,8 +167,10 @@ class Minnen20CharmContextModel(BaseContextModel):
         mu_all, sg_all = run.as_nchw(run.MSL, 0, run.Cy), run.as_nchw(run.MSL, run.Cy, run.Cy)
         yh_all, yp_all = run.as_nchw(run.Yh), run.as_nchw(run.Ypre)
         syms = torch.empty((run.n, run.Cy, run.h, run.w), dtype=torch.int32, device=hyper_out.device)
+        t = self._tick(None)
         for st in run.stages():
             run.mean_scale(st)
+            t = self._tick("charm", t)
             # the stream holds the symbols in (channel, row, column) order: the channels of a stage are consecutive in it
             a, b = st[0] * sc, (st[-1] + 1) * sc
             idx = entropy_model_y.build_indexes(sg_all[:, a:b])
@@ -163,5 +180,7 @@ class Minnen20CharmContextModel(BaseContextModel):
             v = entropy_model_y.dequantize(sym, mu_all[:, a:b])
             yh_all[:, a:b] = v
             yp_all[:, a:b] = v
+            t = self._tick("rans", t)
             run.lrp(st)
+        self._tick("charm", t)
         return yh_all, syms

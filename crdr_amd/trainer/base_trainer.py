@@ -69,6 +69,9 @@ class BaseTrainer:
         if self.opt.get("pretrained_weight_path", None):
             self.comp_model.load_learned_weight(self.opt.pretrained_weight_path)
         D.broadcast_module_(self.comp_model)
+        cm = getattr(self.comp_model, "context_model", None)
+        if cm is not None and hasattr(cm, "seed_noise"):  # in-kernel Philox noise: one stream per rank
+            cm.seed_noise((torch.initial_seed() + 7919 * (D.rank() + 1)) & 0x7FFFFFFFFFFFFFFF)
         self.comp_model.train()
 
     def set_optimizer_scheduler(self) -> None:

@@ -8,6 +8,9 @@ Per iteration (q = rate index, beta = realism weight, both sampled once per batc
   D: L_D = 1/2 BCE(D(x) - D(x_hat)^, 1) + 1/2 BCE(D(x_hat)^ - D(x)^, 0), ^ = detached; Adam.
 The reference evaluates D(x_hat) three times per iteration with unchanged discriminator weights; here the two
 discriminator-phase evaluations share one forward (identical values, gradients sum to the same total).
+One documented deviation: with a spectral-norm discriminator (HiFiCDiscriminator, not used by any shipped config) every
+training-mode forward runs one power iteration, so the reference's 5 forwards per step advance u / v five times where
+this step advances them three times (hr, fake, [fake; real]) -- same fixed point, slightly slower convergence to it.
 Data parallel: every rank draws the same (q, beta) from a shared seeded generator so exactly one
 sub-discriminator is active per iteration and gradients average like one big batch."""
 from __future__ import annotations

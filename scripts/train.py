@@ -39,6 +39,15 @@ def main():
         from crdr_amd.hip import ops
         ops.AUTOTUNE = True
         ops.load_tune_cache(os.environ.get("CRDR_TUNE_DB", ops.DEFAULT_TUNE_DB))
+    # per-rank seeding (the reference is single-GPU and unseeded): decorrelates the noise draws and shuffles of the
+    # replicas, and makes a run reproducible for a given `seed` (config / CLI overlay; default 0)
+    import random
+    import numpy as np
+    import torch
+    seed = int(opt.get("seed", 0)) + 1000003 * D.rank()
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
     trainer = build_trainer(opt)
     trainer.train_loop()
 

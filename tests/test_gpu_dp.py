@@ -1,0 +1,127 @@
+"""BASELINE config #4 (stage-3 data parallel, RCCL all-reduce of G + D gradients) on ONE GPU:
+
+* the real trainer's data-parallel path through a 1-rank RCCL group (`CRDR_FORCE_DIST=1`, child processes, HIP graphs on
+  and off) logs the same scalars and ends with bit-identical generator / discriminator parameters as the plain run;
+* the data-parallel identity on the real trainer: the mean of the flat G / D gradient buffers of two half-batch passes
+  equals the full-batch pass (what the all-reduce computes across ranks), with the skip flag OR-ed.
+The 2-rank collective logic itself runs on CPU in tests/test_dp_gloo.py (gloo)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests.golden.seeded_weights import seeded_input
+from tests.test_gpu_model import dev, rel
+from tests.test_gpu_step import _opt, _seed_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_worker(out, force_dist, graphs, extra=()):
+    env = dict(os.environ, CRDR_FORCE_DIST="1" if force_dist else "0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "tests.dp_step_worker", str(out)] + (["--graphs"] if graphs else []) + list(extra)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return torch.load(out, map_location="cpu", weights_only=False)
+
+
+@pytest.mark.parametrize("graphs", [True, False])
+def test_trainer_dp_path_on_one_rank_rccl_is_bit_identical(tmp_path, graphs):
+    plain = _run_worker(tmp_path / "plain.pt", False, graphs)
+    dp = _run_worker(tmp_path / "dp.pt", True, graphs)
+    assert plain["dist"] is False and dp["dist"] is True and dp["world"] == 1
+    if graphs:
+        assert dp["graphs"] >= 4, "the data-parallel run did not capture its segments"
+    for a, b in zip(plain["logs"], dp["logs"]):
+        assert a is not None and b is not None and a.keys() == b.keys()
+        for k in a:
+            assert a[k] == b[k], (k, a[k], b[k])
+    for part in ("G", "D"):
+        for k in plain[part]:
+            assert torch.equal(plain[part][k], dp[part][k]), (part, k)
+
+
+def test_dp_ranks_draw_shared_conditions(tmp_path):
+    """with the trainer drawing (q, beta) itself, the data-parallel path uses the seeded shared generators
+    (same sequence on every rank): two runs give identical logs"""
+    a = _run_worker(tmp_path / "a.pt", True, False, ("--draw-conditions", "--iters", "4"))
+    b = _run_worker(tmp_path / "b.pt", True, False, ("--draw-conditions", "--iters", "4"))
+    assert [l["qbpp"] for l in a["logs"]] == [l["qbpp"] for l in b["logs"]]
+    assert len({round(l["qbpp"], 6) for l in a["logs"]}) > 1, "the rate index never changed over 4 draws"
+
+
+def test_dp_identity_on_the_real_trainer():
+    """mean over two half-batch 'ranks' of the flat gradient buffers == the full-batch gradients (generator and active
+    sub-discriminator), same (q, beta), explicit per-sample noise.
+
+    Tolerances.  Everything downstream of the quantiser is bit-identical in the forward pass between the batch splits
+    (asserted on x_hat: rounding absorbs the fp32 summation-order noise of the analysis transform, whose tile / split-K
+    choice depends on the batch size), and its gradients -- decoder, LRP transforms, hyper-decoder / -encoder, the active
+    sub-discriminator -- agree to 2e-5 relative L2.  The ENCODER's own forward differs in the last bits between the splits;
+    a pre-activation that lands on the other side of zero flips its ReLU mask in the backward (a finite jump: measured on
+    the encoder alone, 3e-5 median / 5e-4 worst per tensor at these sizes), so the encoder is held to
+    5e-3; the mean / scale transforms see y only through the heavy-tailed -1/(p ln 2) likelihood gradient (p down to the
+    1e-9 floor under seeded random weights) and are held to 5e-4 with the rate term on, and are exactly zero with it off."""
+    from crdr_amd.trainer import build_trainer
+    tr = build_trainer(_opt(3, bs=4))
+    _seed_params(tr.comp_model, "")
+    _seed_params(tr.discriminator, "")
+    _seed_params(tr.perceptual_loss.lpips, "lpips.")
+    tr.loss_huge_threshold = float("inf")
+    x = seeded_input("image4", (4, 3, 64, 64)).to(dev())
+    ny = seeded_input("noise4.y", (4, 320, 4, 4), 0.5).to(dev())
+    nz = seeded_input("noise4.z", (4, 192, 1, 1), 0.5).to(dev())
+    q, beta = 1, 3.2
+    names = {id(p): n for n, p in tr.comp_model.named_parameters()}
+    g_params = [p for g in tr.g_optimizer.param_groups for p in g["params"]]
+
+    def grads(sl):
+        with tr._step_scope():
+            cond, key = tr._conditions({"rate_ind": q, "beta": beta})
+            tr._runner(key, allow_graph=False)
+            real = tr._stage_input(x[sl])
+            ctx = tr._seg_generator(real, cond, {"y": ny[sl], "z": nz[sl]}, 1)
+            tr._seg_dfwdbwd(ctx)
+            g = torch.cat([b.reshape(-1) for b in tr.g_optimizer.flat_grads()]).clone()
+            d = torch.cat([b.reshape(-1) for b in tr.d_optimizer.flat_grads(partitions=tr._d_parts(q))]).clone()
+            return g, d, float(ctx["bad"]), {k: float(v.detach()) for k, v in ctx["losses"].items()}, ctx["fake"].clone()
+
+    def by_module(avg, full):
+        off, acc = 0, {}
+        for p in g_params:
+            n = p.numel()
+            top = names[id(p)].split(".")
+            top = ".".join(top[:2]) if top[0] == "context_model" else top[0]
+            a = acc.setdefault(top, [0.0, 0.0])
+            a[0] += float((avg[off:off + n] - full[off:off + n]).double().square().sum())
+            a[1] += float(full[off:off + n].double().square().sum())
+            off += n
+        assert off == full.numel()
+        return {k: (d2 / max(n2, 1e-300)) ** 0.5 for k, (d2, n2) in acc.items()}
+
+    lam = (list(tr.rate_loss.lambda_A), list(tr.rate_loss.lambda_B))
+    for rate_on in (False, True):
+        if not rate_on:
+            tr.rate_loss.lambda_A, tr.rate_loss.lambda_B = [0.0] * len(lam[0]), [0.0] * len(lam[1])
+        else:
+            tr.rate_loss.lambda_A, tr.rate_loss.lambda_B = lam
+        gf, df, badf, lf, ff = grads(slice(0, 4))
+        g0, d0, bad0, l0, f0 = grads(slice(0, 2))
+        g1, d1, bad1, l1, f1 = grads(slice(2, 4))
+        assert torch.equal(torch.cat([f0, f1]), ff), "the forward must not depend on how the batch is split"
+        assert gf.abs().max() > 0 and df.abs().max() > 0
+        assert rel((d0 + d1) / 2, df) < 2e-5
+        errs = by_module((g0 + g1) / 2, gf)
+        tol = {"encoder": 5e-3, "context_model.mean_slice_transforms": 5e-4 if rate_on else 1e-30,
+               "context_model.scale_slice_transforms": 5e-4 if rate_on else 1e-30}
+        for k, e in errs.items():
+            assert e < tol.get(k, 2e-5), (rate_on, k, e, errs)
+        assert max(bad0, bad1) == badf == 0.0
+        for k in lf:
+            assert abs((l0[k] + l1[k]) / 2 - lf[k]) <= 2e-5 * max(1.0, abs(lf[k])), (k, l0[k], l1[k], lf[k])

@@ -87,6 +87,76 @@ def test_codec_round_trip_at_kodak_size(tmp_path):
     assert torch.equal(fake.cpu(), fake2.cpu()) and fake.shape == (1, 3, 512, 768)
 
 
+def _smooth_image(h, w, seed):
+    """seeded smooth noise (stand-in for a CLIC photograph: the dataset is not available offline)"""
+    g = torch.Generator().manual_seed(seed)
+    small = torch.rand(1, 3, h // 16 + 1, w // 16 + 1, generator=g) * 2 - 1
+    return torch.nn.functional.interpolate(small, size=(h, w), mode="bicubic", align_corners=False).clamp(-1, 1)
+
+
+FULLRES_WORKER = r"""
+import hashlib, json, sys, torch
+sys.path.insert(0, %(root)r)
+from tests.test_gpu_fullsize import _smooth_image
+from tests.test_gpu_model import _full_model
+model, _ = _full_model(True)
+model.eval(); model.codec_setup()
+out = {}
+for (h, w) in ((1365, 2048), (2048, 1365)):
+    x = _smooth_image(h, w, h)
+    for q in (0.0, 2.25, 4.0):
+        s = model.compress(x, rate_ind=q)["string_list"]
+        out["%%dx%%d q%%g" %% (h, w, q)] = [hashlib.sha256(b).hexdigest() for b in s]
+print("DIGESTS " + json.dumps(out))
+"""
+
+
+def test_fullres_codec_sweep_config5(tmp_path):
+    """BASELINE config #5 stand-in (CLIC-sized inputs, both orientations, q in {0, 2.25, 4}, beta in {0, 3.84}; bpp does not
+    depend on beta, so one encode serves both decodes, README.md:76): the decoder reproduces y_hat and z_hat bit for bit,
+    the same bytes decode to the same image, a second PROCESS produces the same bytes, and the wall-time split
+    {transforms, Charm, rANS} is reported."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.test_gpu_model import _full_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model, _ = _full_model(True)
+    model.eval()
+    model.codec_setup()
+    digests, report = {}, []
+    for (h, w) in ((1365, 2048), (2048, 1365)):
+        x = _smooth_image(h, w, h)
+        for q in (0.0, 2.25, 4.0):
+            model.codec_profile = {}
+            out = model.compress(x, rate_ind=q)
+            enc = dict(model.codec_profile)
+            strings = out["string_list"]
+            digests["%dx%d q%g" % (h, w, q)] = [hashlib.sha256(b).hexdigest() for b in strings]
+            for beta in (0.0, 3.84):
+                model.codec_profile = {}
+                fake, z_hat, y_hat = model.decompress(strings, beta=beta)
+                dec = dict(model.codec_profile)
+                assert torch.equal(y_hat, out["y_hat"]) and torch.equal(z_hat, out["z_hat"]), (h, w, q, beta)
+                assert fake.shape == (1, 3, h, w) and bool(torch.isfinite(fake).all())
+                report.append({"size": [h, w], "q": q, "beta": beta, "bytes": sum(len(s) for s in strings) + 12,
+                               "compress_s": {k: round(v, 4) for k, v in enc.items()}, "decompress_s": {k: round(v, 4) for k, v in dec.items()}})
+                assert set(enc) >= {"transforms", "charm", "rans"} and set(dec) >= {"transforms", "charm", "rans"}
+            model.codec_profile = None
+            fake2, _, _ = model.decompress(strings, beta=3.84)
+            assert torch.equal(fake, fake2)
+    print("FULLRES " + json.dumps(report))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "fullres_sweep.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    r = subprocess.run([sys.executable, "-c", FULLRES_WORKER % {"root": root}], capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("DIGESTS ")][0]
+    assert json.loads(line[8:]) == digests, "a second process produced different bytes"
+
+
 @pytest.mark.parametrize("graphs", [False, True])
 def test_full_stage3_step_is_bit_reproducible(graphs):
     import bench
