@@ -98,13 +98,20 @@ class BaseModel(nn.Module):
         assert len(main) + len(aux) == len(named)
         return main, aux
 
-    def load_state_dict(self, state_dict, strict: bool = True):
+    @staticmethod
+    def _canonical_keys(state_dict) -> "OrderedDict":
+        """compressai >= 1.2.5 stores the factorised prior's parameters as ParameterLists (`matrices.0`); 1.2.4 -- the
+        reference's pin -- and this package use `_matrix0`."""
         sd = OrderedDict()
         for k, v in state_dict.items():
             parts = k.split(".")
             if len(parts) >= 3 and parts[-2] in _EB_RENAMES and parts[-1].isdigit():  # entropy_model_z.matrices.0
                 k = ".".join(parts[:-2] + [f"{_EB_RENAMES[parts[-2]]}{parts[-1]}"])
             sd[k] = v
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        sd = self._canonical_keys(state_dict)
         if isinstance(getattr(self, "entropy_model_z", None), EntropyBottleneck):
             _resize_registered_buffers(self.entropy_model_z, "entropy_model_z", ["_quantized_cdf", "_offset", "_cdf_length"], sd)
         if isinstance(getattr(self, "entropy_model_y", None), GaussianMeanScaleConditional):
@@ -115,7 +122,7 @@ class BaseModel(nn.Module):
     def load_learned_weight(self, ckpt_path: str) -> None:
         get_root_logger().info(f"load checkpoint: {ckpt_path}")
         ckpt = torch.load(ckpt_path, map_location="cpu")
-        incoming = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in ckpt["comp_model"].items())
+        incoming = self._canonical_keys(OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in ckpt["comp_model"].items()))
         own = self.state_dict()
         merged = dict(own)
         merged.update({k: v for k, v in incoming.items() if k in own})  # key intersection (warm start across stages)

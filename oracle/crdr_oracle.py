@@ -210,7 +210,17 @@ def ste_round(x):
     return (torch.round(x) - x).detach() + x  # ste_round.py:4-5
 
 
-FORCE_TOL = 2e-3
+# Window around a rounding boundary (k + 1/2) inside which another correct fp32 implementation may decide differently.
+# y - mu is O(10) after ~100 stacked fp32 convs (relative noise ~1e-6 per conv under a different summation order), so
+# the two implementations' y - mu differ by up to a few 1e-4 in absolute terms; 5e-4 covers that with little slack.
+FORCE_TOL = 5e-4
+
+
+def check_forced(report, numel: int) -> None:
+    """Gate used by every parity test that hands rounding decisions to the oracle: none outside the window, and the
+    adopted ones must stay the rare boundary cases they are meant to be (<= 0.1 % of the symbols, at least 2 allowed)."""
+    assert report.get("mismatch", 0) == 0, report
+    assert report.get("adopted", 0) <= max(2, int(1e-3 * numel)), (report, numel)
 
 
 def forced_round(v, forced=None, report=None):
@@ -225,6 +235,7 @@ def forced_round(v, forced=None, report=None):
     if report is not None:
         report["mismatch"] = report.get("mismatch", 0) + int(((q != forced) & ~near).sum())
         report["adopted"] = report.get("adopted", 0) + int(((q != forced) & near).sum())
+        report["symbols"] = report.get("symbols", 0) + int(q.numel())
     return torch.where(near, forced.to(q.dtype), q)
 
 

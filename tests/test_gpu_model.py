@@ -193,7 +193,7 @@ def test_generator_forward_backward(stage3):
     kw = dict(rate_ind=q, beta=beta) if stage3 else {}
     model.context_model.record_symbols = []
     out = model.run_model(x, is_train=True, noise={"y": ny.to(dev()), "z": nz.to(dev())}, **kw)
-    # rounding decisions of the device are adopted by the oracle only where y - mu sits within 2e-3 of a rounding
+    # rounding decisions of the device are adopted by the oracle only where y - mu sits within 5e-4 (oracle.FORCE_TOL) of a rounding
     # boundary (fp32 summation order may flip those); everywhere else they must agree exactly
     forced = {"y": [t.cpu() for t in model.context_model.record_symbols],
               "z": torch.round(out["z_hat"].detach().cpu() - sd["entropy_model_z.quantiles"][:, 0, 1].reshape(1, -1, 1, 1))}
@@ -201,7 +201,7 @@ def test_generator_forward_backward(stage3):
     sdg = grad_sd(sd)
     rep = {}
     ref = O.generator_forward(sdg, x, q, beta, ny, nz, forced=forced, report=rep)
-    assert rep.get("mismatch", 0) == 0, rep
+    O.check_forced(rep, rep.get("symbols", 0))
     loss_ref = O.mse_loss(x, ref["fake_images"]) + 0.4 * ref["bpp"].mean()
     loss_ref.backward()
     close(out["y_hat"], ref["y_hat"], "y_hat", 3e-4)

@@ -170,7 +170,7 @@ def test_stage3_step():
     hr_forced = {"y": syms[10:], "z": torch.round(z_hats[1] - med)}
     g_ref, d_ref, rep = grad_sd(sd_g), grad_sd(sd_d), {}
     losses, out = O.stage3_g_losses(g_ref, d_ref, sd_l, x, q, beta, ny, nz, forced=forced, hr_forced=hr_forced, report=rep)
-    assert rep.get("mismatch", 0) == 0, rep
+    O.check_forced(rep, rep.get("symbols", 0))
     losses["total"].backward()
     d_ref = grad_sd(sd_g), grad_sd(sd_d)
     d_ref = d_ref[1]
@@ -238,7 +238,7 @@ def test_stage1_step():
     forced = {"y": [t.cpu() for t in tr.comp_model.context_model.record_symbols], "z": torch.round(z_hats[0] - med)}
     g_ref, rep = grad_sd(sd_g), {}
     losses, out = O.stage1_losses(g_ref, sd_l, x, ny, nz, forced=forced, report=rep)
-    assert rep.get("mismatch", 0) == 0, rep
+    O.check_forced(rep, rep.get("symbols", 0))
     losses["total"].backward()
     for k in ("distortion", "rate", "perceptual"):
         close(log[k], losses[k], f"loss {k}", 3e-4)
