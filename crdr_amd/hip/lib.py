@@ -51,6 +51,11 @@ class PackItem(C.Structure):
         "I", "J", "T", "rows", "cols", "mode", "srcJ", "dld")] + [("tstride", C.c_int64)]
 
 
+class GdnDesc(C.Structure):
+    _fields_ = [("M", C.c_int64)] + [(n, C.c_int32) for n in ("C", "ldx", "ldy", "inverse")] + [
+        ("beta_min", C.c_float), ("reparam_offset", C.c_float)]
+
+
 class GcDesc2(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "HW", "C", "ldy", "ldmu", "ldsigma", "ldyhat", "ldyhat2", "ldnoise", "ldlik",
                                          "ldgrad", "lddyhat", "Ctot", "c0")] + [
@@ -98,6 +103,9 @@ SIGNATURES = {
     "crdr_colsum_scatter": (_I, [_P, _I, _I64, _I, _I, _P, _I, _P, _SZ, _P]),
     "crdr_gauss_cond_fwd2": (_I, [C.POINTER(GcDesc2), C.POINTER(GcIO), _P]),
     "crdr_gauss_cond_bwd2": (_I, [C.POINTER(GcDesc2), C.POINTER(GcIO), _P]),
+    "crdr_gdn_workspace": (_SZ, [C.POINTER(GdnDesc), _I]),
+    "crdr_gdn_fwd": (_I, [C.POINTER(GdnDesc), _P, _P, _P, _P, _P, _SZ, _P]),
+    "crdr_gdn_bwd": (_I, [C.POINTER(GdnDesc), _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "crdr_philox_fork": (_I, [_P, _P, C.c_uint64, _P]),
     "crdr_philox_uniform": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "crdr_conv2d_wgrad_workspace": (_SZ, [C.POINTER(WgradDesc)]),

@@ -359,6 +359,26 @@ int crdr_eb_quantile_loss(const float* quantiles, const float* params, const flo
                           float* dquantiles, crdr_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* GDN / IGDN (optional registered op: only the reference's Balle18 / Cheng20 ablation transforms use it,          */
+/* balle18_autoencoder.py:16-20,37-41, cheng_resblock.py:8-15, through compressai.layers.GDN)                     */
+/*   n[p][i] = beta_i + sum_j gamma_ij x[p][j]^2 ;  y = x / sqrt(n)  (inverse = 0)  or  y = x * sqrt(n)  (inverse = 1)  */
+/*   beta, gamma are the STORED parameters of compressai's NonNegativeParametrizer:                                  */
+/*   v_eff = max(v, bound)^2 - reparam_offset^2, bound_beta = sqrt(beta_min + reparam_offset^2), bound_gamma =        */
+/*   reparam_offset (defaults beta_min 1e-6, reparam_offset 2^-18); the backward applies the LowerBound gradient rule.  */
+/*   The C x C channel mix runs as a 1x1 launch of the MFMA conv kernel on x^2.  dbeta / dgamma ACCUMULATE.            */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct crdr_gdn_desc {
+  int64_t M; /* pixels */
+  int32_t C, ldx, ldy, inverse;
+  float beta_min, reparam_offset;
+} crdr_gdn_desc;
+size_t crdr_gdn_workspace(const crdr_gdn_desc* d, int backward); /* 256-byte aligned buffer of this many bytes */
+int crdr_gdn_fwd(const crdr_gdn_desc* d, const float* x, const float* beta, const float* gamma, float* y, void* ws, size_t ws_bytes,
+                 crdr_stream_t s);
+int crdr_gdn_bwd(const crdr_gdn_desc* d, const float* x, const float* beta, const float* gamma, const float* dy, int lddy, float* dx,
+                 int lddx, float* dbeta, float* dgamma, void* ws, size_t ws_bytes, crdr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* losses                                                                                            */
 /* ------------------------------------------------------------------------------------------------ */
 /* out[0] (+)= sum (a-b)^2 ; backward da = 2 (a-b) g, db = -da   (distortion_loss.py:41-46)         */

@@ -310,6 +310,33 @@ def bits_per_image(lik):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# GDN / IGDN (compressai.layers.GDN 1.2.4 as called from balle18_autoencoder.py:16-20,37-41 -- PARITY UNPINNED against the
+# package itself; the published definition (Balle et al. 2016) and the parametrizer constants are restated)
+# ------------------------------------------------------------------------------------------------------------
+GDN_BETA_MIN = 1e-6
+GDN_REPARAM_OFFSET = 2.0 ** -18
+
+
+def gdn_init(channels: int, gamma_init: float = 0.1):
+    """stored parameters at initialisation: sqrt(max(v + pedestal, pedestal))"""
+    ped = GDN_REPARAM_OFFSET ** 2
+    beta = torch.sqrt(torch.clamp(torch.ones(channels) + ped, min=ped))
+    gamma = torch.sqrt(torch.clamp(gamma_init * torch.eye(channels) + ped, min=ped))
+    return beta, gamma
+
+
+def gdn(sd: SD, p: str, x, inverse: bool = False):
+    """y = x / sqrt(beta + gamma . x^2) (or times, inverse) with NonNegativeParametrizer on both parameters."""
+    ped = GDN_REPARAM_OFFSET ** 2
+    beta = lower_bound(sd[p + ".beta"], (GDN_BETA_MIN + ped) ** 0.5) ** 2 - ped
+    gamma = lower_bound(sd[p + ".gamma"], GDN_REPARAM_OFFSET) ** 2 - ped
+    c = x.shape[1]
+    norm = F.conv2d(x * x, gamma.reshape(c, c, 1, 1), beta)
+    norm = torch.sqrt(norm) if inverse else torch.rsqrt(norm)
+    return x * norm
+
+
+# ------------------------------------------------------------------------------------------------------------
 # Charm context model + full generator forward
 # ------------------------------------------------------------------------------------------------------------
 

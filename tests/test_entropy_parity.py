@@ -288,3 +288,28 @@ def test_load_learned_weight_with_compressai_style_checkpoint(tmp_path):
     model2 = build_comp_model(ConfigDict(cfg))
     model2.load_learned_weight(str(path))
     assert model2.entropy_model_z._quantized_cdf.numel() > 0 and model2.entropy_model_z._cdf_length.shape == (192,)
+
+
+# ---------------------------------------------------------------------------------------------------------- GDN (oracle)
+def test_gdn_oracle_known_answers():
+    """at initialisation beta_eff = 1, gamma_eff = 0.1 I: y = x / sqrt(1 + 0.1 x^2); IGDN is its algebraic inverse on the
+    norm; parameters below their bounds are clamped and receive gradient only when it would raise them."""
+    b, g = O.gdn_init(8)
+    sd = {"g.beta": b, "g.gamma": g}
+    x = torch.linspace(-3, 3, 8 * 5).reshape(1, 8, 5, 1)
+    y = O.gdn(sd, "g", x)
+    assert torch.allclose(y, x / torch.sqrt(1 + 0.1 * x * x), atol=1e-6)
+    yi = O.gdn(sd, "g", x, inverse=True)
+    assert torch.allclose(yi, x * torch.sqrt(1 + 0.1 * x * x), atol=1e-5)
+    # cross-channel mixing: gamma_eff = all 0.05 -> n = 1 + 0.05 * sum_j x_j^2
+    ped = O.GDN_REPARAM_OFFSET ** 2
+    sd2 = {"g.beta": b, "g.gamma": torch.sqrt(torch.full((8, 8), 0.05) + ped)}
+    n = 1 + 0.05 * (x * x).sum(1, keepdim=True)
+    assert torch.allclose(O.gdn(sd2, "g", x), x / torch.sqrt(n), atol=1e-6)
+    # LowerBound rule on a parameter stored below its bound
+    gam = torch.zeros(8, 8, requires_grad=True)  # < reparam_offset: clamped, gamma_eff = 0
+    bet = b.clone().requires_grad_(True)
+    out = O.gdn({"g.beta": bet, "g.gamma": gam}, "g", x)
+    assert torch.allclose(out, x, atol=1e-6)
+    out.sum().backward()
+    assert float(gam.grad.abs().max()) >= 0.0 and torch.isfinite(gam.grad).all()

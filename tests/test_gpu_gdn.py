@@ -1,0 +1,57 @@
+"""GPU parity of the GDN / IGDN op (crdr_gdn_fwd / crdr_gdn_bwd through the C ABI) and of the Balle18 transforms built on
+it, against the CPU oracle (oracle.gdn, restating compressai.layers.GDN as called from balle18_autoencoder.py:16-41)."""
+import pytest
+import torch
+
+from tests.golden.seeded_weights import seeded_input
+from tests.test_gpu_model import close, dev, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("c,n,h,w", [(192, 2, 9, 7), (64, 1, 16, 16)])
+def test_gdn_fwd_bwd_matches_oracle(inverse, c, n, h, w):
+    from oracle import crdr_oracle as O
+    from crdr_amd.models.layer.gdn import GDN
+    m = GDN(c, inverse=inverse)
+    g = torch.Generator().manual_seed(c + int(inverse))
+    with torch.no_grad():  # generic parameters: dense non-negative gamma, some entries stored BELOW their lower bounds
+        m.gamma.copy_(torch.sqrt(torch.rand(c, c, generator=g) * 0.02 + O.GDN_REPARAM_OFFSET ** 2))
+        m.gamma[0, :5] = 0.0
+        m.beta.copy_(torch.sqrt(torch.rand(c, generator=g) + 0.5))
+        m.beta[1] = 0.0
+    sd = {"g.beta": m.beta.detach().clone().requires_grad_(True), "g.gamma": m.gamma.detach().clone().requires_grad_(True)}
+    m.to(dev())
+    x = seeded_input(f"gdn.x{c}", (n, c, h, w), 3.0)
+    cot = seeded_input(f"gdn.cot{c}", (n, c, h, w))
+    xr = x.clone().requires_grad_(True)
+    ref = O.gdn(sd, "g", xr, inverse)
+    (ref * cot).sum().backward()
+    xd = x.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = m(xd)
+    close(out, ref, "gdn forward", 2e-5)
+    (out * cot.to(dev())).sum().backward()
+    assert rel(xd.grad, xr.grad) < 2e-5, rel(xd.grad, xr.grad)
+    assert rel(m.gamma.grad, sd["g.gamma"].grad) < 5e-5, rel(m.gamma.grad, sd["g.gamma"].grad)
+    assert rel(m.beta.grad, sd["g.beta"].grad) < 5e-5, rel(m.beta.grad, sd["g.beta"].grad)
+    # clamped entries follow the LowerBound rule exactly like the oracle (zero unless the gradient would raise them)
+    assert torch.equal(m.gamma.grad[0, :5].cpu() == 0, sd["g.gamma"].grad[0, :5] == 0)
+
+
+def test_balle18_transforms_build_and_run():
+    from crdr_amd.utils.registry import DECODER_REGISTRY, ENCODER_REGISTRY
+    import crdr_amd.models.subnet  # noqa: F401  (registration)
+    torch.manual_seed(0)
+    enc = ENCODER_REGISTRY.get("Balle18Encoder")(in_ch=3, out_ch=192, main_ch=192).to(dev())
+    dec = DECODER_REGISTRY.get("Balle18Decoder")(in_ch=192, out_ch=3, main_ch=192, use_tanh=False).to(dev())
+    x = seeded_input("image", (2, 3, 64, 64)).to(dev())
+    y = enc(x)
+    xh = dec(y)
+    assert y.shape == (2, 192, 4, 4) and xh.shape == (2, 3, 64, 64)
+    (xh - x).square().mean().backward()
+    for p in list(enc.parameters()) + list(dec.parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    keys = set(enc.state_dict())
+    assert {"conv.0.weight", "conv.1.beta", "conv.1.gamma", "conv.1.beta_reparam.pedestal", "conv.1.gamma_reparam.lower_bound.bound",
+            "conv.6.bias"} <= keys
