@@ -31,18 +31,6 @@ def draw_crops(shapes: Sequence[Sequence[int]], idx: np.ndarray, size: int, rng:
     return out
 
 
-def crop_reference(img: np.ndarray, size: int, sy0: int, sx0: int, flip: int) -> np.ndarray:
-    """numpy statement of one sample (tests): reflect-pad, crop, flip, ToTensor, Normalize(0.5, 0.5) -> [3][size][size] f32."""
-    h, w, _ = img.shape
-    ph, pw = max(0, size - h), max(0, size - w)
-    pad = np.pad(img, ((ph, ph), (pw, pw), (0, 0)), mode="reflect") if (ph or pw) else img
-    c = pad[sy0 + ph:sy0 + ph + size, sx0 + pw:sx0 + pw + size]
-    if flip:
-        c = c[:, ::-1]
-    t = c.astype(np.float32) / np.float32(255.0)
-    return ((t - np.float32(0.5)) / np.float32(0.5)).transpose(2, 0, 1)
-
-
 class DeviceImagePool:
     """Decoded uint8 RGB images, back to back in one device buffer."""
 

@@ -8,7 +8,7 @@ import torch
 
 def tensor2img(t: torch.Tensor) -> np.ndarray:
     """[1,3,H,W] in [-1,1] -> HWC uint8 by truncation."""
-    x = t.detach().float().cpu().clamp(-1, 1)
+    x = t.detach().float().cpu()
     if x.dim() == 4:
         assert x.shape[0] == 1
         x = x[0]
@@ -17,11 +17,17 @@ def tensor2img(t: torch.Tensor) -> np.ndarray:
 
 
 def calc_psnr(real: torch.Tensor, fake: torch.Tensor, max_val: float = 255) -> float:
-    a, b = tensor2img(real).astype(np.float64), tensor2img(fake).astype(np.float64)
-    mse = np.mean((a - b) ** 2)
+    """src/utils/img_utils.py:102-132 arithmetic, step for step: both images to [0, 255] by (x + 1) / 2 * 255, TRUNCATED to
+    uint8, float32 mean of the squared float32 differences, 10 log10(255^2 / mse) in Python floats (pinned by
+    tests/golden/reference_metrics.json, recorded from the reference's own function)."""
+    import math
+    assert max_val == 255
+    a = tensor2img(real).astype(np.float32)
+    b = tensor2img(fake).astype(np.float32)
+    mse = np.mean(np.power(a - b, 2))
     if mse == 0:
         return float("inf")
-    return float(20 * np.log10(max_val / np.sqrt(mse)))
+    return 10.0 * math.log10((255.0 ** 2) / mse)
 
 
 def imwrite(path: str, t: torch.Tensor) -> None:

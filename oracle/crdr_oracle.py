@@ -310,6 +310,25 @@ def bits_per_image(lik):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# training input transform (src/dataset/data_transform.py:34-39 builds it from torchvision, which is not installed here:
+# RandomCrop(size, pad_if_needed=True, padding_mode='reflect') -> RandomHorizontalFlip -> ToTensor -> Normalize(.5, .5).
+# torchvision's RandomCrop pads BOTH sides of a too-small axis by the full deficit (F.pad with [deficit, 0] / [0, deficit])
+# and pads PIL images through numpy's `reflect` mode -- no edge repeat -- which is what is restated below)
+# ------------------------------------------------------------------------------------------------------------
+def train_transform_sample(img_u8, size: int, sy0: int, sx0: int, flip: int):
+    """One sample: img_u8 [H][W][3] uint8, crop origin (sy0, sx0) in the coordinates of the UNPADDED image (it may be
+    negative / reach past the image exactly when that axis was padded), flip 0 / 1 -> float32 [3][size][size] in [-1, 1]."""
+    h, w, _ = img_u8.shape
+    ph, pw = max(0, size - h), max(0, size - w)
+    pad = np.pad(img_u8, ((ph, ph), (pw, pw), (0, 0)), mode="reflect") if (ph or pw) else img_u8
+    c = pad[sy0 + ph:sy0 + ph + size, sx0 + pw:sx0 + pw + size]
+    if flip:
+        c = c[:, ::-1]
+    t = c.astype(np.float32) / np.float32(255.0)             # ToTensor
+    return ((t - np.float32(0.5)) / np.float32(0.5)).transpose(2, 0, 1)  # Normalize(0.5, 0.5)
+
+
+# ------------------------------------------------------------------------------------------------------------
 # GDN / IGDN (compressai.layers.GDN 1.2.4 as called from balle18_autoencoder.py:16-20,37-41 -- PARITY UNPINNED against the
 # package itself; the published definition (Balle et al. 2016) and the parametrizer constants are restated)
 # ------------------------------------------------------------------------------------------------------------

@@ -292,3 +292,25 @@ def test_lpips_loss_refuses_random_weights_unless_allowed(tmp_path, monkeypatch)
     torch.save({"x": 1}, bad)
     with pytest.raises(ValueError):
         n.load_lpips_file(str(bad))
+
+
+def test_eval_grid_csv_layout_and_gate(tmp_path):
+    """scripts/eval_grid.py writes the reference's rd_results column layout and applies BASELINE.json's gate
+    (bpp +-1e-4, PSNR +-0.01 dB) row by row."""
+    import csv
+    from scripts import eval_grid as E
+    assert E.COLUMNS == ["dataset", "quality", "beta", "bpp", "PSNR", "LPIPS", "DISTS"]
+    assert E.default_qualities() == [0.25 * i for i in range(17)]
+    rows = [{"dataset": "kodak", "quality": 0.0, "beta": 3.84, "bpp": 0.10945, "PSNR": 27.4451, "LPIPS": "", "DISTS": ""},
+            {"dataset": "kodak", "quality": 4.0, "beta": 0.0, "bpp": 1.0501, "PSNR": 37.70, "LPIPS": 0.1, "DISTS": ""}]
+    out = tmp_path / "k.csv"
+    E.write_csv(rows, str(out))
+    with open(out) as f:
+        got = list(csv.reader(f))
+    assert got[0] == E.COLUMNS and got[1][:3] == ["kodak", "0.0", "3.84"] and len(got) == 3
+    ref = tmp_path / "ref.csv"
+    with open(ref, "w") as f:
+        f.write("dataset,quality,beta,bpp,PSNR,LPIPS,DISTS\nkodak,0.0,3.84,0.10944959852430554,27.44512440303645,0.0963,0.104\n"
+                "kodak,4.0,0.0,1.0503268771701388,37.640484422314252,0.03,0.04\nkodak,2.0,0.0,0.4,32.9,0.1,0.1\n")
+    cmp = E.compare_with_reference(rows, str(ref))
+    assert [(c[0], c[1], c[4]) for c in cmp] == [(0.0, 3.84, True), (4.0, 0.0, False)]

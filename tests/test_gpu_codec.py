@@ -54,7 +54,8 @@ def test_device_input_pipeline_matches_torchvision_semantics():
     """crdr_crop_flip_normalize vs the numpy statement of RandomCrop(pad_if_needed, reflect) -> HFlip -> ToTensor ->
     Normalize (data_transform.py:34-39): bit-exact, including images smaller than the crop (reflect padding on both
     sides) and flips."""
-    from crdr_amd.dataset.device_pipeline import DeviceCropLoader, DeviceImagePool, crop_reference, draw_crops
+    from crdr_amd.dataset.device_pipeline import DeviceCropLoader, DeviceImagePool, draw_crops
+    from oracle.crdr_oracle import train_transform_sample as crop_reference  # the checker lives with the oracle, not the product
     rng = np.random.default_rng(7)
     shapes = [(300, 400), (256, 256), (200, 310), (257, 180), (513, 129)]
     imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in shapes]

@@ -180,3 +180,21 @@ dataset:
     sd = torch.load(model_dir / names[0], map_location="cpu")
     keys = list(next(v for k, v in sd.items() if isinstance(v, dict)).keys())
     assert "model.0.weight_orig" in keys and "model.0.weight_u" in keys and "model.8.weight_v" in keys, keys[:8]
+
+
+def test_eval_grid_on_demo_images(tmp_path):
+    """Kodak (q, beta) grid harness on the three demo images with random weights: the reference's csv layout, one bpp per
+    quality shared by both betas (the bitstream does not depend on beta), finite PSNR."""
+    import csv
+    from scripts import eval_grid
+    out = tmp_path / "grid.csv"
+    res = eval_grid.main(["--config_path", os.path.join(ROOT, "config", "crdr.yaml"), "--img_dir", os.path.join(ROOT, "demo_images"),
+                          "--out_csv", str(out), "--qualities", "0.0", "2.25", "--betas", "3.84", "0.0"])
+    assert res["rows"] == 4 and res["images"] == 3
+    with open(out) as f:
+        rows = list(csv.DictReader(f))
+    assert list(rows[0].keys()) == eval_grid.COLUMNS
+    assert [(float(r["quality"]), float(r["beta"])) for r in rows] == [(0.0, 3.84), (2.25, 3.84), (0.0, 0.0), (2.25, 0.0)]
+    # (with freshly initialised InterpChAtt weights every rate level is the identity, so q does not move bpp here)
+    assert rows[0]["bpp"] == rows[2]["bpp"] and rows[1]["bpp"] == rows[3]["bpp"] and float(rows[0]["bpp"]) > 0
+    assert all(np.isfinite(float(r["PSNR"])) for r in rows) and all(r["dataset"] == "kodak" for r in rows)

@@ -212,3 +212,38 @@ def test_hific_discriminator_oracle_matches_reference(name):
         got = sd[gk[len(name) + 6:]].grad
         got = got[:, :8] if got.numel() > 20000 else got
         np.testing.assert_allclose(got.numpy(), g[gk], rtol=2e-4, atol=2e-6)
+
+
+def test_psnr_and_uint8_truncation_match_the_reference():
+    """tests/golden/reference_metrics.json was recorded from the reference's `calc_psnr` / `torch2npimg`
+    (src/utils/img_utils.py:17-42,102-132) by tests/golden/gen_golden_metrics.py."""
+    import hashlib
+    import json
+    from crdr_amd.utils.img_utils import calc_psnr, tensor2img
+    from tests.golden.gen_golden_metrics import images
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_metrics.json")) as f:
+        gold = json.load(f)
+    assert len(gold) >= 4
+    for tag, g in gold.items():
+        real, fake = images(tag, tuple(g["shape"]), g["noise"])
+        img = tensor2img(fake)
+        assert list(img.shape) == g["npimg_shape"] and int(img.astype(np.int64).sum()) == g["npimg_sum"]
+        assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == g["npimg_sha256"], tag
+        assert calc_psnr(real, fake) == g["psnr"], (tag, calc_psnr(real, fake), g["psnr"])
+
+
+def test_train_transform_known_answers():
+    """RandomCrop(pad_if_needed, reflect) -> flip -> ToTensor -> Normalize restated in the oracle: hand-checkable cases."""
+    from oracle.crdr_oracle import train_transform_sample
+    img = np.arange(3 * 4 * 3, dtype=np.uint8).reshape(3, 4, 3) * 7   # 3 rows x 4 cols
+    # no padding needed: plain 2x2 window at (1, 2), flipped horizontally
+    out = train_transform_sample(img, 2, 1, 2, 1)
+    ref = img[1:3, 2:4][:, ::-1].astype(np.float32) / 255.0
+    assert np.array_equal(out, ((ref - 0.5) / 0.5).transpose(2, 0, 1))
+    # crop 5 > both axes: rows padded by 2 on both sides, cols by 1; reflect WITHOUT repeating the edge
+    out = train_transform_sample(img, 5, -2, -1, 0)
+    rows = [2, 1, 0, 1, 2]          # reflect of 3 rows padded by 2: r2 r1 | r0 r1 r2 | r1 r0 -> first five
+    cols = [1, 0, 1, 2, 3]          # reflect of 4 cols padded by 1: c1 | c0 c1 c2 c3 | c2 -> first five
+    ref = img[np.ix_(rows, cols)].astype(np.float32) / 255.0
+    assert np.array_equal(out, ((ref - 0.5) / 0.5).transpose(2, 0, 1))
+    assert out.dtype == np.float32 and out.min() >= -1.0 and out.max() <= 1.0
