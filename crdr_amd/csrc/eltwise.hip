@@ -174,6 +174,40 @@ __global__ __launch_bounds__(256) void colsum_final_scatter(const float* partial
   }
 }
 
+// finish the in-epilogue column sums of the conv kernels (CRDR_EPI_COLSUM): all pending jobs in one launch; tile = 64
+// columns of one job, rows added in order (4 interleaved row lanes, then the lanes in order)
+__global__ __launch_bounds__(256) void colsum_finish_batched_kernel(const crdr_colsum_job* jobs, const long long* prefix,
+                                                                    const long long* meta) {
+  __shared__ float red[2][4][64];
+  const int n = (int)meta[0];
+  const long long total = meta[1];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (long long tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= tl) lo = mid; else hi = mid - 1;
+    }
+    const crdr_colsum_job jb = jobs[lo];
+    const int c = (int)(tl - prefix[lo]) * 64 + tx;
+    float a = 0.f, b = 0.f;
+    if (c < jb.C)
+      for (int r = ty; r < jb.rows; r += 4) {
+        a += jb.cs[((size_t)r * 2 + 0) * jb.ld + c];
+        b += jb.cs[((size_t)r * 2 + 1) * jb.ld + c];
+      }
+    red[0][ty][tx] = a; red[1][ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && c < jb.C) {
+      const float sa = ((red[0][0][tx] + red[0][1][tx]) + red[0][2][tx]) + red[0][3][tx];
+      const float sb = ((red[1][0][tx] + red[1][1][tx]) + red[1][2][tx]) + red[1][3][tx];
+      if (jb.out_pre) jb.out_pre[c] = jb.accumulate ? jb.out_pre[c] + sa : sa;
+      if (jb.out_post) jb.out_post[c] = jb.accumulate ? jb.out_post[c] + sb : sb;
+    }
+    __syncthreads();
+  }
+}
+
 // rows per strip: large enough that the second stage sums <= 512 partials per column
 static int ebwd_blocks(int64_t M, int* rpb) {
   int r = 64;
@@ -820,6 +854,15 @@ extern "C" int crdr_colsum(const float* x, int ldx, int64_t M, int C, float* out
   hipLaunchKernelGGL(colsum_final, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(s), (const float*)ws, M > 0 ? nb : 0, 1,
                      C, out, accumulate, (float*)nullptr);
   CRDR_CHECK_LAUNCH("colsum_final");
+  return 0;
+}
+
+extern "C" int crdr_colsum_finish_batched(const crdr_colsum_job* jobs, const int64_t* prefix, const int64_t* meta,
+                                          crdr_stream_t s) {
+  CRDR_REQUIRE(jobs && prefix && meta, "colsum_finish_batched: null pointer");
+  hipLaunchKernelGGL(colsum_finish_batched_kernel, dim3(1024), dim3(256), 0, as_stream(s), jobs,
+                     reinterpret_cast<const long long*>(prefix), reinterpret_cast<const long long*>(meta));
+  CRDR_CHECK_LAUNCH("colsum_finish_batched_kernel");
   return 0;
 }
 

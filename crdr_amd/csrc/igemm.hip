@@ -40,7 +40,9 @@ struct IgemmArgs {
   float* sig;
   const float* pre;
   const float* mask;
+  float* cs;       // CRDR_EPI_COLSUM: per-tile partial column sums [rows][2][cs_ld] (pre-mask, post-mask)
   int ldpre, ldmask;
+  int cs_ld, cs_rows;
   int ngroup;
   int N, H, W, Cin, ldx;
   int GH, GW, so, OH, OW, ldy, Cout;
@@ -75,12 +77,14 @@ struct IgemmGroup {
   const float* bias[CRDR_MAX_GROUP];
   const float* pre[CRDR_MAX_GROUP];
   const float* mask[CRDR_MAX_GROUP];
+  const float* res[CRDR_MAX_GROUP];
+  float* cs[CRDR_MAX_GROUP];
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 // epilogue on one element; opix = output pixel index, oc = channel
-__device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, int oc, float v) {
+__device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, int oc, float v, float& vpre, float& vpost) {
   const int f = p.flags;
   if (f & CRDR_EPI_PREADD) v += p.pre[opix * p.ldpre + oc];
   if (f & CRDR_EPI_BIAS) v += p.bias[oc];
@@ -94,7 +98,12 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, 
     v = p.gx[opix * p.ldg + oc] + p.gt[opix * p.ldg + oc] * s;
   }
   if (f & CRDR_EPI_AFFINE) v = v * p.scale[oc] + p.shift[oc];
-  if (f & CRDR_EPI_RELUMASK) v = p.mask[opix * p.ldmask + oc] > 0.0f ? v : 0.0f;
+  vpre = v;
+  if (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) {
+    const float mv = p.mask[opix * p.ldmask + oc] - ((f & CRDR_EPI_MASKOFF) ? p.vec2[oc] : 0.0f);
+    v = mv > 0.0f ? v : ((f & CRDR_EPI_LRELUMASK) ? 0.2f * v : 0.0f);
+  }
+  vpost = v;
   float* dst = p.y + opix * p.ldy + oc;
   if (f & CRDR_EPI_ACCUM) v += *dst;
   *dst = v;
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   tile_z -= gidx * zper;
   if (p.ngroup > 1) {
     p.x = grp.x[gidx]; p.w = grp.w[gidx]; p.y = grp.y[gidx];
-    p.bias = grp.bias[gidx]; p.pre = grp.pre[gidx]; p.mask = grp.mask[gidx];
+    p.bias = grp.bias[gidx]; p.pre = grp.pre[gidx]; p.mask = grp.mask[gidx]; p.res = grp.res[gidx]; p.cs = grp.cs[gidx];
   }
   const int phase = tile_z / p.nsplit, split = tile_z % p.nsplit;
   const int tb = tp.tap_begin[phase], te = tp.tap_begin[phase + 1];
@@ -313,6 +322,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   const int hw = p.GH * p.GW;
   const bool direct = (p.nphase == 1) && (p.so == 1);  // output pixel index == GEMM row
   const bool vec = p.vec_epi != 0;
+  // CRDR_EPI_COLSUM: column sums of this tile's outputs (value before / after the ReLU mask), reduced lane -> wave ->
+  // workgroup in a fixed order and written as one partial row per (phase, M tile); crdr_colsum_finish adds the rows up.
+  // Only tile shapes whose passes stage 1, 2 or 4 column blocks qualify (a lane then keeps one 4-channel column group
+  // for the whole pass); build_plan enforces it.
+  const bool do_cs = (f & CRDR_EPI_COLSUM) && p.nsplit == 1;
+  float* sS = smem + WM * WN * 32 * CLD;  // [WM][2][BN] behind the staged accumulators
   // one pass = GC column blocks [JG, JG+GC) of accumulator row-block I (all compile-time so acc stays in registers)
   auto pass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
     constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
@@ -322,6 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
       for (int r = 0; r < 16; ++r)
         sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
     __syncthreads();
+    f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4 * GC; ++k) {
       const int q = lane + 64 * k;
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
           f32x4 res4 = {0.f, 0.f, 0.f, 0.f}, gx4 = res4, gt4 = res4, old4 = res4, pre4 = res4, msk4 = res4;
           if (full) {
             if (f & CRDR_EPI_PREADD) pre4 = *reinterpret_cast<const f32x4*>(p.pre + opix * p.ldpre + oc0);
-            if (f & CRDR_EPI_RELUMASK) msk4 = *reinterpret_cast<const f32x4*>(p.mask + opix * p.ldmask + oc0);
+            if (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) msk4 = *reinterpret_cast<const f32x4*>(p.mask + opix * p.ldmask + oc0);
             if (f & CRDR_EPI_RES) res4 = *reinterpret_cast<const f32x4*>(p.res + opix * p.ldres + oc0);
             if (f & CRDR_EPI_GATE) {
               gx4 = *reinterpret_cast<const f32x4*>(p.gx + opix * p.ldg + oc0);
@@ -375,7 +391,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
               v = gxv + gtv * sgm;
             }
             if (f & CRDR_EPI_AFFINE) v = live ? v * p.scale[oc] + p.shift[oc] : v;
-            if (f & CRDR_EPI_RELUMASK) v = (full ? msk4[e] : (live ? p.mask[opix * p.ldmask + oc] : 0.f)) > 0.0f ? v : 0.0f;
+            if (do_cs && live) cpre[e] += v;
+            if (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) {
+              float mv = full ? msk4[e] : (live ? p.mask[opix * p.ldmask + oc] : 0.f);
+              if (f & CRDR_EPI_MASKOFF) mv -= live ? p.vec2[oc] : 0.f;
+              v = mv > 0.0f ? v : ((f & CRDR_EPI_LRELUMASK) ? 0.2f * v : 0.0f);
+            }
+            if (do_cs && live) cpost[e] += v;
             if (f & CRDR_EPI_ACCUM) v += full ? old4[e] : (live ? p.y[opix * p.ldy + oc] : 0.f);
             o4[e] = v;
           }
@@ -393,6 +415,27 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
         }
       }
     }
+    if (do_cs) {
+      if constexpr (GC == 1 || GC == 2 || GC == 4) {
+        // lanes that share a column group differ in the lane bits >= 8 GC: fixed-order butterfly
+#pragma unroll
+        for (int off = 32; off >= 8 * GC; off >>= 1)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            cpre[e] += __shfl_xor(cpre[e], off, 64);
+            cpost[e] += __shfl_xor(cpost[e], off, 64);
+          }
+        if (lane < 8 * GC) {
+          float* d0 = sS + (wm * 2 + 0) * BN + (wn * NB + JG) * 32 + lane * 4;
+          float* d1 = sS + (wm * 2 + 1) * BN + (wn * NB + JG) * 32 + lane * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (I == 0) { d0[e] = cpre[e]; d1[e] = cpost[e]; }
+            else { d0[e] += cpre[e]; d1[e] += cpost[e]; }
+          }
+        }
+      }
+    }
     __syncthreads();
   };
   pass(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
@@ -402,18 +445,30 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     if constexpr (NB > 4) pass(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
   }
   static_assert(MB <= 2 && NB <= 8, "epilogue passes are written out for MB <= 2, NB <= 8");
+  if (do_cs) {  // (the last pass ended with a barrier) sum the WM row groups in order, one partial row per (phase, M tile)
+    float* dst = p.cs + ((size_t)(phase * gridDim.x + tile_m) * 2) * p.cs_ld;
+    for (int t = tid; t < 2 * BN; t += NT) {
+      const int which = t / BN, c = t - which * BN;
+      float v = sS[(0 * 2 + which) * BN + c];
+#pragma unroll
+      for (int w2 = 1; w2 < WM; ++w2) v += sS[(w2 * 2 + which) * BN + c];
+      if (n0 + c < p.Cout) dst[(size_t)which * p.cs_ld + n0 + c] = v;
+    }
+  }
 }
 
-// reduce split-K slabs in split order, then the same epilogue. grid: (ceil(Cout/64), M rows chunked, nphase)
+// reduce split-K slabs in split order, then the same epilogue. grid: (ceil(Cout/64), M rows chunked, nphase * G)
 __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
+  __shared__ float red[2][4][64];
   IgemmArgs p = p_;
   const int gidx = blockIdx.z / p.nphase;
   const int phase = blockIdx.z - gidx * p.nphase;
   if (p.ngroup > 1) {
-    p.y = grp.y[gidx]; p.bias = grp.bias[gidx]; p.pre = grp.pre[gidx]; p.mask = grp.mask[gidx];
+    p.y = grp.y[gidx]; p.bias = grp.bias[gidx]; p.pre = grp.pre[gidx]; p.mask = grp.mask[gidx]; p.res = grp.res[gidx]; p.cs = grp.cs[gidx];
   }
   const int oc = blockIdx.x * 64 + (threadIdx.x & 63);
   const int hw = p.GH * p.GW;
+  float spre = 0.f, spost = 0.f;
   for (int m = blockIdx.y * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.y * 4) {
     if (oc >= p.Cout) continue;
     float v = 0.f;
@@ -421,7 +476,19 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p_,
     const int n = m / hw, rem = m - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
     const int oh = ga * p.so + tp.poh[phase], ow = gb * p.so + tp.pow[phase];
     if (oh >= p.OH || ow >= p.OW) continue;
-    epilogue_store(p, ((size_t)n * p.OH + oh) * p.OW + ow, oc, v);
+    float a, b;
+    epilogue_store(p, ((size_t)n * p.OH + oh) * p.OW + ow, oc, v, a, b);
+    spre += a; spost += b;
+  }
+  if (p.flags & CRDR_EPI_COLSUM) {  // one partial row per (phase, row chunk): the four row lanes added in order
+    red[0][threadIdx.x >> 6][threadIdx.x & 63] = spre;
+    red[1][threadIdx.x >> 6][threadIdx.x & 63] = spost;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int which = threadIdx.x >> 6, c = threadIdx.x & 63, col = blockIdx.x * 64 + c;
+      const float v = ((red[which][0][c] + red[which][1][c]) + red[which][2][c]) + red[which][3][c];
+      if (col < p.Cout) p.cs[((size_t)(phase * gridDim.y + blockIdx.y) * 2 + which) * p.cs_ld + col] = v;
+    }
   }
 }
 
@@ -496,6 +563,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
   a.wrows = d->wrows; a.wcols = d->wcols;
   a.ldres = d->ldres; a.ldg = d->ldg; a.flags = d->flags;
   a.ldpre = d->ldpre; a.ldmask = d->ldmask; a.ngroup = G;
+  const bool want_cs = (d->flags & CRDR_EPI_COLSUM) != 0;
   CRDR_REQUIRE(G >= 1 && G <= CRDR_MAX_GROUP, "conv2d: group of %d problems (max %d)", G, CRDR_MAX_GROUP);
   a.smallc = d->wlayout == 1;
   CRDR_REQUIRE(!a.smallc || (!d->transposed && d->C <= 4 && d->wcols >= 4 * d->kh * d->kw),
@@ -547,6 +615,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
   for (int c = 0; c < kNumCfgs; ++c) {
     const TileCfg& t = kCfgs[c];
     if (a.smallc && !t.kern_smallc) continue;
+    if (want_cs && (t.nb == 3 || t.nb == 7)) continue;  // in-epilogue column sums need passes of 1, 2 or 4 column blocks
     const int BM = 32 * t.wm * t.mb, BN = 32 * t.wn * t.nb;
     const long long tiles = (long long)cdiv(a.M, BM) * cdiv(d->OC, BN) * a.nphase;
     for (int ns = 1; ns <= 16; ns *= 2) {
@@ -565,6 +634,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
     CRDR_REQUIRE(bc >= 0 && bc < kNumCfgs, "conv2d: forced config %d out of range", bc);
     CRDR_REQUIRE(!a.smallc || kCfgs[bc].kern_smallc, "conv2d: config %d has no tap-major variant", bc);
     CRDR_REQUIRE(bs == 1 || KT / bs >= 2, "conv2d: forced split %d too deep for %d K-iterations", bs, KT);
+    CRDR_REQUIRE(!(want_cs && (kCfgs[bc].nb == 3 || kCfgs[bc].nb == 7)), "conv2d: config %d cannot produce column sums", bc);
   }
   CRDR_REQUIRE(bc >= 0, "conv2d: no tile config");
   const TileCfg& t = kCfgs[bc];
@@ -575,9 +645,12 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
   a.ws_ld = pl->grid.y * BN;
   {
     const size_t staging = (size_t)2 * (BM + BN) * 32 * sizeof(float) + 132 * sizeof(int);
-    const size_t epi = (size_t)t.wm * t.wn * 32 * 32 * std::min(t.nb, 4) * sizeof(float);
+    size_t epi = (size_t)t.wm * t.wn * 32 * 32 * std::min(t.nb, 4) * sizeof(float);
+    if (want_cs && bs == 1) epi += (size_t)t.wm * 2 * BN * sizeof(float);
     pl->lds = std::max(staging, epi);
   }
+  a.cs_ld = round_up(d->OC, 32);
+  a.cs_rows = want_cs ? a.nphase * (bs == 1 ? (int)pl->grid.x : std::min(cdiv(a.M, 4), 2048)) : 0;
   pl->ws_bytes = bs > 1 ? (size_t)G * a.nphase * bs * a.M * a.ws_ld * sizeof(float) : 0;
   return 0;
 }
@@ -600,6 +673,15 @@ extern "C" size_t crdr_conv2d_grouped_workspace(const crdr_conv_desc* d, int G) 
   return pl.ws_bytes;
 }
 
+extern "C" int crdr_conv2d_colsum_layout(const crdr_conv_desc* d, int G, int* rows, int* ld) {
+  CRDR_REQUIRE(d && rows && ld, "conv2d_colsum_layout: null pointer");
+  Plan pl;
+  if (int rc = build_plan(d, &pl, G)) return rc;
+  *rows = pl.a.cs_rows;
+  *ld = pl.a.cs_ld;
+  return 0;
+}
+
 extern "C" double crdr_conv2d_flops(const crdr_conv_desc* d) {
   // exact count of in-bounds multiply-accumulates is shape dependent only at the borders; report the dense count
   if (!d->transposed) return 2.0 * d->N * d->OH * d->OW * (double)d->OC * d->C * d->kh * d->kw;
@@ -613,14 +695,17 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   const crdr_conv_io* io = ios;
   a.x = io->x; a.w = io->w; a.y = io->y; a.ws = (float*)ws;
   a.bias = io->bias; a.vec2 = io->vec2; a.res = io->res; a.scale = io->scale; a.shift = io->shift;
-  a.gx = io->gx; a.gt = io->gt; a.sig = io->sig; a.pre = io->pre; a.mask = io->mask;
+  a.gx = io->gx; a.gt = io->gt; a.sig = io->sig; a.pre = io->pre; a.mask = io->mask; a.cs = io->cs;
   if (a.M == 0) return 0;  // empty batch: nothing to compute (tensors may legitimately be null)
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_VEC2) || a.vec2, "conv2d: VEC2 flag without vec2");
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_RES) || a.res, "conv2d: RES flag without res");
+  CRDR_REQUIRE(!((a.flags & CRDR_EPI_RELUMASK) && (a.flags & CRDR_EPI_LRELUMASK)), "conv2d: RELUMASK and LRELUMASK are exclusive");
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_AFFINE) || (a.scale && a.shift), "conv2d: AFFINE flag without scale/shift");
   CRDR_REQUIRE(!(a.flags & CRDR_EPI_GATE) || (a.gx && a.gt && a.sig), "conv2d: GATE flag without gx/gt/sig");
-  CRDR_REQUIRE(G == 1 || !(a.flags & (CRDR_EPI_VEC2 | CRDR_EPI_RES | CRDR_EPI_AFFINE | CRDR_EPI_GATE)),
+  CRDR_REQUIRE(G == 1 || !(a.flags & (CRDR_EPI_VEC2 | CRDR_EPI_AFFINE | CRDR_EPI_GATE | CRDR_EPI_MASKOFF)),
                "conv2d_grouped: epilogue flags %d not supported in a grouped launch", a.flags);
+  CRDR_REQUIRE(!(a.flags & CRDR_EPI_MASKOFF) || ((a.flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) && a.vec2 && !(a.flags & CRDR_EPI_VEC2)),
+               "conv2d: MASKOFF needs a mask flag and vec2, and excludes VEC2");
   CRDR_REQUIRE(pl.ws_bytes <= ws_bytes, "conv2d: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   IgemmGroup grp;
@@ -629,17 +714,21 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   if (a.flags & CRDR_EPI_RES) v = v && (a.ldres % 4 == 0) && al16(a.res);
   if (a.flags & CRDR_EPI_GATE) v = v && (a.ldg % 4 == 0) && al16(a.gx) && al16(a.gt) && al16(a.sig);
   if (a.flags & CRDR_EPI_PREADD) v = v && (a.ldpre % 4 == 0);
-  if (a.flags & CRDR_EPI_RELUMASK) v = v && (a.ldmask % 4 == 0);
+  if (a.flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) v = v && (a.ldmask % 4 == 0);
   for (int g = 0; g < G; ++g) {
     const crdr_conv_io& q = ios[g];
     CRDR_REQUIRE(q.x && q.w && q.y, "conv2d: null tensor (problem %d)", g);
     CRDR_REQUIRE(!(a.flags & CRDR_EPI_BIAS) || q.bias, "conv2d: BIAS flag without bias (problem %d)", g);
     CRDR_REQUIRE(!(a.flags & CRDR_EPI_PREADD) || q.pre, "conv2d: PREADD flag without pre (problem %d)", g);
-    CRDR_REQUIRE(!(a.flags & CRDR_EPI_RELUMASK) || q.mask, "conv2d: RELUMASK flag without mask (problem %d)", g);
+    CRDR_REQUIRE(!(a.flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) || q.mask, "conv2d: mask flag without mask (problem %d)", g);
+    CRDR_REQUIRE(!(a.flags & CRDR_EPI_RES) || q.res, "conv2d: RES flag without res (problem %d)", g);
+    CRDR_REQUIRE(!(a.flags & CRDR_EPI_COLSUM) || q.cs, "conv2d: COLSUM flag without cs (problem %d)", g);
     grp.x[g] = q.x; grp.w[g] = q.w; grp.y[g] = q.y; grp.bias[g] = q.bias; grp.pre[g] = q.pre; grp.mask[g] = q.mask;
+    grp.res[g] = q.res; grp.cs[g] = q.cs;
     v = v && al16(q.y);
+    if (a.flags & CRDR_EPI_RES) v = v && al16(q.res);
     if (a.flags & CRDR_EPI_PREADD) v = v && al16(q.pre);
-    if (a.flags & CRDR_EPI_RELUMASK) v = v && al16(q.mask);
+    if (a.flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) v = v && al16(q.mask);
   }
   a.vec_epi = v ? 1 : 0;
   const TileCfg& t = kCfgs[pl.cfg];

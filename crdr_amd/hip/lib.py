@@ -27,7 +27,12 @@ class ConvDesc(C.Structure):
 
 class ConvIO(C.Structure):
     _fields_ = [(n, c_void_p) for n in (
-        "x", "w", "y", "bias", "vec2", "res", "scale", "shift", "gx", "gt", "sig", "pre", "mask")]
+        "x", "w", "y", "bias", "vec2", "res", "scale", "shift", "gx", "gt", "sig", "pre", "mask", "cs")]
+
+
+class ColsumJob(C.Structure):
+    _fields_ = [("cs", c_void_p), ("out_pre", c_void_p), ("out_post", c_void_p)] + [(n, C.c_int32) for n in (
+        "rows", "ld", "C", "accumulate")]
 
 
 class WgradDesc(C.Structure):
@@ -78,7 +83,7 @@ class GcDesc(C.Structure):
 
 
 EPI_BIAS, EPI_RELU, EPI_LRELU, EPI_VEC2, EPI_RES, EPI_GATE, EPI_AFFINE, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64, 128
-EPI_PREADD, EPI_RELUMASK = 256, 512
+EPI_PREADD, EPI_RELUMASK, EPI_LRELUMASK, EPI_MASKOFF, EPI_COLSUM = 256, 512, 1024, 2048, 4096
 MAX_GROUP = 16
 EB_PARAMS = 58
 
@@ -95,6 +100,8 @@ SIGNATURES = {
     "crdr_conv2d_workspace": (_SZ, [C.POINTER(ConvDesc)]),
     "crdr_conv2d": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvIO), _P, _SZ, _P]),
     "crdr_conv2d_flops": (_D, [C.POINTER(ConvDesc)]),
+    "crdr_conv2d_colsum_layout": (_I, [C.POINTER(ConvDesc), _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "crdr_colsum_finish_batched": (_I, [_P, _P, _P, _P]),
     "crdr_conv2d_grouped_workspace": (_SZ, [C.POINTER(ConvDesc), _I]),
     "crdr_conv2d_grouped": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _SZ, _P]),
     "crdr_conv2d_wgrad_grouped_workspace": (_SZ, [C.POINTER(WgradDesc), _I]),

@@ -657,3 +657,227 @@ def colsum_scatter(x: V, m: int, block: int, outs_table: torch.Tensor, device, a
     ws, ws_n = workspace(nbytes, device)
     L.check(lib.crdr_colsum_scatter(x.ptr, x.ld, m, x.c, block, outs_table.data_ptr(), int(accumulate), ws, ws_n, _stream()),
             "colsum_scatter")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# general pointer-level conv launch (any stride / transposed / group size / epilogue) + in-epilogue column sums
+# ---------------------------------------------------------------------------------------------------------
+class ColsumQueue:
+    """Pending CRDR_EPI_COLSUM reductions of one device, finished by ONE crdr_colsum_finish_batched launch per flush.
+    The partial-sum buffers are bump-allocated from an arena that is recycled at every flush, so a flush site sees the
+    same addresses every iteration and its device-side job table -- kept per site, rewritten only when the content
+    changes -- survives HIP-graph capture (same scheme as DeferredWgrad)."""
+    CAP = 512
+
+    def __init__(self, device, arena_bytes: int = 128 << 20):
+        self.device = torch.device(device)
+        self.arena = torch.empty(arena_bytes, dtype=torch.uint8, device=self.device)
+        self._old = []
+        self.off = 0
+        self.jobs = []
+        self.tables = {}
+
+    def alloc(self, nfloats: int) -> int:
+        nbytes = (4 * nfloats + 255) // 256 * 256
+        if self.off + nbytes > self.arena.numel():
+            if torch.cuda.is_current_stream_capturing():
+                raise L.CrdrHipError("ColsumQueue: arena too small during graph capture (run eager warm-up iterations first)")
+            self._old.append(self.arena)
+            self.arena = torch.empty(max(2 * self.arena.numel(), 4 * nbytes), dtype=torch.uint8, device=self.device)
+            self.off = 0
+        p = self.arena.data_ptr() + self.off
+        self.off += nbytes
+        return p
+
+    def add(self, cs_ptr: int, rows: int, ld: int, c: int, out_pre: Optional[int], out_post: Optional[int], accumulate: bool):
+        self.jobs.append(L.ColsumJob(cs=cs_ptr, out_pre=out_pre, out_post=out_post, rows=rows, ld=ld, C=c, accumulate=int(accumulate)))
+
+    def _table(self, tkey, host, pre, njobs, cap):
+        tb = self.tables.get(tkey)
+        if tb is None:
+            if cap:
+                raise L.CrdrHipError("ColsumQueue: first flush of this site happened during graph capture")
+            tb = self.tables[tkey] = {"jobs": torch.zeros(self.CAP * C.sizeof(L.ColsumJob), dtype=torch.uint8, device=self.device),
+                                      "prefix": torch.zeros(self.CAP + 1, dtype=torch.int64, device=self.device),
+                                      "meta": torch.zeros(2, dtype=torch.int64, device=self.device), "host": None}
+        if tb["host"] != host:
+            if cap:
+                raise L.CrdrHipError("ColsumQueue: the job table of a captured site changed")
+            tb["jobs"][:len(host)].copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
+            tb["prefix"][:njobs + 1].copy_(torch.from_numpy(pre))
+            tb["meta"].copy_(torch.tensor([njobs, int(pre[-1])], dtype=torch.int64))
+            tb["host"] = host
+        return tb
+
+    def flush(self, key) -> None:
+        if not self.jobs:
+            self.off = 0
+            return
+        import numpy as np
+        lib = L.load()
+        js = self.jobs
+        assert len(js) <= self.CAP
+        host = b"".join(bytes(j) for j in js)
+        pre = np.zeros(len(js) + 1, dtype=np.int64)
+        for k, j in enumerate(js):
+            pre[k + 1] = pre[k] + (j.C + 63) // 64
+        cap = torch.cuda.is_current_stream_capturing()
+        if not cap:  # the twin a later capture of this site will find (it cannot upload)
+            self._table((key, True), host, pre, len(js), False)
+        tb = self._table((key, cap), host, pre, len(js), cap)
+        L.check(lib.crdr_colsum_finish_batched(tb["jobs"].data_ptr(), tb["prefix"].data_ptr(), tb["meta"].data_ptr(), _stream()),
+                "colsum_finish_batched")
+        self.jobs = []
+        self.off = 0
+        if not cap and self._old:
+            self._old = self._old[-1:]  # (the launch just issued may still read the previous arena)
+
+
+_colsum_queues = {}
+
+
+def colsum_queue(device) -> ColsumQueue:
+    dev = torch.device(device)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev.index is None else dev
+    q = _colsum_queues.get(dev)
+    if q is None:
+        q = _colsum_queues[dev] = ColsumQueue(dev)
+    return q
+
+
+def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int, k: Tuple[int, int], stride: int, pad: int,
+               transposed: bool, *, wrows: int, wcols: int, biases=None, pres=None, masks=None, ress=None, vec2=None, scale=None,
+               shift=None, flags: int = 0, colsum: bool = False, wlayout: int = 0, device=None, label: str = ""):
+    """G convolutions of one geometry in one launch, any stride / direction / epilogue (see crdr_conv2d_grouped for what a
+    grouped launch may carry).  xs / ys / pres / masks / ress: lists of V; wpacks / biases: addresses; vec2 / scale / shift:
+    addresses shared by the group (G = 1 only).  colsum=True adds CRDR_EPI_COLSUM and returns [(cs address, rows, ld)] per
+    problem for colsum_queue(device).add (the partial rows live in that queue's arena until its next flush)."""
+    lib = L.load()
+    G = len(xs)
+    x0, y0 = xs[0], ys[0]
+    if biases is not None:
+        flags |= L.EPI_BIAS
+    if pres is not None:
+        flags |= L.EPI_PREADD
+    if ress is not None:
+        flags |= L.EPI_RES
+    if scale is not None:
+        flags |= L.EPI_AFFINE
+    if colsum:
+        flags |= L.EPI_COLSUM
+    cin = min((x0.c + 3) // 4 * 4, x0.ld)  # RGB / single-channel operands: the zeroed padding lanes ride along
+    d = L.ConvDesc(N=n, H=h, W=w, C=cin, OH=oh, OW=ow, OC=oc, kh=k[0], kw=k[1], stride=stride, pad=pad, transposed=int(transposed),
+                   ldx=x0.ld, ldy=y0.ld, wrows=wrows, wcols=wcols, flags=flags, ldres=ress[0].ld if ress is not None else 0, ldg=0,
+                   wlayout=wlayout, reserved=0, ldpre=pres[0].ld if pres is not None else 0,
+                   ldmask=masks[0].ld if masks is not None else 0)
+    ios = (L.ConvIO * G)()
+    for g in range(G):
+        io = ios[g]
+        io.x, io.w, io.y = xs[g].ptr, wpacks[g], ys[g].ptr
+        if biases is not None:
+            io.bias = biases[g]
+        if pres is not None:
+            io.pre = pres[g].ptr
+        if masks is not None:
+            io.mask = masks[g].ptr
+        if ress is not None:
+            io.res = ress[g].ptr
+        if vec2 is not None:
+            io.vec2 = vec2
+        if scale is not None:
+            io.scale, io.shift = scale, shift
+    span = (n * oh * ow - 1) * y0.ld + oc
+
+    def cs_alloc(scratch_ok=False):
+        rows, ld = C.c_int(), C.c_int()
+        L.check(lib.crdr_conv2d_colsum_layout(C.byref(d), G, C.byref(rows), C.byref(ld)), "conv2d_colsum_layout")
+        nf = max(1, rows.value * 2 * ld.value)
+        if scratch_ok:  # tuner trial: any scratch will do
+            t = torch.empty(G * nf, dtype=torch.float32, device=device)
+            return [t.data_ptr() + 4 * g * nf for g in range(G)], rows.value, ld.value, t
+        q = colsum_queue(device)
+        return [q.alloc(nf) for _ in range(G)], rows.value, ld.value, None
+    if AUTOTUNE:
+        key = ("m", G, n, h, w, oh, ow, d.C, oc, k, stride, pad, int(transposed), d.ldx, d.ldy, flags, d.ldres, d.ldpre, d.ldmask,
+               wrows, wcols, wlayout)
+        algo = _algo_cache.get(key)
+        if algo is None:
+            tio = (L.ConvIO * G)()
+            C.memmove(tio, ios, C.sizeof(ios))
+            if flags & (L.EPI_ACCUM | L.EPI_PREADD):  # timing runs must not accumulate into live data
+                scratch = torch.empty(G * span + 64, dtype=torch.float32, device=device)
+                for g in range(G):
+                    tio[g].y = scratch.data_ptr() + 4 * g * span
+                    if pres is not None and pres[g].ptr == ys[g].ptr:
+                        tio[g].pre = tio[g].y
+            keep = []
+
+            def run(a):
+                d.reserved = a
+                if colsum:
+                    try:
+                        bufs, _, _, t = cs_alloc(True)
+                    except L.CrdrHipError:
+                        return False
+                    keep[:] = [t]
+                    for g in range(G):
+                        tio[g].cs = bufs[g]
+                nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
+                w_, wn_ = workspace(nb, device) if nb else (None, 0)
+                return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
+            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run)
+        d.reserved = algo
+    out = None
+    if colsum:
+        bufs, rows, ld, _ = cs_alloc()
+        for g in range(G):
+            ios[g].cs = bufs[g]
+        out = [(b, rows, ld) for b in bufs]
+    nbytes = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
+    ws, ws_n = workspace(nbytes, device) if nbytes else (None, 0)
+    e0 = _prof_begin()
+    L.check(lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream()), "conv2d_grouped")
+    _prof_end("igemm", 2.0 * G * n * (h * w if transposed else oh * ow) * x0.c * oc * k[0] * k[1], e0,
+              f"{'T' if transposed else 'C'} {G}x {x0.c}->{oc} k{k[0]}s{stride} in{h}x{w} f{flags} {label}")
+    return out
+
+
+def wgrad_multi(n: int, ph: int, pw: int, qh: int, qw: int, ps, qs, gs, gi: int, gj: int, k: Tuple[int, int], stride: int, pad: int, *,
+                device, label: str = ""):
+    """G weight gradients of one geometry (any stride), reductions deferred: ps = dense operands (V), qs = gathered operands
+    (V), gs = gradient addresses (full parameters [gi][gj][kh][kw], accumulated)."""
+    lib = L.load()
+    G = len(ps)
+    p0, q0 = ps[0], qs[0]
+    pc, qc = min((p0.c + 3) // 4 * 4, p0.ld), min((q0.c + 3) // 4 * 4, q0.ld)
+    d = L.WgradDesc(N=n, PH=ph, PW=pw, PC=pc, ldp=p0.ld, QH=qh, QW=qw, QC=qc, ldq=q0.ld, kh=k[0], kw=k[1], stride=stride, pad=pad,
+                    gI=gi, gJ=gj, accumulate=1, algo=0)
+    pa, qa, ga = (C.c_void_p * G)(*[v.ptr for v in ps]), (C.c_void_p * G)(*[v.ptr for v in qs]), (C.c_void_p * G)(*gs)
+    if AUTOTUNE:
+        key = ("wm", G, n, ph, pw, pc, p0.ld, qh, qw, qc, q0.ld, k, stride, pad, gi, gj)
+        algo = _algo_cache.get(key)
+        if algo is None:
+            tmp = torch.empty(G * gi * gj * k[0] * k[1] + 64, dtype=torch.float32, device=device)
+            ta = (C.c_void_p * G)(*[tmp.data_ptr() + 4 * g * gi * gj * k[0] * k[1] for g in range(G)])
+            jobs_t = (L.WgradJob * G)()
+
+            def run(a):
+                d.algo = a
+                nb = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
+                if nb == 0 or nb > (2 << 30):
+                    return False
+                w_, wn_ = workspace(nb, device)
+                return lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ta, G, w_, wn_, jobs_t, _stream()) == 0
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run)
+        d.algo = algo
+    nbytes = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
+    jobs = (L.WgradJob * G)()
+    e0 = _prof_begin()
+    assert WGRAD_DEFER is not None, "wgrad_multi needs deferred weight-gradient reductions (ops.WGRAD_DEFER)"
+    L.check(lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ga, G, WGRAD_DEFER.alloc(nbytes), nbytes, jobs, _stream()),
+            "conv2d_wgrad_partial_grouped")
+    for g in range(G):
+        jb = L.WgradJob()
+        C.memmove(C.byref(jb), C.byref(jobs[g]), C.sizeof(L.WgradJob))
+        WGRAD_DEFER.jobs.append(jb)
+    _prof_end("wgrad", 2.0 * G * n * ph * pw * gi * gj * k[0] * k[1], e0, f"W {G}x {gi}x{gj} k{k[0]}s{stride} p{ph}x{pw} {label}")

@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import torch.nn as nn
 
+from crdr_amd.hip import chain as CH
 from crdr_amd.models.layer.hip_layers import HipConv2d, to_image_nhwc
 from crdr_amd.utils.registry import DISCRIMINATOR_REGISTRY
 
@@ -27,11 +28,25 @@ class _Blocks(nn.Module):
         if head:
             self.add_module(str(2 * self.n_act), HipConv2d(c, out_ch, 3, stride=1, padding=1))
 
+    def _chain(self) -> "CH.ChainSpec":
+        """the conv trunk as one hand-scheduled autograd node: LeakyReLU backward fused into the input-gradient convs,
+        bias gradients from their epilogues (crdr_amd/hip/chain.py)"""
+        sp = self.__dict__.get("_chain_spec")
+        if sp is None:
+            layers = [CH.Layer(getattr(self, str(2 * i)), "lrelu") for i in range(self.n_act)]
+            if self.head:
+                layers.append(CH.Layer(getattr(self, str(2 * self.n_act)), None))
+            else:
+                layers[-1] = CH.Layer(layers[-1].conv, None)
+            sp = CH.ChainSpec([[CH.Unit(layers, residual=False)]], name="disc")
+            self.__dict__["_chain_spec"] = sp
+        return sp
+
     def forward(self, x):
+        if self.head:
+            return CH.run_chain(x, self._chain())[0]
         for i in range(self.n_act):
             x = getattr(self, str(2 * i))(x, act="lrelu")
-        if self.head:
-            x = getattr(self, str(2 * self.n_act))(x)
         return x
 
 

@@ -5,6 +5,8 @@ from __future__ import annotations
 
 import torch.nn as nn
 
+from crdr_amd.hip import chain as CH
+
 from .hip_layers import HipConv2d
 
 
@@ -42,7 +44,18 @@ class ChengNLAM(nn.Module):
         self.attention_block = _Seq3(ch)
         self.conv = HipConv2d(ch, ch, 1)
 
+    def _chain(self) -> "CH.ChainSpec":
+        """trunk and attention branches (three residual 1-3-1 bottlenecks each, both reading x) as ONE autograd node of
+        grouped launches (crdr_amd/hip/chain.py)"""
+        sp = self.__dict__.get("_chain_spec")
+        if sp is None:
+            def units(seq):
+                return [CH.Unit([CH.Layer(b.c1, "relu"), CH.Layer(b.c2, "relu"), CH.Layer(b.c3, None)], residual=True)
+                        for b in (getattr(seq, str(i)) for i in range(3))]
+            sp = CH.ChainSpec([units(self.trunk_block), units(self.attention_block)], name="nlam")
+            self.__dict__["_chain_spec"] = sp
+        return sp
+
     def forward(self, x, affine=None):
-        trunk = self.trunk_block(x)
-        attn = self.attention_block(x)
+        trunk, attn = CH.run_chain(x, self._chain())
         return self.conv(attn, gate=(x, trunk), affine=affine)

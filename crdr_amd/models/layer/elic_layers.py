@@ -6,6 +6,8 @@ from __future__ import annotations
 
 import torch.nn as nn
 
+from crdr_amd.hip import chain as CH
+
 from .hip_layers import HipConv2d, HipConvTranspose2d
 
 
@@ -48,10 +50,22 @@ class ResidualBottleneckBlocks(nn.Module):
         for i in range(num_blocks):
             setattr(self, f"block{i}", BaseBlock(ch, mid_ch))
 
+    def _chain(self, affine: bool) -> "CH.ChainSpec":
+        """the whole stack as one hand-scheduled autograd node (crdr_amd/hip/chain.py)"""
+        key = "_chain_aff" if affine else "_chain_plain"
+        sp = self.__dict__.get(key)
+        if sp is None:
+            units = []
+            for i in range(self.num_blocks):
+                c = getattr(self, f"block{i}").conv
+                units.append(CH.Unit([CH.Layer(c[0], "relu"), CH.Layer(c[2], "relu"), CH.Layer(c[4], None)], residual=True))
+            sp = CH.ChainSpec([units], affine=affine, name="bottleneck")
+            self.__dict__[key] = sp
+        return sp
+
     def forward(self, x, affine=None):
-        for i in range(self.num_blocks):
-            x = getattr(self, f"block{i}")(x, affine=affine if i == self.num_blocks - 1 else None)
-        return x
+        s, t = affine if affine is not None else (None, None)
+        return CH.run_chain(x, self._chain(affine is not None), s, t)[0]
 
 
 class BetaCondBaseBlock(nn.Module):
@@ -82,7 +96,23 @@ class BetaCondResidualBottleneckBlocks(nn.Module):
         for i in range(num_blocks):
             setattr(self, f"block{i}", BetaCondBaseBlock(ch, mid_ch, cond_ch))
 
+    def _chain(self, affine: bool) -> "CH.ChainSpec":
+        key = "_chain_aff" if affine else "_chain_plain"
+        sp = self.__dict__.get(key)
+        if sp is None:
+            units = []
+            for i in range(self.num_blocks):
+                c = getattr(self, f"block{i}").conv
+                units.append(CH.Unit([CH.Layer(c[0], "relu", 3 * i), CH.Layer(c[2], "relu", 3 * i + 1), CH.Layer(c[4], None, 3 * i + 2)],
+                                     residual=True))
+            sp = CH.ChainSpec([units], affine=affine, nvec=3 * self.num_blocks, name="beta_bottleneck")
+            self.__dict__[key] = sp
+        return sp
+
     def forward(self, x, cond_feat, affine=None):
+        vecs = []
         for i in range(self.num_blocks):
-            x = getattr(self, f"block{i}")(x, cond_feat, affine=affine if i == self.num_blocks - 1 else None)
-        return x
+            b = getattr(self, f"block{i}")
+            vecs += [b.proj_1(cond_feat).reshape(-1), b.proj_2(cond_feat).reshape(-1), b.proj_3(cond_feat).reshape(-1)]
+        s, t = affine if affine is not None else (None, None)
+        return CH.run_chain(x, self._chain(affine is not None), s, t, vecs)[0]

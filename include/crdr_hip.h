@@ -62,6 +62,14 @@ int crdr_profile_read(int kind, double* flops, double* ms, long long* launches);
 /* v = mask[pix][oc] > 0 ? v : 0, applied last (before ACCUM): the ReLU backward of the layer below, fused into the
  * input-gradient conv that produces its output gradient (mask = that layer's saved post-ReLU activation) */
 #define CRDR_EPI_RELUMASK 512
+#define CRDR_EPI_LRELUMASK 1024 /* v = mask > 0 ? v : 0.2 v: the LeakyReLU(0.2) backward, same position as RELUMASK */
+#define CRDR_EPI_MASKOFF 2048   /* with (L)RELUMASK: compare mask[pix][oc] - vec2[oc] (the layer below added vec2 AFTER its
+                                 * ReLU, so its saved output is relu(z) + vec2); vec2 is NOT added to v in this case */
+/* cs[row][0][oc] = sum over the rows of one (phase, M tile) of v right before the mask step, cs[row][1][oc] = after it
+ * (both before ACCUM): partial column sums of what this launch writes, e.g. the bias / beta-vector gradients of the layer
+ * whose output gradient an input-gradient launch produces.  crdr_conv2d_colsum_layout gives the number of partial rows
+ * and their stride; crdr_colsum_finish_batched adds them up in row order (deterministic). */
+#define CRDR_EPI_COLSUM 4096
 
 typedef struct crdr_conv_desc {
   /* "in" tensor [N][H][W][C] (NHWC, pixel stride ldx) and "out" tensor [N][OH][OW][OC] (pixel stride ldy) */
@@ -101,6 +109,7 @@ typedef struct crdr_conv_io {
   float* sig;
   const float* pre;
   const float* mask;
+  float* cs; /* CRDR_EPI_COLSUM: [rows][2][ld] floats, see crdr_conv2d_colsum_layout */
 } crdr_conv_io;
 
 /* number of tile configurations a forced algorithm may name */
@@ -108,9 +117,23 @@ int crdr_conv2d_num_configs(void);
 /* bytes of workspace crdr_conv2d needs for this problem (split-K partial slabs; may be 0) */
 size_t crdr_conv2d_workspace(const crdr_conv_desc* d);
 int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);
+/* partial-row count and row stride (floats) of io.cs for this problem (depends on the tile configuration the plan picks,
+ * so pass the same desc -- including `reserved` -- and group size as the launch) */
+int crdr_conv2d_colsum_layout(const crdr_conv_desc* d, int G, int* rows, int* ld);
+/* finish pending column sums: job k adds the `rows` partial rows of cs (stride 2 * ld) in order and (accumulating if
+ * accumulate != 0) writes out_pre[c] / out_post[c], c < C (either may be NULL).  `jobs`, `prefix` (first 64-column tile of each
+ * job) and `meta` = {number of jobs, total tiles} are DEVICE arrays, like crdr_wgrad_reduce_batched. */
+typedef struct crdr_colsum_job {
+  const float* cs;
+  float* out_pre;
+  float* out_post;
+  int32_t rows, ld, C, accumulate;
+} crdr_colsum_job;
+int crdr_colsum_finish_batched(const crdr_colsum_job* jobs, const int64_t* prefix, const int64_t* meta, crdr_stream_t s);
+
 /* G <= CRDR_MAX_GROUP independent convolutions of ONE geometry (same desc) in one launch; problem g reads
- * ios[g].{x, w, bias, pre, mask} and writes ios[g].y (the other io fields must be unused: flags limited to BIAS, RELU,
- * LRELU, PREADD, RELUMASK, ACCUM).  The mean and scale transforms of a Charm slice -- and, from slice 5 on, those of
+ * ios[g].{x, w, bias, pre, mask, res, cs} and writes ios[g].y (the other io fields must be unused: flags limited to BIAS,
+ * RELU, LRELU, RES, PREADD, RELUMASK, LRELUMASK, COLSUM, ACCUM).  The mean and scale transforms of a Charm slice -- and, from slice 5 on, those of
  * all remaining slices, whose support no longer grows (minnen20_charm_context_model.py:104-105) -- are independent
  * and identically shaped: one launch fills the chip where 2..15 small ones each pay their own ramp.
  * Workspace: crdr_conv2d_grouped_workspace(d, G).  No two problems may write overlapping outputs. */
