@@ -174,28 +174,66 @@ __global__ __launch_bounds__(256) void colsum_final_scatter(const float* partial
   }
 }
 
-// finish the in-epilogue column sums of the conv kernels (CRDR_EPI_COLSUM): all pending jobs in one launch; tile = 64
-// columns of one job, rows added in order (4 interleaved row lanes, then the lanes in order)
-__global__ __launch_bounds__(256) void colsum_finish_batched_kernel(const crdr_colsum_job* jobs, const long long* prefix,
-                                                                    const long long* meta) {
+// Finish the in-epilogue column sums of the conv kernels (CRDR_EPI_COLSUM): all pending jobs in two launches.  A conv
+// leaves one partial row per (phase, M tile) -- up to 16 K rows for the discriminator's 2 M-pixel layers -- so pass A sums
+// slabs of kColsumSlab rows (tile = 64 columns x one slab, four interleaved row lanes added in order) into a scratch row
+// per slab, pass B adds the slab rows in order and writes / accumulates the targets.  Fixed order throughout.
+constexpr int kColsumSlab = 128;
+__device__ __forceinline__ int find_job(const long long* prefix, int n, long long tl) {
+  int lo = 0, hi = n - 1;  // last job with prefix[job] <= tl  (block-uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= tl) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_a_kernel(const crdr_colsum_job* jobs, const long long* prefix_a,
+                                                              const long long* meta, float* scratch) {
   __shared__ float red[2][4][64];
   const int n = (int)meta[0];
   const long long total = meta[1];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (long long tl = blockIdx.x; tl < total; tl += gridDim.x) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (prefix[mid] <= tl) lo = mid; else hi = mid - 1;
-    }
+    const int lo = find_job(prefix_a, n, tl);
     const crdr_colsum_job jb = jobs[lo];
-    const int c = (int)(tl - prefix[lo]) * 64 + tx;
+    const int rel = (int)(tl - prefix_a[lo]);
+    const int cb = rel / jb.nslab, slab = rel - cb * jb.nslab;
+    const int c = cb * 64 + tx;
+    const int r0 = slab * kColsumSlab, r1 = min(jb.rows, r0 + kColsumSlab);
     float a = 0.f, b = 0.f;
     if (c < jb.C)
-      for (int r = ty; r < jb.rows; r += 4) {
+      for (int r = r0 + ty; r < r1; r += 4) {
         a += jb.cs[((size_t)r * 2 + 0) * jb.ld + c];
         b += jb.cs[((size_t)r * 2 + 1) * jb.ld + c];
       }
+    red[0][ty][tx] = a; red[1][ty][tx] = b;
+    __syncthreads();
+    if (ty == 0) {
+      float* dst = scratch + jb.scratch_off + ((size_t)slab * 2) * jb.cpad + c;
+      dst[0] = ((red[0][0][tx] + red[0][1][tx]) + red[0][2][tx]) + red[0][3][tx];
+      dst[jb.cpad] = ((red[1][0][tx] + red[1][1][tx]) + red[1][2][tx]) + red[1][3][tx];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_b_kernel(const crdr_colsum_job* jobs, const long long* prefix_b,
+                                                              const long long* meta, const float* scratch) {
+  __shared__ float red[2][4][64];
+  const int n = (int)meta[0];
+  const long long total = meta[2];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (long long tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    const int lo = find_job(prefix_b, n, tl);
+    const crdr_colsum_job jb = jobs[lo];
+    const int c = (int)(tl - prefix_b[lo]) * 64 + tx;
+    const float* src = scratch + jb.scratch_off + c;
+    float a = 0.f, b = 0.f;
+    for (int sl = ty; sl < jb.nslab; sl += 4) {
+      a += src[((size_t)sl * 2 + 0) * jb.cpad];
+      b += src[((size_t)sl * 2 + 1) * jb.cpad];
+    }
     red[0][ty][tx] = a; red[1][ty][tx] = b;
     __syncthreads();
     if (ty == 0 && c < jb.C) {
@@ -857,12 +895,17 @@ extern "C" int crdr_colsum(const float* x, int ldx, int64_t M, int C, float* out
   return 0;
 }
 
-extern "C" int crdr_colsum_finish_batched(const crdr_colsum_job* jobs, const int64_t* prefix, const int64_t* meta,
-                                          crdr_stream_t s) {
-  CRDR_REQUIRE(jobs && prefix && meta, "colsum_finish_batched: null pointer");
-  hipLaunchKernelGGL(colsum_finish_batched_kernel, dim3(1024), dim3(256), 0, as_stream(s), jobs,
-                     reinterpret_cast<const long long*>(prefix), reinterpret_cast<const long long*>(meta));
-  CRDR_CHECK_LAUNCH("colsum_finish_batched_kernel");
+extern "C" int crdr_colsum_slab_rows(void) { return kColsumSlab; }
+
+extern "C" int crdr_colsum_finish_batched(const crdr_colsum_job* jobs, const int64_t* prefix_a, const int64_t* prefix_b,
+                                          const int64_t* meta, float* scratch, crdr_stream_t s) {
+  CRDR_REQUIRE(jobs && prefix_a && prefix_b && meta && scratch, "colsum_finish_batched: null pointer");
+  hipLaunchKernelGGL(colsum_finish_a_kernel, dim3(4096), dim3(256), 0, as_stream(s), jobs, reinterpret_cast<const long long*>(prefix_a),
+                     reinterpret_cast<const long long*>(meta), scratch);
+  CRDR_CHECK_LAUNCH("colsum_finish_a_kernel");
+  hipLaunchKernelGGL(colsum_finish_b_kernel, dim3(512), dim3(256), 0, as_stream(s), jobs, reinterpret_cast<const long long*>(prefix_b),
+                     reinterpret_cast<const long long*>(meta), (const float*)scratch);
+  CRDR_CHECK_LAUNCH("colsum_finish_b_kernel");
   return 0;
 }
 

@@ -32,7 +32,7 @@ class ConvIO(C.Structure):
 
 class ColsumJob(C.Structure):
     _fields_ = [("cs", c_void_p), ("out_pre", c_void_p), ("out_post", c_void_p)] + [(n, C.c_int32) for n in (
-        "rows", "ld", "C", "accumulate")]
+        "rows", "ld", "C", "accumulate", "nslab", "cpad")] + [("scratch_off", C.c_int64)]
 
 
 class WgradDesc(C.Structure):
@@ -101,7 +101,8 @@ SIGNATURES = {
     "crdr_conv2d": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvIO), _P, _SZ, _P]),
     "crdr_conv2d_flops": (_D, [C.POINTER(ConvDesc)]),
     "crdr_conv2d_colsum_layout": (_I, [C.POINTER(ConvDesc), _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "crdr_colsum_finish_batched": (_I, [_P, _P, _P, _P]),
+    "crdr_colsum_slab_rows": (_I, []),
+    "crdr_colsum_finish_batched": (_I, [_P, _P, _P, _P, _P, _P]),
     "crdr_conv2d_grouped_workspace": (_SZ, [C.POINTER(ConvDesc), _I]),
     "crdr_conv2d_grouped": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _SZ, _P]),
     "crdr_conv2d_wgrad_grouped_workspace": (_SZ, [C.POINTER(WgradDesc), _I]),

@@ -676,6 +676,8 @@ class ColsumQueue:
         self.off = 0
         self.jobs = []
         self.tables = {}
+        self.scratch_off = 0   # floats of pass-A scratch handed out since the last flush
+        self.scratch = torch.empty(4 << 20, dtype=torch.float32, device=self.device)
 
     def alloc(self, nfloats: int) -> int:
         nbytes = (4 * nfloats + 255) // 256 * 256
@@ -690,7 +692,12 @@ class ColsumQueue:
         return p
 
     def add(self, cs_ptr: int, rows: int, ld: int, c: int, out_pre: Optional[int], out_post: Optional[int], accumulate: bool):
-        self.jobs.append(L.ColsumJob(cs=cs_ptr, out_pre=out_pre, out_post=out_post, rows=rows, ld=ld, C=c, accumulate=int(accumulate)))
+        slab = L.load().crdr_colsum_slab_rows()
+        nslab, cpad = (rows + slab - 1) // slab, (c + 63) // 64 * 64
+        off = self.scratch_off
+        self.scratch_off += nslab * 2 * cpad
+        self.jobs.append(L.ColsumJob(cs=cs_ptr, out_pre=out_pre, out_post=out_post, rows=rows, ld=ld, C=c, accumulate=int(accumulate),
+                                     nslab=nslab, cpad=cpad, scratch_off=off))
 
     def _table(self, tkey, host, pre, njobs, cap):
         tb = self.tables.get(tkey)
@@ -698,37 +705,46 @@ class ColsumQueue:
             if cap:
                 raise L.CrdrHipError("ColsumQueue: first flush of this site happened during graph capture")
             tb = self.tables[tkey] = {"jobs": torch.zeros(self.CAP * C.sizeof(L.ColsumJob), dtype=torch.uint8, device=self.device),
-                                      "prefix": torch.zeros(self.CAP + 1, dtype=torch.int64, device=self.device),
-                                      "meta": torch.zeros(2, dtype=torch.int64, device=self.device), "host": None}
+                                      "prefix": torch.zeros(2 * (self.CAP + 1), dtype=torch.int64, device=self.device),
+                                      "meta": torch.zeros(3, dtype=torch.int64, device=self.device), "host": None}
         if tb["host"] != host:
             if cap:
                 raise L.CrdrHipError("ColsumQueue: the job table of a captured site changed")
             tb["jobs"][:len(host)].copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
-            tb["prefix"][:njobs + 1].copy_(torch.from_numpy(pre))
-            tb["meta"].copy_(torch.tensor([njobs, int(pre[-1])], dtype=torch.int64))
+            tb["prefix"][:pre.size].copy_(torch.from_numpy(pre.reshape(-1)))
+            tb["meta"].copy_(torch.tensor([njobs, int(pre[0, njobs]), int(pre[1, njobs])], dtype=torch.int64))
             tb["host"] = host
         return tb
 
     def flush(self, key) -> None:
         if not self.jobs:
             self.off = 0
+            self.scratch_off = 0
             return
         import numpy as np
         lib = L.load()
         js = self.jobs
         assert len(js) <= self.CAP
-        host = b"".join(bytes(j) for j in js)
-        pre = np.zeros(len(js) + 1, dtype=np.int64)
-        for k, j in enumerate(js):
-            pre[k + 1] = pre[k] + (j.C + 63) // 64
         cap = torch.cuda.is_current_stream_capturing()
+        if self.scratch_off > self.scratch.numel():
+            if cap:
+                raise L.CrdrHipError("ColsumQueue: scratch too small during graph capture (run eager warm-up iterations first)")
+            self._old.append(self.scratch)
+            self.scratch = torch.empty(2 * self.scratch_off, dtype=torch.float32, device=self.device)
+        host = b"".join(bytes(j) for j in js) + self.scratch.data_ptr().to_bytes(8, "little")
+        pre = np.zeros((2, self.CAP + 1), dtype=np.int64)   # row 0: pass-A tiles, row 1: pass-B tiles
+        for k, j in enumerate(js):
+            pre[0, k + 1] = pre[0, k] + (j.cpad // 64) * j.nslab
+            pre[1, k + 1] = pre[1, k] + j.cpad // 64
         if not cap:  # the twin a later capture of this site will find (it cannot upload)
             self._table((key, True), host, pre, len(js), False)
         tb = self._table((key, cap), host, pre, len(js), cap)
-        L.check(lib.crdr_colsum_finish_batched(tb["jobs"].data_ptr(), tb["prefix"].data_ptr(), tb["meta"].data_ptr(), _stream()),
-                "colsum_finish_batched")
+        L.check(lib.crdr_colsum_finish_batched(tb["jobs"].data_ptr(), tb["prefix"].data_ptr(),
+                                               tb["prefix"].data_ptr() + 8 * (self.CAP + 1), tb["meta"].data_ptr(),
+                                               self.scratch.data_ptr(), _stream()), "colsum_finish_batched")
         self.jobs = []
         self.off = 0
+        self.scratch_off = 0
         if not cap and self._old:
             self._old = self._old[-1:]  # (the launch just issued may still read the previous arena)
 

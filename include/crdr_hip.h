@@ -120,16 +120,24 @@ int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void* ws, size_
 /* partial-row count and row stride (floats) of io.cs for this problem (depends on the tile configuration the plan picks,
  * so pass the same desc -- including `reserved` -- and group size as the launch) */
 int crdr_conv2d_colsum_layout(const crdr_conv_desc* d, int G, int* rows, int* ld);
-/* finish pending column sums: job k adds the `rows` partial rows of cs (stride 2 * ld) in order and (accumulating if
- * accumulate != 0) writes out_pre[c] / out_post[c], c < C (either may be NULL).  `jobs`, `prefix` (first 64-column tile of each
- * job) and `meta` = {number of jobs, total tiles} are DEVICE arrays, like crdr_wgrad_reduce_batched. */
+/* Finish pending column sums, all jobs in two launches: pass A adds slabs of crdr_colsum_slab_rows() partial rows (stride
+ * 2 * ld) in row order into scratch[scratch_off + (slab * 2 + which) * cpad + c], pass B adds a job's nslab scratch rows in
+ * order and writes (accumulate != 0: adds to) out_pre[c] / out_post[c], c < C (either may be NULL).  nslab = ceil(rows /
+ * slab rows), cpad = C rounded up to 64; scratch_off (floats) must give every job its own nslab * 2 * cpad floats.  `jobs`,
+ * `prefix_a` (first pass-A tile of each job; a job has cpad / 64 * nslab of them), `prefix_b` (first pass-B tile; cpad / 64 per
+ * job) and `meta` = {number of jobs, total pass-A tiles, total pass-B tiles} are DEVICE arrays (a table rewritten in place keeps
+ * working under a captured HIP graph), like crdr_wgrad_reduce_batched. */
 typedef struct crdr_colsum_job {
   const float* cs;
   float* out_pre;
   float* out_post;
   int32_t rows, ld, C, accumulate;
+  int32_t nslab, cpad;
+  int64_t scratch_off;
 } crdr_colsum_job;
-int crdr_colsum_finish_batched(const crdr_colsum_job* jobs, const int64_t* prefix, const int64_t* meta, crdr_stream_t s);
+int crdr_colsum_slab_rows(void);
+int crdr_colsum_finish_batched(const crdr_colsum_job* jobs, const int64_t* prefix_a, const int64_t* prefix_b, const int64_t* meta,
+                               float* scratch, crdr_stream_t s);
 
 /* G <= CRDR_MAX_GROUP independent convolutions of ONE geometry (same desc) in one launch; problem g reads
  * ios[g].{x, w, bias, pre, mask, res, cs} and writes ios[g].y (the other io fields must be unused: flags limited to BIAS,
