@@ -56,7 +56,7 @@ def _cpu_baseline_worker(stage: int, size: int, threads: int, budget_s: float) -
     torch.set_num_threads(threads)
     g = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in build_comp_model(ConfigDict(cfg)).state_dict().items() if v.numel() > 0}
     lp = {"lpips." + k: v.detach() for k, v in LpipsAlex().state_dict().items()}
-    n = 1
+    n = 2   # time N = 2 and scale linearly when a full batch does not fit the time budget
     x = torch.rand(n, 3, size, size) * 2 - 1
     ny, nz = torch.rand(n, 320, size // 16, size // 16) - 0.5, torch.rand(n, 192, size // 64, size // 64) - 0.5
     d = None
@@ -80,14 +80,17 @@ def _cpu_baseline_worker(stage: int, size: int, threads: int, budget_s: float) -
         k += 1
     dt = (time.time() - t0) / k
     return {"value": round(n / dt, 4), "unit": "img/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (stock torch fp32, oneDNN, {threads} threads) stage-{stage} step at N={n}, {size}x{size}, q=2: "
-                      f"{k} timed iteration(s) after 1 warm-up ({warm:.1f} s)"}
+            "sample": f"oracle (stock torch fp32, oneDNN, {threads} threads of {os.cpu_count()} logical CPUs) stage-{stage} step (G fwd + HR pass + LPIPS + D, "
+                      f"all backward passes) at N={n} instead of {16 if stage == 3 else 8} images, {size}x{size}, q=2, img/s = N / step time "
+                      f"(per-image cost scales linearly): {k} timed iteration(s) after 1 warm-up ({warm:.1f} s)"}
 
 
 def cpu_baseline(stage: int, size: int, budget_s: float = 25.0, hard_timeout_s: float = 240.0) -> dict:
     """Runs the worker in a child process (bounded wall time; the GPU process is not disturbed by its threads)."""
     import subprocess
-    threads = max(1, min(os.cpu_count() or 1, 32))
+    # all host cores up to 64 threads: with more, oneDNN's fork-join over these small (N = 2) convolutions stops scaling --
+    # measured on the 256-logical-CPU GPU box: one step does not finish within 4 minutes at 256 threads, ~2.5 s at 32-64
+    threads = max(1, min(os.cpu_count() or 1, 64))
     code = (f"import json,sys; sys.path.insert(0, {ROOT!r}); import bench; "
             f"print('CPUBASE ' + json.dumps(bench._cpu_baseline_worker({stage}, {size}, {threads}, {budget_s})))")
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
@@ -102,6 +105,158 @@ def cpu_baseline(stage: int, size: int, budget_s: float = 25.0, hard_timeout_s: 
                 "sample": f"one stage-{stage} oracle step at N=1 did not finish within {hard_timeout_s:.0f} s on {threads} threads"}
 
 
+def _newest_profile(pattern: str):
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return fs[-1] if fs else None
+
+
+def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: int, shape_table=None) -> dict:
+    """Build the stage's trainer, warm up (autotune + graph capture per rate index), time `steps` iterations with the rate
+    index CYCLED deterministically (q = iteration mod rate levels: the expectation over the uniform draw of the reference,
+    interpca_hyperprior_model.py:28-29, without sampling noise in the step mix), then `profile_steps` eager iterations
+    with HIP events around every conv launch."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from crdr_amd.hip import ops
+    from crdr_amd.trainer import dist as D
+    ws = D.world_size()
+    device = f"cuda:{torch.cuda.current_device()}"
+    tr = build_trainer(stage, bs, a.size, device, graphs=not a.no_graph)
+    loader = iter(tr.train_loader)
+    lib = __import__("crdr_amd.hip.lib", fromlist=["load"]).load()
+    levels = getattr(tr.comp_model, "rate_level", 0)
+
+    def barrier():
+        if ws > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+
+    def step(q=None):
+        nonlocal it
+        it += 1
+        d = next(loader)
+        if levels:
+            d = {**d, "rate_ind": (it % levels) if q is None else q}
+        tr.optimize_parameters(it, d)
+    # untimed preparation: autotune every shape eagerly and capture one graph set per rate index (each graph key needs
+    # `graph_warmup` eager iterations first)
+    for q in (range(levels) if levels else [None]):
+        for _ in range(tr.graph_warmup + 1 if tr.graphs.enabled else 1):
+            step(q)
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    # per-kernel roofline: HIP events bracket every conv launch inside the library (they cannot be recorded inside a
+    # graph replay), over `profile_steps` eager iterations of the same step mix right after the timed region
+    graphs_on = tr.graphs.enabled
+    tr.graphs.enabled = False
+    lib.crdr_profile_enable(1)
+    ops.PROFILE = {}
+    for _ in range(profile_steps):
+        step()
+    torch.cuda.synchronize()
+    lib.crdr_profile_enable(0)
+    prof, ops.PROFILE = ops.PROFILE or {}, None
+    tr.graphs.enabled = graphs_on
+    if ws > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    def fam(kind):
+        fl, ms, n = C.c_double(), C.c_double(), C.c_longlong()
+        lib.crdr_profile_read(kind, C.byref(fl), C.byref(ms), C.byref(n))
+        if n.value == 0 or ms.value <= 0:
+            return None
+        ps = max(profile_steps, 1)
+        return {"launches_per_step": round(n.value / ps, 1), "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                "avg_gflop_per_launch": round(fl.value / n.value / 1e9, 3), "tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
+                "ms_per_step": round(ms.value / ps, 2)}
+    ig, wg, sk = fam(0), fam(1), fam(2)
+    if ig is not None and sk is not None:
+        ig["splitk_epilogue"] = {"launches_per_step": sk["launches_per_step"], "avg_launch_us": sk["avg_launch_us"], "ms_per_step": sk["ms_per_step"]}
+    alg_bytes = None
+    if prof.get("igemm"):
+        alg_bytes = sum(r[4] for r in prof["igemm"]) / len(prof["igemm"])
+    if shape_table:
+        agg = {}
+        for kind, rec in prof.items():
+            for fl, e0, e1, label, nb in rec:
+                t = agg.setdefault((kind, label), [0, 0.0, 0.0])
+                t[0] += 1; t[1] += e0.elapsed_time(e1); t[2] += fl
+        with open(shape_table, "w") as f:
+            for (kind, label), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{ms / max(profile_steps, 1):8.3f} ms/step  {cnt / max(profile_steps, 1):6.1f} calls/step  {fl / (ms * 1e-3) / 1e12:6.1f} TF  {kind:5s} {label}\n")
+    out = {"value": ws * bs * steps / dt, "ms_per_step": dt / steps * 1e3, "igemm": ig, "wgrad": wg, "alg_bytes_per_igemm_launch": alg_bytes,
+           "graphs": bool(graphs_on), "trainer": tr}
+    return out
+
+
+def fused_ops_roofline(tr) -> dict:
+    """Achieved HBM bandwidth of the bandwidth-bound fused kernels at the step's own sizes, live (HIP events on the
+    trainer's stream, 5 repetitions each): algorithmic bytes / time against the 8 TB/s HBM3E peak."""
+    import torch
+    from crdr_amd.hip import functional as HF
+    from crdr_amd.hip import ops
+    dev = torch.device(tr.device)
+    out = {}
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    def entry(name, nbytes, sec, note):
+        out[name] = {"bytes": int(nbytes), "us": round(sec * 1e6, 1), "GBps": round(nbytes / sec / 1e9, 1), "frac_of_8TBps": round(nbytes / sec / 8e12, 4),
+                     "what": note}
+    from crdr_amd.hip import lib as L
+    lib = L.load()
+    opt = tr.g_optimizer
+    g = next(gr for gr in opt.param_groups if gr["flat"] is not None)
+    npar = g["flat"].numel()
+    scratch = [g["flat"].clone(), torch.randn_like(g["flat"]) * 1e-3, torch.zeros_like(g["flat"]), torch.zeros_like(g["flat"])]
+    dyn = torch.tensor([1e-4, 1.0, 0.0], device=dev)
+    entry("adam_dyn_kernel", 28.0 * npar,
+          timed(lambda: lib.crdr_adam_step_dyn(*[t.data_ptr() for t in scratch], npar, 0.9, 0.999, 1e-8, dyn.data_ptr(), None, 0.0, ops._stream())),
+          f"fused Adam on a copy of the generator's flat buffers ({npar / 1e6:.1f} M parameters; 16 B read + 12 B written each)")
+    del scratch
+    pt = g["parts"][0] if g.get("parts") else None
+    if pt is not None and pt.get("packs") is not None and pt["packs"].entries:
+        pk = pt["packs"]
+        nb = 8.0 * sum(e.T * e.rows * e.cols for e in pk.entries)
+        entry("pack_weights_batched_kernel", nb, timed(pk.refill), f"all {len(pk.entries)} weight packs of the generator refilled by one launch (4 B read + 4 B written per packed element)")
+    n, c, hw = 16, 320, 16
+    y, mu, sg = (torch.randn(n, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last) for _ in range(3))
+    noise = torch.rand(n, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last) - 0.5
+    entry("gauss_cond_fwd (training size)", 20.0 * y.numel(), timed(lambda: HF.gauss_cond(y, mu, sg, noise, 0.11, 1e-9, False)),
+          "16 x 320 x 16 x 16 latent: launch-latency bound at 256^2 crops (1.3 M elements)")
+    yb, mb, sb = (torch.randn(1, c, 128, 86, device=dev).contiguous(memory_format=torch.channels_last) for _ in range(3))
+    entry("gauss_cond_fwd (2048x1365 codec size)", 20.0 * yb.numel(), timed(lambda: HF.gauss_cond(yb, mb, sb, None, 0.11, 1e-9, True)),
+          "1 x 320 x 128 x 86 latent, quantised likelihood + y_hat written")
+    x = torch.randn(16, 256, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
+    o = torch.randn_like(x)
+    s, t = torch.rand(256, device=dev) + 0.5, torch.rand(256, device=dev)
+    entry("ebwd_kernel_v4 (affine + residual)", 12.0 * x.numel(),
+          timed(lambda: ops.epilogue_bwd(x, o, L.EPI_AFFINE | L.EPI_RES, scale=s, shift=t, need_dz=False)),
+          "InterpChAtt backward at the decoder's 256-channel 128x128 stage (read dout, read out, write the pre-affine gradient)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,13 +266,14 @@ def main():
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the stage-1 bs 8 line and the fused-op bandwidth measurements")
     ap.add_argument("--shape-table", default=None, help="write per-shape conv timing of the timed region to this file")
     ap.add_argument("--no-autotune", action="store_true", help="use the library's built-in tile heuristic instead of timing candidates once per shape")
     ap.add_argument("--tune-log", default=None)
     ap.add_argument("--tune-db", default=None, help="perf database to preload (default: the one shipped in crdr_amd/hip); shapes it lacks are tuned live")
     ap.add_argument("--save-tune-db", default=None, help="write the tuner's choices after the run")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying captured HIP graphs")
-    ap.add_argument("--profile-steps", type=int, default=3, help="eager steps after the timed region used for the per-kernel roofline")
+    ap.add_argument("--profile-steps", type=int, default=5, help="eager steps after the timed region used for the per-kernel roofline")
     a = ap.parse_args()
 
     import torch
@@ -127,125 +283,79 @@ def main():
     local = D.init_from_env()
     ws, rk = D.world_size(), D.rank()
     assert ws == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
-    device = f"cuda:{local}"
     torch.cuda.set_device(local)
-    tr = build_trainer(a.stage, a.bs, a.size, device, graphs=not a.no_graph)
-    loader = iter(tr.train_loader)
     ops.AUTOTUNE = not a.no_autotune  # the reference runs with cudnn.benchmark = True (base_trainer.py:20)
     if ops.AUTOTUNE and a.tune_db != "none":
         ops.load_tune_cache(a.tune_db or ops.DEFAULT_TUNE_DB)
-    lib = __import__("crdr_amd.hip.lib", fromlist=["load"]).load()
-
-    def barrier():
-        if ws > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    it = 0
-    # untimed preparation: autotune every shape eagerly and capture one graph set per rate index (each graph key needs
-    # `graph_warmup` eager iterations first), by cycling the rate index deterministically
-    if a.stage == 3 or hasattr(tr.comp_model, "rate_level"):
-        for q in range(tr.comp_model.rate_level):
-            for _ in range(tr.graph_warmup + 1 if tr.graphs.enabled else 1):
-                it += 1
-                tr.optimize_parameters(it, {**next(loader), "rate_ind": q})
-    else:
-        for _ in range(tr.graph_warmup + 1 if tr.graphs.enabled else 1):
-            it += 1
-            tr.optimize_parameters(it, next(loader))
-    for _ in range(a.warmup):
-        it += 1
-        tr.optimize_parameters(it, next(loader))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        it += 1
-        tr.optimize_parameters(it, next(loader))
-    barrier()
-    dt = time.perf_counter() - t0
-    # per-kernel roofline: HIP events bracket every conv launch inside the library (they cannot be recorded inside a
-    # graph replay), over `profile_steps` eager iterations of the same step right after the timed region
-    graphs_on = tr.graphs.enabled
-    tr.graphs.enabled = False
-    lib.crdr_profile_enable(1)
-    ops.PROFILE = {} if a.shape_table else None
-    for _ in range(a.profile_steps):
-        it += 1
-        tr.optimize_parameters(it, next(loader))
-    torch.cuda.synchronize()
-    lib.crdr_profile_enable(0)
-    prof, ops.PROFILE = ops.PROFILE or {}, None
-    tr.graphs.enabled = graphs_on
-    if ws > 1:
-        t = torch.tensor([dt], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    from crdr_amd.hip import functional as HF
-    if rk == 0 and HF.PACK_MISS_LOG is not None:
-        for k, v in sorted(HF.PACK_MISS_LOG.items(), key=lambda kv: -kv[1])[:40]:
-            print("[pack-miss]", k, v, file=sys.stderr)
+    main_run = run_stage(a, a.stage, a.bs, a.steps, a.warmup, a.profile_steps, a.shape_table)
+    tr = main_run.pop("trainer")
     if rk == 0 and a.save_tune_db:
         ops.save_tune_cache(a.save_tune_db)
+    if a.tune_log and rk == 0:
+        with open(a.tune_log, "w") as f:
+            for key, best, t0, t1 in ops.TUNE_LOG:
+                f.write(f"{t0 * 1e3:9.1f}us -> {t1 * 1e3:9.1f}us  algo cfg={(best & 0xff) - 1} split={1 << (best >> 8)}  {key}\n")
     if rk != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
         return
-    imgs = ws * a.bs * a.steps
-    value = imgs / dt
+    value, ig, wg = main_run["value"], main_run["igemm"], main_run["wgrad"]
     gflop = GFLOP_PER_IMG_STAGE3 if a.stage == 3 else GFLOP_PER_IMG_STAGE1
-
-    import ctypes as C
-
-    def fam(kind):
-        fl, ms, n = C.c_double(), C.c_double(), C.c_longlong()
-        lib.crdr_profile_read(kind, C.byref(fl), C.byref(ms), C.byref(n))
-        if n.value == 0 or ms.value <= 0:
-            return None
-        ps = max(a.profile_steps, 1)
-        return {"launches_per_step": n.value / ps, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
-                "avg_gflop_per_launch": round(fl.value / n.value / 1e9, 3), "tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
-                "ms_per_step": round(ms.value / ps, 2)}
-    ig, wg, sk = fam(0), fam(1), fam(2)
-    if ig is not None and sk is not None:
-        ig["splitk_epilogue"] = {"launches_per_step": sk["launches_per_step"], "avg_launch_us": sk["avg_launch_us"],
-                                 "ms_per_step": sk["ms_per_step"]}
-    if a.tune_log:
-        with open(a.tune_log, "w") as f:
-            for key, best, t0, t1 in ops.TUNE_LOG:
-                f.write(f"{t0 * 1e3:9.1f}us -> {t1 * 1e3:9.1f}us  algo cfg={(best & 0xff) - 1} split={1 << (best >> 8)}  {key}\n")
-    if a.shape_table:
-        agg = {}
-        for kind, rec in prof.items():
-            for fl, e0, e1, label in rec:
-                t = agg.setdefault((kind, label), [0, 0.0, 0.0])
-                t[0] += 1; t[1] += e0.elapsed_time(e1); t[2] += fl
-        with open(a.shape_table, "w") as f:
-            for (kind, label), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                f.write(f"{ms / max(a.profile_steps, 1):8.3f} ms/step  {cnt / max(a.profile_steps, 1):6.1f} calls/step  {fl / (ms * 1e-3) / 1e12:6.1f} TF  {kind:5s} {label}\n")
     # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over one step (counters cannot
-    # be read inside this process): tools/pmc_step.py + tools/pmc_traffic.py, result committed under profiles/
+    # be read inside this process): tools/pmc_step.py + tools/pmc_families.py, newest result committed under profiles/
     traffic, traffic_src = None, None
-    tp = os.path.join(ROOT, "profiles", "r1_h_hbm_traffic_pmc_xcd.json")
-    if a.stage == 3 and a.bs == 16 and a.size == 256 and os.path.exists(tp):
+    tp = _newest_profile("r*_hbm_families.json")
+    if a.stage == 3 and a.bs == 16 and a.size == 256 and tp:
         with open(tp) as f:
-            traffic = round(json.load(f)["igemm"]["hbm_bytes_per_launch"])
-        traffic_src = "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step (profiles/r1_h_hbm_traffic_pmc_xcd.json)"
+            traffic = round(json.load(f)["families"]["igemm_kernel"]["hbm_bytes_per_launch"])
+        traffic_src = (f"HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step at q = 2 "
+                       f"({os.path.relpath(tp, ROOT)}); re-measure with tools/pmc_step.py + tools/pmc_families.py after kernel changes")
     roof = {"bound": "mfma", "achieved": ig["tflops"] if ig else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "igemm_kernel<*> (conv / convT forward + input-gradient launches, v_mfma_f32_32x32x2_f32; split-K epilogue launches timed separately under detail.splitk_epilogue)",
-            "measured_over": f"{a.profile_steps} eager steps after the timed region (HIP events around each launch, on its stream)",
+            "algorithmic_bytes_per_launch": round(main_run["alg_bytes_per_igemm_launch"]) if main_run["alg_bytes_per_igemm_launch"] else None,
+            "flop_convention": "dense: 2 * Cin * Cout * kh * kw per output pixel (input pixel for transposed convs), zero-padding taps at "
+                               "the borders included (5x5 at 16x16: 14 % of the counted taps multiply padding)",
+            "kernel": "igemm_kernel<*> (conv / convT forward + input-gradient launches incl. grouped ones, v_mfma_f32_32x32x2_f32; split-K "
+                      "epilogue launches timed separately under detail.splitk_epilogue)",
+            "measured_over": f"{a.profile_steps} eager steps after the timed region, rate index cycled (HIP events around each launch, on its stream)",
             "detail": ig, "wgrad_kernel": wg,
             "whole_step": {"algorithmic_gflop_per_img": gflop, "achieved": round(value / ws * gflop / 1e3, 2),
                            "frac": round(value / ws * gflop / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}}
     line = {"metric": f"stage-{a.stage} training img/s at {a.size}x{a.size}", "value": round(value, 3), "unit": "img/s",
-            "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(main_run["ms_per_step"], 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "autotune": bool(ops.AUTOTUNE), "hip_graphs": bool(graphs_on),
+            "autotune": bool(ops.AUTOTUNE), "hip_graphs": main_run["graphs"],
             "peak_device_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-            "config": {"workload": f"config/crdr_stage_{a.stage}.yaml -b {a.bs}: full GAN step (G + 5x CLIC21GVAE D + LPIPS-Alex, random-init weights)"
-                                   if a.stage == 3 else f"config/crdr_stage_1.yaml -b {a.bs}: R-D step (+LPIPS-Alex, random-init weights)",
+            "config": {"workload": f"config/crdr_stage_{a.stage}.yaml -b {a.bs}: full GAN step (G + 5x CLIC21GVAE D + LPIPS-Alex, random-init weights), "
+                                   f"rate index cycled 0..4" if a.stage == 3 else f"config/crdr_stage_1.yaml -b {a.bs}: R-D step (+LPIPS-Alex, random-init weights)",
                        "global_batch": ws * a.bs, "crop": a.size, "parallelism": f"dp{ws}"},
             "roofline": roof}
+    if ws == 1 and not a.no_secondary:
+        try:
+            roof["fused_ops"] = fused_ops_roofline(tr)
+            fp = _newest_profile("r*_hbm_families.json")
+            if fp:
+                with open(fp) as f:
+                    fams = json.load(f)["families"]
+                roof["fused_ops"]["pmc_in_step"] = {"source": os.path.relpath(fp, ROOT) + " (HBM bytes by FETCH_SIZE / WRITE_SIZE over one eager step, kernel durations of that pass)",
+                                                     **{k: {"GBps": v["achieved_GBps"], "frac_of_8TBps": v["frac_of_8TBps"], "launches": v["launches"], "ms": v["ms"]}
+                                                        for k, v in fams.items() if k in ("adam_dyn", "ebwd", "wgrad_reduce_batched", "pack_weights_batched",
+                                                                                          "colsum_finish", "gauss_cond_fwd", "gauss_cond_bwd", "igemm_splitk_epilogue")}}
+        except Exception as e:  # the headline line must not depend on the secondary measurements
+            roof["fused_ops"] = {"error": repr(e)[:300]}
+        del tr
+        torch.cuda.empty_cache()
+        if a.stage == 3:
+            try:
+                s1 = run_stage(a, 1, 8, 10, 3, 2)
+                s1.pop("trainer")
+                line["stage1_bs8"] = {"metric": f"stage-1 training img/s at {a.size}x{a.size}", "value": round(s1["value"], 3), "unit": "img/s",
+                                      "ms_per_step": round(s1["ms_per_step"], 2), "steps": 10, "warmup": 3,
+                                      "config": {"workload": "config/crdr_stage_1.yaml -b 8: R-D step (+LPIPS-Alex, random-init weights)"},
+                                      "igemm_tflops": s1["igemm"]["tflops"] if s1["igemm"] else None,
+                                      "whole_step_frac": round(s1["value"] * GFLOP_PER_IMG_STAGE1 / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+            except Exception as e:
+                line["stage1_bs8"] = {"error": repr(e)[:300]}
     if ws == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.stage, a.size)
     print(json.dumps(line), flush=True)

@@ -105,12 +105,14 @@ def _prof_begin():
     return e
 
 
-def _prof_end(kind: str, flops: float, e0, label: str = "") -> None:
+def _prof_end(kind: str, flops: float, e0, label: str = "", nbytes: float = 0.0) -> None:
+    """nbytes: ALGORITHMIC HBM bytes of the launch (each operand / result element once: activations in and out, the
+    weight pack, residual / pre-activation / mask operands) -- what bench.py prices `roofline.traffic` against."""
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.setdefault(kind, []).append((flops, e0, e1, label))
+    PROFILE.setdefault(kind, []).append((flops, e0, e1, label, nbytes))
 
 
 def _stream() -> int:
@@ -282,7 +284,8 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
     e0 = _prof_begin()
     L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), ws, ws_n, _stream()), "conv2d")
     _prof_end("igemm", 2.0 * n * (h * w if transposed else oh * ow) * c * oc * k[0] * k[1], e0,
-              f"{'T' if transposed else 'C'} {c}->{oc} k{k[0]}s{stride} in{h}x{w} f{flags}")
+              f"{'T' if transposed else 'C'} {c}->{oc} k{k[0]}s{stride} in{h}x{w} f{flags}",
+              4.0 * (n * h * w * c + n * oh * ow * oc * (1 + (res is not None) + 3 * (gate_x is not None)) + k[0] * k[1] * c * oc))
     return out
 
 
@@ -566,7 +569,9 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
     e0 = _prof_begin()
     L.check(lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream()), "conv2d_grouped")
     _prof_end("igemm", 2.0 * G * n * h * w * x0.c * oc * k[0] * k[1], e0,
-              f"{'T' if transposed else 'C'} {G}x {x0.c}->{oc} k{k[0]} in{h}x{w} f{flags} {label}")
+              f"{'T' if transposed else 'C'} {G}x {x0.c}->{oc} k{k[0]} in{h}x{w} f{flags} {label}",
+              4.0 * G * (n * h * w * x0.c + n * h * w * oc * (1 + (pres is not None) + (masks is not None) + bool(flags & L.EPI_ACCUM))
+                         + k[0] * k[1] * x0.c * oc))
 
 
 def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[int, int], pad: int, *, device, accumulate=True,
@@ -854,7 +859,9 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
     e0 = _prof_begin()
     L.check(lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream()), "conv2d_grouped")
     _prof_end("igemm", 2.0 * G * n * (h * w if transposed else oh * ow) * x0.c * oc * k[0] * k[1], e0,
-              f"{'T' if transposed else 'C'} {G}x {x0.c}->{oc} k{k[0]}s{stride} in{h}x{w} f{flags} {label}")
+              f"{'T' if transposed else 'C'} {G}x {x0.c}->{oc} k{k[0]}s{stride} in{h}x{w} f{flags} {label}",
+              4.0 * G * (n * h * w * x0.c + n * oh * ow * oc * (1 + (pres is not None) + (masks is not None) + (ress is not None)
+                                                                 + bool(flags & L.EPI_ACCUM)) + k[0] * k[1] * x0.c * oc))
     return out
 
 
