@@ -393,6 +393,45 @@ extern "C" int crdr_gauss_cond_bwd2(const crdr_gc_desc2* d, const crdr_gc_io* io
   return 0;
 }
 
+// symbols / CDF indexes of the coded latent, written in the (channel, row, column) order the host coder consumes
+// (compressai GaussianConditional.quantize(..., "symbols", means) and build_indexes as called from
+// minnen20_charm_context_model.py:186-187,197-199): sym = round(y - mu) as int32, idx = #{table entries < max(sigma, bound)}
+// capped at levels - 1.  Thread -> output element (pixel fastest): coalesced 4-byte stores, strided NHWC loads (the tensors
+// are a few MB at most).
+__global__ __launch_bounds__(256) void gauss_symbols_kernel(const float* y, int ldy, const float* mu, int ldmu, const float* sigma,
+                                                            int ldsg, const float* table, int levels, float bound, int N, int HW,
+                                                            int C, int* sym, int* idx) {
+  __shared__ float st[256];
+  for (int i = threadIdx.x; i < levels; i += 256) st[i] = table[i];
+  __syncthreads();
+  const long long total = (long long)N * C * HW;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int px = (int)(e % HW);
+    const long long r = e / HW;
+    const int c = (int)(r % C), n = (int)(r / C);
+    const size_t pix = (size_t)n * HW + px;
+    if (sym) sym[e] = (int)rintf(y[pix * ldy + c] - mu[pix * ldmu + c]);
+    if (idx) {
+      const float s = fmaxf(sigma[pix * ldsg + c], bound);
+      int k = 0;
+      for (int i = 0; i < levels - 1; ++i) k += (s > st[i]) ? 1 : 0;
+      idx[e] = k;
+    }
+  }
+}
+
+extern "C" int crdr_gauss_symbols(const float* y, int ldy, const float* mu, int ldmu, const float* sigma, int ldsigma,
+                                  const float* scale_table, int levels, float scale_bound, int N, int HW, int C, int32_t* symbols,
+                                  int32_t* indexes, crdr_stream_t s) {
+  CRDR_REQUIRE((!symbols || (y && mu)) && (!indexes || (sigma && scale_table)) && levels >= 1 && levels <= 256, "gauss_symbols: bad arguments");
+  const long long total = (long long)N * C * HW;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(gauss_symbols_kernel, dim3((int)std::min<long long>(cdiv64(total, 256), 8192)), dim3(256), 0, as_stream(s), y, ldy, mu,
+                     ldmu, sigma, ldsigma, scale_table, levels, scale_bound, N, HW, C, symbols, indexes);
+  CRDR_CHECK_LAUNCH("gauss_symbols");
+  return 0;
+}
+
 __global__ void philox_fork_kernel(uint64_t* state, uint64_t* call, unsigned long long inc) {
   call[0] = state[0];
   call[1] = state[1];

@@ -114,6 +114,7 @@ SIGNATURES = {
     "crdr_gdn_workspace": (_SZ, [C.POINTER(GdnDesc), _I]),
     "crdr_gdn_fwd": (_I, [C.POINTER(GdnDesc), _P, _P, _P, _P, _P, _SZ, _P]),
     "crdr_gdn_bwd": (_I, [C.POINTER(GdnDesc), _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _SZ, _P]),
+    "crdr_gauss_symbols": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _F, _I, _I, _I, _P, _P, _P]),
     "crdr_philox_fork": (_I, [_P, _P, C.c_uint64, _P]),
     "crdr_philox_uniform": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "crdr_conv2d_wgrad_workspace": (_SZ, [C.POINTER(WgradDesc)]),

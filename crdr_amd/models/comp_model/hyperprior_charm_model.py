@@ -146,8 +146,21 @@ class HyperpriorCharmModel(BaseModel):
     def _header_cond(self, header: Dict) -> Dict:
         return {}
 
+    # compress = compress_device (GPU: transforms, Charm, symbols / CDF indexes in coder order, asynchronous copies into
+    # pinned host memory; returns without waiting) + compress_finish (host: waits for that image's copies, serial rANS,
+    # header).  A sweep overlaps the two across images: while a host thread codes image k, the GPU already works on image
+    # k+1 (`compress_many`; the rANS calls release the GIL).
+    def _pinned(self, shape, dtype) -> Tensor:
+        pool = self.__dict__.setdefault("_pin_pool", {})
+        key = (tuple(shape), dtype)
+        free = pool.setdefault(key, [])
+        return free.pop() if free else torch.empty(shape, dtype=dtype, pin_memory=True)
+
+    def _unpin(self, t: Tensor) -> None:
+        self.__dict__.setdefault("_pin_pool", {}).setdefault((tuple(t.shape), t.dtype), []).append(t)
+
     @torch.no_grad()
-    def compress(self, real_images: Tensor, **cond) -> Dict:
+    def compress_device(self, real_images: Tensor, **cond) -> Dict:
         N, _, H, W = real_images.shape
         assert N == 1, f"In compress mode, batchsize must be 1, but {N}"
         t = self._tick(None)
@@ -155,19 +168,61 @@ class HyperpriorCharmModel(BaseModel):
         y = self._encode(x, **cond)
         z = self.hyperencoder(y)
         z_hat, z_lik = self.entropy_model_z(z, is_train=False)
-        t = self._tick("transforms", t)
-        z_str = self.entropy_model_z.compress(z)
-        t = self._tick("rans", t)
+        z_sym = self.entropy_model_z.quantize_symbols(z).contiguous()
         hyper_out = self.hyperdecoder(z_hat)
         t = self._tick("transforms", t)
-        self.context_model.codec_profile = self.codec_profile
-        y_str, y_hat, y_lik = self.context_model.forward_compress(y, hyper_out, self.entropy_model_y)
-        header = self._header_encode((H, W), y_hat, **cond)
-        y_bit, y_bpp = self.likelihood_to_bit(y_lik, H * W)
-        z_bit, z_bpp = self.likelihood_to_bit(z_lik, H * W)
-        return {"string_list": [header, z_str[0], y_str[0]], "z_hat": z_hat, "y_hat": y_hat, "z_likelihood": z_lik,
-                "y_likelihood": y_lik, "pred_y_bit": y_bit.item(), "pred_y_bpp": y_bpp.item(), "pred_z_bit": z_bit.item(),
-                "pred_z_bpp": z_bpp.item()}
+        sym, idx, y_hat, y_lik = self.context_model.forward_compress_device(y, hyper_out, self.entropy_model_y)
+        stats = torch.stack([torch.max(torch.abs(y_hat)), -torch.log2(y_lik).sum(), -torch.log2(z_lik).sum()])
+        host = {"sym": self._pinned(sym.shape, torch.int32), "idx": self._pinned(idx.shape, torch.int32),
+                "zsym": self._pinned(z_sym.shape, torch.int32), "stats": self._pinned((3,), torch.float32)}
+        host["sym"].copy_(sym, non_blocking=True)
+        host["idx"].copy_(idx, non_blocking=True)
+        host["zsym"].copy_(z_sym, non_blocking=True)
+        host["stats"].copy_(stats, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._tick("charm", t)
+        return {"host": host, "event": ev, "size": (H, W), "cond": cond, "z_hat": z_hat, "y_hat": y_hat, "z_likelihood": z_lik,
+                "y_likelihood": y_lik, "_keep": (sym, idx, z_sym, stats)}
+
+    def compress_finish(self, ticket: Dict) -> Dict:
+        import time
+        from crdr_amd.codec import rans
+        t0 = time.perf_counter()
+        ticket["event"].synchronize()
+        h = ticket["host"]
+        H, W = ticket["size"]
+        cdf, sizes, offs = self.entropy_model_y.host_tables()
+        y_str = rans.encode_with_indexes(h["sym"].numpy().reshape(-1), h["idx"].numpy().reshape(-1), cdf, sizes, offs)
+        z_str = self.entropy_model_z.compress_symbols(h["zsym"].numpy())[0]
+        ymax, y_bit, z_bit = (float(v) for v in h["stats"])
+        header = self._header_encode((H, W), torch.tensor([ymax]), **ticket["cond"])
+        for v in h.values():
+            self._unpin(v)
+        if self.codec_profile is not None:
+            self.codec_profile["rans"] = self.codec_profile.get("rans", 0.0) + (time.perf_counter() - t0)
+        return {"string_list": [header, z_str, y_str], "z_hat": ticket["z_hat"], "y_hat": ticket["y_hat"],
+                "z_likelihood": ticket["z_likelihood"], "y_likelihood": ticket["y_likelihood"], "pred_y_bit": y_bit,
+                "pred_y_bpp": y_bit / (H * W), "pred_z_bit": z_bit, "pred_z_bpp": z_bit / (H * W)}
+
+    @torch.no_grad()
+    def compress(self, real_images: Tensor, **cond) -> Dict:
+        return self.compress_finish(self.compress_device(real_images, **cond))
+
+    @torch.no_grad()
+    def compress_many(self, images, workers: int = 2, **cond):
+        """Generator over compress() results for a sequence of [1, 3, H, W] images with the host coder of image k running
+        (in `workers` threads) beside the GPU work of the following images; results come back in order."""
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        pending = deque()
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            for img in images:
+                pending.append(pool.submit(self.compress_finish, self.compress_device(img, **cond)))
+                while len(pending) > workers:
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
 
     @torch.no_grad()
     def decompress(self, string_list: List, **cond) -> Tuple[Tensor, Tensor, Tensor]:

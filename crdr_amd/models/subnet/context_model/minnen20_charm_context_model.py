@@ -133,12 +133,22 @@ class Minnen20CharmContextModel(BaseContextModel):
         return t
 
     @torch.no_grad()
-    def forward_compress(self, y: Tensor, hyper_out: Tensor, entropy_model_y) -> Tuple[List[bytes], Tensor, Tensor]:
-        t = self._tick(None)
+    def forward_compress_device(self, y: Tensor, hyper_out: Tensor, entropy_model_y):
+        """GPU half of forward_compress (:143-187): all transforms, then ONE launch turns (y, mu, sigma) into the int32 symbols
+        and CDF indexes in coder order.  -> (symbols, indexes, y_hat, likelihood), all on the device; nothing synchronises."""
         yh, _, _, _, lik_q, mu, sigma = self.forward_raw_eval(y, hyper_out, entropy_model_y)
+        sym, idx = entropy_model_y.symbols_and_indexes(y, mu, sigma)
+        return sym, idx, yh, lik_q
+
+    @torch.no_grad()
+    def forward_compress(self, y: Tensor, hyper_out: Tensor, entropy_model_y) -> Tuple[List[bytes], Tensor, Tensor]:
+        from crdr_amd.codec import rans
+        t = self._tick(None)
+        sym, idx, yh, lik_q = self.forward_compress_device(y, hyper_out, entropy_model_y)
         t = self._tick("charm", t)
-        indexes = entropy_model_y.build_indexes(sigma)
-        y_str = entropy_model_y.compress(y, indexes=indexes, means=mu)
+        cdf, sizes, offs = entropy_model_y.host_tables()
+        sym, idx = sym.cpu().numpy(), idx.cpu().numpy()
+        y_str = [rans.encode_with_indexes(sym[i].reshape(-1), idx[i].reshape(-1), cdf, sizes, offs) for i in range(sym.shape[0])]
         self._tick("rans", t)
         return y_str, yh, lik_q
 
@@ -154,9 +164,7 @@ class Minnen20CharmContextModel(BaseContextModel):
         trips (one per sequential slice, one for the whole tail) instead of one per slice."""
         from crdr_amd.codec import rans
         from crdr_amd.hip import charm
-        cdf = entropy_model_y._quantized_cdf.cpu().numpy()
-        sizes = entropy_model_y._cdf_length.cpu().numpy()
-        offs = entropy_model_y._offset.cpu().numpy()
+        cdf, sizes, offs = entropy_model_y.host_tables()
         dec = rans.RansDecoder()
         dec.set_stream(y_str)
         h_mu, h_sc = torch.chunk(hyper_out, 2, dim=1)
@@ -173,8 +181,8 @@ class Minnen20CharmContextModel(BaseContextModel):
             t = self._tick("charm", t)
             # the stream holds the symbols in (channel, row, column) order: the channels of a stage are consecutive in it
             a, b = st[0] * sc, (st[-1] + 1) * sc
-            idx = entropy_model_y.build_indexes(sg_all[:, a:b])
-            vals = dec.decode_stream(idx.cpu().reshape(-1).int().numpy(), cdf, sizes, offs)
+            _, idx = entropy_model_y.symbols_and_indexes(None, None, sg_all[:, a:b])
+            vals = dec.decode_stream(idx.cpu().numpy().reshape(-1), cdf, sizes, offs)
             sym = torch.from_numpy(vals).view(run.n, b - a, run.h, run.w).to(hyper_out.device)
             syms[:, a:b] = sym
             v = entropy_model_y.dequantize(sym, mu_all[:, a:b])

@@ -128,6 +128,14 @@ class EntropyBottleneck(nn.Module):
         cdf, sizes, offs = self._quantized_cdf.cpu().numpy(), self._cdf_length.cpu().numpy(), self._offset.cpu().numpy()
         return [rans.encode_with_indexes(sym[i].reshape(-1).numpy(), idx[i].reshape(-1).numpy(), cdf, sizes, offs) for i in range(n)]
 
+    def compress_symbols(self, sym) -> List[bytes]:
+        """host half of compress(): sym = int32 numpy [N, C, H, W] (quantize_symbols, copied to the host by the caller)"""
+        from crdr_amd.codec import rans
+        n, c, h, w = sym.shape
+        idx = np.broadcast_to(np.arange(c, dtype=np.int32).reshape(c, 1, 1), (c, h, w)).reshape(-1)
+        cdf, sizes, offs = self._quantized_cdf.cpu().numpy(), self._cdf_length.cpu().numpy(), self._offset.cpu().numpy()
+        return [rans.encode_with_indexes(sym[i].reshape(-1), idx, cdf, sizes, offs) for i in range(n)]
+
     @torch.no_grad()
     def decompress(self, strings: List[bytes], size: Tuple[int, int]) -> Tensor:
         """-> integer symbols + medians (the caller's `dequantize` convention differs between reference models:

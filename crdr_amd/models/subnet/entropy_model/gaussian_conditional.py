@@ -69,6 +69,15 @@ class GaussianMeanScaleConditional(nn.Module):
         self._offset = (-center).int().to(dev)
         return True
 
+    def host_tables(self):
+        """(quantised CDFs, lengths, offsets) as numpy arrays, cached until the tables are rebuilt"""
+        key = (self._quantized_cdf.data_ptr(), tuple(self._quantized_cdf.shape))
+        c = self.__dict__.get("_host_tables")
+        if c is None or c[0] != key:
+            c = (key, (self._quantized_cdf.cpu().numpy(), self._cdf_length.cpu().numpy(), self._offset.cpu().numpy()))
+            self.__dict__["_host_tables"] = c
+        return c[1]
+
     @torch.no_grad()
     def build_indexes(self, scales: Tensor) -> Tensor:
         s = torch.clamp(scales, min=self.scale_bound)
@@ -76,6 +85,31 @@ class GaussianMeanScaleConditional(nn.Module):
         for v in self.scale_table[:-1].tolist():
             idx -= (s <= v).int()
         return idx
+
+    @torch.no_grad()
+    def symbols_and_indexes(self, y: Optional[Tensor], means: Optional[Tensor], scales: Tensor, out_sym: Optional[Tensor] = None,
+                            out_idx: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Tensor]:
+        """One launch: int32 symbols round(y - means) and CDF indexes of `scales`, both [N, C, H, W] CONTIGUOUS (the order the
+        host coder walks), from NHWC device tensors (crdr_gauss_symbols).  y = None: indexes only (decoder side)."""
+        import ctypes as C
+        from crdr_amd.hip import lib as L
+        from crdr_amd.hip import ops
+        sg, lds = ops.nhwc(scales)
+        n, c, h, w = sg.shape
+        dev = sg.device
+        idx = out_idx if out_idx is not None else torch.empty((n, c, h, w), dtype=torch.int32, device=dev)
+        sym = None
+        yp = mp = None
+        ldy = ldm = 0
+        if y is not None:
+            yy, ldy = ops.nhwc(y)
+            mm, ldm = ops.nhwc(means)
+            yp, mp = yy.data_ptr(), mm.data_ptr()
+            sym = out_sym if out_sym is not None else torch.empty((n, c, h, w), dtype=torch.int32, device=dev)
+        tab = self.scale_table.to(dev) if self.scale_table.device != dev else self.scale_table
+        L.check(L.load().crdr_gauss_symbols(yp, ldy, mp, ldm, sg.data_ptr(), lds, tab.data_ptr(), tab.numel(), self.scale_bound, n, h * w, c,
+                                            None if sym is None else sym.data_ptr(), idx.data_ptr(), ops._stream()), "gauss_symbols")
+        return sym, idx
 
     @staticmethod
     def quantize(inputs: Tensor, mode: str, means: Optional[Tensor] = None) -> Tensor:

@@ -367,6 +367,12 @@ int crdr_gauss_cond_fwd2(const crdr_gc_desc2* d, const crdr_gc_io* io, crdr_stre
 int crdr_gauss_cond_bwd2(const crdr_gc_desc2* d, const crdr_gc_io* io, crdr_stream_t s);
 /* U(-1/2, 1/2) samples of the generator above written out: out[(n * HW + px) * ld + c] for c < C (tests, and the noisy
  * latent the reference's non-STE GaussianConditional returns) */
+/* What the host rANS coder consumes, straight from the device tensors: symbols[n][c][p] = (int32) round(y - mu) and
+ * indexes[n][c][p] = number of scale-table entries below max(sigma, scale_bound), capped at levels - 1 (compressai
+ * GaussianConditional.quantize(.., "symbols", means) / build_indexes, minnen20_charm_context_model.py:186-187,197-199), in
+ * (channel, pixel) order so that one contiguous device-to-host copy per array suffices.  Either output may be NULL. */
+int crdr_gauss_symbols(const float* y, int ldy, const float* mu, int ldmu, const float* sigma, int ldsigma, const float* scale_table,
+                       int levels, float scale_bound, int N, int HW, int C, int32_t* symbols, int32_t* indexes, crdr_stream_t s);
 /* call[0..1] = state[0..1]; state[1] += inc -- one launch hands a forward pass its own (seed, offset) pair (kept for the
  * backward) and moves the generator on, so a captured HIP graph draws fresh noise at every replay */
 int crdr_philox_fork(uint64_t* state, uint64_t* call, uint64_t inc, crdr_stream_t s);

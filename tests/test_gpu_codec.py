@@ -71,3 +71,36 @@ def test_device_input_pipeline_matches_torchvision_semantics():
         assert np.array_equal(out[k].cpu().numpy(), ref), f"sample {k} (image {i}, draw {draws[k]})"
     batch = next(loader)["real_images"]
     assert batch.shape == (16, 3, 256, 256) and float(batch.min()) >= -1.0 and float(batch.max()) <= 1.0
+
+
+def test_symbols_kernel_matches_torch_statement():
+    """crdr_gauss_symbols == quantize(y, "symbols", mu) / build_indexes(sigma) of the module's torch statement, NCHW order."""
+    from crdr_amd.models.subnet.entropy_model.gaussian_conditional import GaussianMeanScaleConditional, get_scale_table
+    em = GaussianMeanScaleConditional().to(dev())
+    em.update_scale_table(get_scale_table(), force=True)
+    em.to(dev())
+    n, c, h, w = 2, 64, 9, 7
+    y = (seeded_input("sym.y", (n, c, h, w), 9.0)).to(dev()).contiguous(memory_format=torch.channels_last)
+    mu = (seeded_input("sym.mu", (n, c, h, w), 4.0)).to(dev()).contiguous(memory_format=torch.channels_last)
+    sg = torch.exp(seeded_input("sym.sg", (n, c, h, w), 6.0)).to(dev()).contiguous(memory_format=torch.channels_last)
+    sg[0, 0, 0, :3] = torch.tensor([0.0, 0.11, 300.0], device=dev())
+    sg[0, 1, 0, :2] = em.scale_table[[5, 40]].to(dev())      # exactly on a table entry
+    sym, idx = em.symbols_and_indexes(y, mu, sg)
+    assert sym.is_contiguous() and idx.is_contiguous() and sym.dtype == torch.int32
+    assert torch.equal(sym, em.quantize(y, "symbols", mu).contiguous())
+    assert torch.equal(idx, em.build_indexes(sg).contiguous())
+    _, idx2 = em.symbols_and_indexes(None, None, sg[:, 16:48])
+    assert torch.equal(idx2, idx[:, 16:48])
+
+
+def test_pipelined_sweep_equals_serial_compress():
+    model, _ = _full_model(True)
+    model.eval()
+    model.codec_setup()
+    imgs = [seeded_input(f"sweep{k}", (1, 3, 96 + 32 * k, 128)) for k in range(4)]
+    serial = [model.compress(im, rate_ind=1.5) for im in imgs]
+    for workers in (1, 3):
+        piped = list(model.compress_many(imgs, workers=workers, rate_ind=1.5))
+        for a, b in zip(serial, piped):
+            assert a["string_list"] == b["string_list"]
+            assert torch.equal(a["y_hat"], b["y_hat"]) and a["pred_y_bit"] == b["pred_y_bit"]

@@ -1,6 +1,9 @@
-"""BASELINE config #5 stand-in: compress -> decompress of one CLIC-sized image (seeded smooth noise, random-init weights)
-on one GPU; prints the wall-time split and checks the decoder reproduces y_hat bit for bit.
-Usage: python tools/fullres_codec.py [H W] [q] [beta]"""
+"""BASELINE config #5 stand-in: compress -> decompress of CLIC-sized images (seeded smooth noise, random-init weights) on one
+GPU.  Prints the wall-time split {transforms, Charm, rANS} of one image, checks the decoder reproduces y_hat / z_hat bit for
+bit, and times a sweep of K images serially (compress() per image) against the pipelined form (compress_many: the host coder
+of image k in worker threads beside the GPU work of image k+1).
+Usage: python tools/fullres_codec.py [H W] [q] [beta] [K]"""
+import json
 import os
 import sys
 import time
@@ -14,32 +17,57 @@ from crdr_amd.utils.options import BaseConfig, ConfigDict  # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def smooth_image(h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    small = torch.rand(1, 3, h // 16 + 1, w // 16 + 1, generator=g) * 2 - 1
+    return torch.nn.functional.interpolate(small, size=(h, w), mode="bicubic", align_corners=False).clamp(-1, 1)
+
+
 def main():
     h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1365, 2048)
     q = float(sys.argv[3]) if len(sys.argv) > 3 else 2.25
     beta = float(sys.argv[4]) if len(sys.argv) > 4 else 3.84
+    K = int(sys.argv[5]) if len(sys.argv) > 5 else 8
     cfg, _, _ = BaseConfig._file2dict_yaml(os.path.join(ROOT, "config", "crdr.yaml"))
     cfg["device"], cfg["is_train"] = "cuda:0", False
     torch.manual_seed(0)
-    t = time.perf_counter()
     model = build_comp_model(ConfigDict(cfg)).to("cuda:0").eval()
-    print("build", round(time.perf_counter() - t, 2), flush=True); t = time.perf_counter()
     model.codec_setup()
-    print("codec_setup", round(time.perf_counter() - t, 2), flush=True)
-    g = torch.Generator().manual_seed(1)
-    small = torch.rand(1, 3, h // 16 + 1, w // 16 + 1, generator=g) * 2 - 1
-    x = torch.nn.functional.interpolate(small, size=(h, w), mode="bicubic", align_corners=False).clamp(-1, 1)
-    for rep in range(2):  # second pass: warm (packs, workspaces, tuned paths)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = model.compress(x, rate_ind=q)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        fake, z_hat, y_hat = model.decompress(out["string_list"], beta=beta)
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        print("pass", rep, "compress", round(t1 - t0, 3), "decompress", round(t2 - t1, 3), flush=True)
+    imgs = [smooth_image(h, w, 1 + k) for k in range(K)]
+    out = model.compress(imgs[0], rate_ind=q)          # warm-up: packs, workspaces, pinned buffers
+    model.decompress(out["string_list"], beta=beta)
+    torch.cuda.synchronize()
+    # one image, with the split
+    model.codec_profile = {}
+    t0 = time.perf_counter()
+    out = model.compress(imgs[0], rate_ind=q)
+    t1 = time.perf_counter()
+    enc = dict(model.codec_profile)
+    model.codec_profile = {}
+    fake, z_hat, y_hat = model.decompress(out["string_list"], beta=beta)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    dec = dict(model.codec_profile)
+    model.codec_profile = None
+    ok = torch.equal(y_hat, out["y_hat"]) and torch.equal(z_hat, out["z_hat"])
+    # sweep: serial vs pipelined
+    torch.cuda.synchronize(); t = time.perf_counter()
+    serial = [model.compress(im, rate_ind=q)["string_list"] for im in imgs]
+    torch.cuda.synchronize(); t_serial = time.perf_counter() - t
+    res = {}
+    for workers in (1, 2, 3):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        piped = [o["string_list"] for o in model.compress_many(imgs, workers=workers, rate_ind=q)]
+        torch.cuda.synchronize()
+        res[workers] = time.perf_counter() - t
+        assert piped == serial, "the pipelined sweep produced different bytes"
     nbytes = sum(len(s) for s in out["string_list"]) + 12
-    ok = torch.equal(y_hat.cpu(), out["y_hat"].cpu()) and torch.equal(z_hat.cpu(), out["z_hat"].cpu())
-    print({"size": (h, w), "q": q, "beta": beta, "compress_s": round(t1 - t0, 3), "decompress_s": round(t2 - t1, 3),
-           "bpp": round(nbytes * 8 / h / w, 4), "roundtrip_bit_exact": ok, "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
+    print(json.dumps({"size": [h, w], "q": q, "beta": beta, "bpp": round(nbytes * 8 / h / w, 4), "roundtrip_bit_exact": ok,
+                      "one_image": {"compress_s": round(t1 - t0, 4), "decompress_s": round(t2 - t1, 4),
+                                    "compress_split": {k: round(v, 4) for k, v in enc.items()}, "decompress_split": {k: round(v, 4) for k, v in dec.items()}},
+                      "sweep": {"images": K, "serial_s": round(t_serial, 4), **{f"pipelined_{k}_workers_s": round(v, 4) for k, v in res.items()},
+                                "speedup_2_workers": round(t_serial / res[2], 3)},
+                      "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
     assert ok and fake.shape == (1, 3, h, w)
 
 
