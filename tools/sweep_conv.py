@@ -19,6 +19,8 @@ SHAPES = {
     "enc96k3": (96, 128, 96, 3, 1, 0, 3),
     "enc96k3@64": (96, 64, 96, 3, 1, 0, 3),
     "dec256k1": (256, 128, 128, 1, 1, 0, 3),
+    "enc192k1@128": (192, 128, 96, 1, 1, 0, 3),
+    "dec128to256k1@128": (128, 128, 256, 1, 1, 0, 17),
     "enc192k1@64": (192, 64, 96, 1, 1, 0, 3),
     "enc96to192k1@64": (96, 64, 192, 1, 1, 0, 17),
     "dec128to256k1@64": (128, 64, 256, 1, 1, 0, 17),
