@@ -15,7 +15,7 @@ def dur(d):
     return sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows) / len(rows) / 1e3, rows[-1]
 us, r = dur("a")
 print(tag, "kernel", r["Kernel_Name"][:60], "grid", r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], "wg", r["Workgroup_Size_X"], "lds", r["LDS_Block_Size"], "vgpr", r["VGPR_Count"])
-print("  duration %.1f us -> %.1f TF" % (us, gflop / us * 1e-3))
+print("  duration %.1f us -> %.1f TF" % (us, gflop * 1e3 / us))
 mf, _ = last("a", "SQ_VALU_MFMA_BUSY_CYCLES"); gui, _ = last("a", "GRBM_GUI_ACTIVE")
 wc, _ = last("a", "SQ_WAVE_CYCLES"); wa, _ = last("a", "SQ_WAIT_ANY"); wi, _ = last("a", "SQ_WAIT_INST_ANY"); ai, _ = last("a", "SQ_ACTIVE_INST_ANY")
 cyc = gui / 8
