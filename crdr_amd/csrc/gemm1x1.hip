@@ -1,0 +1,275 @@
+// Streaming 1x1 convolution kernel of the implicit-GEMM family (see igemm.hip for the tiled kernels and the host side).
+
+#include <atomic>
+
+#include "common.hpp"
+#include "igemm_args.hpp"
+
+namespace crdr {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------------
+// Streaming 1x1 convolution (a plain GEMM  out[m][oc] = epi(sum_c in[m][c] w[oc][c]),  K = Cin <= 320).
+//
+// The generic kernel above runs the 1x1 layers of the bottleneck blocks at ~40 % MFMA occupancy and ~2 TB/s: a K loop of
+// 3..8 iterations cannot hide the load latency behind a double buffer, and every tile pays its own ramp and epilogue
+// (PMC: profiles/r2_f_pmc_1x1_vs_3x3.txt).  Here a workgroup is PERSISTENT: it loads its weight tile [BN][K] into LDS once,
+// then walks its share of the 128-row M tiles with an S-stage ring of [128][32] activation tiles that keeps running across
+// tile boundaries -- the DMA of the next tiles is in flight during the epilogue of the current one -- with counted vmcnt
+// waits and raw s_barriers (a __syncthreads() would drain the ring).  Block = 4 waves (one per SIMD), wave tile = 32 rows x
+// BN columns (NB = BN / 32 accumulators); fragment layout and epilogue arithmetic are those of the generic kernel, so the
+// results are bit-identical to its unsplit configurations.  Workgroups that share M tiles (different N tiles) sit on one
+// XCD, so the activation rows come from HBM once.  Plain launches only (no split-K, no groups, no gate epilogue).
+// ------------------------------------------------------------------------------------------------------------
+// OPS: operands read by the epilogue besides the per-column vectors: bit 0 = res (CRDR_EPI_RES), bit 1 = mask (the ReLU masks)
+template <int NB, int S, int OPS>
+__global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p, const StreamArgs sa) {
+  constexpr int BM = 128, BN = 32 * NB, NT = 256, AV = BM * 8 / NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int KT = p.kchunks;
+  float* sB = smem;                            // [KT][BN * 32]   weight tile, one swizzled image per 32-channel chunk
+  float* sA = sB + KT * BN * 32;               // [S][BM * 32]    activation ring
+  float* sCall = sA + S * BM * 32;             // [4 waves][32 * 32]  epilogue transpose (private to a wave)
+  float* sS = sCall + 4 * 1024;                // [4][2][BN]      column sums of the four row groups
+  float* sV = sS + 4 * 2 * BN;                 // [4][BN]         bias, vec2, scale, shift of this column tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3;        // consecutive workgroup ids rotate over the XCDs
+  const int tile_n = slot % sa.gridN;
+  const int mlane = (slot / sa.gridN) * 8 + xcd;
+  const int nlanes = sa.nlanes;
+  const int n0 = tile_n * BN;
+  const int mtiles = (p.M + BM - 1) / BM;
+  const int my_tiles = mlane < mtiles ? (mtiles - mlane + nlanes - 1) / nlanes : 0;
+  const int ldx = p.ldx;
+
+  const int srow = tid >> 3;
+  const int csrc = (tid & 7) ^ ((srow >> 1) & 7);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  // ---- weight tile, once
+  for (int kc = 0; kc < KT; ++kc) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int oc = n0 + srow + j * 32;
+      const unsigned off = oc < p.wrows ? (unsigned)(oc * p.wcols + kc * 32 + csrc * 4) * 4u : kOobOffset;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sB + kc * BN * 32 + wave * 8 * 32 + j * 32 * 32), 16, (int)off, 0, 0, 0);
+    }
+  }
+  // ---- activation ring: every call loads the next (tile, K chunk) of this workgroup into the next slot; past the end it
+  // issues out-of-range loads (they write zeros) so that the number of pieces in flight per thread stays uniform
+  int f_t = 0, f_kc = 0, f_slot = 0;
+  auto fetch = [&]() __attribute__((always_inline)) {
+    const bool live = f_t < my_tiles;
+    const long long m0 = (long long)(mlane + f_t * nlanes) * BM;
+    const unsigned long long base_bytes = live ? (unsigned long long)m0 * ldx * 4ull : 0ull;
+    const unsigned long long left = live ? p.x_bytes - base_bytes : 0ull;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x) + (live ? m0 * ldx : 0), 0, (unsigned)(left < 0x7fffffffull ? left : 0x7fffffffull), 0x00020000);
+    float* a = sA + f_slot * BM * 32 + wave * 8 * 32;
+#pragma unroll
+    for (int j = 0; j < AV; ++j) {
+      const int r = srow + j * 32;
+      const bool ok = live && (m0 + r < p.M);
+      const unsigned off = (unsigned)(r * ldx + f_kc * 32 + csrc * 4) * 4u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(a + j * 32 * 32), 16, (int)(ok ? off : kOobOffset), 0, 0, 0);
+    }
+    if (++f_kc == KT) { f_kc = 0; ++f_t; }
+    if (++f_slot == S) f_slot = 0;
+  };
+#pragma unroll
+  for (int g = 0; g < S - 1; ++g) fetch();
+
+  f32x16 acc[NB];
+  const int frow = lane & 31, fh = lane >> 5;
+  int fo[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) fo[kk] = lds_off(frow, kk * 2 + fh);
+  const int f = p.flags;
+  const bool do_cs = (f & CRDR_EPI_COLSUM) != 0;
+  constexpr bool HAS_RES = (OPS & 1) != 0, HAS_MASK = (OPS & 2) != 0;
+  float* sC = sCall + wave * 1024;
+  // per-column epilogue vectors, staged once (neutral values beyond Cout): the epilogue never waits on them
+  for (int c = tid; c < BN; c += NT) {
+    const bool live = n0 + c < p.Cout;
+    sV[0 * BN + c] = (live && (f & CRDR_EPI_BIAS)) ? p.bias[n0 + c] : 0.f;
+    sV[1 * BN + c] = (live && (f & (CRDR_EPI_VEC2 | CRDR_EPI_MASKOFF))) ? p.vec2[n0 + c] : 0.f;
+    sV[2 * BN + c] = (live && (f & CRDR_EPI_AFFINE)) ? p.scale[n0 + c] : 1.f;
+    sV[3 * BN + c] = (live && (f & CRDR_EPI_AFFINE)) ? p.shift[n0 + c] : 0.f;
+  }
+  constexpr int kWait = (S - 2) * AV;  // pieces that may still be in flight when the stage to be consumed must have landed
+  constexpr int kWaitEpi = kWait + 4 * NB;  // ... plus the stores of an epilogue issued since that stage was requested
+  static_assert(kWaitEpi <= 63, "vmcnt immediate");
+  constexpr int kImmWait = 0x0F70 | (kWait & 15) | ((kWait >> 4) << 14);
+  constexpr int kImmWaitEpi = 0x0F70 | (kWaitEpi & 15) | ((kWaitEpi >> 4) << 14);
+  const int c4 = lane & 7, rbase = lane >> 3;  // epilogue: a lane keeps one 4-channel column group, rows rbase + 8 k
+
+  int c_slot = 0;
+  for (int t = 0; t < my_tiles; ++t) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int kc = 0; kc < KT; ++kc) {
+      // vmcnt counts loads, DMA pieces and stores in issue order: the stage consumed now is older than S - 2 stages and,
+      // during the first S - 1 iterations after an epilogue, than that epilogue's 4 NB stores
+      if (t > 0 && kc < S - 1) __builtin_amdgcn_s_waitcnt(kImmWaitEpi);
+      else __builtin_amdgcn_s_waitcnt(kImmWait);
+      __builtin_amdgcn_s_barrier();                 // this stage is complete for every wave; the previous slot is free
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const float* fa = sA + c_slot * BM * 32 + (wave * 32) * 32;
+      const float* fb = sB + kc * BN * 32;
+      // fragments of k group kk + 1 are requested before the MFMAs of group kk are issued
+      f32x4 af[2], bf[2][NB];
+      af[0] = *reinterpret_cast<const f32x4*>(fa + fo[0]);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(fb + fo[0] + j * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+          af[(kk + 1) & 1] = *reinterpret_cast<const f32x4*>(fa + fo[kk + 1]);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) bf[(kk + 1) & 1][j] = *reinterpret_cast<const f32x4*>(fb + fo[kk + 1] + j * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][s2], bf[kk & 1][j][s2], acc[j], 0, 0, 0);
+#ifndef EXP_NOFETCH
+        if (kk == 0) fetch();                       // issued in the shadow of the first MFMAs
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (++c_slot == S) c_slot = 0;
+    }
+    // ---- epilogue of this M tile (the ring keeps filling meanwhile).  sC is private to the wave: no barriers.  Every
+    // global access is a buffer instruction issued by all lanes (rows past M / column groups past Cout get an out-of-range
+    // offset: loads return 0, stores are dropped), so the code is straight-line, the compiler's vmcnt waits are exact and
+    // the operands of pass j + 1 are in flight while pass j is computed and stored.
+    const int mt = mlane + t * nlanes;
+    const long long mw = (long long)mt * BM + wave * 32;  // first row of this wave
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + mw * p.ldy, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_RES ? p.res + mw * p.ldres : p.y), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_MASK ? p.mask + mw * p.ldmask : p.y), 0, 0x7fffffff, 0x00020000);
+    bool rowok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rowok[k] = mw + rbase + 8 * k < p.M;
+    f32x4 res4[2][4], msk4[2][4];
+    auto load_ops = [&](int j) __attribute__((always_inline)) {
+      const int oc0 = n0 + j * 32 + c4 * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = rowok[k] && oc0 < p.Cout;
+        if constexpr (HAS_RES)
+          res4[j & 1][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+              rr, ok ? (unsigned)((rbase + 8 * k) * p.ldres + oc0) * 4u : kOobOffset, 0, 0));
+        if constexpr (HAS_MASK)
+          msk4[j & 1][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+              rm, ok ? (unsigned)((rbase + 8 * k) * p.ldmask + oc0) * 4u : kOobOffset, 0, 0));
+      }
+    };
+    load_ops(0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int oc0 = n0 + j * 32 + c4 * 4;
+      const bool colok = oc0 < p.Cout;  // Cout % 4 == 0 (checked by the host): column groups are whole
+      if (j + 1 < NB) load_ops(j + 1);
+      const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sV + 0 * BN + j * 32 + c4 * 4);
+      const f32x4 vec24 = *reinterpret_cast<const f32x4*>(sV + 1 * BN + j * 32 + c4 * 4);
+      const f32x4 scale4 = *reinterpret_cast<const f32x4*>(sV + 2 * BN + j * 32 + c4 * 4);
+      const f32x4 shift4 = *reinterpret_cast<const f32x4*>(sV + 3 * BN + j * 32 + c4 * 4);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + frow] = acc[j][r];
+      f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + (rbase + 8 * k) * 32 + c4 * 4);
+        const bool ok = rowok[k] && colok;
+        f32x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = a4[e];
+          if (f & CRDR_EPI_BIAS) v += bias4[e];
+          if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
+          if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
+          if (f & CRDR_EPI_VEC2) v += vec24[e];
+          if constexpr (HAS_RES) v += res4[j & 1][k][e];
+          if (f & CRDR_EPI_AFFINE) v = v * scale4[e] + shift4[e];
+          if (do_cs) cpre[e] += ok ? v : 0.f;
+          if constexpr (HAS_MASK) {
+            float mv = msk4[j & 1][k][e];
+            if (f & CRDR_EPI_MASKOFF) mv -= vec24[e];
+            v = mv > 0.0f ? v : ((f & CRDR_EPI_LRELUMASK) ? 0.2f * v : 0.0f);
+          }
+          if (do_cs) cpost[e] += ok ? v : 0.f;
+          o4[e] = v;
+        }
+#ifndef EXP_NOSTORE
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), ry,
+                                               ok ? (unsigned)((rbase + 8 * k) * p.ldy + oc0) * 4u : kOobOffset, 0, 0);
+#endif
+      }
+      if (do_cs) {
+#pragma unroll
+        for (int off = 32; off >= 8; off >>= 1)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            cpre[e] += __shfl_xor(cpre[e], off, 64);
+            cpost[e] += __shfl_xor(cpost[e], off, 64);
+          }
+        if (lane < 8) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            sS[(wave * 2 + 0) * BN + j * 32 + lane * 4 + e] = cpre[e];
+            sS[(wave * 2 + 1) * BN + j * 32 + lane * 4 + e] = cpost[e];
+          }
+        }
+      }
+    }
+    if (do_cs) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): my sS writes are done
+      __builtin_amdgcn_s_barrier();
+      float* dst = p.cs + ((size_t)mt * 2) * p.cs_ld;
+      for (int t2 = tid; t2 < 2 * BN; t2 += NT) {
+        const int which = t2 / BN, c = t2 - which * BN;
+        const float v = ((sS[(0 * 2 + which) * BN + c] + sS[(1 * 2 + which) * BN + c]) + sS[(2 * 2 + which) * BN + c]) + sS[(3 * 2 + which) * BN + c];
+        if (n0 + c < p.Cout) dst[(size_t)which * p.cs_ld + n0 + c] = v;
+      }
+      // the next writes to sS come after the barrier at the top of the next iteration
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): no DMA may land in LDS after the workgroup is gone
+}
+
+struct StreamCfg {
+  int nb, stages;
+  void (*kern[4])(const IgemmArgs, const StreamArgs);  // by OPS
+};
+#define SCFG(nb, st) {nb, st, {gemm1x1_kernel<nb, st, 0>, gemm1x1_kernel<nb, st, 1>, gemm1x1_kernel<nb, st, 2>, gemm1x1_kernel<nb, st, 3>}}
+static const StreamCfg kStreamCfgs[] = {SCFG(2, 4), SCFG(3, 4), SCFG(4, 4), SCFG(6, 3)};
+#undef SCFG
+static const int kNumStreamCfgs = sizeof(kStreamCfgs) / sizeof(kStreamCfgs[0]);
+
+int stream_num_variants() { return kNumStreamCfgs; }
+
+void stream_variant_shape(int v, int* nb, int* stages) {
+  *nb = kStreamCfgs[v].nb;
+  *stages = kStreamCfgs[v].stages;
+}
+
+void stream_launch(int v, const IgemmArgs& a, const StreamArgs& sa, unsigned grid, size_t lds, hipStream_t s) {
+  const StreamCfg& sc = kStreamCfgs[v];
+  const int ops = ((a.flags & CRDR_EPI_RES) ? 1 : 0) | ((a.flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) ? 2 : 0);
+  static std::atomic<bool> attr_done[16][4];
+  if (!attr_done[v][ops].load(std::memory_order_acquire)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc.kern[ops]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done[v][ops].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(sc.kern[ops], dim3(grid), dim3(256), lds, s, a, sa);
+}
+
+}  // namespace crdr

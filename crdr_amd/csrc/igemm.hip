@@ -18,68 +18,13 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "igemm_args.hpp"
 
 #ifndef CRDR_IGEMM_FETCH_FIRST
 #define CRDR_IGEMM_FETCH_FIRST 1
 #endif
 
 namespace crdr {
-
-struct IgemmArgs {
-  const float* x;
-  const float* w;
-  float* y;
-  float* ws;
-  const float* bias;
-  const float* vec2;
-  const float* res;
-  const float* scale;
-  const float* shift;
-  const float* gx;
-  const float* gt;
-  float* sig;
-  const float* pre;
-  const float* mask;
-  float* cs;       // CRDR_EPI_COLSUM: per-tile partial column sums [rows][2][cs_ld] (pre-mask, post-mask)
-  int ldpre, ldmask;
-  int cs_ld, cs_rows;
-  int ngroup;
-  int N, H, W, Cin, ldx;
-  int GH, GW, so, OH, OW, ldy, Cout;
-  int si;
-  int wrows, wcols;
-  int ldres, ldg;
-  int flags;
-  int M;  // rows per phase = N*GH*GW
-  int nphase, nsplit;
-  int kchunks;
-  int ws_ld;  // columns of a partial slab row (= gridDim.y * BN)
-  int vec_epi;  // 1: y / res / gx / gt / sig rows are 16-byte aligned -> vector epilogue
-  int smallc;   // 1: Cin <= 4 and the weight pack is tap-major ([rows][taps*4]): a K-tile covers 8 taps x 4 channels
-  unsigned long long x_bytes;  // extent of the input tensor (the descriptor is re-based per workgroup, see kernel)
-  unsigned w_bytes;            // extent of the weight pack's buffer descriptor
-};
-
-// Tap / phase tables travel as a second by-value kernel argument that is only ever indexed with wave-uniform
-// indices in the kernel prologue (keeps the scalar argument block above in SGPRs).
-struct IgemmTaps {
-  int packed[128];  // (dh & 0xff) | (dw & 0xff) << 8 | widx << 16
-  short tap_begin[17];
-  int8_t poh[16], pow[16];
-};
-
-// Per-problem pointers of a grouped launch (crdr_conv2d_grouped); a plain launch is a group of one.  Only ever indexed
-// with the workgroup-uniform problem index.
-struct IgemmGroup {
-  const float* x[CRDR_MAX_GROUP];
-  const float* w[CRDR_MAX_GROUP];
-  float* y[CRDR_MAX_GROUP];
-  const float* bias[CRDR_MAX_GROUP];
-  const float* pre[CRDR_MAX_GROUP];
-  const float* mask[CRDR_MAX_GROUP];
-  const float* res[CRDR_MAX_GROUP];
-  float* cs[CRDR_MAX_GROUP];
-};
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
@@ -115,8 +60,6 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, 
 // offset beyond the buffer descriptor's range and the hardware range check returns zeros for them.  The XOR swizzle
 // of the tile image (lds_off) is applied on the SOURCE side: the lane that fills slot s of row r fetches chunk
 // s ^ ((r >> 1) & 7).
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-static constexpr unsigned kOobOffset = 0x80000000u;  // >= any descriptor size accepted by build_plan (< 2 GiB)
 
 template <int WM, int WN, int MB, int NB, bool SMALLC>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
@@ -537,6 +480,8 @@ struct Plan {
   IgemmArgs a;
   IgemmTaps t;
   int cfg;
+  int stream;  // index into kStreamCfgs, or -1: the tiled kernel
+  StreamArgs sa;
   dim3 grid;
   size_t lds;
   size_t ws_bytes;
@@ -628,6 +573,36 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
       if (cost < best) { best = cost; bc = c; bs = ns; }
     }
   }
+  pl->stream = -1;
+  if (d->reserved != 0 && (d->reserved & 0xff) - 1 >= kNumCfgs) {  // forced streaming 1x1 variant
+    const int sv = (d->reserved & 0xff) - 1 - kNumCfgs;
+    CRDR_REQUIRE(sv < stream_num_variants(), "conv2d: forced config %d out of range", sv + kNumCfgs);
+    CRDR_REQUIRE(((d->reserved >> 8) & 0xf) == 0, "conv2d: the streaming 1x1 kernel has no split-K");
+    CRDR_REQUIRE(G == 1 && !a.smallc && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->C % 32 == 0 &&
+                     !(d->flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM)) && d->OC % 4 == 0,
+                 "conv2d: the streaming kernel takes ungrouped 1x1 stride-1 convolutions with C %% 32 == 0, OC %% 4 == 0 and no "
+                 "gate / pre-add / accumulate epilogue");
+    int snb, sstages;
+    stream_variant_shape(sv, &snb, &sstages);
+    const int BN = 32 * snb;
+    const size_t lds = ((size_t)a.kchunks * BN * 32 + (size_t)sstages * 128 * 32 + 4 * 1024 + 4 * 2 * BN + 4 * BN) * sizeof(float);
+    CRDR_REQUIRE(lds <= 160 * 1024, "conv2d: streaming variant %d needs %zu B of LDS for C = %d", sv, lds, d->C);
+    const int gridN = cdiv(d->OC, BN), mtiles = cdiv(a.M, 128);
+    CRDR_REQUIRE(gridN <= 32, "conv2d: streaming variant %d: %d column tiles", sv, gridN);
+    const int nlanes = std::max(8, std::min(256 / gridN / 8 * 8, round_up(mtiles, 8)));
+    pl->stream = sv;
+    pl->cfg = -1;
+    pl->sa.gridN = gridN;
+    pl->sa.nlanes = nlanes;
+    a.nsplit = 1;
+    a.ws_ld = 0;
+    pl->grid = dim3(gridN * nlanes, 1, 1);
+    pl->lds = lds;
+    a.cs_ld = round_up(d->OC, 32);
+    a.cs_rows = want_cs ? mtiles : 0;
+    pl->ws_bytes = 0;
+    return 0;
+  }
   if (d->reserved != 0) {  // caller-forced algorithm (autotuner): (config index + 1) | log2(split) << 8
     bc = (d->reserved & 0xff) - 1;
     bs = 1 << ((d->reserved >> 8) & 0xf);
@@ -660,6 +635,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
 using namespace crdr;
 
 extern "C" int crdr_conv2d_num_configs(void) { return kNumCfgs; }
+extern "C" int crdr_conv2d_num_stream_configs(void) { return stream_num_variants(); }
 
 extern "C" size_t crdr_conv2d_workspace(const crdr_conv_desc* d) {
   Plan pl;
@@ -731,6 +707,14 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
     if (a.flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) v = v && al16(q.mask);
   }
   a.vec_epi = v ? 1 : 0;
+  if (pl.stream >= 0) {
+    CRDR_REQUIRE(a.vec_epi, "conv2d: the streaming kernel needs 16-byte aligned operand rows");
+    void* prof = profile_begin(as_stream(s));
+    stream_launch(pl.stream, a, pl.sa, pl.grid.x, pl.lds, as_stream(s));
+    CRDR_CHECK_LAUNCH("gemm1x1_kernel");
+    profile_end(0, crdr_conv2d_flops(d), prof, as_stream(s));
+    return 0;
+  }
   const TileCfg& t = kCfgs[pl.cfg];
   auto kern = a.smallc ? t.kern_smallc : t.kern;
   static std::atomic<bool> attr_done[2][64];

@@ -96,6 +96,7 @@ SIGNATURES = {
     "crdr_profile_enable": (None, [_I]),
     "crdr_profile_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "crdr_conv2d_num_configs": (_I, []),
+    "crdr_conv2d_num_stream_configs": (_I, []),
     "crdr_conv2d_wgrad_num_configs": (_I, []),
     "crdr_conv2d_workspace": (_SZ, [C.POINTER(ConvDesc)]),
     "crdr_conv2d": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvIO), _P, _SZ, _P]),

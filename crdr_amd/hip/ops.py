@@ -41,21 +41,27 @@ def _time_call(fn, reps: int = 2) -> float:
     return best
 
 
-def _autotune(key, ncfg: int, max_log2_split: int, run) -> int:
+def _stream_ids():
+    """Forced-algorithm ids of the streaming 1x1 variants (the library rejects them for other shapes)."""
+    lib = L.load()
+    n = lib.crdr_conv2d_num_configs()
+    return [n + 1 + v for v in range(lib.crdr_conv2d_num_stream_configs())]
+
+
+def _autotune(key, ncfg: int, max_log2_split: int, run, extra=()) -> int:
     """run(algo) -> bool (False if the library rejects the combination). Returns the fastest algo id."""
     best, best_t = 0, _time_call(lambda: run(0))
     base_t = best_t
-    for c in range(ncfg):
-        for ls in range(max_log2_split + 1):
-            algo = (c + 1) | (ls << 8)
-            try:
-                if not run(algo):
-                    continue
-                t = _time_call(lambda: run(algo))
-            except L.CrdrHipError:
+    cands = [(c + 1) | (ls << 8) for c in range(ncfg) for ls in range(max_log2_split + 1)] + list(extra)
+    for algo in cands:
+        try:
+            if not run(algo):
                 continue
-            if t < best_t:
-                best, best_t = algo, t
+            t = _time_call(lambda: run(algo))
+        except L.CrdrHipError:
+            continue
+        if t < best_t:
+            best, best_t = algo, t
     _algo_cache[key] = best
     TUNE_LOG.append((key, best, base_t, best_t))
     return best
@@ -66,7 +72,8 @@ DEFAULT_TUNE_DB = __import__("os").path.join(__import__("os").path.dirname(__fil
 
 def _tune_signature() -> str:
     lib = L.load()
-    return f"v{lib.crdr_version()}-c{lib.crdr_conv2d_num_configs()}-w{lib.crdr_conv2d_wgrad_num_configs()}"
+    return (f"v{lib.crdr_version()}-c{lib.crdr_conv2d_num_configs()}-s{lib.crdr_conv2d_num_stream_configs()}"
+            f"-w{lib.crdr_conv2d_wgrad_num_configs()}")
 
 
 def save_tune_cache(path: str) -> None:
@@ -277,7 +284,7 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
                 nb = lib.crdr_conv2d_workspace(C.byref(d))
                 w_, wn_ = workspace(nb, x.device) if nb else (None, 0)
                 return lib.crdr_conv2d(C.byref(d), C.byref(io), w_, wn_, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run)
+            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids())
         d.reserved = algo
     nbytes = lib.crdr_conv2d_workspace(C.byref(d))
     ws, ws_n = workspace(nbytes, x.device) if nbytes else (None, 0)
@@ -562,7 +569,7 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
                 nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
                 w_, wn_ = workspace(nb, device) if nb else (None, 0)
                 return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run)
+            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids())
         d.reserved = algo
     nbytes = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
     ws, ws_n = workspace(nbytes, device) if nbytes else (None, 0)
@@ -846,7 +853,7 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
                 nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
                 w_, wn_ = workspace(nb, device) if nb else (None, 0)
                 return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run)
+            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids())
         d.reserved = algo
     out = None
     if colsum:

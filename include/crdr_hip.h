@@ -114,6 +114,11 @@ typedef struct crdr_conv_io {
 
 /* number of tile configurations a forced algorithm may name */
 int crdr_conv2d_num_configs(void);
+/* number of streaming 1x1 variants: forced algorithm ids crdr_conv2d_num_configs() + 1 + v, no split bits.  A persistent
+ * workgroup keeps its weight tile in LDS and streams 128-row activation tiles through a DMA ring (the 1x1 layers of
+ * ResidualBottleneck, elic_layers.py:17-36, and of the NLAM branches); rejected for anything but an ungrouped 1x1
+ * stride-1 convolution with C % 32 == 0, no gate epilogue, and a weight tile that fits LDS */
+int crdr_conv2d_num_stream_configs(void);
 /* bytes of workspace crdr_conv2d needs for this problem (split-K partial slabs; may be 0) */
 size_t crdr_conv2d_workspace(const crdr_conv_desc* d);
 int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);

@@ -357,3 +357,99 @@ def test_degenerate_shapes():
     w1 = torch.nn.Parameter(_rand(1, 1, 5, 5, seed=5).to(dev))
     x = _rand(1, 1, 9, 11, seed=6)
     _close(HF.fused_conv(x.to(dev), w1, None, spec1), F.conv2d(x.double(), w1.detach().cpu().double(), stride=2, padding=2), "1->1 k5s2")
+
+
+STREAM_CASES = [
+    # name, N, H, W, Cin, Cout  (M = N*H*W: multiples of 128, ragged, fewer tiles than lanes, more tiles than lanes)
+    ("256_128", 2, 32, 32, 256, 128),
+    ("96_192_ragged", 3, 7, 9, 96, 192),
+    ("192_96", 1, 40, 52, 192, 96),
+    ("128_256_many_tiles", 5, 96, 96, 128, 256),
+    ("256_100_partial_cols", 2, 17, 23, 256, 100),
+    ("64_64", 1, 5, 5, 64, 64),
+    ("32_32_one_chunk", 2, 30, 30, 32, 32),
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=[c[0] for c in STREAM_CASES])
+def test_streaming_1x1_variants(case):
+    """The persistent 1x1 kernel (forced ids num_configs + 1 + v) against the fp64 reference and, bit for bit, against the
+    tiled kernel -- same MFMA order per output, same epilogue arithmetic -- for every epilogue it implements, including
+    channel-slice operands (ld > C), the in-epilogue column sums and accumulation into the output."""
+    import ctypes as C
+    from crdr_amd.hip import ops, lib as L
+    name, n, h, w, ci, co = case
+    dev = _dev()
+    lib = L.load()
+    ids = ops._stream_ids()
+    assert len(ids) >= 1
+    M = n * h * w
+    ldx, ldy = ci + 32, co + 8
+    X = _rand(M, ldx, seed=1).to(dev)
+    wt = _rand(co, ci, 1, 1, seed=2, scale=ci ** -0.5)
+    wp = ops.pack_weight(wt.to(dev), False)
+    b = _rand(co, seed=3).to(dev)
+    v2 = _rand(co, seed=4).to(dev)
+    sc, sh = (_rand(co, seed=5) + 1.5).to(dev), _rand(co, seed=6).to(dev)
+    RES = _rand(M, co + 4, seed=7).to(dev)
+    PRE = _rand(M, co, seed=8).to(dev)
+    MSK = _rand(M, co + 12, seed=9).to(dev)
+    Y0 = _rand(M, ldy, seed=10).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    ref = (X[:, :ci].double().cpu() @ wt.view(co, ci).double().t())
+
+    def run(algo, flags):
+        d = L.ConvDesc(N=n, H=h, W=w, C=ci, OH=h, OW=w, OC=co, kh=1, kw=1, stride=1, pad=0, transposed=0, ldx=ldx, ldy=ldy,
+                       wrows=wp.shape[1], wcols=wp.shape[2], flags=flags, ldres=co + 4, ldg=0, wlayout=0, reserved=algo,
+                       ldpre=co, ldmask=co + 12)
+        y = Y0.clone()
+        io = L.ConvIO(x=X.data_ptr(), w=wp.data_ptr(), y=y.data_ptr(), bias=b.data_ptr(), vec2=v2.data_ptr(), res=RES.data_ptr(),
+                      scale=sc.data_ptr(), shift=sh.data_ptr(), pre=PRE.data_ptr(), mask=MSK.data_ptr())
+        cs = None
+        if flags & L.EPI_COLSUM:
+            rows, ld = C.c_int(), C.c_int()
+            L.check(lib.crdr_conv2d_colsum_layout(C.byref(d), 1, C.byref(rows), C.byref(ld)), "layout")
+            cs = torch.full((rows.value, 2, ld.value), float("nan"), device=dev)
+            io.cs = cs.data_ptr()
+        nb = lib.crdr_conv2d_workspace(C.byref(d))
+        ws = torch.empty(max(nb, 4) // 4, device=dev)
+        L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), ws.data_ptr(), nb, s), f"conv2d algo {algo} flags {flags}")
+        torch.cuda.synchronize()
+        return y, cs
+
+    FLAGSETS = [
+        0,
+        L.EPI_BIAS | L.EPI_RELU,
+        L.EPI_BIAS | L.EPI_LRELU | L.EPI_VEC2,
+        L.EPI_BIAS | L.EPI_RES | L.EPI_AFFINE,
+        L.EPI_RELUMASK | L.EPI_COLSUM,
+        L.EPI_RELUMASK | L.EPI_MASKOFF | L.EPI_COLSUM,
+        L.EPI_BIAS | L.EPI_LRELUMASK | L.EPI_MASKOFF | L.EPI_COLSUM | L.EPI_RES,
+        L.EPI_RES | L.EPI_COLSUM,
+    ]
+    ran = 0
+    for algo in ids:
+        try:
+            y, _ = run(algo, 0)
+        except L.CrdrHipError:
+            continue  # this variant's weight tile does not fit LDS for this C (or too many column tiles)
+        ran += 1
+        _close(y[:, :co], ref, f"{name} stream {algo}")
+        assert torch.equal(y[:, co:], Y0[:, co:]), "wrote outside its channel slice"
+        for fl in FLAGSETS[1:]:
+            y, cs = run(algo, fl)
+            yt, cst = run(1, fl)  # tile config 0: 128 x 32, the same 128-row partial-sum rows
+            assert torch.equal(y, yt), f"{name}: stream {algo} flags {fl} differs from the tiled kernel"
+            if cs is not None:
+                assert cs.shape == cst.shape
+                assert torch.isfinite(cs[:, :, :co]).all()
+                _close(cs[:, :, :co].sum(0), cst[:, :, :co].sum(0), f"{name} colsum {algo} flags {fl}", rtol=1e-5)
+    assert ran >= 1, f"{name}: no streaming variant accepted"
+    # and it refuses what it does not implement
+    d = L.ConvDesc(N=1, H=8, W=8, C=64, OH=8, OW=8, OC=64, kh=3, kw=3, stride=1, pad=1, transposed=0, ldx=64, ldy=64, wrows=64,
+                   wcols=64, flags=0, ldres=0, ldg=0, wlayout=0, reserved=ids[0], ldpre=0, ldmask=0)
+    rows, ld = C.c_int(), C.c_int()
+    assert lib.crdr_conv2d_colsum_layout(C.byref(d), 1, C.byref(rows), C.byref(ld)) != 0
+    for bad in (L.EPI_PREADD, L.EPI_ACCUM, L.EPI_GATE):
+        with pytest.raises(L.CrdrHipError):
+            run(ids[0], bad)

@@ -83,9 +83,17 @@ def main():
                     continue
                 res.append((t, c, 1 << ls))
         res.sort()
+        stream = []
+        for v, algo in enumerate(ops._stream_ids()):
+            try:
+                t = timeit(lambda: ops.conv2d_raw(x, wf, co, (k, k), s, p, bool(tr), (oh, oh), bias=bias, res=resid, flags=flags, algo=algo))
+            except L.CrdrHipError:
+                continue
+            stream.append((t, v))
         t0 = timeit(lambda: ops.conv2d_raw(x, wf, co, (k, k), s, p, bool(tr), (oh, oh), bias=bias, res=resid, flags=flags))
         print(f"{name:14s} heuristic {t0 * 1e6:8.1f} us {flops / t0 / 1e12:6.1f} TF | " +
-              "  ".join(f"cfg{c}/s{sp} {t * 1e6:.1f}us {flops / t / 1e12:.1f}TF" for t, c, sp in res[:a.top]), flush=True)
+              "  ".join(f"cfg{c}/s{sp} {t * 1e6:.1f}us {flops / t / 1e12:.1f}TF" for t, c, sp in res[:a.top]) +
+              (" | stream " + "  ".join(f"v{v} {t * 1e6:.1f}us {flops / t / 1e12:.1f}TF" for t, v in stream) if stream else ""), flush=True)
         if a.wgrad and not tr:
             dy = torch.randn(a.bs, co, oh, oh, device=dev).contiguous(memory_format=torch.channels_last)
             g = torch.empty(co, ci, k, k, device=dev)
