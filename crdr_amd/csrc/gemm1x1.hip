@@ -5,6 +5,10 @@
 #include "common.hpp"
 #include "igemm_args.hpp"
 
+#ifndef CRDR_STORE_AUX
+#define CRDR_STORE_AUX 0
+#endif
+
 namespace crdr {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -16,9 +20,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 3..8 iterations cannot hide the load latency behind a double buffer, and every tile pays its own ramp and epilogue
 // (PMC: profiles/r2_f_pmc_1x1_vs_3x3.txt).  Here a workgroup is PERSISTENT: it loads its weight tile [BN][K] into LDS once,
 // then walks its share of the 128-row M tiles with an S-stage ring of [128][32] activation tiles that keeps running across
-// tile boundaries -- the DMA of the next tiles is in flight during the epilogue of the current one -- with counted vmcnt
-// waits and raw s_barriers (a __syncthreads() would drain the ring).  Block = 4 waves (one per SIMD), wave tile = 32 rows x
-// BN columns (NB = BN / 32 accumulators); fragment layout and epilogue arithmetic are those of the generic kernel, so the
+// tile boundaries -- the DMA of the next tiles is in flight during the epilogue of the current one.  Every wave fetches the
+// 32 rows it multiplies itself, so the ring is private to the wave: counted vmcnt waits, no workgroup barrier in the loop.
+// Block = 4 waves (one per SIMD), wave tile = 32 rows x BN columns (NB = BN / 32 accumulators); fragment layout and epilogue arithmetic are those of the generic kernel, so the
 // results are bit-identical to its unsplit configurations.  Workgroups that share M tiles (different N tiles) sit on one
 // XCD, so the activation rows come from HBM once.  Plain launches only (no split-K, no groups, no gate epilogue).
 // ------------------------------------------------------------------------------------------------------------
@@ -61,18 +65,24 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p, const S
   int f_t = 0, f_kc = 0, f_slot = 0;
   auto fetch = [&]() __attribute__((always_inline)) {
     const bool live = f_t < my_tiles;
+#ifdef EXP_SAMETILE
+    const long long m0 = (long long)mlane * BM;
+#else
     const long long m0 = (long long)(mlane + f_t * nlanes) * BM;
+#endif
     const unsigned long long base_bytes = live ? (unsigned long long)m0 * ldx * 4ull : 0ull;
     const unsigned long long left = live ? p.x_bytes - base_bytes : 0ull;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x) + (live ? m0 * ldx : 0), 0, (unsigned)(left < 0x7fffffffull ? left : 0x7fffffffull), 0x00020000);
-    float* a = sA + f_slot * BM * 32 + wave * 8 * 32;
+    // a wave fetches exactly the 32 rows it multiplies (8 rows per instruction): the ring needs no workgroup barrier
+    float* a = sA + f_slot * BM * 32 + wave * 32 * 32;
 #pragma unroll
     for (int j = 0; j < AV; ++j) {
-      const int r = srow + j * 32;
+      const int r = wave * 32 + (lane >> 3) + j * 8;
+      const int cs = (lane & 7) ^ ((((lane >> 3) + j * 8) >> 1) & 7);
       const bool ok = live && (m0 + r < p.M);
-      const unsigned off = (unsigned)(r * ldx + f_kc * 32 + csrc * 4) * 4u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(a + j * 32 * 32), 16, (int)(ok ? off : kOobOffset), 0, 0, 0);
+      const unsigned off = (unsigned)(r * ldx + f_kc * 32 + cs * 4) * 4u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(a + j * 8 * 32), 16, (int)(ok ? off : kOobOffset), 0, 0, 0);
     }
     if (++f_kc == KT) { f_kc = 0; ++f_t; }
     if (++f_slot == S) f_slot = 0;
@@ -97,6 +107,13 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p, const S
     sV[2 * BN + c] = (live && (f & CRDR_EPI_AFFINE)) ? p.scale[n0 + c] : 1.f;
     sV[3 * BN + c] = (live && (f & CRDR_EPI_AFFINE)) ? p.shift[n0 + c] : 0.f;
   }
+  {  // the weight tile and the vectors are shared: everyone's pieces must have landed (the ring stays in flight)
+    constexpr int kPro = (S - 1) * AV;
+    static_assert(kPro <= 15, "vmcnt immediate");
+    __builtin_amdgcn_s_waitcnt(0x0070 | kPro);      // vmcnt(kPro), lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
   constexpr int kWait = (S - 2) * AV;  // pieces that may still be in flight when the stage to be consumed must have landed
   constexpr int kWaitEpi = kWait + 4 * NB;  // ... plus the stores of an epilogue issued since that stage was requested
   static_assert(kWaitEpi <= 63, "vmcnt immediate");
@@ -115,7 +132,6 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p, const S
       // during the first S - 1 iterations after an epilogue, than that epilogue's 4 NB stores
       if (t > 0 && kc < S - 1) __builtin_amdgcn_s_waitcnt(kImmWaitEpi);
       else __builtin_amdgcn_s_waitcnt(kImmWait);
-      __builtin_amdgcn_s_barrier();                 // this stage is complete for every wave; the previous slot is free
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       const float* fa = sA + c_slot * BM * 32 + (wave * 32) * 32;
@@ -150,7 +166,22 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p, const S
     // global access is a buffer instruction issued by all lanes (rows past M / column groups past Cout get an out-of-range
     // offset: loads return 0, stores are dropped), so the code is straight-line, the compiler's vmcnt waits are exact and
     // the operands of pass j + 1 are in flight while pass j is computed and stored.
+#ifdef EXP_NOEPI
+    {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[j][r];
+      if (sum == 1.2345f) p.y[0] = sum;
+      continue;
+    }
+#endif
+#ifdef EXP_SAMEOUT
+    const int mt = mlane;
+#else
     const int mt = mlane + t * nlanes;
+#endif
     const long long mw = (long long)mt * BM + wave * 32;  // first row of this wave
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + mw * p.ldy, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_RES ? p.res + mw * p.ldres : p.y), 0, 0x7fffffff, 0x00020000);
@@ -210,7 +241,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p, const S
         }
 #ifndef EXP_NOSTORE
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), ry,
-                                               ok ? (unsigned)((rbase + 8 * k) * p.ldy + oc0) * 4u : kOobOffset, 0, 0);
+                                               ok ? (unsigned)((rbase + 8 * k) * p.ldy + oc0) * 4u : kOobOffset, 0, CRDR_STORE_AUX);
 #endif
       }
       if (do_cs) {
@@ -239,7 +270,8 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p, const S
         const float v = ((sS[(0 * 2 + which) * BN + c] + sS[(1 * 2 + which) * BN + c]) + sS[(2 * 2 + which) * BN + c]) + sS[(3 * 2 + which) * BN + c];
         if (n0 + c < p.Cout) dst[(size_t)which * p.cs_ld + n0 + c] = v;
       }
-      // the next writes to sS come after the barrier at the top of the next iteration
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();              // sS is free for the next tile
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): no DMA may land in LDS after the workgroup is gone

@@ -381,6 +381,19 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     }
     __syncthreads();
   };
+#ifdef EXP_NOEPI
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (sum == 1.2345f) p.y[0] = sum;
+    return;
+  }
+#endif
   pass(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
   if constexpr (NB > 4) pass(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
   if constexpr (MB > 1) {
