@@ -26,6 +26,8 @@
 
 namespace crdr {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 // epilogue on one element; opix = output pixel index, oc = channel
@@ -151,7 +153,23 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     const int oc = n0 + srow + j * RPP;
     b_off[j] = oc < p.wrows ? (unsigned)(oc * p.wcols + csrc * 4) * 4u : kOobOffset;
   }
-  __syncthreads();  // sTap visible
+  // per-column epilogue vectors of this N tile (neutral values where a flag is off or past Cout), read by the fast epilogue
+  constexpr int kG = NB < 4 ? NB : 4;
+  constexpr int kStagingFloats = 2 * (BM + BN) * 32 + 132;
+  constexpr int kEpiFloats = WM * WN * 32 * 32 * kG + WM * 2 * BN;
+  constexpr int kSvOff = ((kStagingFloats > kEpiFloats ? kStagingFloats : kEpiFloats) + 3) & ~3;
+  float* sV = smem + kSvOff;  // [4][BN]: bias, vec2, scale, shift
+  if (p.fast_epi) {
+    const int f0 = p.flags;
+    for (int c = tid; c < BN; c += NT) {
+      const bool live = n0 + c < p.Cout;
+      sV[0 * BN + c] = (live && (f0 & CRDR_EPI_BIAS)) ? p.bias[n0 + c] : 0.f;
+      sV[1 * BN + c] = (live && (f0 & (CRDR_EPI_VEC2 | CRDR_EPI_MASKOFF))) ? p.vec2[n0 + c] : 0.f;
+      sV[2 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.scale[n0 + c] : 1.f;
+      sV[3 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[n0 + c] : 0.f;
+    }
+  }
+  __syncthreads();  // sTap (and sV) visible
 
   // K-iteration cursor of the NEXT tile to fetch: tap index (relative to tb) and channel chunk
   int lt = SMALLC ? 0 : it0 / kchunks, lc = SMALLC ? it0 : it0 - lt * kchunks;
@@ -271,6 +289,133 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   // for the whole pass); build_plan enforces it.
   const bool do_cs = (f & CRDR_EPI_COLSUM) && p.nsplit == 1;
   float* sS = smem + WM * WN * 32 * CLD;  // [WM][2][BN] behind the staged accumulators
+  // ---- fast epilogue (p.fast_epi): every global access is a buffer instruction issued by all lanes -- dead rows / column
+  // groups get an out-of-range offset, loads return 0 and stores are dropped -- relative to this tile's first output pixel;
+  // bias / vec2 / scale / shift come from sV.  The code is straight-line: no wait on a store anywhere, one wait per batch of
+  // four row groups on the res / mask operands.  Arithmetic and order are those of the general path below.
+  if (p.fast_epi) {
+    const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
+    long long opix0 = m0;
+    if (!direct) {
+      const int n = m0 / hw, rem = m0 - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
+      opix0 = ((long long)n * p.OH + ga * p.so + poh) * p.OW + gb * p.so + pow_;
+    }
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + opix0 * p.ldy, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? p.res + opix0 * p.ldres : p.y), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_mask ? p.mask + opix0 * p.ldmask : p.y), 0, 0x7fffffff, 0x00020000);
+    auto fpass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+      constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+#pragma unroll
+      for (int jj = 0; jj < GC; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
+      // sC is private to the wave: program order is enough
+      f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < GC; ++kb) {
+        f32x4 res4[4], msk4[4];
+        unsigned yoff[4];
+        int cc[4];
+        bool okk[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+          const int q = lane + 64 * (kb * 4 + kq);
+          const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+          const int m = m0 + (wm * MB + I) * 32 + row;
+          const int oc0 = n0 + (wn * NB + JG) * 32 + c4 * 4;
+          bool live_row = m < p.M;
+          unsigned rel = (unsigned)(m - m0);
+          if (!direct) {
+            const int mm = live_row ? m : m0;
+            const int n = mm / hw, rem = mm - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
+            const int oh = ga * p.so + poh, ow = gb * p.so + pow_;
+            live_row = live_row && (oh < p.OH) && (ow < p.OW);
+            rel = (unsigned)((((long long)n * p.OH + oh) * p.OW + ow) - opix0);
+          }
+          const bool ok = live_row && oc0 < p.Cout;
+          okk[kq] = ok;
+          cc[kq] = (wn * NB + JG) * 32 + c4 * 4;
+          yoff[kq] = ok ? (rel * p.ldy + oc0) * 4u : kOobOffset;
+          if (has_res)
+            res4[kq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? (rel * p.ldres + oc0) * 4u : kOobOffset, 0, 0));
+          if (has_mask)
+            msk4[kq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, ok ? (rel * p.ldmask + oc0) * 4u : kOobOffset, 0, 0));
+        }
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+          const int q = lane + 64 * (kb * 4 + kq);
+          const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * CLD + c4 * 4);
+          const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sV + 0 * BN + cc[kq]);
+          const f32x4 vec24 = *reinterpret_cast<const f32x4*>(sV + 1 * BN + cc[kq]);
+          const f32x4 scale4 = *reinterpret_cast<const f32x4*>(sV + 2 * BN + cc[kq]);
+          const f32x4 shift4 = *reinterpret_cast<const f32x4*>(sV + 3 * BN + cc[kq]);
+          const bool ok = okk[kq];
+          f32x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = a4[e];
+            if (f & CRDR_EPI_BIAS) v += bias4[e];
+            if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
+            if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
+            if (f & CRDR_EPI_VEC2) v += vec24[e];
+            if (has_res) v += res4[kq][e];
+            if (f & CRDR_EPI_AFFINE) v = v * scale4[e] + shift4[e];
+            if (do_cs) cpre[e] += ok ? v : 0.f;
+            if (has_mask) {
+              float mv = msk4[kq][e];
+              if (f & CRDR_EPI_MASKOFF) mv -= vec24[e];
+              v = mv > 0.0f ? v : ((f & CRDR_EPI_LRELUMASK) ? 0.2f * v : 0.0f);
+            }
+            if (do_cs) cpost[e] += ok ? v : 0.f;
+            o4[e] = v;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), ry, yoff[kq], 0, 0);
+        }
+      }
+      if (do_cs) {
+        if constexpr (GC == 1 || GC == 2 || GC == 4) {
+#pragma unroll
+          for (int off = 32; off >= 8 * GC; off >>= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              cpre[e] += __shfl_xor(cpre[e], off, 64);
+              cpost[e] += __shfl_xor(cpost[e], off, 64);
+            }
+          if (lane < 8 * GC) {
+            float* d0 = sS + (wm * 2 + 0) * BN + (wn * NB + JG) * 32 + lane * 4;
+            float* d1 = sS + (wm * 2 + 1) * BN + (wn * NB + JG) * 32 + lane * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if constexpr (I == 0) { d0[e] = cpre[e]; d1[e] = cpost[e]; }
+              else { d0[e] += cpre[e]; d1[e] += cpost[e]; }
+            }
+          }
+        }
+      }
+    };
+    fpass(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+    if constexpr (NB > 4) fpass(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+    if constexpr (MB > 1) {
+      fpass(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+      if constexpr (NB > 4) fpass(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+    }
+    if (do_cs) {
+      __syncthreads();
+      float* dst = p.cs + ((size_t)(phase * gridDim.x + tile_m) * 2) * p.cs_ld;
+      for (int t = tid; t < 2 * BN; t += NT) {
+        const int which = t / BN, c = t - which * BN;
+        float v = sS[(0 * 2 + which) * BN + c];
+#pragma unroll
+        for (int w2 = 1; w2 < WM; ++w2) v += sS[(w2 * 2 + which) * BN + c];
+        if (n0 + c < p.Cout) dst[(size_t)which * p.cs_ld + n0 + c] = v;
+      }
+    }
+    return;
+  }
   // one pass = GC column blocks [JG, JG+GC) of accumulator row-block I (all compile-time so acc stays in registers)
   auto pass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
     constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
@@ -381,19 +526,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     }
     __syncthreads();
   };
-#ifdef EXP_NOEPI
-  {
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
-    if (sum == 1.2345f) p.y[0] = sum;
-    return;
-  }
-#endif
   pass(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
   if constexpr (NB > 4) pass(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
   if constexpr (MB > 1) {
@@ -632,10 +764,12 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
   pl->grid = dim3(cdiv(a.M, BM), cdiv(d->OC, BN), a.nphase * bs * G);
   a.ws_ld = pl->grid.y * BN;
   {
-    const size_t staging = (size_t)2 * (BM + BN) * 32 * sizeof(float) + 132 * sizeof(int);
-    size_t epi = (size_t)t.wm * t.wn * 32 * 32 * std::min(t.nb, 4) * sizeof(float);
-    if (want_cs && bs == 1) epi += (size_t)t.wm * 2 * BN * sizeof(float);
-    pl->lds = std::max(staging, epi);
+    // floats: K-loop staging (+ tap table) overlaid by the epilogue's transposed accumulators + column sums, then the
+    // per-column vectors sV (kSvOff in the kernel)
+    const size_t staging = (size_t)2 * (BM + BN) * 32 + 132;
+    const size_t epi = (size_t)t.wm * t.wn * 32 * 32 * std::min(t.nb, 4) + (size_t)t.wm * 2 * BN;
+    const size_t sv_off = (std::max(staging, epi) + 3) & ~(size_t)3;
+    pl->lds = (sv_off + (size_t)4 * BN) * sizeof(float);
   }
   a.cs_ld = round_up(d->OC, 32);
   a.cs_rows = want_cs ? a.nphase * (bs == 1 ? (int)pl->grid.x : std::min(cdiv(a.M, 4), 2048)) : 0;
@@ -720,6 +854,10 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
     if (a.flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) v = v && al16(q.mask);
   }
   a.vec_epi = v ? 1 : 0;
+  // 32-bit byte offsets of the fast epilogue span one tile of output pixels (<= 256 rows, a few image rows when transposed)
+  const long long span = (256 + 4ll * a.OW * a.so) * std::max(std::max(a.ldy, a.ldres), a.ldmask) * 4;
+  a.fast_epi = (v && a.Cout % 4 == 0 && a.nsplit == 1 && span < (1ll << 31) &&
+                !(a.flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM))) ? 1 : 0;
   if (pl.stream >= 0) {
     CRDR_REQUIRE(a.vec_epi, "conv2d: the streaming kernel needs 16-byte aligned operand rows");
     void* prof = profile_begin(as_stream(s));
