@@ -24,14 +24,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 32 rows it multiplies itself, so the ring is private to the wave: counted vmcnt waits, no workgroup barrier in the loop.
 // Block = 4 waves (one per SIMD), wave tile = 32 rows x BN columns (NB = BN / 32 accumulators); fragment layout and epilogue arithmetic are those of the generic kernel, so the
 // results are bit-identical to its unsplit configurations.  Workgroups that share M tiles (different N tiles) sit on one
-// XCD, so the activation rows come from HBM once.  Plain launches only (no split-K, no groups, no gate epilogue).
+// XCD, so the activation rows come from HBM once.  A grouped launch spreads its problems over the workgroups.  No split-K,
+// no gate / pre-add / accumulate epilogue.
 // ------------------------------------------------------------------------------------------------------------
 // OPS: operands read by the epilogue besides the per-column vectors: bit 0 = res (CRDR_EPI_RES), bit 1 = mask (the ReLU masks)
 template <int NB, int S, int OPS>
-__global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p, const StreamArgs sa) {
+__global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p_, const StreamArgs sa, const IgemmGroup grp) {
   constexpr int BM = 128, BN = 32 * NB, NT = 256, AV = BM * 8 / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int KT = p.kchunks;
+  const int KT = p_.kchunks;
   float* sB = smem;                            // [KT][BN * 32]   weight tile, one swizzled image per 32-channel chunk
   float* sA = sB + KT * BN * 32;               // [S][BM * 32]    activation ring
   float* sCall = sA + S * BM * 32;             // [4 waves][32 * 32]  epilogue transpose (private to a wave)
@@ -41,8 +42,15 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p, const S
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;        // consecutive workgroup ids rotate over the XCDs
   const int tile_n = slot % sa.gridN;
-  const int mlane = (slot / sa.gridN) * 8 + xcd;
   const int nlanes = sa.nlanes;
+  const int lslot = slot / sa.gridN;           // (problem, group of 8 lanes)
+  const int gidx = lslot / (nlanes >> 3);
+  const int mlane = (lslot - gidx * (nlanes >> 3)) * 8 + xcd;
+  IgemmArgs p = p_;
+  if (p.ngroup > 1) {  // problem of a grouped launch (workgroup-uniform)
+    p.x = grp.x[gidx]; p.w = grp.w[gidx]; p.y = grp.y[gidx];
+    p.bias = grp.bias[gidx]; p.mask = grp.mask[gidx]; p.res = grp.res[gidx]; p.cs = grp.cs[gidx];
+  }
   const int n0 = tile_n * BN;
   const int mtiles = (p.M + BM - 1) / BM;
   const int my_tiles = mlane < mtiles ? (mtiles - mlane + nlanes - 1) / nlanes : 0;
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p, const S
 
 struct StreamCfg {
   int nb, stages;
-  void (*kern[4])(const IgemmArgs, const StreamArgs);  // by OPS
+  void (*kern[4])(const IgemmArgs, const StreamArgs, const IgemmGroup);  // by OPS
 };
 #define SCFG(nb, st) {nb, st, {gemm1x1_kernel<nb, st, 0>, gemm1x1_kernel<nb, st, 1>, gemm1x1_kernel<nb, st, 2>, gemm1x1_kernel<nb, st, 3>}}
 static const StreamCfg kStreamCfgs[] = {SCFG(2, 4), SCFG(3, 4), SCFG(4, 4), SCFG(6, 3)};
@@ -293,7 +301,7 @@ void stream_variant_shape(int v, int* nb, int* stages) {
   *stages = kStreamCfgs[v].stages;
 }
 
-void stream_launch(int v, const IgemmArgs& a, const StreamArgs& sa, unsigned grid, size_t lds, hipStream_t s) {
+void stream_launch(int v, const IgemmArgs& a, const StreamArgs& sa, const IgemmGroup& grp, unsigned grid, size_t lds, hipStream_t s) {
   const StreamCfg& sc = kStreamCfgs[v];
   const int ops = ((a.flags & CRDR_EPI_RES) ? 1 : 0) | ((a.flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) ? 2 : 0);
   static std::atomic<bool> attr_done[16][4];
@@ -301,7 +309,7 @@ void stream_launch(int v, const IgemmArgs& a, const StreamArgs& sa, unsigned gri
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc.kern[ops]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[v][ops].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(sc.kern[ops], dim3(grid), dim3(256), lds, s, a, sa);
+  hipLaunchKernelGGL(sc.kern[ops], dim3(grid), dim3(256), lds, s, a, sa, grp);
 }
 
 }  // namespace crdr

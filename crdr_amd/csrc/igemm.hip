@@ -723,9 +723,9 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
     const int sv = (d->reserved & 0xff) - 1 - kNumCfgs;
     CRDR_REQUIRE(sv < stream_num_variants(), "conv2d: forced config %d out of range", sv + kNumCfgs);
     CRDR_REQUIRE(((d->reserved >> 8) & 0xf) == 0, "conv2d: the streaming 1x1 kernel has no split-K");
-    CRDR_REQUIRE(G == 1 && !a.smallc && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->C % 32 == 0 &&
+    CRDR_REQUIRE(!a.smallc && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->C % 32 == 0 &&
                      !(d->flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM)) && d->OC % 4 == 0,
-                 "conv2d: the streaming kernel takes ungrouped 1x1 stride-1 convolutions with C %% 32 == 0, OC %% 4 == 0 and no "
+                 "conv2d: the streaming kernel takes 1x1 stride-1 convolutions with C %% 32 == 0, OC %% 4 == 0 and no "
                  "gate / pre-add / accumulate epilogue");
     int snb, sstages;
     stream_variant_shape(sv, &snb, &sstages);
@@ -734,14 +734,14 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
     CRDR_REQUIRE(lds <= 160 * 1024, "conv2d: streaming variant %d needs %zu B of LDS for C = %d", sv, lds, d->C);
     const int gridN = cdiv(d->OC, BN), mtiles = cdiv(a.M, 128);
     CRDR_REQUIRE(gridN <= 32, "conv2d: streaming variant %d: %d column tiles", sv, gridN);
-    const int nlanes = std::max(8, std::min(256 / gridN / 8 * 8, round_up(mtiles, 8)));
+    const int nlanes = std::max(8, std::min(256 / (gridN * G) / 8 * 8, round_up(mtiles, 8)));  // per problem
     pl->stream = sv;
     pl->cfg = -1;
     pl->sa.gridN = gridN;
     pl->sa.nlanes = nlanes;
     a.nsplit = 1;
     a.ws_ld = 0;
-    pl->grid = dim3(gridN * nlanes, 1, 1);
+    pl->grid = dim3(G * gridN * nlanes, 1, 1);
     pl->lds = lds;
     a.cs_ld = round_up(d->OC, 32);
     a.cs_rows = want_cs ? mtiles : 0;
@@ -861,9 +861,9 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   if (pl.stream >= 0) {
     CRDR_REQUIRE(a.vec_epi, "conv2d: the streaming kernel needs 16-byte aligned operand rows");
     void* prof = profile_begin(as_stream(s));
-    stream_launch(pl.stream, a, pl.sa, pl.grid.x, pl.lds, as_stream(s));
+    stream_launch(pl.stream, a, pl.sa, grp, pl.grid.x, pl.lds, as_stream(s));
     CRDR_CHECK_LAUNCH("gemm1x1_kernel");
-    profile_end(0, crdr_conv2d_flops(d), prof, as_stream(s));
+    profile_end(0, G * crdr_conv2d_flops(d), prof, as_stream(s));
     return 0;
   }
   const TileCfg& t = kCfgs[pl.cfg];

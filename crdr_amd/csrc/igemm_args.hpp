@@ -69,10 +69,10 @@ static constexpr unsigned kOobOffset = 0x80000000u;  // >= any descriptor size a
 // streaming 1x1 kernel (gemm1x1.hip)
 struct StreamArgs {
   int gridN;   // N tiles
-  int nlanes;  // M-tile lanes (multiple of 8): lane l owns M tiles l, l + nlanes, ...
+  int nlanes;  // M-tile lanes per problem (multiple of 8): lane l owns M tiles l, l + nlanes, ...
 };
 int stream_num_variants();
 void stream_variant_shape(int v, int* nb, int* stages);
-void stream_launch(int v, const IgemmArgs& a, const StreamArgs& sa, unsigned grid, size_t lds, hipStream_t s);
+void stream_launch(int v, const IgemmArgs& a, const StreamArgs& sa, const IgemmGroup& grp, unsigned grid, size_t lds, hipStream_t s);
 
 }  // namespace crdr

@@ -453,3 +453,56 @@ def test_streaming_1x1_variants(case):
     for bad in (L.EPI_PREADD, L.EPI_ACCUM, L.EPI_GATE):
         with pytest.raises(L.CrdrHipError):
             run(ids[0], bad)
+
+
+def test_streaming_1x1_grouped():
+    """A grouped launch (the two NLAM branches) through the persistent 1x1 kernel: every problem has its own tensors and
+    column-sum rows; results equal the tiled kernel's bit for bit."""
+    import ctypes as C
+    from crdr_amd.hip import ops, lib as L
+    dev = _dev()
+    lib = L.load()
+    n, h, w, ci, co, G = 2, 24, 20, 96, 192, 3
+    M = n * h * w
+    X = [_rand(M, ci, seed=10 + g).to(dev) for g in range(G)]
+    W = [ops.pack_weight(_rand(co, ci, 1, 1, seed=20 + g, scale=ci ** -0.5).to(dev), False) for g in range(G)]
+    B = [_rand(co, seed=30 + g).to(dev) for g in range(G)]
+    R = [_rand(M, co, seed=40 + g).to(dev) for g in range(G)]
+    K = [_rand(M, co, seed=50 + g).to(dev) for g in range(G)]
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(algo, flags):
+        d = L.ConvDesc(N=n, H=h, W=w, C=ci, OH=h, OW=w, OC=co, kh=1, kw=1, stride=1, pad=0, transposed=0, ldx=ci, ldy=co,
+                       wrows=W[0].shape[1], wcols=W[0].shape[2], flags=flags, ldres=co, ldg=0, wlayout=0, reserved=algo,
+                       ldpre=0, ldmask=co)
+        ys = [torch.zeros(M, co, device=dev) for _ in range(G)]
+        rows, ld = C.c_int(), C.c_int()
+        L.check(lib.crdr_conv2d_colsum_layout(C.byref(d), G, C.byref(rows), C.byref(ld)), "layout")
+        css = [torch.full((max(rows.value, 1), 2, max(ld.value, 1)), float("nan"), device=dev) for _ in range(G)]
+        ios = (L.ConvIO * G)()
+        for g in range(G):
+            ios[g].x, ios[g].w, ios[g].y = X[g].data_ptr(), W[g].data_ptr(), ys[g].data_ptr()
+            ios[g].bias, ios[g].res, ios[g].mask, ios[g].cs = B[g].data_ptr(), R[g].data_ptr(), K[g].data_ptr(), css[g].data_ptr()
+        nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
+        ws = torch.empty(max(nb, 4) // 4, device=dev)
+        L.check(lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws.data_ptr(), nb, s), f"grouped algo {algo}")
+        torch.cuda.synchronize()
+        return ys, css
+
+    ran = 0
+    for algo in ops._stream_ids():
+        for fl in (L.EPI_BIAS | L.EPI_RELU, L.EPI_BIAS | L.EPI_RES, L.EPI_RELUMASK | L.EPI_COLSUM | L.EPI_RES):
+            try:
+                ys, css = run(algo, fl)
+            except L.CrdrHipError:
+                continue
+            ran += 1
+            yt, cst = run(1, fl)
+            for g in range(G):
+                assert torch.equal(ys[g], yt[g]), f"problem {g} algo {algo} flags {fl}"
+                if fl & L.EPI_COLSUM:
+                    _close(css[g][:, :, :co].sum(0), cst[g][:, :, :co].sum(0), f"colsum problem {g}", rtol=1e-5)
+            if fl == (L.EPI_BIAS | L.EPI_RES):
+                ref = X[1].double().cpu() @ _rand(co, ci, 1, 1, seed=21, scale=ci ** -0.5).view(co, ci).double().t()
+                _close(ys[1], ref + B[1].double().cpu() + R[1].double().cpu(), "grouped stream vs fp64")
+    assert ran >= 3
