@@ -28,16 +28,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // no gate / pre-add / accumulate epilogue.
 // ------------------------------------------------------------------------------------------------------------
 // OPS: operands read by the epilogue besides the per-column vectors: bit 0 = res (CRDR_EPI_RES), bit 1 = mask (the ReLU masks)
-template <int NB, int S, int OPS>
-__global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p_, const StreamArgs sa, const IgemmGroup grp) {
-  constexpr int BM = 128, BN = 32 * NB, NT = 256, AV = BM * 8 / NT;
+// NW: waves per workgroup (4: one per SIMD; 8: two per SIMD, so one wave's epilogue and stores overlap the other's MFMAs)
+template <int NB, int S, int OPS, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm1x1_kernel(const IgemmArgs p_, const StreamArgs sa, const IgemmGroup grp) {
+  constexpr int BM = 32 * NW, BN = 32 * NB, NT = 64 * NW, AV = BM * 8 / NT;
+  static_assert(AV == 4, "a wave fetches its own 32 rows in four instructions");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int KT = p_.kchunks;
   float* sB = smem;                            // [KT][BN * 32]   weight tile, one swizzled image per 32-channel chunk
   float* sA = sB + KT * BN * 32;               // [S][BM * 32]    activation ring
-  float* sCall = sA + S * BM * 32;             // [4 waves][32 * 32]  epilogue transpose (private to a wave)
-  float* sS = sCall + 4 * 1024;                // [4][2][BN]      column sums of the four row groups
-  float* sV = sS + 4 * 2 * BN;                 // [4][BN]         bias, vec2, scale, shift of this column tile
+  float* sS = sA + S * BM * 32;                // [NW][2][BN]     column sums of the row groups
+  float* sV = sS + NW * 2 * BN;                // [4][BN]         bias, vec2, scale, shift of this column tile
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;        // consecutive workgroup ids rotate over the XCDs
@@ -61,11 +62,10 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p_, const 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
   // ---- weight tile, once
   for (int kc = 0; kc < KT; ++kc) {
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int oc = n0 + srow + j * 32;
+    for (int r0 = wave * 8; r0 < BN; r0 += NT / 8) {  // 8 rows per wave instruction; srow = r0 + lane / 8 on the first pass
+      const int oc = n0 + r0 + (lane >> 3);
       const unsigned off = oc < p.wrows ? (unsigned)(oc * p.wcols + kc * 32 + csrc * 4) * 4u : kOobOffset;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sB + kc * BN * 32 + wave * 8 * 32 + j * 32 * 32), 16, (int)off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sB + kc * BN * 32 + r0 * 32), 16, (int)off, 0, 0, 0);
     }
   }
   // ---- activation ring: every call loads the next (tile, K chunk) of this workgroup into the next slot; past the end it
@@ -106,7 +106,6 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p_, const 
   const int f = p.flags;
   const bool do_cs = (f & CRDR_EPI_COLSUM) != 0;
   constexpr bool HAS_RES = (OPS & 1) != 0, HAS_MASK = (OPS & 2) != 0;
-  float* sC = sCall + wave * 1024;
   // per-column epilogue vectors, staged once (neutral values beyond Cout): the epilogue never waits on them
   for (int c = tid; c < BN; c += NT) {
     const bool live = n0 + c < p.Cout;
@@ -190,6 +189,8 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p_, const 
 #else
     const int mt = mlane + t * nlanes;
 #endif
+    // the ring slot consumed last is free until the next fetch: it stages this wave's transposed accumulators
+    float* sC = sA + (c_slot == 0 ? S - 1 : c_slot - 1) * BM * 32 + wave * 1024;
     const long long mw = (long long)mt * BM + wave * 32;  // first row of this wave
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + mw * p.ldy, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_RES ? p.res + mw * p.ldres : p.y), 0, 0x7fffffff, 0x00020000);
@@ -275,7 +276,9 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p_, const 
       float* dst = p.cs + ((size_t)mt * 2) * p.cs_ld;
       for (int t2 = tid; t2 < 2 * BN; t2 += NT) {
         const int which = t2 / BN, c = t2 - which * BN;
-        const float v = ((sS[(0 * 2 + which) * BN + c] + sS[(1 * 2 + which) * BN + c]) + sS[(2 * 2 + which) * BN + c]) + sS[(3 * 2 + which) * BN + c];
+        float v = sS[(0 * 2 + which) * BN + c];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) v += sS[(w2 * 2 + which) * BN + c];
         if (n0 + c < p.Cout) dst[(size_t)which * p.cs_ld + n0 + c] = v;
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -286,19 +289,24 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const IgemmArgs p_, const 
 }
 
 struct StreamCfg {
-  int nb, stages;
+  int nb, stages, nw;
   void (*kern[4])(const IgemmArgs, const StreamArgs, const IgemmGroup);  // by OPS
 };
-#define SCFG(nb, st) {nb, st, {gemm1x1_kernel<nb, st, 0>, gemm1x1_kernel<nb, st, 1>, gemm1x1_kernel<nb, st, 2>, gemm1x1_kernel<nb, st, 3>}}
-static const StreamCfg kStreamCfgs[] = {SCFG(2, 4), SCFG(3, 4), SCFG(4, 4), SCFG(6, 3)};
+#define SCFG(nb, st, nw) \
+  {nb, st, nw, {gemm1x1_kernel<nb, st, 0, nw>, gemm1x1_kernel<nb, st, 1, nw>, gemm1x1_kernel<nb, st, 2, nw>, gemm1x1_kernel<nb, st, 3, nw>}}
+static const StreamCfg kStreamCfgs[] = {
+    SCFG(2, 4, 4), SCFG(3, 4, 4), SCFG(4, 4, 4), SCFG(6, 3, 4),   // one wave per SIMD, deep ring
+    SCFG(2, 2, 8), SCFG(3, 2, 8), SCFG(4, 2, 8), SCFG(5, 2, 8),   // two waves per SIMD, double buffer
+};
 #undef SCFG
 static const int kNumStreamCfgs = sizeof(kStreamCfgs) / sizeof(kStreamCfgs[0]);
 
 int stream_num_variants() { return kNumStreamCfgs; }
 
-void stream_variant_shape(int v, int* nb, int* stages) {
+void stream_variant_shape(int v, int* nb, int* stages, int* nw) {
   *nb = kStreamCfgs[v].nb;
   *stages = kStreamCfgs[v].stages;
+  *nw = kStreamCfgs[v].nw;
 }
 
 void stream_launch(int v, const IgemmArgs& a, const StreamArgs& sa, const IgemmGroup& grp, unsigned grid, size_t lds, hipStream_t s) {
@@ -309,7 +317,7 @@ void stream_launch(int v, const IgemmArgs& a, const StreamArgs& sa, const IgemmG
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc.kern[ops]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[v][ops].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(sc.kern[ops], dim3(grid), dim3(256), lds, s, a, sa, grp);
+  hipLaunchKernelGGL(sc.kern[ops], dim3(grid), dim3(64 * sc.nw), lds, s, a, sa, grp);
 }
 
 }  // namespace crdr

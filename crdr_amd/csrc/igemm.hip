@@ -727,12 +727,12 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
                      !(d->flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM)) && d->OC % 4 == 0,
                  "conv2d: the streaming kernel takes 1x1 stride-1 convolutions with C %% 32 == 0, OC %% 4 == 0 and no "
                  "gate / pre-add / accumulate epilogue");
-    int snb, sstages;
-    stream_variant_shape(sv, &snb, &sstages);
-    const int BN = 32 * snb;
-    const size_t lds = ((size_t)a.kchunks * BN * 32 + (size_t)sstages * 128 * 32 + 4 * 1024 + 4 * 2 * BN + 4 * BN) * sizeof(float);
+    int snb, sstages, snw;
+    stream_variant_shape(sv, &snb, &sstages, &snw);
+    const int BN = 32 * snb, SBM = 32 * snw;
+    const size_t lds = ((size_t)a.kchunks * BN * 32 + (size_t)sstages * SBM * 32 + snw * 2 * BN + 4 * BN) * sizeof(float);
     CRDR_REQUIRE(lds <= 160 * 1024, "conv2d: streaming variant %d needs %zu B of LDS for C = %d", sv, lds, d->C);
-    const int gridN = cdiv(d->OC, BN), mtiles = cdiv(a.M, 128);
+    const int gridN = cdiv(d->OC, BN), mtiles = cdiv(a.M, SBM);
     CRDR_REQUIRE(gridN <= 32, "conv2d: streaming variant %d: %d column tiles", sv, gridN);
     const int nlanes = std::max(8, std::min(256 / (gridN * G) / 8 * 8, round_up(mtiles, 8)));  // per problem
     pl->stream = sv;

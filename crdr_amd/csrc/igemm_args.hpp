@@ -72,7 +72,7 @@ struct StreamArgs {
   int nlanes;  // M-tile lanes per problem (multiple of 8): lane l owns M tiles l, l + nlanes, ...
 };
 int stream_num_variants();
-void stream_variant_shape(int v, int* nb, int* stages);
+void stream_variant_shape(int v, int* nb, int* stages, int* nw);
 void stream_launch(int v, const IgemmArgs& a, const StreamArgs& sa, const IgemmGroup& grp, unsigned grid, size_t lds, hipStream_t s);
 
 }  // namespace crdr

@@ -438,10 +438,9 @@ def test_streaming_1x1_variants(case):
         assert torch.equal(y[:, co:], Y0[:, co:]), "wrote outside its channel slice"
         for fl in FLAGSETS[1:]:
             y, cs = run(algo, fl)
-            yt, cst = run(1, fl)  # tile config 0: 128 x 32, the same 128-row partial-sum rows
+            yt, cst = run(1, fl)  # tile config 0: 128 x 32
             assert torch.equal(y, yt), f"{name}: stream {algo} flags {fl} differs from the tiled kernel"
-            if cs is not None:
-                assert cs.shape == cst.shape
+            if cs is not None:  # one partial row per 128- or 256-row tile
                 assert torch.isfinite(cs[:, :, :co]).all()
                 _close(cs[:, :, :co].sum(0), cst[:, :, :co].sum(0), f"{name} colsum {algo} flags {fl}", rtol=1e-5)
     assert ran >= 1, f"{name}: no streaming variant accepted"
