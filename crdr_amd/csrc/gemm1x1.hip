@@ -1,4 +1,9 @@
 // Streaming 1x1 convolution kernel of the implicit-GEMM family (see igemm.hip for the tiled kernels and the host side).
+//
+// Experiment switches (make EXTRA=-DEXP_..., load the result with CRDR_HIP_LIB; never set in the shipped build): EXP_NOFETCH
+// (ring not refilled), EXP_NOSTORE (results not stored), EXP_NOEPI (no epilogue), EXP_SAMETILE / EXP_SAMEOUT (every tile
+// reads / writes the workgroup's first tile: L2-resident traffic), CRDR_STORE_AUX=2 (non-temporal stores).  They are how
+// DESIGN.md 4c's cost breakdown was measured.
 
 #include <atomic>
 

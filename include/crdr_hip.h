@@ -115,9 +115,11 @@ typedef struct crdr_conv_io {
 /* number of tile configurations a forced algorithm may name */
 int crdr_conv2d_num_configs(void);
 /* number of streaming 1x1 variants: forced algorithm ids crdr_conv2d_num_configs() + 1 + v, no split bits.  A persistent
- * workgroup keeps its weight tile in LDS and streams 128-row activation tiles through a DMA ring (the 1x1 layers of
- * ResidualBottleneck, elic_layers.py:17-36, and of the NLAM branches); rejected for anything but an ungrouped 1x1
- * stride-1 convolution with C % 32 == 0, no gate epilogue, and a weight tile that fits LDS */
+ * workgroup keeps its weight tile in LDS and streams the activation rows through per-wave DMA rings (the 1x1 layers of
+ * ResidualBottleneck, elic_layers.py:17-36, and of the NLAM branches, cheng_nlam.py); plain and grouped launches.  Rejected
+ * (error return, as for any unsuitable forced id) unless the convolution is 1x1 stride 1 with C % 32 == 0, OC % 4 == 0,
+ * 16-byte aligned rows, no GATE / PREADD / ACCUM epilogue and a weight tile that fits LDS.  Results are bit-identical to
+ * the unsplit tile configurations; CRDR_EPI_COLSUM rows are per 128- or 256-row tile (crdr_conv2d_colsum_layout) */
 int crdr_conv2d_num_stream_configs(void);
 /* bytes of workspace crdr_conv2d needs for this problem (split-K partial slabs; may be 0) */
 size_t crdr_conv2d_workspace(const crdr_conv_desc* d);
