@@ -159,17 +159,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   constexpr int kEpiFloats = WM * WN * 32 * 32 * kG + WM * 2 * BN;
   constexpr int kSvOff = ((kStagingFloats > kEpiFloats ? kStagingFloats : kEpiFloats) + 3) & ~3;
   float* sV = smem + kSvOff;  // [4][BN]: bias, vec2, scale, shift
-  if (p.fast_epi) {
-    const int f0 = p.flags;
-    for (int c = tid; c < BN; c += NT) {
-      const bool live = n0 + c < p.Cout;
-      sV[0 * BN + c] = (live && (f0 & CRDR_EPI_BIAS)) ? p.bias[n0 + c] : 0.f;
-      sV[1 * BN + c] = (live && (f0 & (CRDR_EPI_VEC2 | CRDR_EPI_MASKOFF))) ? p.vec2[n0 + c] : 0.f;
-      sV[2 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.scale[n0 + c] : 1.f;
-      sV[3 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[n0 + c] : 0.f;
-    }
-  }
-  __syncthreads();  // sTap (and sV) visible
+  __syncthreads();  // sTap visible
 
   // K-iteration cursor of the NEXT tile to fetch: tap index (relative to tb) and channel chunk
   int lt = SMALLC ? 0 : it0 / kchunks, lc = SMALLC ? it0 : it0 - lt * kchunks;
@@ -262,6 +252,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     __syncthreads();
   };
   if (it0 < it1) fetch(0);
+  // (behind the first DMA so that their latencies overlap; the barrier below publishes both)
+  if (p.fast_epi) {
+    const int f0 = p.flags;
+    for (int c = tid; c < BN; c += NT) {
+      const bool live = n0 + c < p.Cout;
+      sV[0 * BN + c] = (live && (f0 & CRDR_EPI_BIAS)) ? p.bias[n0 + c] : 0.f;
+      sV[1 * BN + c] = (live && (f0 & (CRDR_EPI_VEC2 | CRDR_EPI_MASKOFF))) ? p.vec2[n0 + c] : 0.f;
+      sV[2 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.scale[n0 + c] : 1.f;
+      sV[3 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[n0 + c] : 0.f;
+    }
+  }
   __syncthreads();
   int it = it0;
   for (; it + 2 <= it1; it += 2) {

@@ -367,13 +367,21 @@ class DeferredWgrad:
         self.cycle = 0  # bytes handed out since the last flush (over all arenas)
         self.jobs = []
         self.tables = {}
+        self._pinned = []  # arenas whose addresses are baked into captured graphs: never released
+
+    def _retire(self) -> None:
+        """The current arena is being replaced.  Slab addresses handed out during a capture live on in the graph's kernel
+        arguments, so an arena that was current during any capture stays allocated for the life of the process."""
+        (self._pinned if getattr(self, "_captured", False) else self._keep).append(self.arena)
 
     def alloc(self, nbytes: int) -> int:
         nbytes = (nbytes + 255) // 256 * 256
+        if torch.cuda.is_current_stream_capturing():
+            self._captured = True
         if self.off + nbytes > self.arena.numel():
             if torch.cuda.is_current_stream_capturing():
                 raise L.CrdrHipError("DeferredWgrad: arena too small during graph capture (run eager warm-up iterations first)")
-            self._keep.append(self.arena)  # pending jobs still point into it
+            self._retire()  # pending jobs still point into it
             # big enough for a whole cycle like this one, so that the next iteration never grows again
             self.arena = torch.empty(max(2 * self.arena.numel(), 2 * (self.cycle + nbytes)), dtype=torch.uint8, device=self.device)
             self.off = 0
@@ -416,7 +424,7 @@ class DeferredWgrad:
         self.off = 0
         if not torch.cuda.is_current_stream_capturing():
             if self.arena.numel() < self.cycle:  # the cycle spilled over several arenas: make the next one fit in one
-                self._keep.append(self.arena)    # (the reduce just launched may still be reading it: freed next flush)
+                self._retire()                   # (the reduce just launched may still be reading it: freed next flush)
                 self.arena = torch.empty(2 * self.cycle, dtype=torch.uint8, device=self.device)
             else:
                 self._keep = []
@@ -432,9 +440,15 @@ class DeferredWgrad:
                 "jobs": torch.zeros(self.CAP * C.sizeof(L.WgradJob), dtype=torch.uint8, device=self.device),
                 "prefix": torch.zeros(self.CAP + 1, dtype=torch.int64, device=self.device),
                 "meta": torch.zeros(2, dtype=torch.int64, device=self.device), "host": None}
+        if torch.cuda.is_current_stream_capturing():
+            tb["captured"] = True
         if tb["host"] != host:
             if torch.cuda.is_current_stream_capturing():
                 raise L.CrdrHipError("DeferredWgrad: the job table of a captured site changed")
+            if tb.get("captured"):
+                # a graph replays this table together with kernels that write the slab addresses it held at capture time
+                raise L.CrdrHipError("DeferredWgrad: an eager flush would rewrite the job table of a site captured in a HIP "
+                                     "graph (shapes or slab addresses changed since the capture): re-capture the graphs")
             tb["jobs"][:len(host)].copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
             tb["prefix"][:njobs + 1].copy_(torch.from_numpy(pre))
             tb["meta"].copy_(torch.tensor([njobs, int(pre[-1])], dtype=torch.int64))
