@@ -307,7 +307,8 @@ def main():
     tp = _newest_profile("r*_hbm_families.json")
     if a.stage == 3 and a.bs == 16 and a.size == 256 and tp:
         with open(tp) as f:
-            traffic = round(json.load(f)["families"]["igemm_kernel"]["hbm_bytes_per_launch"])
+            fams_ = json.load(f)["families"]
+            traffic = round(fams_.get("conv_fwd_dgrad", fams_["igemm_kernel"])["hbm_bytes_per_launch"])
         traffic_src = (f"HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step at q = 2 "
                        f"({os.path.relpath(tp, ROOT)}); re-measure with tools/pmc_step.py + tools/pmc_families.py after kernel changes")
     roof = {"bound": "mfma", "achieved": ig["tflops"] if ig else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -315,8 +316,9 @@ def main():
             "algorithmic_bytes_per_launch": round(main_run["alg_bytes_per_igemm_launch"]) if main_run["alg_bytes_per_igemm_launch"] else None,
             "flop_convention": "dense: 2 * Cin * Cout * kh * kw per output pixel (input pixel for transposed convs), zero-padding taps at "
                                "the borders included (5x5 at 16x16: 14 % of the counted taps multiply padding)",
-            "kernel": "igemm_kernel<*> (conv / convT forward + input-gradient launches incl. grouped ones, v_mfma_f32_32x32x2_f32; split-K "
-                      "epilogue launches timed separately under detail.splitk_epilogue)",
+            "kernel": "igemm_kernel<*> + gemm1x1_kernel<*> (conv / convT forward + input-gradient launches incl. grouped ones: tiled "
+                      "implicit GEMM and the streaming 1x1 kernel, v_mfma_f32_32x32x2_f32; split-K epilogue launches timed separately "
+                      "under detail.splitk_epilogue)",
             "measured_over": f"{a.profile_steps} eager steps after the timed region, rate index cycled (HIP events around each launch, on its stream)",
             "detail": ig, "wgrad_kernel": wg,
             "whole_step": {"algorithmic_gflop_per_img": gflop, "achieved": round(value / ws * gflop / 1e3, 2),

@@ -87,9 +87,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     const int nwg = gx * gy * gz, bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
     const int cpx = nwg >> 3;
     const int t = bid < cpx * 8 ? (bid & 7) * cpx + (bid >> 3) : bid;
-    tile_n = t % gy;
-    tile_z = (t / gy) % gz;
-    tile_m = t / (gy * gz);
+    if (p_.m_inner) {  // weights dominate the traffic: keep one weight tile in L2 while the M tiles stream past it
+      tile_m = t % gx;
+      tile_z = (t / gx) % gz;
+      tile_n = t / (gx * gz);
+    } else {
+      tile_n = t % gy;
+      tile_z = (t / gy) % gz;
+      tile_m = t / (gy * gz);
+    }
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   // problem of a grouped launch (workgroup-uniform): its pointers replace the ones in the argument block
@@ -763,6 +769,15 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
   pl->cfg = bc;
   a.nsplit = bs;
   pl->grid = dim3(cdiv(a.M, BM), cdiv(d->OC, BN), a.nphase * bs * G);
+  {  // tile order inside an XCD's contiguous range.  N-inner (default): the activation tile of an M tile stays in L2 while
+     // its N tiles / phases / splits run, and every M tile streams the weight pack -- right while the pack is L2 / MALL
+     // sized.  M-inner: one weight tile stays while the M tiles stream past it -- chosen only when the pack is far beyond
+     // any cache and dwarfs the activations (hoisted Charm convs: 136 MB of weights against 5 MB of activations; measured
+     // 8.8 GB -> of L2-miss traffic for that launch with N-inner).  In-between shapes (5x5 s2 transposed, 6.5 MB pack) are
+     // faster N-inner.
+    const double A = (double)d->N * d->H * d->W * d->C * 4.0, B = (double)a.w_bytes;
+    a.m_inner = (G == 1 && B >= 32.0e6 && A * 4.0 <= B) ? 1 : 0;
+  }
   a.ws_ld = pl->grid.y * BN;
   {
     // floats: K-loop staging (+ tap table) overlaid by the epilogue's transposed accumulators + column sums, then the

@@ -411,6 +411,7 @@ class _InterpCaVectors(torch.autograd.Function):
         L.check(lib.crdr_interp_ca_params(W.data_ptr(), None if B is None else B.data_ptr(), Lv, Cc, float(q),
                                           scale.data_ptr(), shift.data_ptr(), ops._stream()), "interp_ca_params")
         ctx.q, ctx.has_b = float(q), B is not None
+        ctx.B = B  # (a parameter: only its .grad slot is touched in backward)
         ctx.save_for_backward(W)
         return scale, shift
 
@@ -419,11 +420,26 @@ class _InterpCaVectors(torch.autograd.Function):
         (W,) = ctx.saved_tensors
         lib = L.load()
         Lv, Cc = W.shape[0], W.shape[2]
-        dW = torch.zeros_like(W)
-        dB = torch.zeros_like(W) if ctx.has_b else None
-        L.check(lib.crdr_interp_ca_params_bwd(W.data_ptr(), Lv, Cc, ctx.q, dscale.contiguous().data_ptr(),
-                                              dshift.contiguous().data_ptr(), dW.data_ptr(),
-                                              None if dB is None else dB.data_ptr(), ops._stream()), "interp_ca_params_bwd")
+        # the kernel accumulates: leaf parameters get their rows added straight into .grad (the flat gradient buffer), like
+        # the bias gradients of the conv layers -- no zero-filled temporary, no autograd add per module
+        direct = W.is_leaf and (ctx.B is None or ctx.B.is_leaf)
+        if direct:
+            dW = _grad_slot(W) if ctx.needs_input_grad[0] else None
+            dB = _grad_slot(ctx.B) if (ctx.has_b and ctx.needs_input_grad[1]) else None
+        else:
+            dW = torch.zeros_like(W)
+            dB = torch.zeros_like(W) if ctx.has_b else None
+        if dW is not None or dB is not None:
+            scratch = None
+            if dW is None:  # (scale frozen, bias trained: the kernel still wants a destination)
+                scratch = dW = torch.zeros_like(W)
+            L.check(lib.crdr_interp_ca_params_bwd(W.data_ptr(), Lv, Cc, ctx.q, dscale.contiguous().data_ptr(),
+                                                  dshift.contiguous().data_ptr(), dW.data_ptr(),
+                                                  None if dB is None else dB.data_ptr(), ops._stream()), "interp_ca_params_bwd")
+            if scratch is not None:
+                dW = None
+        if direct:
+            return None, None, None
         return dW, dB, None
 
 

@@ -29,6 +29,8 @@ SHAPES = {
     "stem3": (3, 256, 192, 5, 2, 0, 1),
     "up3T": (256, 64, 256, 5, 2, 1, 1),
     "enc5s2": (192, 128, 192, 5, 2, 0, 1),
+    "hoist4256": (320, 16, 4256, 5, 1, 0, 0),
+    "hoist4256T": (4256, 16, 320, 5, 1, 1, 0),
     "charm480": (480, 16, 224, 5, 1, 0, 3),
     "charm224": (224, 16, 128, 5, 1, 0, 3),
     "charm128": (128, 16, 32, 3, 1, 0, 1),
