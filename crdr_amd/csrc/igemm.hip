@@ -644,7 +644,14 @@ static int floordiv(int a, int b) {
   return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
 }
 
-static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
+// Measured large-M throughput of every tile configuration on an unpadded 3x3 layer (TFLOP/s, tools/sweep_conv.py --dump on
+// k3_128to{64,96,128,192,256,320}): what the built-in cost model knows about occupancy, LDS traffic and epilogue cost.
+static const float kCfgTflops[] = {107, 120, 122, 120, 105, 99, 94, 90, 101, 106, 102, 116, 123, 120, 107, 109, 111, 115, 126, 121,
+                                   111, 116, 119, 127, 114, 119, 108};
+
+// fallback = true: the caller found unaligned operands after the queries answered for the streaming kernel: plan an unsplit
+// tiled launch (no workspace, never the streaming kernel)
+static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallback = false) {
   IgemmArgs& a = pl->a;
   IgemmTaps& tp = pl->t;
   memset(&a, 0, sizeof(a));
@@ -715,10 +722,12 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
     if (want_cs && (t.nb == 3 || t.nb == 7)) continue;  // in-epilogue column sums need passes of 1, 2 or 4 column blocks
     const int BM = 32 * t.wm * t.mb, BN = 32 * t.wn * t.nb;
     const long long tiles = (long long)cdiv(a.M, BM) * cdiv(d->OC, BN) * a.nphase;
-    for (int ns = 1; ns <= 16; ns *= 2) {
+    static_assert(sizeof(kCfgTflops) / sizeof(kCfgTflops[0]) == sizeof(kCfgs) / sizeof(kCfgs[0]), "one figure per configuration");
+    for (int ns = 1; ns <= (fallback ? 1 : 16); ns *= 2) {
       if (ns > 1 && KT / ns < 8) break;
       const long long blocks = tiles * ns * G;
-      const double per_iter = 16.0 * t.mb * t.nb * 64.0 + 350.0 + 24.0 * (t.mb + t.nb);  // cycles
+      // MFMA cycles of one workgroup per K-tile (waves beyond four share the SIMDs), scaled by the measured efficiency
+      const double per_iter = 16.0 * t.mb * t.nb * 64.0 * std::max(1.0, t.wm * t.wn / 4.0) * (133.0 / kCfgTflops[c]);
       const double waves = (double)cdiv64(blocks, 256);
       double cost = waves * ((double)cdiv(KT, ns) * per_iter + 3000.0);
       if (ns > 1) cost += 8000.0 + (double)a.M * cdiv(d->OC, BN) * BN * ns * 4.0 * a.nphase / 2000.0;  // slab traffic
@@ -726,8 +735,29 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1) {
     }
   }
   pl->stream = -1;
-  if (d->reserved != 0 && (d->reserved & 0xff) - 1 >= kNumCfgs) {  // forced streaming 1x1 variant
-    const int sv = (d->reserved & 0xff) - 1 - kNumCfgs;
+  int auto_sv = -1;
+  if (d->reserved == 0 && !fallback && !want_cs && !a.smallc && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 &&
+      d->C % 32 == 0 && d->OC % 4 == 0 && !(d->flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM)) &&
+      (long long)a.M * G >= 16384 && d->ldy % 4 == 0 && (!(d->flags & CRDR_EPI_RES) || d->ldres % 4 == 0) &&
+      (!(d->flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) || d->ldmask % 4 == 0)) {
+    // built-in choice for the 1x1 layers: the 8-wave streaming variant with the fewest padded columns (ties: BN 96, 128, 64, 160);
+    // column-sum launches stay tiled so that crdr_conv2d_colsum_layout does not depend on operand alignment
+    static const int pref[] = {1, 2, 0, 3};
+    long long bestpad = 1ll << 60;
+    for (int q = 0; q < 4; ++q) {
+      const int sv = 4 + pref[q];
+      if (sv >= stream_num_variants()) continue;
+      int snb, sst, snw;
+      stream_variant_shape(sv, &snb, &sst, &snw);
+      const int BN = 32 * snb;
+      const size_t lds = ((size_t)a.kchunks * BN * 32 + (size_t)sst * 32 * snw * 32 + snw * 2 * BN + 4 * BN) * sizeof(float);
+      if (lds > 160 * 1024 || cdiv(d->OC, BN) > 32) continue;
+      const long long pad = (long long)cdiv(d->OC, BN) * BN;
+      if (pad < bestpad) { bestpad = pad; auto_sv = sv; }
+    }
+  }
+  if (auto_sv >= 0 || (d->reserved != 0 && (d->reserved & 0xff) - 1 >= kNumCfgs)) {  // streaming 1x1 variant (forced or built-in)
+    const int sv = auto_sv >= 0 ? auto_sv : (d->reserved & 0xff) - 1 - kNumCfgs;
     CRDR_REQUIRE(sv < stream_num_variants(), "conv2d: forced config %d out of range", sv + kNumCfgs);
     CRDR_REQUIRE(((d->reserved >> 8) & 0xf) == 0, "conv2d: the streaming 1x1 kernel has no split-K");
     CRDR_REQUIRE(!a.smallc && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->C % 32 == 0 &&
@@ -874,6 +904,15 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   const long long span = (256 + 4ll * a.OW * a.so) * std::max(std::max(a.ldy, a.ldres), a.ldmask) * 4;
   a.fast_epi = (v && a.Cout % 4 == 0 && a.nsplit == 1 && span < (1ll << 31) &&
                 !(a.flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM))) ? 1 : 0;
+  if (pl.stream >= 0 && !a.vec_epi && d->reserved == 0) {
+    // the built-in choice assumed 16-byte aligned operands (it only knows the strides): take the tiled kernel instead
+    Plan fb;
+    if (int rc = build_plan(d, &fb, G, true)) return rc;
+    fb.a.x = a.x; fb.a.w = a.w; fb.a.y = a.y; fb.a.ws = a.ws; fb.a.bias = a.bias; fb.a.vec2 = a.vec2; fb.a.res = a.res;
+    fb.a.scale = a.scale; fb.a.shift = a.shift; fb.a.gx = a.gx; fb.a.gt = a.gt; fb.a.sig = a.sig; fb.a.pre = a.pre;
+    fb.a.mask = a.mask; fb.a.cs = a.cs; fb.a.vec_epi = 0; fb.a.fast_epi = 0;
+    pl = fb;
+  }
   if (pl.stream >= 0) {
     CRDR_REQUIRE(a.vec_epi, "conv2d: the streaming kernel needs 16-byte aligned operand rows");
     void* prof = profile_begin(as_stream(s));

@@ -25,6 +25,11 @@ SHAPES = {
     "enc96to192k1@64": (96, 64, 192, 1, 1, 0, 17),
     "dec128to256k1@64": (128, 64, 256, 1, 1, 0, 17),
     "enc96to192k1@128": (96, 128, 192, 1, 1, 0, 17),
+    "k3_128to64": (128, 128, 64, 3, 1, 0, 3),
+    "k3_128to96": (128, 128, 96, 3, 1, 0, 3),
+    "k3_128to192": (128, 128, 192, 3, 1, 0, 3),
+    "k3_128to256": (128, 128, 256, 3, 1, 0, 3),
+    "k3_128to320": (128, 64, 320, 3, 1, 0, 3),
     "D3to64": (3, 256, 64, 3, 1, 0, 5),
     "stem3": (3, 256, 192, 5, 2, 0, 1),
     "up3T": (256, 64, 256, 5, 2, 1, 1),
@@ -56,6 +61,7 @@ def main():
     ap.add_argument("--top", type=int, default=4)
     ap.add_argument("--wgrad", action="store_true")
     ap.add_argument("--shapes", default=None)
+    ap.add_argument("--dump", action="store_true", help="print every unsplit tile configuration's TFLOP/s (cost-model fitting)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = L.load()
@@ -84,6 +90,8 @@ def main():
                 except L.CrdrHipError:
                     continue
                 res.append((t, c, 1 << ls))
+        if a.dump:
+            print(f"{name:14s} unsplit TF by cfg: " + " ".join(f"{c}:{flops / t / 1e12:.0f}" for t, c, sp in sorted(res, key=lambda r: r[1]) if sp == 1), flush=True)
         res.sort()
         stream = []
         for v, algo in enumerate(ops._stream_ids()):
