@@ -802,9 +802,9 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
   {  // tile order inside an XCD's contiguous range.  N-inner (default): the activation tile of an M tile stays in L2 while
      // its N tiles / phases / splits run, and every M tile streams the weight pack -- right while the pack is L2 / MALL
      // sized.  M-inner: one weight tile stays while the M tiles stream past it -- chosen only when the pack is far beyond
-     // any cache and dwarfs the activations (hoisted Charm convs: 136 MB of weights against 5 MB of activations; measured
-     // 8.8 GB -> of L2-miss traffic for that launch with N-inner).  In-between shapes (5x5 s2 transposed, 6.5 MB pack) are
-     // faster N-inner.
+     // any cache and dwarfs the activations (hoisted Charm convs: a 136 MB pack against 5 MB of activations; measured L2-miss
+     // traffic of that launch 8.8 -> 4.4 GB, +2 % speed).  Not for their input gradients (70 MB of activations re-read per
+     // tap: M-inner raised the traffic from 5.7 to 7.3 GB) nor for in-between shapes (5x5 s2 transposed, 6.5 MB pack).
     const double A = (double)d->N * d->H * d->W * d->C * 4.0, B = (double)a.w_bytes;
     a.m_inner = (G == 1 && B >= 32.0e6 && A * 4.0 <= B) ? 1 : 0;
   }
