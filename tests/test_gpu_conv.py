@@ -505,3 +505,39 @@ def test_streaming_1x1_grouped():
                 ref = X[1].double().cpu() @ _rand(co, ci, 1, 1, seed=21, scale=ci ** -0.5).view(co, ci).double().t()
                 _close(ys[1], ref + B[1].double().cpu() + R[1].double().cpu(), "grouped stream vs fp64")
     assert ran >= 3
+
+
+def test_builtin_choice_streams_1x1_and_falls_back_when_unaligned():
+    """Without a forced algorithm (the codec scripts run untuned) a large aligned 1x1 layer goes to the streaming kernel --
+    same bits as the tiled kernel -- and an output pointer that is only 4-byte aligned takes the tiled kernel instead of
+    failing (the built-in choice knows strides, not addresses)."""
+    import ctypes as C
+    from crdr_amd.hip import ops, lib as L
+    dev = _dev()
+    lib = L.load()
+    n, h, w, ci, co = 4, 64, 64, 96, 192
+    M = n * h * w
+    X = _rand(M, ci, seed=1).to(dev)
+    wt = _rand(co, ci, 1, 1, seed=2, scale=ci ** -0.5)
+    wp = ops.pack_weight(wt.to(dev), False)
+    b = _rand(co, seed=3).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    ref = X.double().cpu() @ wt.view(co, ci).double().t() + b.double().cpu()
+
+    def run(algo, shift):
+        d = L.ConvDesc(N=n, H=h, W=w, C=ci, OH=h, OW=w, OC=co, kh=1, kw=1, stride=1, pad=0, transposed=0, ldx=ci, ldy=co,
+                       wrows=wp.shape[1], wcols=wp.shape[2], flags=L.EPI_BIAS, ldres=0, ldg=0, wlayout=0, reserved=algo,
+                       ldpre=0, ldmask=0)
+        buf = torch.zeros(M * co + 8, device=dev)
+        io = L.ConvIO(x=X.data_ptr(), w=wp.data_ptr(), y=buf.data_ptr() + 4 * shift, bias=b.data_ptr())
+        assert lib.crdr_conv2d_workspace(C.byref(d)) == 0  # the built-in choice for this layer needs no workspace
+        L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), None, 0, s), "conv2d")
+        torch.cuda.synchronize()
+        return buf[shift:shift + M * co].view(M, co).clone()
+
+    y0 = run(0, 0)
+    _close(y0, ref, "built-in choice, aligned")
+    assert torch.equal(y0, run(1, 0)), "streaming and tiled kernels disagree"
+    y1 = run(0, 1)
+    _close(y1, ref, "built-in choice, output 4-byte aligned only")
+    assert torch.equal(y1, y0)
