@@ -48,16 +48,18 @@ def _stream_ids():
     return [n + 1 + v for v in range(lib.crdr_conv2d_num_stream_configs())]
 
 
-def _autotune(key, ncfg: int, max_log2_split: int, run, extra=()) -> int:
-    """run(algo) -> bool (False if the library rejects the combination). Returns the fastest algo id."""
-    best, best_t = 0, _time_call(lambda: run(0))
+def _autotune(key, ncfg: int, max_log2_split: int, run, extra=(), penalty=None) -> int:
+    """run(algo) -> bool (False if the library rejects the combination). Returns the fastest algo id.  penalty() -> ms added to
+    the candidate just timed: cost the launch causes elsewhere (the batched reduce reads every partial slab a weight-gradient
+    launch writes, so a deeper pixel split that is 1 % faster in isolation can cost more than it gains)."""
+    best, best_t = 0, _time_call(lambda: run(0)) + (penalty() if penalty else 0.0)
     base_t = best_t
     cands = [(c + 1) | (ls << 8) for c in range(ncfg) for ls in range(max_log2_split + 1)] + list(extra)
     for algo in cands:
         try:
             if not run(algo):
                 continue
-            t = _time_call(lambda: run(algo))
+            t = _time_call(lambda: run(algo)) + (penalty() if penalty else 0.0)
         except L.CrdrHipError:
             continue
         if t < best_t:
@@ -615,14 +617,18 @@ def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[i
             ta = (C.c_void_p * G)(*[tmp.data_ptr() + 4 * g * gi * gj * k[0] * k[1] for g in range(G)])
             jobs_t = (L.WgradJob * G)()
 
+            slab = [0]
+
             def run(a):
                 d.algo = a
                 nb = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
                 if nb == 0 or nb > (2 << 30):
                     return False
+                slab[0] = nb
                 w_, wn_ = workspace(nb, device)
                 return lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ta, G, w_, wn_, jobs_t, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run)
+            # + the batched reduce's read of these slabs at its measured 3.8 TB/s (profiles/r2_h_hbm_families.json)
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, penalty=lambda: slab[0] / 3.8e9)
         d.algo = algo
     nbytes = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
     jobs = (L.WgradJob * G)()
@@ -905,14 +911,18 @@ def wgrad_multi(n: int, ph: int, pw: int, qh: int, qw: int, ps, qs, gs, gi: int,
             ta = (C.c_void_p * G)(*[tmp.data_ptr() + 4 * g * gi * gj * k[0] * k[1] for g in range(G)])
             jobs_t = (L.WgradJob * G)()
 
+            slab = [0]
+
             def run(a):
                 d.algo = a
                 nb = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
                 if nb == 0 or nb > (2 << 30):
                     return False
+                slab[0] = nb
                 w_, wn_ = workspace(nb, device)
                 return lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ta, G, w_, wn_, jobs_t, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run)
+            # + the batched reduce's read of these slabs at its measured 3.8 TB/s (profiles/r2_h_hbm_families.json)
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, penalty=lambda: slab[0] / 3.8e9)
         d.algo = algo
     nbytes = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
     jobs = (L.WgradJob * G)()
