@@ -656,6 +656,75 @@ __global__ __launch_bounds__(1024) void linear_bwd_x_kernel(const float* w, int 
     }
 }
 
+// grouped variants (crdr_linear_group_*): blockIdx.y = problem; the shared input rows are read by every problem
+__global__ __launch_bounds__(256) void linear_group_fwd_kernel(const float* x, int M, int I, int ldx, const crdr_linear_group g) {
+  const int gi = blockIdx.y, O = g.O[gi];
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= O) return;
+  const float* w = g.w[gi];
+  float acc[kLinMaxM];
+#pragma unroll
+  for (int m = 0; m < kLinMaxM; ++m) acc[m] = 0.f;
+  for (int i = lane; i < I; i += 64) {
+    const float wv = w[(size_t)o * I + i];
+#pragma unroll
+    for (int m = 0; m < kLinMaxM; ++m)
+      if (m < M) acc[m] += wv * x[(size_t)m * ldx + i];
+  }
+#pragma unroll
+  for (int m = 0; m < kLinMaxM; ++m) {
+    float v = acc[m];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0 && m < M) g.y[gi][(size_t)m * O + o] = v + (g.b[gi] ? g.b[gi][o] : 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void linear_group_bwd_w_kernel(const float* x, int M, int I, int ldx, const crdr_linear_group g) {
+  const int gi = blockIdx.y, O = g.O[gi];
+  const long long e = blockIdx.x * 256ll + threadIdx.x;
+  if (e >= (long long)O * I) return;
+  const int o = (int)(e / I), i = (int)(e % I);
+  const float* dy = g.dy[gi];
+  float a = 0.f, s = 0.f;
+  for (int m = 0; m < M; ++m) {
+    const float gv = dy[(size_t)m * O + o];
+    a += gv * x[(size_t)m * ldx + i];
+    s += gv;
+  }
+  if (g.dw[gi]) g.dw[gi][e] += a;
+  if (g.db[gi] && i == 0) g.db[gi][o] += s;
+}
+// dx over all problems: block = 64 input features, the 16 waves split every problem's output features, fixed-order LDS reduce
+__global__ __launch_bounds__(1024) void linear_group_bwd_x_kernel(int M, int I, const crdr_linear_group g, int G, float* dx, int lddx) {
+  __shared__ float red[16][kLinMaxM][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = blockIdx.x * 64 + lane;
+  float acc[kLinMaxM];
+#pragma unroll
+  for (int m = 0; m < kLinMaxM; ++m) acc[m] = 0.f;
+  if (i < I)
+    for (int gi = 0; gi < G; ++gi) {
+      const int O = g.O[gi];
+      const float* w = g.w[gi];
+      const float* dy = g.dy[gi];
+      for (int o = wave; o < O; o += 16) {
+        const float wv = w[(size_t)o * I + i];
+#pragma unroll
+        for (int m = 0; m < kLinMaxM; ++m)
+          if (m < M) acc[m] += wv * dy[(size_t)m * O + o];
+      }
+    }
+#pragma unroll
+  for (int m = 0; m < kLinMaxM; ++m) red[wave][m][lane] = acc[m];
+  __syncthreads();
+  if (wave == 0 && i < I)
+    for (int m = 0; m < M; ++m) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r][m][lane];
+      dx[(size_t)m * lddx + i] = t;
+    }
+}
+
 // gather half of the GEMM + scatter formulation of RGB-output transposed ops (see crdr_col2im_rgb)
 __global__ __launch_bounds__(256) void col2im_rgb_kernel(const float* cols, int ldc, int N, int H, int W, int kh, int kw, int S,
                                                          int P, const float* bias, float* out, int ldo, int OH, int OW, int C) {
@@ -860,6 +929,44 @@ extern "C" int crdr_linear_bwd(const float* x, int M, int I, int ldx, const floa
     hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(I, 64)), dim3(1024), 0, as_stream(s), w, M, I, dy, lddy, y, ldy, O, dx,
                        lddx);
     CRDR_CHECK_LAUNCH("linear_bwd_x_kernel");
+  }
+  return 0;
+}
+
+extern "C" int crdr_linear_group_fwd(const float* x, int M, int I, int ldx, const crdr_linear_group* g, int G, crdr_stream_t s) {
+  CRDR_REQUIRE(x && g, "linear_group_fwd: null pointer");
+  CRDR_REQUIRE(M >= 1 && M <= kLinMaxM, "linear_group_fwd: M = %d rows (1..%d supported)", M, kLinMaxM);
+  CRDR_REQUIRE(G >= 1 && G <= CRDR_MAX_GROUP, "linear_group_fwd: %d problems (1..%d)", G, CRDR_MAX_GROUP);
+  int omax = 0;
+  for (int i = 0; i < G; ++i) {
+    CRDR_REQUIRE(g->w[i] && g->y[i] && g->O[i] >= 1, "linear_group_fwd: problem %d incomplete", i);
+    omax = std::max(omax, (int)g->O[i]);
+  }
+  hipLaunchKernelGGL(linear_group_fwd_kernel, dim3(cdiv(omax, 4), G), dim3(256), 0, as_stream(s), x, M, I, ldx, *g);
+  CRDR_CHECK_LAUNCH("linear_group_fwd_kernel");
+  return 0;
+}
+
+extern "C" int crdr_linear_group_bwd(const float* x, int M, int I, int ldx, const crdr_linear_group* g, int G, float* dx, int lddx,
+                                     crdr_stream_t s) {
+  CRDR_REQUIRE(x && g, "linear_group_bwd: null pointer");
+  CRDR_REQUIRE(M >= 1 && M <= kLinMaxM, "linear_group_bwd: M = %d rows (1..%d supported)", M, kLinMaxM);
+  CRDR_REQUIRE(G >= 1 && G <= CRDR_MAX_GROUP, "linear_group_bwd: %d problems (1..%d)", G, CRDR_MAX_GROUP);
+  int omax = 0;
+  bool any_w = false;
+  for (int i = 0; i < G; ++i) {
+    CRDR_REQUIRE(g->w[i] && g->dy[i] && g->O[i] >= 1, "linear_group_bwd: problem %d incomplete", i);
+    omax = std::max(omax, (int)g->O[i]);
+    any_w = any_w || g->dw[i] || g->db[i];
+  }
+  if (any_w) {
+    hipLaunchKernelGGL(linear_group_bwd_w_kernel, dim3((unsigned)cdiv64((long long)omax * I, 256), G), dim3(256), 0, as_stream(s), x, M,
+                       I, ldx, *g);
+    CRDR_CHECK_LAUNCH("linear_group_bwd_w_kernel");
+  }
+  if (dx) {
+    hipLaunchKernelGGL(linear_group_bwd_x_kernel, dim3(cdiv(I, 64)), dim3(1024), 0, as_stream(s), M, I, *g, G, dx, lddx);
+    CRDR_CHECK_LAUNCH("linear_group_bwd_x_kernel");
   }
   return 0;
 }

@@ -356,6 +356,71 @@ class _SmallLinear(torch.autograd.Function):
         return (None if dx is None else dx.view(m, i, 1, 1)), None, None, None
 
 
+class _LinearGroup(torch.autograd.Function):
+    """Several linear layers of ONE input (the nine beta projections of a bottleneck stack read the same [1, 512] vector):
+    one launch forward, two backward; the input gradient is summed over the layers inside the kernel (fixed order), so
+    autograd sees a single consumer of the input.  apply(x, n, w_0 .. w_{n-1}, b_0 .. b_{n-1}) -> n outputs [M, O_g]."""
+
+    @staticmethod
+    def forward(ctx, x, n: int, *wb):
+        lib = L.load()
+        ops._require_gpu(x)
+        ws, bs = wb[:n], wb[n:]
+        m, i = x.shape[0], x.shape[1]
+        x2 = x.reshape(m, i).contiguous()
+        g = L.LinearGroup()
+        ys = []
+        for k in range(n):
+            o = ws[k].shape[0]
+            assert ws[k].is_contiguous() and ws[k].numel() == o * i
+            y = torch.empty((m, o), dtype=torch.float32, device=x.device)
+            g.w[k], g.y[k], g.O[k] = ws[k].data_ptr(), y.data_ptr(), o
+            g.b[k] = None if bs[k] is None else bs[k].data_ptr()
+            ys.append(y)
+        L.check(lib.crdr_linear_group_fwd(x2.data_ptr(), m, i, i, C.byref(g), n, ops._stream()), "linear_group_fwd")
+        ctx.n = n
+        ctx.x_shape = tuple(x.shape)
+        ctx.has_b = [b is not None for b in bs]
+        ctx.save_for_backward(x2, *ws, *[b for b in bs if b is not None])
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        x2, ws, rest = saved[0], saved[1:1 + n], list(saved[1 + n:])
+        lib = L.load()
+        m, i = x2.shape
+        needs = ctx.needs_input_grad
+        g = L.LinearGroup()
+        keep = []
+        for k in range(n):
+            o = ws[k].shape[0]
+            dy = dys[k]
+            dy = torch.zeros((m, o), dtype=torch.float32, device=x2.device) if dy is None else dy.reshape(m, o).contiguous()
+            keep.append(dy)
+            b = rest.pop(0) if ctx.has_b[k] else None
+            g.w[k], g.dy[k], g.O[k] = ws[k].data_ptr(), dy.data_ptr(), o
+            g.dw[k] = _grad_slot(ws[k]).data_ptr() if needs[2 + k] else None
+            g.db[k] = _grad_slot(b).data_ptr() if (b is not None and needs[2 + n + k]) else None
+        dx = torch.empty((m, i), dtype=torch.float32, device=x2.device) if needs[0] else None
+        L.check(lib.crdr_linear_group_bwd(x2.data_ptr(), m, i, i, C.byref(g), n, None if dx is None else dx.data_ptr(), i,
+                                          ops._stream()), "linear_group_bwd")
+        return (None if dx is None else dx.view(ctx.x_shape), None) + (None,) * (2 * n)
+
+
+def linear_group(x, layers):
+    """y_g = layer_g(x) for 1x1 conv / linear layers (weight [O, I(, 1, 1)], optional bias) sharing the input x [M <= 16, I(, 1, 1)]:
+    one grouped launch per direction.  Returns a list of [M, O_g] tensors."""
+    outs = []
+    for c0 in range(0, len(layers), L.MAX_GROUP):
+        chunk = layers[c0:c0 + L.MAX_GROUP]
+        ws = [ly.weight for ly in chunk]  # the parameters themselves ([O, I] or [O, I, 1, 1]): their .grad slots are written
+        bs = [ly.bias for ly in chunk]
+        outs += list(_LinearGroup.apply(x, len(chunk), *ws, *bs))
+    return outs
+
+
 def fused_conv(x, weight, bias, spec: ConvSpec, *, act: Optional[str] = None, vec2=None, res=None,
                affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                gate: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, return_wgrad: bool = False):

@@ -51,6 +51,10 @@ class WgradJob(C.Structure):
         "PC", "QC", "gI", "gJ", "T", "nsplit", "smallj", "accumulate", "gJtot", "reserved")]
 
 
+class LinearGroup(C.Structure):  # mirrors struct crdr_linear_group
+    _fields_ = [(n, c_void_p * 16) for n in ("w", "b", "y", "dy", "dw", "db")] + [("O", C.c_int32 * 16)]
+
+
 class PackItem(C.Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p)] + [(n, C.c_int32) for n in (
         "I", "J", "T", "rows", "cols", "mode", "srcJ", "dld")] + [("tstride", C.c_int64)]
@@ -132,6 +136,8 @@ SIGNATURES = {
     "crdr_crop_flip_normalize": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
     "crdr_linear_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "crdr_linear_bwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
+    "crdr_linear_group_fwd": (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    "crdr_linear_group_bwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
     "crdr_affine": (_I, [_P, _I, _P, _P, _P, _I, _I64, _I, _P]),
     "crdr_colsum_workspace": (_SZ, [_I64, _I]),
     "crdr_colsum": (_I, [_P, _I, _I64, _I, _P, _I, _P, _SZ, _P]),

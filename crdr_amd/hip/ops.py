@@ -20,6 +20,10 @@ _ws_max = 0     # largest request seen so far (eager warm-up), so a buffer creat
 # (base_trainer.py:20): with AUTOTUNE on, the first call of a shape times every tile configuration x split depth
 # of the library on the real operands and caches the fastest; off, the library's built-in cost model decides.
 AUTOTUNE = False
+# Nonzero: every forward / input-gradient convolution without an explicit algorithm takes this forced id (tile configuration
+# + split, see crdr_conv_desc.reserved) instead of the tuner's or the cost model's choice.  The choice normally depends on the
+# problem size, and with it the fp32 summation order; tests that compare runs at different batch sizes bit for bit pin it.
+FORCED_CONV_ALGO = 0
 _algo_cache = {}
 TUNE_LOG = []
 
@@ -275,8 +279,8 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
             ldg = oc
         d.ldg = ldg
         io.gx, io.gt, io.sig = gate_x.data_ptr(), gate_t.data_ptr(), sig_out.data_ptr()
-    if algo:
-        d.reserved = algo
+    if algo or FORCED_CONV_ALGO:
+        d.reserved = algo or FORCED_CONV_ALGO
     elif AUTOTUNE and not (flags & L.EPI_ACCUM):
         key = ("c", n, h, w, d.C, oh, ow, oc, k, stride, pad, int(transposed), ldx, ldy, flags, d.ldres, d.ldg, wlayout)
         algo = _algo_cache.get(key)
@@ -562,7 +566,9 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
             io.pre = pres[g].ptr
         if masks is not None:
             io.mask = masks[g].ptr
-    if AUTOTUNE:
+    if FORCED_CONV_ALGO:
+        d.reserved = FORCED_CONV_ALGO
+    elif AUTOTUNE:
         key = ("g", G, n, h, w, d.C, oc, k, pad, int(transposed), d.ldx, d.ldy, flags, d.ldpre, d.ldmask, wrows, wcols)
         algo = _algo_cache.get(key)
         if algo is None:
@@ -845,7 +851,9 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
             return [t.data_ptr() + 4 * g * nf for g in range(G)], rows.value, ld.value, t
         q = colsum_queue(device)
         return [q.alloc(nf) for _ in range(G)], rows.value, ld.value, None
-    if AUTOTUNE:
+    if FORCED_CONV_ALGO:
+        d.reserved = FORCED_CONV_ALGO
+    elif AUTOTUNE:
         key = ("m", G, n, h, w, oh, ow, d.C, oc, k, stride, pad, int(transposed), d.ldx, d.ldy, flags, d.ldres, d.ldpre, d.ldmask,
                wrows, wcols, wlayout)
         algo = _algo_cache.get(key)

@@ -7,6 +7,7 @@ from __future__ import annotations
 import torch.nn as nn
 
 from crdr_amd.hip import chain as CH
+from crdr_amd.hip import functional as HF
 
 from .hip_layers import HipConv2d, HipConvTranspose2d
 
@@ -110,9 +111,9 @@ class BetaCondResidualBottleneckBlocks(nn.Module):
         return sp
 
     def forward(self, x, cond_feat, affine=None):
-        vecs = []
-        for i in range(self.num_blocks):
-            b = getattr(self, f"block{i}")
-            vecs += [b.proj_1(cond_feat).reshape(-1), b.proj_2(cond_feat).reshape(-1), b.proj_3(cond_feat).reshape(-1)]
+        # all projections of the stack in one grouped launch per direction (they read the same conditioning vector)
+        projs = [p for i in range(self.num_blocks) for p in (getattr(self, f"block{i}").proj_1, getattr(self, f"block{i}").proj_2,
+                                                             getattr(self, f"block{i}").proj_3)]
+        vecs = [v.reshape(-1) for v in HF.linear_group(cond_feat, projs)]
         s, t = affine if affine is not None else (None, None)
         return CH.run_chain(x, self._chain(affine is not None), s, t, vecs)[0]

@@ -294,6 +294,23 @@ int crdr_linear_fwd(const float* x, int M, int I, int ldx, const float* w, const
 int crdr_linear_bwd(const float* x, int M, int I, int ldx, const float* w, const float* dy, int lddy, const float* y,
                     int ldy, int O, float* dx, int lddx, float* dw, float* db, crdr_stream_t s);
 
+/* Up to CRDR_MAX_GROUP linear layers that read the SAME input rows, one launch per direction: the three projections of each of
+ * the three blocks of a beta-conditioned bottleneck stack (BetaCondBaseBlock.proj_{1,2,3}, elic_interpca_beta_cond_autoencoder.py
+ * :42-84; 27 projections of one [1, 512] vector per decoder pass).  y[g]: dense [M][O[g]].  Backward: dx[m][i] = sum_g sum_o
+ * dy[g][m][o] w[g][o][i] (written, problems added in index order), dw[g] / db[g] accumulated (null = skipped). */
+typedef struct crdr_linear_group {
+  const float* w[CRDR_MAX_GROUP];
+  const float* b[CRDR_MAX_GROUP]; /* may be null */
+  float* y[CRDR_MAX_GROUP];       /* forward only */
+  const float* dy[CRDR_MAX_GROUP]; /* backward only, dense [M][O[g]] */
+  float* dw[CRDR_MAX_GROUP];
+  float* db[CRDR_MAX_GROUP];
+  int32_t O[CRDR_MAX_GROUP];
+} crdr_linear_group;
+int crdr_linear_group_fwd(const float* x, int M, int I, int ldx, const crdr_linear_group* g, int G, crdr_stream_t s);
+int crdr_linear_group_bwd(const float* x, int M, int I, int ldx, const crdr_linear_group* g, int G, float* dx, int lddx,
+                          crdr_stream_t s);
+
 /* y[m][c] = x[m][c] * scale[c] + shift[c]   (stand-alone InterpChAtt apply) */
 int crdr_affine(const float* x, int ldx, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
                 crdr_stream_t s);

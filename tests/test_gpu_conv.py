@@ -541,3 +541,32 @@ def test_builtin_choice_streams_1x1_and_falls_back_when_unaligned():
     y1 = run(0, 1)
     _close(y1, ref, "built-in choice, output 4-byte aligned only")
     assert torch.equal(y1, y0)
+
+
+def test_linear_group_matches_separate_layers():
+    """crdr_linear_group_{fwd,bwd}: several projections of one conditioning vector in one launch per direction; outputs,
+    the summed input gradient and the parameter gradients (accumulated into .grad) against fp64 torch."""
+    from crdr_amd.hip import functional as HF
+    from crdr_amd.models.layer.hip_layers import HipConv2d
+    dev = _dev()
+    torch.manual_seed(0)
+    outs = [128, 128, 256, 96, 4, 33, 256, 128, 192]
+    layers = [HipConv2d(512, o, 1).to(dev) for o in outs]
+    x = _rand(1, 512, 1, 1, seed=1).to(dev).requires_grad_(True)
+    cots = [_rand(1, o, seed=10 + k).to(dev) for k, o in enumerate(outs)]
+    ys = HF.linear_group(x, layers)
+    loss = sum((y * c).sum() for y, c in zip(ys, cots))
+    loss.backward()
+    xr = x.detach().double().cpu().reshape(1, 512).requires_grad_(True)
+    tot = 0
+    for k, ly in enumerate(layers):
+        w = ly.weight.detach().double().cpu().reshape(outs[k], 512).requires_grad_(True)
+        b = ly.bias.detach().double().cpu().requires_grad_(True)
+        yr = xr @ w.t() + b
+        _close(ys[k], yr, f"group fwd {k}")
+        (yr * cots[k].double().cpu()).sum().backward()
+        _close(ly.weight.grad.reshape(outs[k], 512), w.grad, f"group dW {k}")
+        _close(ly.bias.grad, b.grad, f"group db {k}")
+        tot += 1
+    _close(x.grad.reshape(1, 512), xr.grad, "group dx (sum over the layers)")
+    assert tot == len(outs)
