@@ -21,16 +21,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------------------
 // Streaming 1x1 convolution (a plain GEMM  out[m][oc] = epi(sum_c in[m][c] w[oc][c]),  K = Cin <= 320).
 //
-// The generic kernel above runs the 1x1 layers of the bottleneck blocks at ~40 % MFMA occupancy and ~2 TB/s: a K loop of
-// 3..8 iterations cannot hide the load latency behind a double buffer, and every tile pays its own ramp and epilogue
-// (PMC: profiles/r2_f_pmc_1x1_vs_3x3.txt).  Here a workgroup is PERSISTENT: it loads its weight tile [BN][K] into LDS once,
-// then walks its share of the 128-row M tiles with an S-stage ring of [128][32] activation tiles that keeps running across
-// tile boundaries -- the DMA of the next tiles is in flight during the epilogue of the current one.  Every wave fetches the
-// 32 rows it multiplies itself, so the ring is private to the wave: counted vmcnt waits, no workgroup barrier in the loop.
-// Block = 4 waves (one per SIMD), wave tile = 32 rows x BN columns (NB = BN / 32 accumulators); fragment layout and epilogue arithmetic are those of the generic kernel, so the
-// results are bit-identical to its unsplit configurations.  Workgroups that share M tiles (different N tiles) sit on one
-// XCD, so the activation rows come from HBM once.  A grouped launch spreads its problems over the workgroups.  No split-K,
-// no gate / pre-add / accumulate epilogue.
+// The tiled kernel ran the 1x1 layers of the bottleneck blocks at ~40 % MFMA occupancy and ~2 TB/s: a K loop of 3..8
+// iterations cannot hide the load latency behind a double buffer, and every tile pays its own ramp and epilogue (PMC:
+// profiles/r2_f_pmc_1x1_vs_3x3.txt).  Here a workgroup is PERSISTENT: it loads its weight tile [BN][K] into LDS once, then
+// walks its share of the M tiles (32 NW rows each); every wave streams the 32 activation rows it multiplies through its own
+// ring of S [32][32]-float stages filled by LDS-DMA, which keeps running across tile boundaries -- the next tile's rows are
+// in flight during the epilogue of the current one.  The ring being private to the wave, the loop has no workgroup barrier,
+// only counted vmcnt waits (vmcnt counts loads, DMA pieces and stores in issue order, see the loop).  Wave tile = 32 rows x
+// BN columns (NB = BN / 32 accumulators); fragment layout and epilogue arithmetic are those of the tiled kernel, so the
+// results are bit-identical to its unsplit configurations.  The epilogue is straight-line: per-column vectors staged in LDS
+// once, operands and results moved by buffer instructions issued by all lanes (out-of-range offsets for dead rows / column
+// groups), the ring slot consumed last doubles as the accumulator-transpose buffer.  Workgroups that share M tiles
+// (different N tiles) sit on one XCD, so the activation rows come from HBM once.  A grouped launch spreads its problems over
+// the workgroups.  No split-K, no gate / pre-add / accumulate epilogue.  Design notes and measurements: DESIGN.md 4c.
 // ------------------------------------------------------------------------------------------------------------
 // OPS: operands read by the epilogue besides the per-column vectors: bit 0 = res (CRDR_EPI_RES), bit 1 = mask (the ReLU masks)
 // NW: waves per workgroup (4: one per SIMD; 8: two per SIMD, so one wave's epilogue and stores overlap the other's MFMAs)
