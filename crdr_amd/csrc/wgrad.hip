@@ -260,7 +260,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const crdr_wg
     const int i = (int)(rel / jt), j0 = (int)(rel % jt) * 64;
     const int T = jb.T, jn = min(64, jb.gJ - j0);
     const size_t stride = (size_t)T * jb.PC * jb.QC;
-    // phase 1: thread -> (tap group tid >> 6, channel tid & 63); sums over splits in split order, four loads in flight
+    // phase 1: sums over splits in split order (four partial sums, combined (v0 + v1) + (v2 + v3): the order never changes).
+    // Vector form: thread -> (tap tid >> 4, four channels 4 (tid & 15)): 16-byte loads, 16 taps per pass
+    if ((jb.QC & 3) == 0 && (reinterpret_cast<uintptr_t>(jb.slab) & 15) == 0) {
+      const int l16 = tid & 15;
+      const bool in_row = j0 + 4 * l16 < jb.QC;  // the whole float4 lies inside the (padded) slab row
+      for (int t = tid >> 4; t < T; t += 16) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+        if (in_row) {
+          const float* base = jb.slab + ((size_t)t * jb.PC + i) * jb.QC + j0 + 4 * l16;
+          int s = 0;
+          for (; s + 4 <= jb.nsplit; s += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(base + (size_t)s * stride);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(base + (size_t)(s + 1) * stride);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(base + (size_t)(s + 2) * stride);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(base + (size_t)(s + 3) * stride);
+            v0 += a; v1 += b; v2 += c; v3 += d4;
+          }
+          for (; s < jb.nsplit; ++s) v0 += *reinterpret_cast<const f32x4*>(base + (size_t)s * stride);
+        }
+        const f32x4 v = (v0 + v1) + (v2 + v3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[(4 * l16 + e) * (T + 1) + t] = v[e];
+      }
+    } else {
+    // scalar form: thread -> (tap group tid >> 6, channel tid & 63), four loads in flight
     const int jl = tid & 63;
     for (int t = tid >> 6; t < T; t += 4) {
       float v = 0.f;
@@ -278,6 +302,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const crdr_wg
         v = (v0 + v1) + (v2 + v3);
       }
       tile[jl * (T + 1) + t] = v;  // (T + 1): the transposed read below walks T-strided rows
+    }
     }
     __syncthreads();
     // phase 2: the jn * T outputs of this tile are contiguous in g
