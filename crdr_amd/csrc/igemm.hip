@@ -292,8 +292,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   const bool vec = p.vec_epi != 0;
   // CRDR_EPI_COLSUM: column sums of this tile's outputs (value before / after the ReLU mask), reduced lane -> wave ->
   // workgroup in a fixed order and written as one partial row per (phase, M tile); crdr_colsum_finish adds the rows up.
-  // Only tile shapes whose passes stage 1, 2 or 4 column blocks qualify (a lane then keeps one 4-channel column group
-  // for the whole pass); build_plan enforces it.
+  // A lane must keep one 4-channel column group for a whole pass, which holds for passes of 1, 2 or 4 column blocks; a pass
+  // of 3 runs as three single-block passes when column sums are requested.
   const bool do_cs = (f & CRDR_EPI_COLSUM) && p.nsplit == 1;
   float* sS = smem + WM * WN * 32 * CLD;  // [WM][2][BN] behind the staged accumulators
   // ---- fast epilogue (p.fast_epi): every global access is a buffer instruction issued by all lanes -- dead rows / column
@@ -404,11 +404,24 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
         }
       }
     };
-    fpass(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
-    if constexpr (NB > 4) fpass(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+    // a pass of three column blocks cannot keep one column group per lane: with column sums it runs as three single-block passes
+    auto fgroup = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+      constexpr int JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+      if constexpr (GC == 3) {
+        if (do_cs) {
+          fpass(I_, integral_constant<int, JG>{}, integral_constant<int, 1>{});
+          fpass(I_, integral_constant<int, JG + 1>{}, integral_constant<int, 1>{});
+          fpass(I_, integral_constant<int, JG + 2>{}, integral_constant<int, 1>{});
+          return;
+        }
+      }
+      fpass(I_, JG_, GC_);
+    };
+    fgroup(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+    if constexpr (NB > 4) fgroup(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
     if constexpr (MB > 1) {
-      fpass(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
-      if constexpr (NB > 4) fpass(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+      fgroup(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+      if constexpr (NB > 4) fgroup(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
     }
     if (do_cs) {
       __syncthreads();
@@ -533,11 +546,23 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     }
     __syncthreads();
   };
-  pass(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
-  if constexpr (NB > 4) pass(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+  auto group = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+    constexpr int JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+    if constexpr (GC == 3) {
+      if (do_cs) {  // (see the fast path)
+        pass(I_, integral_constant<int, JG>{}, integral_constant<int, 1>{});
+        pass(I_, integral_constant<int, JG + 1>{}, integral_constant<int, 1>{});
+        pass(I_, integral_constant<int, JG + 2>{}, integral_constant<int, 1>{});
+        return;
+      }
+    }
+    pass(I_, JG_, GC_);
+  };
+  group(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+  if constexpr (NB > 4) group(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
   if constexpr (MB > 1) {
-    pass(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
-    if constexpr (NB > 4) pass(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+    group(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+    if constexpr (NB > 4) group(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
   }
   static_assert(MB <= 2 && NB <= 8, "epilogue passes are written out for MB <= 2, NB <= 8");
   if (do_cs) {  // (the last pass ended with a barrier) sum the WM row groups in order, one partial row per (phase, M tile)
@@ -719,7 +744,6 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
   for (int c = 0; c < kNumCfgs; ++c) {
     const TileCfg& t = kCfgs[c];
     if (a.smallc && !t.kern_smallc) continue;
-    if (want_cs && (t.nb == 3 || t.nb == 7)) continue;  // in-epilogue column sums need passes of 1, 2 or 4 column blocks
     const int BM = 32 * t.wm * t.mb, BN = 32 * t.wn * t.nb;
     const long long tiles = (long long)cdiv(a.M, BM) * cdiv(d->OC, BN) * a.nphase;
     static_assert(sizeof(kCfgTflops) / sizeof(kCfgTflops[0]) == sizeof(kCfgs) / sizeof(kCfgs[0]), "one figure per configuration");
@@ -791,7 +815,6 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
     CRDR_REQUIRE(bc >= 0 && bc < kNumCfgs, "conv2d: forced config %d out of range", bc);
     CRDR_REQUIRE(!a.smallc || kCfgs[bc].kern_smallc, "conv2d: config %d has no tap-major variant", bc);
     CRDR_REQUIRE(bs == 1 || KT / bs >= 2, "conv2d: forced split %d too deep for %d K-iterations", bs, KT);
-    CRDR_REQUIRE(!(want_cs && (kCfgs[bc].nb == 3 || kCfgs[bc].nb == 7)), "conv2d: config %d cannot produce column sums", bc);
   }
   CRDR_REQUIRE(bc >= 0, "conv2d: no tile config");
   const TileCfg& t = kCfgs[bc];

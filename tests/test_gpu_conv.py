@@ -570,3 +570,35 @@ def test_linear_group_matches_separate_layers():
         tot += 1
     _close(x.grad.reshape(1, 512), xr.grad, "group dx (sum over the layers)")
     assert tot == len(outs)
+
+
+def test_column_sums_every_tile_config():
+    """CRDR_EPI_COLSUM (bias / beta-vector gradients out of the input-gradient conv) from every tile configuration, including
+    those whose epilogue passes span three column blocks: sum over the partial rows == column sums of the stored output."""
+    import ctypes as C
+    from crdr_amd.hip import ops, lib as L
+    dev = _dev()
+    lib = L.load()
+    n, h, w, ci, co, k = 2, 17, 19, 64, 224, 3
+    M = n * h * w
+    x = _rand(n, ci, h, w, seed=1).to(dev).contiguous(memory_format=torch.channels_last)
+    xv, ldx = ops.nhwc(x)
+    wt = _rand(co, ci, k, k, seed=2, scale=0.05)
+    wp = ops.pack_weight(wt.to(dev), False)
+    MSK = _rand(M, co, seed=3).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    for c in range(lib.crdr_conv2d_num_configs()):
+        d = L.ConvDesc(N=n, H=h, W=w, C=ci, OH=h, OW=w, OC=co, kh=k, kw=k, stride=1, pad=1, transposed=0, ldx=ldx, ldy=co,
+                       wrows=wp.shape[1], wcols=wp.shape[2], flags=L.EPI_RELUMASK | L.EPI_COLSUM, ldres=0, ldg=0, wlayout=0,
+                       reserved=c + 1, ldpre=0, ldmask=co)
+        rows, ld = C.c_int(), C.c_int()
+        L.check(lib.crdr_conv2d_colsum_layout(C.byref(d), 1, C.byref(rows), C.byref(ld)), f"layout cfg {c}")
+        y = torch.zeros(M, co, device=dev)
+        cs = torch.full((rows.value, 2, ld.value), float("nan"), device=dev)
+        io = L.ConvIO(x=xv.data_ptr(), w=wp.data_ptr(), y=y.data_ptr(), mask=MSK.data_ptr(), cs=cs.data_ptr())
+        L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), None, 0, s), f"conv2d cfg {c}")
+        torch.cuda.synchronize()
+        post = y.double().sum(0).cpu()
+        pre = torch.nn.functional.conv2d(x.double().cpu(), wt.double(), padding=1).permute(0, 2, 3, 1).reshape(M, co).sum(0)
+        _close(cs[:, 1, :co].sum(0), post, f"cfg {c}: column sums after the mask", rtol=1e-4)
+        _close(cs[:, 0, :co].sum(0), pre, f"cfg {c}: column sums before the mask", rtol=1e-4)
