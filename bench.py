@@ -260,8 +260,8 @@ def fused_ops_roofline(tr) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--stage", type=int, default=3)
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
