@@ -226,21 +226,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* ws, float* g, i
 // coalesced (a direct j-fastest mapping writes 4-byte pieces T floats apart and re-touches every output line T times).
 // RGB jobs (smallj: slab rows are [T][4]) keep 256 consecutive outputs per tile.  Tile count per job (host side):
 // smallj ? ceil(gI gJ T / 256) : gI * ceil(gJ / 64).  Splits are summed in a fixed order (deterministic).
+// Batched kernels find the table entry of a work unit by binary search over the prefix sums.  From global memory that is a
+// chain of ~log2(n) dependent loads (4-6 us) per unit -- more than the unit's own traffic takes for small layers -- so a
+// workgroup first copies the prefix table (n <= kPrefixCache entries, totals < 2^31) to LDS.
+constexpr int kPrefixCache = 1024;
+__device__ __forceinline__ bool cache_prefix(const long long* prefix, int n, int* spre) {
+  const bool cached = n + 1 <= kPrefixCache;
+  if (cached) {
+    for (int k = threadIdx.x; k <= n; k += blockDim.x) spre[k] = (int)prefix[k];
+    __syncthreads();
+  }
+  return cached;
+}
+__device__ __forceinline__ int find_entry(const long long* prefix, const int* spre, bool cached, int n, long long g) {
+  int lo = 0, hi = n - 1;  // last entry with prefix[entry] <= g  (block-uniform)
+  if (cached) {
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (spre[mid] <= (int)g) lo = mid; else hi = mid - 1;
+    }
+  } else {
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+  }
+  return lo;
+}
+
 constexpr int kRedMaxT = 32;
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const crdr_wgrad_job* jobs, const long long* prefix,
                                                                    const long long* meta) {
   __shared__ float tile[64 * kRedMaxT + 64];
+  __shared__ int spre[kPrefixCache];
   const int n = (int)meta[0];
   const long long total = meta[1];
   const int tid = threadIdx.x;
+  const bool cached = cache_prefix(prefix, n, spre);
   for (long long tl = blockIdx.x; tl < total; tl += gridDim.x) {
-    int lo = 0, hi = n - 1;  // last job with prefix[job] <= tl  (block-uniform)
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (prefix[mid] <= tl) lo = mid; else hi = mid - 1;
-    }
+    const int lo = find_entry(prefix, spre, cached, n, tl);
     const crdr_wgrad_job jb = jobs[lo];
-    const long long rel = tl - prefix[lo];
+    const long long rel = tl - (cached ? (long long)spre[lo] : prefix[lo]);
     const int gJt = jb.gJtot ? jb.gJtot : jb.gJ;
     if (jb.smallj || jb.T > kRedMaxT) {
       const long long e = rel * 256 + tid;
@@ -362,17 +388,15 @@ constexpr int kPackMaxT = 32;
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const crdr_pack_item* items, const long long* prefix,
                                                                    const long long* meta) {
   __shared__ float tile[256 * kPackMaxT + 32];
+  __shared__ int spre[kPrefixCache];
   const int n = (int)meta[0];
   const long long total = meta[1];
   const int tid = threadIdx.x;
+  const bool cached = cache_prefix(prefix, n, spre);
   for (long long g = blockIdx.x; g < total; g += gridDim.x) {
-    int lo = 0, hi = n - 1;  // last item with prefix[item] <= g  (block-uniform)
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (prefix[mid] <= g) lo = mid; else hi = mid - 1;
-    }
+    const int lo = find_entry(prefix, spre, cached, n, g);
     const crdr_pack_item it = items[lo];
-    const int tl = (int)(g - prefix[lo]);
+    const int tl = (int)(g - (cached ? (long long)spre[lo] : prefix[lo]));
     const int ctiles = it.cols >> 5;
     const int r0 = (tl / ctiles) * 8, c0 = (tl % ctiles) * 32;
     const int T = it.T;
