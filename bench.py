@@ -105,6 +105,45 @@ def cpu_baseline(stage: int, size: int, budget_s: float = 25.0, hard_timeout_s: 
                 "sample": f"one stage-{stage} oracle step at N=1 did not finish within {hard_timeout_s:.0f} s on {threads} threads"}
 
 
+def launcher_argv(n: int, argv, port: int):
+    """The command `python bench.py --gpus N` runs when no launcher set WORLD_SIZE: the driver's own torchrun line."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n: int, argv) -> int:
+    """Start N ranks (one per GPU, RCCL over xGMI) as a child `torch.distributed.run` and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:   # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    r = subprocess.run(launcher_argv(n, argv, port), env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is None:
+        sys.stdout.write(r.stdout)
+        return r.returncode or 1
+    print(line, flush=True)
+    return r.returncode
+
+
+def rccl_check(local: int):
+    """What the collective backend actually is: observed world size + an all-reduce of ones over the ranks."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": 1, "allreduce_of_ones": None}
+    t = torch.ones(1, device=f"cuda:{local}")
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_of_ones": float(t.item())}
+
+
 def _newest_profile(pattern: str):
     import glob
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
@@ -276,14 +315,22 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=5, help="eager steps after the timed region used for the per-kernel roofline")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent has not imported torch
+        # or touched the GPU; the ranks run as a CHILD process tree (never exec from a GPU-initialised process).
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
     from crdr_amd.hip import ops
     from crdr_amd.trainer import dist as D
     local = D.init_from_env()
     ws, rk = D.world_size(), D.rank()
-    assert ws == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+    if ws != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={ws} (launch with torch.distributed.run --nproc-per-node {a.gpus}, "
+                         f"or run `python bench.py --gpus {a.gpus}` without WORLD_SIZE set and let it start the ranks)")
     torch.cuda.set_device(local)
+    rccl = rccl_check(local)
     ops.AUTOTUNE = not a.no_autotune  # the reference runs with cudnn.benchmark = True (base_trainer.py:20)
     if ops.AUTOTUNE and a.tune_db != "none":
         ops.load_tune_cache(a.tune_db or ops.DEFAULT_TUNE_DB)
@@ -326,7 +373,7 @@ def main():
     line = {"metric": f"stage-{a.stage} training img/s at {a.size}x{a.size}", "value": round(value, 3), "unit": "img/s",
             "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(main_run["ms_per_step"], 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "autotune": bool(ops.AUTOTUNE), "hip_graphs": main_run["graphs"],
+            "autotune": bool(ops.AUTOTUNE), "hip_graphs": main_run["graphs"], "rccl_ranks": rccl,
             "peak_device_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             "config": {"workload": f"config/crdr_stage_{a.stage}.yaml -b {a.bs}: full GAN step (G + 5x CLIC21GVAE D + LPIPS-Alex, random-init weights), "
                                    f"rate index cycled 0..4" if a.stage == 3 else f"config/crdr_stage_1.yaml -b {a.bs}: R-D step (+LPIPS-Alex, random-init weights)",

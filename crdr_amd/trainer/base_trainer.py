@@ -103,12 +103,27 @@ class BaseTrainer:
 
     # ---- main loop
     def train_data_generator(self, dataloader, start_itr: int, end_itr: int):
-        it = iter(dataloader)
+        """Endless batches.  Every pass over the loader is a new epoch: a DistributedSampler only reshuffles (and re-deals the
+        shards) when told the epoch, which the reference's shuffle=True DataLoader does by itself (base_trainer.py:74-80); a
+        resumed run continues the epoch sequence from start_itr."""
+        try:
+            per_epoch = max(1, len(dataloader))
+        except TypeError:
+            per_epoch = 1 << 62
+        epoch = start_itr // per_epoch
+
+        def fresh():
+            sampler = getattr(dataloader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)
+            return iter(dataloader)
+        it = fresh()
         for i in range(start_itr, end_itr):
             try:
                 data = next(it)
             except StopIteration:
-                it = iter(dataloader)
+                epoch += 1
+                it = fresh()
                 data = next(it)
             yield i + 1, data
 
