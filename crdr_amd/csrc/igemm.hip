@@ -910,6 +910,9 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   for (int g = 0; g < G; ++g) {
     const crdr_conv_io& q = ios[g];
     CRDR_REQUIRE(q.x && q.w && q.y, "conv2d: null tensor (problem %d)", g);
+    // both kernels stage x and w with 16-byte LDS-DMA: a view at a channel offset that is not a multiple of 4 floats
+    // would be mis-addressed, not slow
+    CRDR_REQUIRE(al16(q.x) && al16(q.w), "conv2d: x and w must be 16-byte aligned (problem %d)", g);
     CRDR_REQUIRE(!(a.flags & CRDR_EPI_BIAS) || q.bias, "conv2d: BIAS flag without bias (problem %d)", g);
     CRDR_REQUIRE(!(a.flags & CRDR_EPI_PREADD) || q.pre, "conv2d: PREADD flag without pre (problem %d)", g);
     CRDR_REQUIRE(!(a.flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) || q.mask, "conv2d: mask flag without mask (problem %d)", g);
@@ -924,7 +927,9 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   }
   a.vec_epi = v ? 1 : 0;
   // 32-bit byte offsets of the fast epilogue span one tile of output pixels (<= 256 rows, a few image rows when transposed)
-  const long long span = (256 + 4ll * a.OW * a.so) * std::max(std::max(a.ldy, a.ldres), a.ldmask) * 4;
+  // a tile of BM <= 256 GEMM rows covers at most BM / GW + 2 grid rows, each of them `so` output rows of OW pixels
+  const long long span_px = (256 / std::max(a.GW, 1) + 2) * (long long)std::max(a.so, 1) * a.OW + a.OW;
+  const long long span = span_px * std::max(std::max(a.ldy, a.ldres), a.ldmask) * 4;
   a.fast_epi = (v && a.Cout % 4 == 0 && a.nsplit == 1 && span < (1ll << 31) &&
                 !(a.flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM))) ? 1 : 0;
   if (pl.stream >= 0 && !a.vec_epi && d->reserved == 0) {

@@ -296,9 +296,13 @@ class _ChainFn(torch.autograd.Function):
             dx = dx_out[0]
             for g in range(1, len(dx_out)):
                 dx = dx + dx_out[g]
-        # (the beta-vector gradients are views of the chain's persistent buffer: consumed by the projections' backward in
-        # this same backward pass, rewritten by the next one)
-        return (dx, None, dscale, dshift, None) + tuple(dvs[i] if ctx.needs_input_grad[5 + i] else None for i in range(len(vecs))) \
+        # the beta-vector gradients live in the chain's persistent buffer, which the next backward of this spec zeroes.  Under
+        # graph capture the fixed address is the point (the projections' backward consumes them inside the same captured
+        # pass); eagerly autograd gets copies, so a second backward of the same chain (retain_graph, the chain used twice in
+        # one graph) cannot clobber gradients the engine still holds
+        keep = torch.cuda.is_current_stream_capturing()
+        return (dx, None, dscale, dshift, None) + tuple((dvs[i] if keep else dvs[i].clone()) if ctx.needs_input_grad[5 + i] else None
+                                                        for i in range(len(vecs))) \
             + (None,) * (ctx.nrest - len(vecs))
 
 

@@ -69,14 +69,31 @@ class Minnen20CharmContextModel(BaseContextModel):
     def _philox(self, device) -> Tensor:
         st = getattr(self, "_philox_state", None)
         if st is None or st.device != device:
-            seed = int(getattr(self, "_noise_seed", torch.initial_seed() & 0x7FFFFFFFFFFFFFFF))
-            st = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+            seed = getattr(self, "_noise_seed", None)
+            if seed is None:   # never seeded by a trainer: still one stream per rank
+                from crdr_amd.trainer import dist as _D
+                seed = (torch.initial_seed() + 7919 * (_D.rank() + 1)) & 0x7FFFFFFFFFFFFFFF
+            st = torch.tensor([int(seed), int(getattr(self, "_noise_offset", 0))], dtype=torch.int64, device=device)
             self._philox_state = st
         return st
 
-    def seed_noise(self, seed: int) -> None:
+    def seed_noise(self, seed: int, offset: int = 0) -> None:
         self._noise_seed = int(seed) & 0x7FFFFFFFFFFFFFFF
+        self._noise_offset = int(offset)
         self._philox_state = None
+
+    def noise_state(self) -> Dict:
+        """(seed, offset) of the in-kernel noise generator, for the trainer's checkpoint: a resumed run continues the
+        sequence instead of replaying it from offset 0.  Synchronises."""
+        st = getattr(self, "_philox_state", None)
+        if st is None:
+            return {"seed": getattr(self, "_noise_seed", None), "offset": int(getattr(self, "_noise_offset", 0))}
+        seed, off = st.tolist()
+        return {"seed": int(seed), "offset": int(off)}
+
+    def load_noise_state(self, state: Dict) -> None:
+        if state and state.get("seed") is not None:
+            self.seed_noise(state["seed"], state.get("offset", 0))
 
     def _record(self, run) -> None:
         """parity tests read the rounding decisions (round(y_hat_pre - mu) per slice)"""
@@ -99,7 +116,9 @@ class Minnen20CharmContextModel(BaseContextModel):
     def forward(self, y: Tensor, hyper_out: Tensor, entropy_model_y, is_train: bool, calc_q_likelihood: bool = True,
                 noise: Tensor = None, want_lik: bool = True, bits_out: Dict = None):
         """-> (y_hat, y_likelihood, y_q_likelihood) like the reference (:88-141); the per-image bit sums produced by the
-        fused kernels are returned through `bits_out["y"], bits_out["y_q"]` when a dict is passed.  The whole slice loop runs
+        fused kernels are returned through `bits_out["y"], bits_out["y_q"]` when a dict is passed -- and ONLY those carry the
+        rate gradient: the likelihood tensors are outputs of the fused node marked non-differentiable (a rate loss must be
+        built from the bit sums, as models/comp_model does; -log2 of the returned likelihoods would train nothing).  The whole slice loop runs
         in crdr_amd.hip.charm (hoisted hyper-prior convs, grouped launches, hand-written backward)."""
         from crdr_amd.hip import charm
         yh, bn, bq, lik_n, lik_q, mu, sigma = charm.charm_forward(

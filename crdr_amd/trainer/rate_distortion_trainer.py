@@ -17,6 +17,16 @@ from .base_trainer import BaseTrainer
 from .optimizer import build_optimizer, build_scheduler
 
 
+class _NoiseState:
+    """Checkpoint adapter (Saver.save calls .state_dict()) for the context model's device-resident Philox state."""
+
+    def __init__(self, cm):
+        self.cm = cm
+
+    def state_dict(self) -> Dict:
+        return self.cm.noise_state()
+
+
 @TRAINER_REGISTRY.register()
 class RateDistortionTrainer(BaseTrainer):
     def _set_losses(self):
@@ -135,6 +145,9 @@ class RateDistortionTrainer(BaseTrainer):
             st["aux_optimizer"] = self.aux_optimizer
         if self.g_scheduler:
             st["g_scheduler"] = self.g_scheduler
+        cm = getattr(self.comp_model, "context_model", None)
+        if cm is not None and hasattr(cm, "noise_state"):   # in-kernel Philox (seed, offset): a resumed run continues it
+            st["noise_state"] = _NoiseState(cm)
         return st
 
     def save(self, current_iter: int):
@@ -159,3 +172,9 @@ class RateDistortionTrainer(BaseTrainer):
             self.g_scheduler.load_state_dict(st["g_scheduler"])
         if self.aux_optimizer:
             self.aux_optimizer.load_state_dict(st["aux_optimizer"])
+        cm = getattr(self.comp_model, "context_model", None)
+        if st.get("noise_state") and cm is not None and hasattr(cm, "load_noise_state"):
+            ns = dict(st["noise_state"])   # written by rank 0; every rank keeps a stream of its own
+            if ns.get("seed") is not None:
+                ns["seed"] = (int(ns["seed"]) + 7919 * D.rank()) & 0x7FFFFFFFFFFFFFFF
+            cm.load_noise_state(ns)
