@@ -42,6 +42,20 @@ class HyperpriorCharmModel(BaseModel):
     def _extra_outputs(self, **cond) -> Dict:
         return {}
 
+    # ---- staged backward (data-parallel training): with `backward_cuts` set to a dict, a training forward detaches the graph
+    # at the Charm's inputs and output -- name -> (tensor upstream of the cut, leaf downstream of it; same storage) -- so the
+    # trainer can run the backward in three pieces in gradient order (synthesis transform | context model | hyper-prior +
+    # analysis transform) and start the all-reduce of each piece's gradients while the next piece computes
+    backward_cuts: Optional[Dict[str, Tuple[Tensor, Tensor]]] = None
+
+    def _cut(self, name: str, t: Tensor, is_train: bool) -> Tensor:
+        cuts = self.backward_cuts
+        if cuts is None or not is_train or not torch.is_grad_enabled() or not t.requires_grad:
+            return t
+        leaf = t.detach().requires_grad_(True)
+        cuts[name] = (t, leaf)
+        return leaf
+
     # ---- training / evaluation forward
     def run_model(self, real_images, is_train: bool = True, noise: Optional[Dict[str, Tensor]] = None, **cond):
         N, _, H, W = real_images.size()
@@ -73,7 +87,7 @@ class HyperpriorCharmModel(BaseModel):
         The bit sums come straight out of the fused entropy kernels."""
         b = out_dict["bits"]
         return dict(y_likelihood=out_dict["likelihoods"]["y"], z_likelihood=out_dict["likelihoods"]["z"],
-                    bpp=(b["y"] + b["z"]) / num_pixel,
+                    bpp=(b["y"] + b["z"]) / num_pixel, bits_y=b["y"], bits_z=b["z"], num_pixel=num_pixel,
                     y_q_likelihood=out_dict["q_likelihoods"]["y"], z_q_likelihood=out_dict["q_likelihoods"]["z"],
                     qbpp=(b["y_q"] + b["z_q"]).detach() / num_pixel)
 
@@ -90,10 +104,11 @@ class HyperpriorCharmModel(BaseModel):
         hyper_out = self.hyperdecoder(z_hat)
         want_lik = self.return_likelihoods or not is_train
         yb: Dict = {}
-        y_hat, y_lik, y_qlik = self.context_model(y, hyper_out, self.entropy_model_y, is_train=is_train,
+        y_in, hyper_in = self._cut("y", y, is_train), self._cut("hyper_out", hyper_out, is_train)
+        y_hat, y_lik, y_qlik = self.context_model(y_in, hyper_in, self.entropy_model_y, is_train=is_train,
                                                   calc_q_likelihood=True, noise=noise.get("y"), want_lik=want_lik, bits_out=yb)
         y_bits, y_qbits = yb["y"], yb["y_q"]
-        fake = self._decode(y_hat, **cond)
+        fake = self._decode(self._cut("y_hat", y_hat, is_train), **cond)
         if not is_train:
             fake = torch.clamp(fake, min=-1.0, max=1.0)
         with torch.no_grad():

@@ -54,7 +54,7 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         return {"rate_ind": q, "beta": beta}, ("s3", q)
 
     # ------------------------------------------------------------------ G phase: forward, losses, backward
-    def _seg_generator(self, real, cond: Dict, noise, current_iter: int) -> Dict:
+    def _g_forward(self, real, cond: Dict, noise, current_iter: int) -> Dict:
         q, beta_t = cond["rate_ind"], self._beta_t
         self.discriminator.requires_grad_(False)
         self.g_optimizer.zero_grad()
@@ -74,7 +74,6 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
             hr["rate_ind"] = float(q + self.relative_score_rate_delta)
             relative = self.comp_model.reconstruct(**hr)["fake_images"]
         dist_loss = self.distortion_loss(real_p, fake, **other)
-        rate_loss = self.rate_loss(bpp, **other, **self._rate_kwargs(other), current_iter=current_iter)
         assert self.perceptual_loss
         percep = self.perceptual_loss(real_p, fake)
         with torch.no_grad():
@@ -82,11 +81,18 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         fake_g = self.discriminator(fake, **other)
         adv = (self.gan_loss.forward_diff(real_d, fake_g, is_real=False, is_disc=False)
                + self.gan_loss.forward_diff(fake_g, real_d, is_real=True, is_disc=False)) / 2
-        l_total = dist_loss + rate_loss + beta_t * (percep + adv)
+        return {"bpp": bpp, "other": other, "terms": {"distortion": dist_loss, "perceptual": percep, "adv": adv},
+                "nonrate": dist_loss + beta_t * (percep + adv), "extra": {"real": real_p, "fake": fake.detach(), "q": q}}
+
+    def _seg_generator(self, real, cond: Dict, noise, current_iter: int) -> Dict:
+        f = self._g_forward(real, cond, noise, current_iter)
+        other, t = f["other"], f["terms"]
+        rate_loss = self.rate_loss(f["bpp"], **other, **self._rate_kwargs(other), current_iter=current_iter)
+        l_total = t["distortion"] + rate_loss + self._beta_t * (t["perceptual"] + t["adv"])
         l_total.backward()
         self._flush_wgrads("g")
-        return {"losses": {"distortion": dist_loss, "rate": rate_loss, "perceptual": percep, "adv": adv},
-                "bad": self._bad_flag(l_total), "qbpp": other.get("qbpp", None), "real": real_p, "fake": fake.detach(), "q": q}
+        return {"losses": {"distortion": t["distortion"], "rate": rate_loss, "perceptual": t["perceptual"], "adv": t["adv"]},
+                "bad": self._bad_flag(l_total), "qbpp": other.get("qbpp", None), **f["extra"]}
 
     # ------------------------------------------------------------------ D forward + backward (needs only x and x̂)
     def _seg_dfwdbwd(self, ctx: Dict) -> Dict:
@@ -128,11 +134,15 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         run = self._runner(key, allow_graph=not scheduled)  # explicit noise tensors must be persistent device buffers
         self.g_optimizer.sync_lr_to_device()
         self.d_optimizer.sync_lr_to_device()
-        ctx = run("g", lambda: self._seg_generator(real, cond, noise, current_iter))
-        g_sync = D.AsyncGradSync(self.g_optimizer.flat_grads(), [ctx["bad"]])       # overlaps the D forward/backward
+        if self._staged():   # three gradient buckets in backward order, each all-reduce behind the next piece / the D segment
+            ctx, g_syncs = self._run_generator_staged(run, real, cond, noise, current_iter)
+        else:
+            ctx = run("g", lambda: self._seg_generator(real, cond, noise, current_iter))
+            g_syncs = [D.AsyncGradSync(self.g_optimizer.flat_grads(), [ctx["bad"]])]       # overlaps the D forward/backward
         ctx_d = run("dfb", lambda: self._seg_dfwdbwd(ctx))
         d_sync = D.AsyncGradSync(self.d_optimizer.flat_grads(partitions=self._d_parts(ctx["q"])))  # overlaps the G update
-        g_sync.wait()
+        for sy in g_syncs:
+            sy.wait()
         ctx2 = run("u", lambda: self._seg_update(ctx))
         d_sync.wait()
         run("d", lambda: self._seg_dstep(ctx))

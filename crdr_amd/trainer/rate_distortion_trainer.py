@@ -73,7 +73,8 @@ class RateDistortionTrainer(BaseTrainer):
         return aux
 
     # ---- segments (each is captured as one HIP graph per condition key)
-    def _seg_generator(self, real, cond: Dict, noise, current_iter: int) -> Dict:
+    def _g_forward(self, real, cond: Dict, noise, current_iter: int) -> Dict:
+        """Generator forward + every loss term except the rate loss (which needs the -- possibly global -- mean qbpp)."""
         self.g_optimizer.zero_grad()
         if self.aux_optimizer:
             self.aux_optimizer.zero_grad()
@@ -81,14 +82,98 @@ class RateDistortionTrainer(BaseTrainer):
         if noise is not None:
             data["noise"] = noise
         real_p, fake, bpp, other = self.run_comp_model(data)
-        g = {"distortion": self.distortion_loss(real_p, fake, **other),
-             "rate": self.rate_loss(bpp, **other, **self._rate_kwargs(other), current_iter=current_iter)}
+        terms = {"distortion": self.distortion_loss(real_p, fake, **other)}
         if self.perceptual_loss:
-            g["perceptual"] = self.perceptual_loss(real_p, fake)
-        l_total = sum(g.values())
+            terms["perceptual"] = self.perceptual_loss(real_p, fake)
+        return {"bpp": bpp, "other": other, "terms": terms, "nonrate": sum(terms.values()), "extra": {}}
+
+    def _seg_generator(self, real, cond: Dict, noise, current_iter: int) -> Dict:
+        f = self._g_forward(real, cond, noise, current_iter)
+        other = f["other"]
+        rate = self.rate_loss(f["bpp"], **other, **self._rate_kwargs(other), current_iter=current_iter)
+        l_total = f["nonrate"] + rate
         l_total.backward()
         self._flush_wgrads("g")
-        return {"losses": g, "bad": self._bad_flag(l_total), "qbpp": other.get("qbpp", None)}
+        return {"losses": {**f["terms"], "rate": rate}, "bad": self._bad_flag(l_total), "qbpp": other.get("qbpp", None), **f["extra"]}
+
+    # ---- staged generator step (data parallel): forward | all-reduce of mean qbpp | backward in three pieces, each followed by
+    # the asynchronous all-reduce of the gradients it completed.  Same arithmetic as _seg_generator: the pieces are disjoint
+    # sub-graphs of one backward pass (comp_model.backward_cuts), the rate loss is linear in the two bit sums.
+    PIECES = ("decoder", "context_model", None)   # gradient order; None = everything else (hyper-prior, analysis transform)
+
+    def _staged(self) -> bool:
+        return D.is_dist() and bool(self.opt.get("dp_buckets", True)) and hasattr(self.comp_model, "backward_cuts") \
+            and hasattr(self.comp_model, "context_model")
+
+    def _piece_buffers(self):
+        """Flat-gradient slices of each backward piece (parameters are laid out sorted by name, so a piece is one or two
+        contiguous runs): [[tensor, ...] per piece]."""
+        if getattr(self, "_pieces", None) is None:
+            names = {id(p): n for n, p in self.comp_model.named_parameters()}
+            pieces = [[] for _ in self.PIECES]
+            for g in self.g_optimizer.param_groups:
+                if g["grad"] is None:
+                    continue
+                off, runs = 0, []
+                for p in g["params"]:
+                    top = names[id(p)].split(".", 1)[0]
+                    k = self.PIECES.index(top) if top in self.PIECES else len(self.PIECES) - 1
+                    if runs and runs[-1][0] == k and runs[-1][2] == off:
+                        runs[-1][2] = off + p.numel()
+                    else:
+                        runs.append([k, off, off + p.numel()])
+                    off += p.numel()
+                for k, lo, hi in runs:
+                    pieces[k].append(g["grad"][lo:hi])
+            self._pieces = pieces
+        return self._pieces
+
+    def _seg_gfwd(self, real, cond: Dict, noise, current_iter: int) -> Dict:
+        self.comp_model.backward_cuts = {}
+        try:
+            f = self._g_forward(real, cond, noise, current_iter)
+            f["cuts"] = self.comp_model.backward_cuts
+        finally:
+            self.comp_model.backward_cuts = None
+        assert set(f["cuts"]) == {"y", "hyper_out", "y_hat"}, f"staged backward: cuts {sorted(f['cuts'])}"
+        q = f["other"].get("qbpp", None)
+        f["qbpp_mean"] = q.detach().mean().reshape(1) if q is not None else None   # all-reduced between the segments
+        return f
+
+    def _seg_gbwd(self, f: Dict, piece: int, current_iter: int) -> Dict:
+        other, cuts = f["other"], f["cuts"]
+        if piece == 0:
+            kw = {} if f["qbpp_mean"] is None else {"qbpp_mean": f["qbpp_mean"].reshape(())}
+            npix = other["num_pixel"]
+            rest = {k: v for k, v in other.items() if k != "qbpp_mean"}
+            f["rate"] = self.rate_loss(f["bpp"], **rest, **kw, current_iter=current_iter).detach()
+            # d rate / d bits is the same constant for both sums: one root per piece
+            f["rate_y"] = self.rate_loss(other["bits_y"] / npix, **rest, **kw, current_iter=current_iter)
+            f["rate_z"] = self.rate_loss(other["bits_z"] / npix, **rest, **kw, current_iter=current_iter)
+            l_total = f["nonrate"].detach() + f["rate"]
+            f["nonrate"].backward()
+            self._flush_wgrads("g0")
+            return {"losses": {**f["terms"], "rate": f["rate"]}, "bad": self._bad_flag(l_total), "qbpp": other.get("qbpp", None), **f["extra"]}
+        if piece == 1:
+            torch.autograd.backward([cuts["y_hat"][0], f["rate_y"]], [cuts["y_hat"][1].grad, None])
+            self._flush_wgrads("g1")
+        else:
+            torch.autograd.backward([cuts["y"][0], cuts["hyper_out"][0], f["rate_z"]], [cuts["y"][1].grad, cuts["hyper_out"][1].grad, None])
+            self._flush_wgrads("g2")
+        return {}
+
+    def _run_generator_staged(self, run, real, cond: Dict, noise, current_iter: int):
+        """-> (ctx like _seg_generator's, [AsyncGradSync per piece]); the caller waits for the syncs before the update."""
+        f = run("gf", lambda: self._seg_gfwd(real, cond, noise, current_iter))
+        if f["qbpp_mean"] is not None:   # lambda_A / lambda_B switch on the GLOBAL mean (rate_loss.py:172-175 at global batch)
+            D.all_reduce_mean_([f["qbpp_mean"]])
+        bufs = self._piece_buffers()
+        ctx, syncs = None, []
+        for k in range(len(self.PIECES)):
+            out = run(f"gb{k}", lambda k=k: self._seg_gbwd(f, k, current_iter))
+            ctx = out if k == 0 else ctx
+            syncs.append(D.AsyncGradSync(bufs[k], [ctx["bad"]] if k == len(self.PIECES) - 1 else None))
+        return ctx, syncs
 
     def _seg_update(self, ctx: Dict) -> Dict:
         self._generator_update(ctx["bad"])
@@ -124,8 +209,13 @@ class RateDistortionTrainer(BaseTrainer):
         scheduled = bool(getattr(self.rate_loss, "lambda_schedule", None) or getattr(self.rate_loss, "target_rate_schedule", None))
         run = self._runner(key, allow_graph=not scheduled)  # explicit noise tensors must be persistent device buffers
         self.g_optimizer.sync_lr_to_device()
-        ctx = run("g", lambda: self._seg_generator(real, cond, noise, current_iter))
-        self._sync_between_segments(ctx, self.g_optimizer)
+        if self._staged():
+            ctx, syncs = self._run_generator_staged(run, real, cond, noise, current_iter)
+            for sy in syncs:
+                sy.wait()
+        else:
+            ctx = run("g", lambda: self._seg_generator(real, cond, noise, current_iter))
+            self._sync_between_segments(ctx, self.g_optimizer)
         ctx2 = run("u", lambda: self._seg_update(ctx))
         log = {"qbpp": ctx["qbpp"] if ctx["qbpp"] is not None else -1, **ctx["losses"], **ctx2, "_bad": ctx["bad"]}
         return self._finish_step(current_iter, log)

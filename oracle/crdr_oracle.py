@@ -760,3 +760,189 @@ class RansDecoder:
                 v = -v - 1 if raw & 1 else v + mv
             out.append(v + int(offsets[ci]))
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# end-to-end codec: compress / decompress of the multi-rate Charm model, on the tables and the Python coder above
+# (interpca_hyperprior_charm_model.py:83-149, beta_cond_interpca_hyperprior_charm_model.py:85-149,
+#  minnen20_charm_context_model.py:143-240, hyperprior_model.py:120-136, codec_utils.py:22-125, base_model.py:35-58,146-167)
+# ------------------------------------------------------------------------------------------------------------
+MODEL_STRIDE = 64   # base_model.py:30; = 2**4 (encoder) * 2**2 (hyper-encoder), hyperprior_model.py:131-136
+
+# Relative window around a scale-table entry inside which another correct fp32 implementation may pick the neighbouring
+# CDF index: sigma comes out of ~10 stacked fp32 convs (relative noise ~1e-6 each), and build_indexes compares it with
+# the 64 table entries -- a discontinuity exactly like rounding.
+INDEX_TOL = 1e-4
+
+
+def forced_indexes(sigma, forced=None, report=None, scale_table=None):
+    """build_indexes(sigma); where sigma (after the 0.11 bound) sits within INDEX_TOL (relative) of a table entry the index
+    chosen by another implementation (`forced`) is adopted, everywhere else the two must agree exactly
+    (`report["idx_mismatch"]`, `report["idx_adopted"]`)."""
+    st = get_scale_table() if scale_table is None else scale_table
+    idx = build_indexes(sigma, st)
+    if forced is None:
+        return idx
+    forced = forced.to(idx.dtype).reshape(idx.shape)
+    s = torch.clamp(sigma, min=SCALE_BOUND).double()
+    d = (torch.log(s).unsqueeze(-1) - torch.log(st.double())).abs().amin(-1)
+    near = d < INDEX_TOL
+    if report is not None:
+        report["idx_mismatch"] = report.get("idx_mismatch", 0) + int(((idx != forced) & ~near).sum())
+        report["idx_adopted"] = report.get("idx_adopted", 0) + int(((idx != forced) & near).sum())
+        report["indexes"] = report.get("indexes", 0) + int(idx.numel())
+    return torch.where(near & ((idx - forced).abs() <= 1), forced, idx)
+
+
+def check_forced_indexes(report) -> None:
+    assert report.get("idx_mismatch", 0) == 0, report
+    assert report.get("idx_adopted", 0) <= max(2, int(1e-3 * report.get("indexes", 0))), report
+
+
+def header_bytes(size: Tuple[int, int], y_hat, rate_ind: Optional[float] = None) -> bytes:
+    """HeaderHandler.encode / MultiRateHeaderHandler.encode (codec_utils.py:22-39, 82-106): u16 H, u16 W, u8 floor(max|y_hat|)
+    [, u8 int(16 q)], little endian."""
+    h, w = size
+    assert isinstance(h, int) and isinstance(w, int)
+    out = np.array([h, w], dtype=np.uint16).tobytes() + np.array(int(torch.max(torch.abs(y_hat))), dtype=np.uint8).tobytes()
+    if rate_ind is not None:
+        out += np.array(int(float(rate_ind) * 16), dtype=np.uint8).tobytes()
+    return out
+
+
+def header_parse(b: bytes, multirate: bool = True) -> Dict:
+    """{Multi,}RateHeaderHandler.decode (codec_utils.py:41-58, 108-125)."""
+    hw = np.frombuffer(b[:4], dtype=np.uint16)
+    out = {"img_size": (int(hw[0]), int(hw[1])), "max_sample": int(np.frombuffer(b[4:5], dtype=np.uint8)[0])}
+    if multirate:
+        out["rate_ind"] = float(np.frombuffer(b[5:6], dtype=np.uint8)[0]) / 16
+    return out
+
+
+def pad_image(x, stride: int = MODEL_STRIDE):
+    """BaseModel._pad_image (base_model.py:146-152): reflect, bottom / right only."""
+    _, _, H, W = x.shape
+    pw, ph = int(np.ceil(W / stride) * stride - W), int(np.ceil(H / stride) * stride - H)
+    return x if (ph == 0 and pw == 0) else F.pad(x, (0, pw, 0, ph), mode="reflect")
+
+
+def codec_tables(sd: SD) -> Dict:
+    """HyperpriorModel.codec_setup (hyperprior_model.py:120-124): entropy_model_z.update(force=True) and
+    entropy_model_y.update_scale_table(get_scale_table(), force=True), as lists the coder indexes."""
+    zt, zl, zo = eb_cdf_tables(sd, "entropy_model_z")
+    yt, yl, yo = gaussian_cdf_tables()
+    return {"z": (zt.tolist(), zl.tolist(), zo.tolist()), "y": (yt.tolist(), yl.tolist(), yo.tolist())}
+
+
+def compress(sd: SD, x, q: Optional[float], tables: Optional[Dict] = None, forced: Optional[Dict] = None, report: Optional[Dict] = None) -> Dict:
+    """{InterpCa,BetaCondInterpCa}HyperpriorCharmModel.compress (interpca_hyperprior_charm_model.py:83-117): one image
+    [1,3,H,W] in [-1,1] -> [header, z string, y string] + y_hat, z_hat, likelihoods, predicted bits.
+    forced = {"z": int symbols [1,192,h,w], "y": int symbols [1,320,h,w], "idx": CDF indexes [1,320,h,w]} of another
+    implementation, adopted only inside FORCE_TOL / INDEX_TOL (see forced_round / forced_indexes)."""
+    n, _, H, W = x.shape
+    assert n == 1
+    report = {} if report is None else report
+    tables = codec_tables(sd) if tables is None else tables
+    with torch.no_grad():
+        xp = pad_image(x)
+        y = encoder(sd, xp, q)
+        z = hyper_encoder(sd, y)
+        med = sd["entropy_model_z.quantiles"].detach()[:, 0, 1].reshape(1, -1, 1, 1)
+        fz = None if forced is None else forced["z"].to(torch.float32).reshape(z.shape)
+        # EntropyBottleneck.compress: symbols = round(z - medians), index = channel (entropy_bottleneck.py:28, compressai)
+        z_sym = forced_round(z - med, fz, report)
+        z_hat = z_sym + med
+        z_lik = eb_likelihood(sd, "entropy_model_z", z_hat)
+        zc = z.shape[1]
+        z_idx = torch.arange(zc).reshape(1, zc, 1, 1).expand_as(z_sym)
+        z_str = rans_encode(z_sym.reshape(-1).int().tolist(), z_idx.reshape(-1).tolist(), *tables["z"])
+        hyper = hyper_decoder(sd, z_hat)
+        # forward_compress (minnen20_charm_context_model.py:143-189): the slice loop with is_train False, then ONE stream over
+        # the whole latent in NCHW order with indexes from the concatenated scales and means from the concatenated mus
+        ys = torch.chunk(y, 10, 1)
+        h_mu, h_sc = torch.chunk(hyper, 2, 1)
+        fy = None if forced is None else torch.chunk(forced["y"].to(torch.float32).reshape(y.shape), 10, 1)
+        hats, liks, mus, sgs, syms = [], [], [], [], []
+        for i, ysl in enumerate(ys):
+            sup = hats[:5]
+            ms, ss = torch.cat([h_mu] + sup, 1), torch.cat([h_sc] + sup, 1)
+            mu = slice_transform(sd, f"context_model.mean_slice_transforms.{i}", ms)
+            sg = slice_transform(sd, f"context_model.scale_slice_transforms.{i}", ss)
+            s = forced_round(ysl - mu, None if fy is None else fy[i], report)
+            yh = s + mu
+            liks.append(gaussian_likelihood(yh, mu, sg))
+            lrp = slice_transform(sd, f"context_model.lrp_slice_transforms.{i}", torch.cat([ms, yh], 1))
+            hats.append(yh + 0.5 * torch.tanh(lrp))
+            mus.append(mu); sgs.append(sg); syms.append(s)
+        y_hat, y_lik, sigma, y_sym = torch.cat(hats, 1), torch.cat(liks, 1), torch.cat(sgs, 1), torch.cat(syms, 1)
+        idx = forced_indexes(sigma, None if forced is None else forced["idx"], report)
+        y_str = rans_encode(y_sym.reshape(-1).int().tolist(), idx.reshape(-1).tolist(), *tables["y"])
+        header = header_bytes((H, W), y_hat, q)
+        y_bit, z_bit = float(bits_per_image(y_lik)), float(bits_per_image(z_lik))
+    return {"string_list": [header, z_str, y_str], "y_hat": y_hat, "z_hat": z_hat, "y_likelihood": y_lik, "z_likelihood": z_lik,
+            "pred_y_bit": y_bit, "pred_y_bpp": y_bit / (H * W), "pred_z_bit": z_bit, "pred_z_bpp": z_bit / (H * W),
+            "y_symbols": y_sym.int(), "z_symbols": z_sym.int(), "indexes": idx, "report": report}
+
+
+def ideal_code_length_bits(symbols, indexes, tables, bypass: int = 4) -> float:
+    """sum of -log2(freq / 2^16) over the coded symbols of one stream (+ the escape nibbles of out-of-table symbols): what an
+    ideal arithmetic coder spends on these tables; rANS ends within the 64-bit state flush of it."""
+    cdfs, sizes, offs = tables
+    total = 0.0
+    for s, ci in zip(symbols, indexes):
+        cdf, mv = cdfs[ci], int(sizes[ci]) - 2
+        v = int(s) - int(offs[ci])
+        raw = 0
+        if v < 0:
+            raw, v = -2 * v - 1, mv
+        elif v >= mv:
+            raw, v = 2 * (v - mv), mv
+        total += 16.0 - math.log2(cdf[v + 1] - cdf[v])
+        if v == mv:
+            nb = 0
+            while (raw >> (nb * bypass)) != 0:
+                nb += 1
+            total += bypass * (nb // ((1 << bypass) - 1) + 1 + nb)
+    return total
+
+
+def decompress(sd: SD, strings: Sequence[bytes], beta: Optional[float] = 0.0, tables: Optional[Dict] = None, forced: Optional[Dict] = None,
+               report: Optional[Dict] = None, multirate: bool = True) -> Dict:
+    """{InterpCa,BetaCondInterpCa}HyperpriorCharmModel.decompress (interpca_hyperprior_charm_model.py:119-149) with
+    forward_decompress (minnen20_charm_context_model.py:192-240): header -> z symbols -> hyper-decoder -> per slice
+    {mu, sigma -> indexes -> decode -> dequantise -> LRP} -> synthesis -> crop + clamp.
+    forced = {"idx": CDF indexes [1,320,h,w]} of another implementation (INDEX_TOL window only)."""
+    assert len(strings) == 3
+    report = {} if report is None else report
+    tables = codec_tables(sd) if tables is None else tables
+    hd = header_parse(strings[0], multirate)
+    H, W = hd["img_size"]
+    q = hd.get("rate_ind")
+    zH, zW = int(np.ceil(H / MODEL_STRIDE)), int(np.ceil(W / MODEL_STRIDE))
+    with torch.no_grad():
+        med = sd["entropy_model_z.quantiles"].detach()[:, 0, 1].reshape(1, -1, 1, 1)
+        zc = med.shape[1]
+        z_idx = torch.arange(zc).reshape(1, zc, 1, 1).expand(1, zc, zH, zW)
+        z_sym = torch.tensor(RansDecoder(strings[1]).decode(z_idx.reshape(-1).tolist(), *tables["z"]), dtype=torch.float32).reshape(1, zc, zH, zW)
+        z_hat = z_sym + med   # EntropyBottleneck.dequantize adds the medians back
+        hyper = hyper_decoder(sd, z_hat)
+        h_mu, h_sc = torch.chunk(hyper, 2, 1)
+        dec = RansDecoder(strings[2])
+        fi = None if forced is None else torch.chunk(forced["idx"].reshape(1, 320, 4 * zH, 4 * zW), 10, 1)
+        hats, syms = [], []
+        for i in range(10):
+            sup = hats[:5]
+            ms, ss = torch.cat([h_mu] + sup, 1), torch.cat([h_sc] + sup, 1)
+            mu = slice_transform(sd, f"context_model.mean_slice_transforms.{i}", ms)
+            sg = slice_transform(sd, f"context_model.scale_slice_transforms.{i}", ss)
+            idx = forced_indexes(sg, None if fi is None else fi[i], report)
+            s = torch.tensor(dec.decode(idx.reshape(-1).tolist(), *tables["y"]), dtype=torch.float32).reshape(sg.shape)
+            yh = s + mu
+            lrp = slice_transform(sd, f"context_model.lrp_slice_transforms.{i}", torch.cat([ms, yh], 1))
+            hats.append(yh + 0.5 * torch.tanh(lrp))
+            syms.append(s)
+        y_hat = torch.cat(hats, 1)
+        fake = decoder(sd, y_hat, q, beta if multirate else None)
+        fake = fake[:, :, :H, :W].clamp(-1, 1)
+    return {"fake_images": fake, "z_hat": z_hat, "y_hat": y_hat, "y_symbols": torch.cat(syms, 1).int(), "z_symbols": z_sym.int(),
+            "rate_ind": q, "report": report}

@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--graphs", action="store_true")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--draw-conditions", action="store_true", help="let the trainer draw (q, beta) itself")
+    ap.add_argument("--stage", type=int, default=3)
+    ap.add_argument("--no-buckets", action="store_true", help="data-parallel path with ONE gradient bucket after an unstaged backward")
+    ap.add_argument("--target-rate", type=float, default=None, help="override the rate loss' target(s): the lambda_A / lambda_B switch goes live")
     a = ap.parse_args()
     import torch
     from crdr_amd.trainer import build_trainer
@@ -29,26 +32,33 @@ def main():
     local = D.init_from_env()
     torch.cuda.set_device(local)
     torch.manual_seed(0)  # the factorised prior's noise comes from torch's (graph-safe) CUDA generator
-    opt = _opt(3)
+    opt = _opt(a.stage)
     opt["hip_graphs"] = a.graphs
     opt["hip_graph_warmup"] = 1
+    opt["dp_buckets"] = not a.no_buckets
     tr = build_trainer(opt)
     _seed_params(tr.comp_model, "")
-    _seed_params(tr.discriminator, "")
-    _seed_params(tr.perceptual_loss.lpips, "lpips.")
+    if a.stage == 3:
+        _seed_params(tr.discriminator, "")
+    if tr.perceptual_loss is not None:
+        _seed_params(tr.perceptual_loss.lpips, "lpips.")
+    if a.target_rate is not None:
+        rl = tr.rate_loss
+        rl.target_rate = [a.target_rate] * len(rl.target_rate) if isinstance(rl.target_rate, list) else a.target_rate
     tr.comp_model.context_model.seed_noise(1234)
     tr.loss_huge_threshold = float("inf")
     x = seeded_input("image", (2, 3, 64, 64)).to("cuda:0")
     logs = []
     for it in range(1, a.iters + 1):
         data = {"real_images": x}
-        if not a.draw_conditions:
+        if not a.draw_conditions and a.stage == 3:
             data.update(rate_ind=it % 2 + 1, beta=2.56 + 0.01 * it)
         logs.append(tr.optimize_parameters(it, data))
     torch.cuda.synchronize()
     state = {"logs": logs, "dist": D.is_dist(), "world": D.world_size(),
              "G": {k: p.detach().cpu() for k, p in tr.comp_model.named_parameters()},
-             "D": {k: p.detach().cpu() for k, p in tr.discriminator.named_parameters()},
+             "D": {k: p.detach().cpu() for k, p in tr.discriminator.named_parameters()} if a.stage == 3 else {},
+             "staged": bool(tr._staged()),
              "graphs": len(tr.graphs)}
     torch.save(state, a.out)
     if torch.distributed.is_available() and torch.distributed.is_initialized():

@@ -68,11 +68,97 @@ def _worker(rank, world, port, q):
         D.all_reduce_mean_([flat])
         ref_flat = torch.cat([full[k].grad.reshape(-1) for k in sorted(full)])
         assert torch.allclose(flat, ref_flat, rtol=1e-5, atol=1e-6)
+        # 5) the trainer's staged generator step (forward | global mean qbpp | backward in three pieces, one asynchronous
+        # gradient bucket each) driven through the REAL trainer methods on a toy CPU model with the product's cut mechanism
+        _staged_step_check(rank, world, D)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
     finally:
         dist.destroy_process_group()
+
+
+def _staged_step_check(rank, world, D):
+    import types
+    import torch.nn as nn
+    from crdr_amd.losses.rate_loss import HificRateLoss
+    from crdr_amd.models.comp_model.hyperprior_charm_model import HyperpriorCharmModel
+    from crdr_amd.trainer.base_trainer import BaseTrainer
+    from crdr_amd.trainer.rate_distortion_trainer import RateDistortionTrainer
+
+    class Toy(nn.Module):
+        """encoder -> hyper pair -> 'context model' (bits + y_hat) -> decoder, cut like HyperpriorCharmModel.forward"""
+        backward_cuts = None
+        _cut = HyperpriorCharmModel._cut
+
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            self.encoder, self.hyperencoder = nn.Conv2d(3, 4, 3, padding=1), nn.Conv2d(4, 2, 3, padding=1)
+            self.hyperdecoder, self.context_model = nn.Conv2d(2, 4, 3, padding=1), nn.Conv2d(8, 4, 3, padding=1)
+            self.decoder = nn.Conv2d(4, 3, 3, padding=1)
+
+        def run_model(self, real_images):
+            y = self.encoder(real_images)
+            z = self.hyperencoder(y)
+            hyper = self.hyperdecoder(z)
+            bits_z = z.square().sum((1, 2, 3))
+            y_in, h_in = self._cut("y", y, True), self._cut("hyper_out", hyper, True)
+            mu = self.context_model(torch.cat([y_in, h_in], 1))
+            bits_y = (y_in - mu).square().sum((1, 2, 3))
+            y_hat = y_in + 0.1 * mu
+            fake = self.decoder(self._cut("y_hat", y_hat, True))
+            npix = real_images.shape[2] * real_images.shape[3]
+            return dict(real_images=real_images, fake_images=fake, bpp=(bits_y + bits_z) / npix, qbpp=((bits_y + bits_z) / npix).detach(),
+                        bits_y=bits_y, bits_z=bits_z, num_pixel=npix)
+
+    def make(x):
+        tr = RateDistortionTrainer.__new__(RateDistortionTrainer)
+        tr.comp_model = Toy()
+        named = dict(sorted(tr.comp_model.named_parameters()))
+        flat = torch.zeros(sum(p.numel() for p in named.values()))
+        off = 0
+        for p in named.values():
+            p.grad = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        tr.g_optimizer = types.SimpleNamespace(param_groups=[{"params": list(named.values()), "grad": flat}], zero_grad=lambda: flat.zero_())
+        tr.aux_optimizer, tr.perceptual_loss, tr._pieces = None, None, None
+        tr.distortion_loss = lambda real, fake, **kw: (real - fake).square().mean()
+        tr.rate_loss = HificRateLoss(lambda_A=2.0, lambda_B=0.5, target_rate=target)
+        tr.opt = {"dp_buckets": True}
+        tr.loss_huge_threshold = 1e4
+        tr._flush_wgrads = lambda site: None
+        return tr, flat
+
+    torch.manual_seed(11)
+    x = torch.randn(4, 3, 8, 8)
+    x[2:] *= 3.0   # rank 1's shard has the larger rate: the local means straddle the target
+    probe, _ = None, None
+    with torch.no_grad():
+        out = Toy().run_model(x)
+    q_all = out["qbpp"]
+    lo, hi, mid = float(q_all[:2].mean()), float(q_all[2:].mean()), float(q_all.mean())
+    assert lo < hi
+    for target in (0.5 * (lo + mid), 0.5 * (mid + hi)):   # global mean above / below the target; one rank on each side locally
+        tr, flat = make(x)
+        assert tr._staged()
+        pieces = tr._piece_buffers()
+        assert [sum(b.numel() for b in p) for p in pieces] == [sum(q.numel() for q in m.parameters()) for m in
+                                                               (tr.comp_model.decoder, tr.comp_model.context_model)] + \
+            [sum(q.numel() for n, q in tr.comp_model.named_parameters() if n.split(".")[0] not in ("decoder", "context_model"))]
+        ctx, syncs = tr._run_generator_staged(lambda name, fn: fn(), x[rank * 2:(rank + 1) * 2], {}, None, 1)
+        for sy in syncs:
+            sy.wait()
+        # reference: one unstaged backward over the whole batch with the switch on the global mean
+        ref, ref_flat = make(x)
+        ref._staged = lambda: False
+        f = ref._g_forward(x, {}, None, 1)
+        rate = ref.rate_loss(f["bpp"], **f["other"], current_iter=1)
+        (f["nonrate"] + rate).backward()
+        want_lambda = 2.0 if mid > target else 0.5
+        assert abs(float(rate) - want_lambda * mid) < 1e-5 * max(1.0, mid)
+        assert torch.allclose(flat, ref_flat, rtol=1e-4, atol=1e-6), (target, float((flat - ref_flat).abs().max()))
+        assert float(ctx["bad"]) == 0.0 and abs(float(ctx["losses"]["rate"]) - want_lambda * float(q_all[rank * 2:(rank + 1) * 2].mean())) < 1e-4 * hi
 
 
 def test_dp_two_ranks_gloo():

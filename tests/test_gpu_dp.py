@@ -47,6 +47,30 @@ def test_trainer_dp_path_on_one_rank_rccl_is_bit_identical(tmp_path, graphs):
             assert torch.equal(plain[part][k], dp[part][k]), (part, k)
 
 
+@pytest.mark.parametrize("stage,target", [(1, None), (3, 100.0), (3, 0.5)], ids=["stage1", "stage3-lambdaB", "stage3-target0.5"])
+def test_staged_backward_and_global_rate_switch_are_bit_identical(tmp_path, stage, target):
+    """Config #4 semantics on one rank, HIP graphs on: the data-parallel generator step -- forward graph | all-reduce of the
+    mean qbpp (lambda_A / lambda_B on the GLOBAL mean, rate_loss.py:172-175) | backward in three captured pieces with one
+    asynchronous gradient bucket each -- against (a) the same path with one bucket behind an unstaged backward and (b) the
+    plain single-GPU run: same logs, bit-identical parameters.  target 100 forces the lambda_B branch, 0.5 sits among the
+    seeded model's qbpp values; stage 1 (crdr_stage_1.yaml: HificRateLoss, target 1.5) is the path where the all-reduce is
+    otherwise fully exposed."""
+    extra = ("--stage", str(stage)) + (("--target-rate", str(target)) if target is not None else ())
+    plain = _run_worker(tmp_path / "plain.pt", False, True, extra)
+    staged = _run_worker(tmp_path / "staged.pt", True, True, extra)
+    single = _run_worker(tmp_path / "single.pt", True, True, extra + ("--no-buckets",))
+    assert staged["staged"] is True and single["staged"] is False and plain["staged"] is False
+    assert staged["graphs"] >= single["graphs"] + 3, (staged["graphs"], single["graphs"])
+    for other in (single, plain):
+        for a, b in zip(other["logs"], staged["logs"]):
+            assert a is not None and b is not None and a.keys() == b.keys()
+            for k in a:
+                assert a[k] == b[k], (k, a[k], b[k])
+        for part in ("G", "D"):
+            for k in other[part]:
+                assert torch.equal(other[part][k], staged[part][k]), (part, k)
+
+
 def test_dp_ranks_draw_shared_conditions(tmp_path):
     """with the trainer drawing (q, beta) itself, the data-parallel path uses the seeded shared generators
     (same sequence on every rank): two runs give identical logs"""
