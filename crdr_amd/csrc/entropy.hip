@@ -61,79 +61,186 @@ __device__ __forceinline__ float gc_noise(const GcArgs& p, size_t pix, int c) {
   return philox_uniform(p.io.philox, (unsigned long long)pix * p.d.Ctot + p.d.c0 + c);
 }
 
-// grid (B, N): block b of image n strides over that image's HW*C elements
-__global__ __launch_bounds__(1024) void gauss_cond_fwd_kernel(const GcArgs p) {
+// One element of the forward: quantise, both likelihoods, bit terms.
+__device__ __forceinline__ void gc_elem(const GcArgs& p, float yv, float m, float sraw, float u, bool noisy, bool want_q, float& q_plus_m,
+                                        float& lq, float& ln, float& sn, float& sq) {
+  const float inv_ln2 = 1.4426950408889634f;
+  const float sg = fmaxf(sraw, p.d.scale_bound);
+  const float q = rintf(yv - m);  // torch.round: half to even
+  q_plus_m = q + m;
+  if (want_q) {
+    const float a = fabsf(q);  // |round(y - mu) + mu - mu|
+    float l = std_cdf((0.5f - a) / sg) - std_cdf((-0.5f - a) / sg);
+    l = fmaxf(l, p.d.likelihood_bound);
+    lq = l;
+    sq -= logf(l) * inv_ln2;
+  }
+  if (noisy) {
+    const float a = fabsf(yv + u - m);
+    float l = std_cdf((0.5f - a) / sg) - std_cdf((-0.5f - a) / sg);
+    l = fmaxf(l, p.d.likelihood_bound);
+    ln = l;
+    sn -= logf(l) * inv_ln2;
+  }
+}
+
+// grid (B, N), 256 threads: block b of image n strides over that image's HW*C elements.  VEC: four consecutive channels per
+// thread through 16-byte accesses (every pointer 16-byte aligned, C / strides / Ctot / c0 multiples of 4), one Philox call
+// per four samples.  The two bit sums of a block go to part[(n * B + b) * 2 + {0, 1}] when `part` is set (finished in fixed
+// order by gauss_cond_finish_kernel: no float atomics, any size, bit-reproducible run to run); with B == 1 and no `part` the
+// block adds straight into bits[n].
+template <bool VEC>
+__global__ __launch_bounds__(256) void gauss_cond_fwd_kernel(const GcArgs p, float* part) {
   __shared__ float red[16];
   const int n = blockIdx.y, C = p.d.C;
   const int per_img = p.d.HW * C;
-  const float inv_ln2 = 1.4426950408889634f;
   const bool noisy = p.io.noise || p.io.philox;
+  const bool want_q = p.io.lik_quant || p.io.bits_quant;
   float sn = 0.f, sq = 0.f;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < per_img; e += gridDim.x * blockDim.x) {
-    const int px = e / C, c = e - px * C;
-    const size_t pix = (size_t)n * p.d.HW + px;
-    const float yv = p.io.y[pix * p.d.ldy + c], m = p.io.mu[pix * p.d.ldmu + c];
-    const float sg = fmaxf(p.io.sigma[pix * p.d.ldsigma + c], p.d.scale_bound);
-    const float q = rintf(yv - m);  // torch.round: half to even
-    if (p.io.yhat) p.io.yhat[pix * p.d.ldyhat + c] = q + m;
-    if (p.io.yhat2) p.io.yhat2[pix * p.d.ldyhat2 + c] = q + m;
-    if (p.io.lik_quant || p.io.bits_quant) {
-      const float a = fabsf(q);  // |round(y - mu) + mu - mu|
-      float l = std_cdf((0.5f - a) / sg) - std_cdf((-0.5f - a) / sg);
-      l = fmaxf(l, p.d.likelihood_bound);
-      if (p.io.lik_quant) p.io.lik_quant[pix * p.d.ldlik + c] = l;
-      sq -= logf(l) * inv_ln2;
+  if (VEC) {
+    const int C4 = C >> 2;
+    for (int e4 = blockIdx.x * 256 + threadIdx.x; e4 < (per_img >> 2); e4 += gridDim.x * 256) {
+      const int px = e4 / C4, c = (e4 - px * C4) << 2;
+      const size_t pix = (size_t)n * p.d.HW + px;
+      const float4 yv = *reinterpret_cast<const float4*>(p.io.y + pix * p.d.ldy + c);
+      const float4 mv = *reinterpret_cast<const float4*>(p.io.mu + pix * p.d.ldmu + c);
+      const float4 sv = *reinterpret_cast<const float4*>(p.io.sigma + pix * p.d.ldsigma + c);
+      float u[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.io.noise) {
+        const float4 nv = *reinterpret_cast<const float4*>(p.io.noise + pix * p.d.ldnoise + c);
+        u[0] = nv.x; u[1] = nv.y; u[2] = nv.z; u[3] = nv.w;
+      } else if (p.io.philox) {  // element index = pix * Ctot + c0 + c, a multiple of 4: the four samples of one counter
+        const unsigned long long idx = (unsigned long long)pix * p.d.Ctot + p.d.c0 + c;
+        const unsigned long long seed = p.io.philox[0], ctr = p.io.philox[1] + (idx >> 2);
+        unsigned o[4];
+        philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = (float)(o[j] >> 8) * (1.0f / 16777216.0f) - 0.5f;
+      }
+      const float ya[4] = {yv.x, yv.y, yv.z, yv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, sa[4] = {sv.x, sv.y, sv.z, sv.w};
+      float qm[4], lq[4], ln[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gc_elem(p, ya[j], ma[j], sa[j], u[j], noisy, want_q, qm[j], lq[j], ln[j], sn, sq);
+      const float4 qv = make_float4(qm[0], qm[1], qm[2], qm[3]);
+      if (p.io.yhat) *reinterpret_cast<float4*>(p.io.yhat + pix * p.d.ldyhat + c) = qv;
+      if (p.io.yhat2) *reinterpret_cast<float4*>(p.io.yhat2 + pix * p.d.ldyhat2 + c) = qv;
+      if (p.io.lik_quant) *reinterpret_cast<float4*>(p.io.lik_quant + pix * p.d.ldlik + c) = make_float4(lq[0], lq[1], lq[2], lq[3]);
+      if (p.io.lik_noisy && noisy) *reinterpret_cast<float4*>(p.io.lik_noisy + pix * p.d.ldlik + c) = make_float4(ln[0], ln[1], ln[2], ln[3]);
     }
-    if (noisy) {
-      const float a = fabsf(yv + gc_noise(p, pix, c) - m);
-      float l = std_cdf((0.5f - a) / sg) - std_cdf((-0.5f - a) / sg);
-      l = fmaxf(l, p.d.likelihood_bound);
-      if (p.io.lik_noisy) p.io.lik_noisy[pix * p.d.ldlik + c] = l;
-      sn -= logf(l) * inv_ln2;
+  } else {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per_img; e += gridDim.x * 256) {
+      const int px = e / C, c = e - px * C;
+      const size_t pix = (size_t)n * p.d.HW + px;
+      float qm, lq = 0.f, ln = 0.f;
+      gc_elem(p, p.io.y[pix * p.d.ldy + c], p.io.mu[pix * p.d.ldmu + c], p.io.sigma[pix * p.d.ldsigma + c],
+              noisy ? gc_noise(p, pix, c) : 0.f, noisy, want_q, qm, lq, ln, sn, sq);
+      if (p.io.yhat) p.io.yhat[pix * p.d.ldyhat + c] = qm;
+      if (p.io.yhat2) p.io.yhat2[pix * p.d.ldyhat2 + c] = qm;
+      if (p.io.lik_quant) p.io.lik_quant[pix * p.d.ldlik + c] = lq;
+      if (p.io.lik_noisy && noisy) p.io.lik_noisy[pix * p.d.ldlik + c] = ln;
     }
   }
   sn = block_sum(sn, red);
   sq = block_sum(sq, red);
   if (threadIdx.x == 0) {
-    if (gridDim.x == 1) {  // the training shapes: deterministic
+    if (part) {
+      float* o = part + ((size_t)n * gridDim.x + blockIdx.x) * 2;
+      o[0] = sn; o[1] = sq;
+    } else {  // gridDim.x == 1
       if (p.io.bits_noisy && noisy) p.io.bits_noisy[n] += sn;
       if (p.io.bits_quant) p.io.bits_quant[n] += sq;
-    } else {
-      if (p.io.bits_noisy && noisy) atomicAdd(p.io.bits_noisy + n, sn);
-      if (p.io.bits_quant) atomicAdd(p.io.bits_quant + n, sq);
     }
   }
 }
 
+// one wave per image: lane l adds the partials of blocks l, l + 64, ... in that order, then the fixed shuffle tree
+__global__ __launch_bounds__(64) void gauss_cond_finish_kernel(const float* part, int B, float* bits_noisy, float* bits_quant) {
+  const int n = blockIdx.x;
+  float sn = 0.f, sq = 0.f;
+  for (int b = threadIdx.x; b < B; b += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)n * B + b) * 2);
+    sn += v.x; sq += v.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sn += __shfl_down(sn, o, 64); sq += __shfl_down(sq, o, 64); }
+  if (threadIdx.x == 0) {
+    if (bits_noisy) bits_noisy[n] += sn;
+    if (bits_quant) bits_quant[n] += sq;
+  }
+}
+
+__device__ __forceinline__ void gc_elem_bwd(const GcArgs& p, float yv, float m, float sraw, float u, float gb, float ste, float& gy_out,
+                                            float& gmu, float& gsig) {
+  const float inv_ln2 = 1.4426950408889634f;
+  const float sg = fmaxf(sraw, p.d.scale_bound);
+  const float dlt = yv + u - m;
+  const float a = fabsf(dlt), sgn = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
+  const float zu = (0.5f - a) / sg, zl = (-0.5f - a) / sg;
+  const float lraw = std_cdf(zu) - std_cdf(zl);
+  const float l = fmaxf(lraw, p.d.likelihood_bound);
+  const float glik = gb * (-inv_ln2 / l);                                         // d(-log2 l)/dl scaled
+  const float graw = (lraw >= p.d.likelihood_bound || glik < 0.f) ? glik : 0.f;  // LowerBound backward
+  const float pu = std_pdf(zu), pl = std_pdf(zl);
+  const float dl_da = (pl - pu) / sg;
+  const float dl_dsg = (zl * pl - zu * pu) / sg;
+  const float gy = graw * dl_da * sgn;
+  const float gsg = graw * dl_dsg;
+  gsig = (sraw >= p.d.scale_bound || gsg < 0.f) ? gsg : 0.f;
+  gy_out = gy + ste;   // yhat = ste_round(y - mu) + mu: d/dy = 1, d/dmu = 0
+  gmu = -gy;
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void gauss_cond_bwd_kernel(const GcArgs p) {
   const int C = p.d.C;
   const int per_img = p.d.HW * C;
   const int64_t total = (int64_t)p.d.N * per_img;
-  const float inv_ln2 = 1.4426950408889634f;
+  if (VEC) {
+    const int C4 = C >> 2;
+    for (int64_t e4 = blockIdx.x * 256ll + threadIdx.x; e4 < (total >> 2); e4 += gridDim.x * 256ll) {
+      const size_t pix = (size_t)(e4 / C4);
+      const int c = (int)(e4 - (int64_t)pix * C4) << 2;
+      const int n = (int)(pix / p.d.HW);
+      const float4 yv = *reinterpret_cast<const float4*>(p.io.y + pix * p.d.ldy + c);
+      const float4 mv = *reinterpret_cast<const float4*>(p.io.mu + pix * p.d.ldmu + c);
+      const float4 sv = *reinterpret_cast<const float4*>(p.io.sigma + pix * p.d.ldsigma + c);
+      float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.io.dyhat) dv = *reinterpret_cast<const float4*>(p.io.dyhat + pix * p.d.lddyhat + c);
+      float u[4];
+      if (p.io.noise) {
+        const float4 nv = *reinterpret_cast<const float4*>(p.io.noise + pix * p.d.ldnoise + c);
+        u[0] = nv.x; u[1] = nv.y; u[2] = nv.z; u[3] = nv.w;
+      } else {
+        const unsigned long long idx = (unsigned long long)pix * p.d.Ctot + p.d.c0 + c;
+        const unsigned long long seed = p.io.philox[0], ctr = p.io.philox[1] + (idx >> 2);
+        unsigned o[4];
+        philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = (float)(o[j] >> 8) * (1.0f / 16777216.0f) - 0.5f;
+      }
+      const float gb = p.io.gbits[n];
+      const float ya[4] = {yv.x, yv.y, yv.z, yv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, sa[4] = {sv.x, sv.y, sv.z, sv.w};
+      const float da[4] = {dv.x, dv.y, dv.z, dv.w};
+      float gy[4], gm[4], gs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gc_elem_bwd(p, ya[j], ma[j], sa[j], u[j], gb, da[j], gy[j], gm[j], gs[j]);
+      *reinterpret_cast<float4*>(p.io.dy + pix * p.d.ldgrad + c) = make_float4(gy[0], gy[1], gy[2], gy[3]);
+      *reinterpret_cast<float4*>(p.io.dmu + pix * p.d.ldgrad + c) = make_float4(gm[0], gm[1], gm[2], gm[3]);
+      *reinterpret_cast<float4*>(p.io.dsigma + pix * p.d.ldgrad + c) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+    }
+    return;
+  }
   for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
     const int n = (int)(e / per_img);
     const size_t pix = (size_t)(e / C);
     const int c = (int)(e - (int64_t)pix * C);
-    const float yv = p.io.y[pix * p.d.ldy + c], m = p.io.mu[pix * p.d.ldmu + c];
-    const float sraw = p.io.sigma[pix * p.d.ldsigma + c];
-    const float sg = fmaxf(sraw, p.d.scale_bound);
-    const float dlt = yv + gc_noise(p, pix, c) - m;
-    const float a = fabsf(dlt), sgn = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
-    const float zu = (0.5f - a) / sg, zl = (-0.5f - a) / sg;
-    const float lraw = std_cdf(zu) - std_cdf(zl);
-    const float l = fmaxf(lraw, p.d.likelihood_bound);
-    const float glik = p.io.gbits[n] * (-inv_ln2 / l);                      // d(-log2 l)/dl scaled
-    const float graw = (lraw >= p.d.likelihood_bound || glik < 0.f) ? glik : 0.f;  // LowerBound backward
-    const float pu = std_pdf(zu), pl = std_pdf(zl);
-    const float dl_da = (pl - pu) / sg;
-    const float dl_dsg = (zl * pl - zu * pu) / sg;
-    const float gy = graw * dl_da * sgn;
-    const float gsg = graw * dl_dsg;
-    const float gsig = (sraw >= p.d.scale_bound || gsg < 0.f) ? gsg : 0.f;
     const float ste = p.io.dyhat ? p.io.dyhat[pix * p.d.lddyhat + c] : 0.f;
-    p.io.dy[pix * p.d.ldgrad + c] = gy + ste;   // yhat = ste_round(y - mu) + mu: d/dy = 1, d/dmu = 0
-    p.io.dmu[pix * p.d.ldgrad + c] = -gy;
-    p.io.dsigma[pix * p.d.ldgrad + c] = gsig;
+    float gy, gm, gs;
+    gc_elem_bwd(p, p.io.y[pix * p.d.ldy + c], p.io.mu[pix * p.d.ldmu + c], p.io.sigma[pix * p.d.ldsigma + c], gc_noise(p, pix, c),
+                p.io.gbits[n], ste, gy, gm, gs);
+    p.io.dy[pix * p.d.ldgrad + c] = gy;
+    p.io.dmu[pix * p.d.ldgrad + c] = gm;
+    p.io.dsigma[pix * p.d.ldgrad + c] = gs;
   }
 }
 
@@ -364,18 +471,50 @@ static void gc_fill_defaults(crdr_gc_desc2& d) {
   if (!d.Ctot) d.Ctot = d.C;
 }
 
+// blocks per image: one 16-byte group per thread, a whole number of waves over the chip at the codec's sizes
+static int gc_blocks(const crdr_gc_desc2* d) {
+  const long long per_img = (long long)d->HW * d->C;
+  return (int)std::max<long long>(1, std::min<long long>(cdiv64(per_img, 1024), 2048));
+}
+
+extern "C" size_t crdr_gauss_cond_fwd_workspace(const crdr_gc_desc2* d) {
+  if (!d) return 0;
+  return (size_t)d->N * gc_blocks(d) * 2 * sizeof(float);
+}
+
 extern "C" int crdr_gauss_cond_fwd2(const crdr_gc_desc2* d, const crdr_gc_io* io, crdr_stream_t s) {
   CRDR_REQUIRE(d && io && io->y && io->mu && io->sigma, "gauss_cond_fwd: null input");
   GcArgs a;
   a.d = *d; a.io = *io;
   gc_fill_defaults(a.d);
-  const int per_img = d->HW * d->C;
+  const long long per_img = (long long)d->HW * d->C;
   if (per_img == 0 || d->N == 0) return 0;
-  // one block per image up to 64 Ki elements (every training shape): the per-image bit sums are then plain stores in a
-  // fixed order, bit-reproducible run to run; larger images (codec / validation) split and combine with atomics
-  const int B = std::max(1, std::min(cdiv(per_img, 65536), 128));
-  hipLaunchKernelGGL(gauss_cond_fwd_kernel, dim3(B, d->N), dim3(1024), 0, as_stream(s), a);
+  CRDR_REQUIRE(per_img < (1ll << 31), "gauss_cond_fwd: %lld elements per image", per_img);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const crdr_gc_desc2& g = a.d;
+  const bool vec = g.C % 4 == 0 && g.ldy % 4 == 0 && g.ldmu % 4 == 0 && g.ldsigma % 4 == 0 && g.Ctot % 4 == 0 && g.c0 % 4 == 0 &&
+                   al16(io->y) && al16(io->mu) && al16(io->sigma) && (!io->noise || (g.ldnoise % 4 == 0 && al16(io->noise))) &&
+                   (!io->yhat || (g.ldyhat % 4 == 0 && al16(io->yhat))) && (!io->yhat2 || (g.ldyhat2 % 4 == 0 && al16(io->yhat2))) &&
+                   ((!io->lik_noisy && !io->lik_quant) || (g.ldlik % 4 == 0 && al16(io->lik_noisy) && al16(io->lik_quant)));
+  // bit sums: per-block partials in the caller's workspace + a fixed-order finishing pass.  Without a workspace one block
+  // per image adds in place -- equally deterministic, slow for big images.  No float atomics either way.
+  int B = gc_blocks(d);
+  float* part = io->ws;
+  if (!part || io->ws_bytes < crdr_gauss_cond_fwd_workspace(d) || !(io->bits_noisy || io->bits_quant)) {
+    part = nullptr;
+    if (io->bits_noisy || io->bits_quant) B = 1;
+  }
+  if (vec)
+    hipLaunchKernelGGL(gauss_cond_fwd_kernel<true>, dim3(B, d->N), dim3(256), 0, as_stream(s), a, part);
+  else
+    hipLaunchKernelGGL(gauss_cond_fwd_kernel<false>, dim3(B, d->N), dim3(256), 0, as_stream(s), a, part);
   CRDR_CHECK_LAUNCH("gauss_cond_fwd");
+  if (part) {
+    const bool noisy = io->noise || io->philox;
+    hipLaunchKernelGGL(gauss_cond_finish_kernel, dim3(d->N), dim3(64), 0, as_stream(s), part, B, noisy ? io->bits_noisy : nullptr,
+                       io->bits_quant);
+    CRDR_CHECK_LAUNCH("gauss_cond_finish");
+  }
   return 0;
 }
 
@@ -387,8 +526,16 @@ extern "C" int crdr_gauss_cond_bwd2(const crdr_gc_desc2* d, const crdr_gc_io* io
   gc_fill_defaults(a.d);
   const int64_t total = (int64_t)d->N * d->HW * d->C;
   if (total == 0) return 0;
-  const int nb = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
-  hipLaunchKernelGGL(gauss_cond_bwd_kernel, dim3(nb), dim3(256), 0, as_stream(s), a);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const crdr_gc_desc2& g = a.d;
+  const bool vec = g.C % 4 == 0 && g.ldy % 4 == 0 && g.ldmu % 4 == 0 && g.ldsigma % 4 == 0 && g.ldgrad % 4 == 0 && g.Ctot % 4 == 0 &&
+                   g.c0 % 4 == 0 && al16(io->y) && al16(io->mu) && al16(io->sigma) && al16(io->dy) && al16(io->dmu) && al16(io->dsigma) &&
+                   (!io->noise || (g.ldnoise % 4 == 0 && al16(io->noise))) && (!io->dyhat || (g.lddyhat % 4 == 0 && al16(io->dyhat)));
+  const int nb = (int)std::min<int64_t>(cdiv64(vec ? total / 4 : total, 256), 4096);
+  if (vec)
+    hipLaunchKernelGGL(gauss_cond_bwd_kernel<true>, dim3(nb), dim3(256), 0, as_stream(s), a);
+  else
+    hipLaunchKernelGGL(gauss_cond_bwd_kernel<false>, dim3(nb), dim3(256), 0, as_stream(s), a);
   CRDR_CHECK_LAUNCH("gauss_cond_bwd");
   return 0;
 }

@@ -350,7 +350,7 @@ class CharmRun:
                     yhat=self.yh(c0, c).ptr, yhat2=self.yp(c0, c).ptr,
                     lik_noisy=None if lik_n is None else lik_n.data_ptr() + 4 * c0,
                     lik_quant=None if lik_q is None else lik_q.data_ptr() + 4 * c0, bits_noisy=bits_n, bits_quant=bits_q)
-        L.check(lib.crdr_gauss_cond_fwd2(C.byref(d), C.byref(io), ops._stream()), "gauss_cond_fwd2")
+        HF.gauss_cond_fwd2(d, io, self.dev)
 
     def lrp(self, st):
         """LRP transforms of stage `st` on the pre-correction latent in Yh, then Yh = Ypre + 0.5 tanh(.)"""

@@ -570,6 +570,13 @@ def _gc_desc(y, ldy, ldmu, ldsg, ldyh, scale_bound, lik_bound):
                     likelihood_bound=lik_bound)
 
 
+def gauss_cond_fwd2(d, io, device) -> None:
+    """crdr_gauss_cond_fwd2 with the scratch for its per-block partial bit sums attached (fixed-order finishing pass)."""
+    lib = L.load()
+    io.ws, io.ws_bytes = ops.workspace(lib.crdr_gauss_cond_fwd_workspace(C.byref(d)), device)
+    L.check(lib.crdr_gauss_cond_fwd2(C.byref(d), C.byref(io), ops._stream()), "gauss_cond_fwd2")
+
+
 class _GaussCond(torch.autograd.Function):
     """(y, mu, sigma, noise) -> (y_hat, bits_noisy[N], bits_quant[N], lik_noisy?, lik_quant?)"""
 
@@ -590,10 +597,10 @@ class _GaussCond(torch.autograd.Function):
             noise, ldn = ops.nhwc(noise)
             if ldn != c:
                 noise = noise.contiguous(memory_format=torch.channels_last)
-        d = _gc_desc(y, ldy, ldmu, ldsg, c, scale_bound, lik_bound)
-        L.check(lib.crdr_gauss_cond_fwd(C.byref(d), y.data_ptr(), mu.data_ptr(), sigma.data_ptr(), ops._p(noise),
-                                        yhat.data_ptr(), ops._p(lik_n), ops._p(lik_q), bits_n.data_ptr(),
-                                        bits_q.data_ptr(), ops._stream()), "gauss_cond_fwd")
+        d = L.GcDesc2(N=n, HW=h * w, C=c, ldy=ldy, ldmu=ldmu, ldsigma=ldsg, ldyhat=c, scale_bound=scale_bound, likelihood_bound=lik_bound)
+        io = L.GcIO(y=y.data_ptr(), mu=mu.data_ptr(), sigma=sigma.data_ptr(), noise=ops._p(noise), yhat=yhat.data_ptr(),
+                    lik_noisy=ops._p(lik_n), lik_quant=ops._p(lik_q), bits_noisy=bits_n.data_ptr(), bits_quant=bits_q.data_ptr())
+        gauss_cond_fwd2(d, io, dev)
         ctx.bounds = (scale_bound, lik_bound)
         ctx.save_for_backward(y, mu, sigma, noise)
         ctx.mark_non_differentiable(bits_q)

@@ -73,7 +73,8 @@ class GcDesc2(C.Structure):
 
 class GcIO(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("y", "mu", "sigma", "noise", "philox", "yhat", "yhat2", "lik_noisy", "lik_quant",
-                                        "bits_noisy", "bits_quant", "gbits", "dyhat", "dy", "dmu", "dsigma")]
+                                        "bits_noisy", "bits_quant", "gbits", "dyhat", "dy", "dmu", "dsigma", "ws")] + [
+        ("ws_bytes", C.c_size_t)]
 
 
 class EbwdIO(C.Structure):
@@ -114,6 +115,7 @@ SIGNATURES = {
     "crdr_conv2d_wgrad_partial_grouped": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _I, _P, _SZ, _P, _P]),
     "crdr_pack_weight_item": (_I, [C.POINTER(PackItem), _P]),
     "crdr_colsum_scatter": (_I, [_P, _I, _I64, _I, _I, _P, _I, _P, _SZ, _P]),
+    "crdr_gauss_cond_fwd_workspace": (_SZ, [C.POINTER(GcDesc2)]),
     "crdr_gauss_cond_fwd2": (_I, [C.POINTER(GcDesc2), C.POINTER(GcIO), _P]),
     "crdr_gauss_cond_bwd2": (_I, [C.POINTER(GcDesc2), C.POINTER(GcIO), _P]),
     "crdr_gdn_workspace": (_SZ, [C.POINTER(GdnDesc), _I]),

@@ -386,7 +386,13 @@ typedef struct crdr_gc_io {
   float *yhat, *yhat2, *lik_noisy, *lik_quant, *bits_noisy, *bits_quant;
   const float *gbits, *dyhat;
   float *dy, *dmu, *dsigma;
+  /* forward only: scratch of crdr_gauss_cond_fwd_workspace(d) bytes for the per-block partial bit sums, which a finishing pass
+   * adds in fixed order (no float atomics: bit sums are bit-reproducible at any size).  NULL / too small: one block per image
+   * adds in place -- same determinism, slow for large images. */
+  float* ws;
+  size_t ws_bytes;
 } crdr_gc_io;
+size_t crdr_gauss_cond_fwd_workspace(const crdr_gc_desc2* d);
 int crdr_gauss_cond_fwd2(const crdr_gc_desc2* d, const crdr_gc_io* io, crdr_stream_t s);
 int crdr_gauss_cond_bwd2(const crdr_gc_desc2* d, const crdr_gc_io* io, crdr_stream_t s);
 /* U(-1/2, 1/2) samples of the generator above written out: out[(n * HW + px) * ld + c] for c < C (tests, and the noisy
