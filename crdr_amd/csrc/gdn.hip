@@ -128,6 +128,7 @@ static int gdn_conv_desc(const crdr_gdn_desc* d, crdr_conv_desc* cd, int CP) {
   cd->N = (int32_t)d->M; cd->H = 1; cd->W = 1; cd->C = d->C; cd->OH = 1; cd->OW = 1; cd->OC = d->C;
   cd->kh = 1; cd->kw = 1; cd->stride = 1; cd->pad = 0; cd->transposed = 0;
   cd->ldx = d->C; cd->ldy = d->C; cd->wrows = CP; cd->wcols = CP;
+  cd->flags = CRDR_CONV_NOSPLIT;   // the scratch of these launches is shared with other kernels: no ticket area
   return 0;
 }
 
@@ -172,7 +173,7 @@ static int gdn_norm(const crdr_gdn_desc* d, const GdnLayout& L, char* ws, const 
   CRDR_CHECK_LAUNCH("gdn_square");
   crdr_conv_desc cd;
   if (int rc = gdn_conv_desc(d, &cd, L.CP)) return rc;
-  cd.flags = CRDR_EPI_BIAS;
+  cd.flags |= CRDR_EPI_BIAS;
   crdr_conv_io io;
   memset(&io, 0, sizeof(io));
   io.x = (const float*)(ws + L.x2); io.w = (const float*)(ws + L.pack_f); io.y = (float*)(ws + L.norm); io.bias = beta_eff;

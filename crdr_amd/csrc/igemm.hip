@@ -11,7 +11,9 @@
 // "rows of 128 B": staged global -> registers -> LDS (zero fill for padding taps), double buffered, one
 // barrier per K-tile.  Each lane reads 16 B (4 consecutive k) per 32-row fragment and feeds 4 MFMAs: lane half
 // h owns k = 4h..4h+3 of every 8-wide k group, identically for A and B, so the sum over k is complete.
-// Split-K (blockIdx.z) writes raw partial slabs; igemm_splitk_epilogue reduces them in a fixed order.
+// Split-K (blockIdx.z): every split publishes its raw partial tile (write-through stores), takes a ticket on the tile's
+// counter, and the workgroup that arrives last adds the slabs in split order and runs the epilogue -- one launch, and the
+// result does not depend on which split came last.
 
 #include <algorithm>
 #include <atomic>
@@ -290,11 +292,94 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   const int hw = p.GH * p.GW;
   const bool direct = (p.nphase == 1) && (p.so == 1);  // output pixel index == GEMM row
   const bool vec = p.vec_epi != 0;
+
+  // ---- split-K inside the launch.  Slabs: ws[group][phase][split][M][ws_ld], this tile's part addressed through ONE buffer
+  // descriptor based at split 0 (build_plan keeps nsplit * M * ws_ld * 4 below 2 GiB).  Hand-off (MI355X_MICROARCH.md,
+  // "Workgroup dispatch, XCD placement & inter-workgroup visibility"): every slab byte is stored sc1 (write-through: no L2
+  // write-back needed), every storing wave drains vmcnt, the workgroup barrier, then ONE lane takes the ticket with an
+  // agent-scope atomic; the workgroup whose ticket is nsplit - 1 acquires (buffer_inv sc1) and reads all slabs with sc1 loads
+  // in split order.  Placement independent, no spinning: a workgroup either leaves or reduces.
+  const bool splitk = p.nsplit > 1;
+  const unsigned slab_bytes = splitk ? (unsigned)((size_t)p.M * p.ws_ld * 4u) : 0u;
+  __amdgpu_buffer_rsrc_t rws = rw;
+  if (splitk)
+    rws = __builtin_amdgcn_make_buffer_rsrc(
+        p.ws + (size_t)(gidx * p.nphase + phase) * p.nsplit * ((size_t)p.M * p.ws_ld) + (size_t)m0 * p.ws_ld + n0, 0, 0x7fffffff, 0x00020000);
+  // byte offset (relative to rws) of the 16-byte group that lane position q of pass (I, JG, GC) owns in split 0's slab
+  auto slab_off = [&](int I, int JG, int GC, int q) __attribute__((always_inline)) {
+    const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+    const int rr = (wm * MB + I) * 32 + row;
+    return (m0 + rr < p.M) ? (unsigned)(rr * p.ws_ld + (wn * NB + JG) * 32 + c4 * 4) * 4u : kOobOffset;
+  };
+  if (splitk) {
+    auto wpass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+      constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+#pragma unroll
+      for (int jj = 0; jj < GC; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
+      // sC is private to the wave: program order is enough
+#pragma unroll
+      for (int k = 0; k < 4 * GC; ++k) {
+        const int q = lane + 64 * k;
+        const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * CLD + c4 * 4);
+        const unsigned o = slab_off(I, JG, GC, q);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a4), rws, o == kOobOffset ? o : o + (unsigned)split * slab_bytes, 0,
+                                               16 /* sc1 */);
+      }
+    };
+    wpass(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+    if constexpr (NB > 4) wpass(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+    if constexpr (MB > 1) {
+      wpass(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+      if constexpr (NB > 4) wpass(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* sFlag = reinterpret_cast<int*>(smem + kSvOff + 4 * BN);
+    if (tid == 0) {
+      int* cnt = p.counters + ((gidx * p.nphase + phase) * (int)gridDim.x + tile_m) * (int)gridDim.y + tile_n;
+      const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == p.nsplit - 1;
+      if (last) {
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next launch finds zeros again
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      *sFlag = last;
+    }
+    __syncthreads();
+    if (!*sFlag) return;
+  }
+  // what the reducer of a split tile puts into sC instead of its accumulators: the sum of the slabs in split order
+  // (((s0 + s1) + s2) + ...), four splits of loads in flight at a time
+  auto rfill = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+    constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+#pragma unroll
+    for (int k = 0; k < 4 * GC; ++k) {
+      const int q = lane + 64 * k;
+      const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+      const unsigned o = slab_off(I, JG, GC, q);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < p.nsplit; s0 += 4) {
+        f32x4 l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          l[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rws, (o == kOobOffset || s0 + j >= p.nsplit) ? kOobOffset : o + (unsigned)(s0 + j) * slab_bytes, 0, 16));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += l[j];   // splits past nsplit read zeros: + 0.f is exact
+      }
+      *reinterpret_cast<f32x4*>(sC + row * CLD + c4 * 4) = v;
+    }
+  };
   // CRDR_EPI_COLSUM: column sums of this tile's outputs (value before / after the ReLU mask), reduced lane -> wave ->
   // workgroup in a fixed order and written as one partial row per (phase, M tile); crdr_colsum_finish adds the rows up.
   // A lane must keep one 4-channel column group for a whole pass, which holds for passes of 1, 2 or 4 column blocks; a pass
   // of 3 runs as three single-block passes when column sums are requested.
-  const bool do_cs = (f & CRDR_EPI_COLSUM) && p.nsplit == 1;
+  const bool do_cs = (f & CRDR_EPI_COLSUM) != 0;   // (of a split tile: by its reducer, from the summed values)
   float* sS = smem + WM * WN * 32 * CLD;  // [WM][2][BN] behind the staged accumulators
   // ---- fast epilogue (p.fast_epi): every global access is a buffer instruction issued by all lanes -- dead rows / column
   // groups get an out-of-range offset, loads return 0 and stores are dropped -- relative to this tile's first output pixel;
@@ -314,11 +399,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_mask ? p.mask + opix0 * p.ldmask : p.y), 0, 0x7fffffff, 0x00020000);
     auto fpass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
       constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+      if (splitk) {
+        rfill(I_, JG_, GC_);
+      } else {
 #pragma unroll
-      for (int jj = 0; jj < GC; ++jj)
+        for (int jj = 0; jj < GC; ++jj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
+          for (int r = 0; r < 16; ++r)
+            sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
+      }
       // sC is private to the wave: program order is enough
       f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -439,11 +528,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   // one pass = GC column blocks [JG, JG+GC) of accumulator row-block I (all compile-time so acc stays in registers)
   auto pass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
     constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+    if (splitk) {
+      rfill(I_, JG_, GC_);
+    } else {
 #pragma unroll
-    for (int jj = 0; jj < GC; ++jj)
+      for (int jj = 0; jj < GC; ++jj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
+        for (int r = 0; r < 16; ++r)
+          sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
+    }
     __syncthreads();
     f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -454,10 +547,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
       const int m = m0 + (wm * MB + I) * 32 + row;
       const int oc0 = n0 + (wn * NB + JG) * 32 + c4 * 4;
       bool live_row = m < p.M;
-      if (p.nsplit > 1) {
-        if (live_row)
-          *reinterpret_cast<f32x4*>(p.ws + ((size_t)((gidx * p.nphase + phase) * p.nsplit + split) * p.M + m) * p.ws_ld + oc0) = a4;
-      } else {
+      {
         size_t opix = (size_t)m;
         if (!direct) {
           const int mm = live_row ? m : 0;
@@ -577,41 +667,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   }
 }
 
-// reduce split-K slabs in split order, then the same epilogue. grid: (ceil(Cout/64), M rows chunked, nphase * G)
-__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
-  __shared__ float red[2][4][64];
-  IgemmArgs p = p_;
-  const int gidx = blockIdx.z / p.nphase;
-  const int phase = blockIdx.z - gidx * p.nphase;
-  if (p.ngroup > 1) {
-    p.y = grp.y[gidx]; p.bias = grp.bias[gidx]; p.pre = grp.pre[gidx]; p.mask = grp.mask[gidx]; p.res = grp.res[gidx]; p.cs = grp.cs[gidx];
-  }
-  const int oc = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int hw = p.GH * p.GW;
-  float spre = 0.f, spost = 0.f;
-  for (int m = blockIdx.y * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.y * 4) {
-    if (oc >= p.Cout) continue;
-    float v = 0.f;
-    for (int s = 0; s < p.nsplit; ++s) v += p.ws[((size_t)((gidx * p.nphase + phase) * p.nsplit + s) * p.M + m) * p.ws_ld + oc];
-    const int n = m / hw, rem = m - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
-    const int oh = ga * p.so + tp.poh[phase], ow = gb * p.so + tp.pow[phase];
-    if (oh >= p.OH || ow >= p.OW) continue;
-    float a, b;
-    epilogue_store(p, ((size_t)n * p.OH + oh) * p.OW + ow, oc, v, a, b);
-    spre += a; spost += b;
-  }
-  if (p.flags & CRDR_EPI_COLSUM) {  // one partial row per (phase, row chunk): the four row lanes added in order
-    red[0][threadIdx.x >> 6][threadIdx.x & 63] = spre;
-    red[1][threadIdx.x >> 6][threadIdx.x & 63] = spost;
-    __syncthreads();
-    if (threadIdx.x < 128) {
-      const int which = threadIdx.x >> 6, c = threadIdx.x & 63, col = blockIdx.x * 64 + c;
-      const float v = ((red[which][0][c] + red[which][1][c]) + red[which][2][c]) + red[which][3][c];
-      if (col < p.Cout) p.cs[((size_t)(phase * gridDim.y + blockIdx.y) * 2 + which) * p.cs_ld + col] = v;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // host side: geometry, config choice, launch
 // ------------------------------------------------------------------------------------------------------------
@@ -663,6 +718,11 @@ struct Plan {
   size_t lds;
   size_t ws_bytes;
 };
+
+// split-K plans: tickets fit the workspace head and one buffer descriptor spans all slabs of a (group, phase)
+static bool splitk_ok(long long tiles, int M, int ws_ld, int ns) {
+  return tiles <= CRDR_CONV_TICKETS && (long long)ns * M * ws_ld * 4 < (1ll << 31) - (1 << 24);
+}
 
 static int floordiv(int a, int b) {
   int q = a / b, r = a % b;
@@ -747,14 +807,16 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
     const int BM = 32 * t.wm * t.mb, BN = 32 * t.wn * t.nb;
     const long long tiles = (long long)cdiv(a.M, BM) * cdiv(d->OC, BN) * a.nphase;
     static_assert(sizeof(kCfgTflops) / sizeof(kCfgTflops[0]) == sizeof(kCfgs) / sizeof(kCfgs[0]), "one figure per configuration");
-    for (int ns = 1; ns <= (fallback ? 1 : 16); ns *= 2) {
-      if (ns > 1 && KT / ns < 8) break;
+    for (int ns = 1; ns <= ((fallback || (d->flags & CRDR_CONV_NOSPLIT)) ? 1 : 16); ns *= 2) {
+      if (ns > 1 && KT / ns < 4) break;
+      if (ns > 1 && !splitk_ok(tiles * G, a.M, cdiv(d->OC, BN) * BN, ns)) break;
       const long long blocks = tiles * ns * G;
       // MFMA cycles of one workgroup per K-tile (waves beyond four share the SIMDs), scaled by the measured efficiency
       const double per_iter = 16.0 * t.mb * t.nb * 64.0 * std::max(1.0, t.wm * t.wn / 4.0) * (133.0 / kCfgTflops[c]);
       const double waves = (double)cdiv64(blocks, 256);
       double cost = waves * ((double)cdiv(KT, ns) * per_iter + 3000.0);
-      if (ns > 1) cost += 8000.0 + (double)a.M * cdiv(d->OC, BN) * BN * ns * 4.0 * a.nphase / 2000.0;  // slab traffic
+      // in-launch reduce: publish + ticket + acquire (~3 us) and the last arriver's slab reads (~100 GB/s per workgroup)
+      if (ns > 1) cost += 7000.0 + (double)BM * BN * ns * 4.0 / 40.0;
       if (cost < best) { best = cost; bc = c; bs = ns; }
     }
   }
@@ -815,6 +877,13 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
     CRDR_REQUIRE(bc >= 0 && bc < kNumCfgs, "conv2d: forced config %d out of range", bc);
     CRDR_REQUIRE(!a.smallc || kCfgs[bc].kern_smallc, "conv2d: config %d has no tap-major variant", bc);
     CRDR_REQUIRE(bs == 1 || KT / bs >= 2, "conv2d: forced split %d too deep for %d K-iterations", bs, KT);
+    CRDR_REQUIRE(bs == 1 || !(d->flags & CRDR_CONV_NOSPLIT), "conv2d: forced split %d with CRDR_CONV_NOSPLIT", bs);
+    if (bs > 1) {
+      const TileCfg& ft = kCfgs[bc];
+      const int fBM = 32 * ft.wm * ft.mb, fBN = 32 * ft.wn * ft.nb;
+      CRDR_REQUIRE(splitk_ok((long long)cdiv(a.M, fBM) * cdiv(d->OC, fBN) * a.nphase * G, a.M, cdiv(d->OC, fBN) * fBN, bs),
+                   "conv2d: forced split %d: too many tiles or slabs too large for the in-launch reduce", bs);
+    }
   }
   CRDR_REQUIRE(bc >= 0, "conv2d: no tile config");
   const TileCfg& t = kCfgs[bc];
@@ -838,11 +907,12 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
     const size_t staging = (size_t)2 * (BM + BN) * 32 + 132;
     const size_t epi = (size_t)t.wm * t.wn * 32 * 32 * std::min(t.nb, 4) + (size_t)t.wm * 2 * BN;
     const size_t sv_off = (std::max(staging, epi) + 3) & ~(size_t)3;
-    pl->lds = (sv_off + (size_t)4 * BN) * sizeof(float);
+    pl->lds = (sv_off + (size_t)4 * BN + 4) * sizeof(float);   // (+ the reducer flag of a split launch)
   }
   a.cs_ld = round_up(d->OC, 32);
-  a.cs_rows = want_cs ? a.nphase * (bs == 1 ? (int)pl->grid.x : std::min(cdiv(a.M, 4), 2048)) : 0;
-  pl->ws_bytes = bs > 1 ? (size_t)G * a.nphase * bs * a.M * a.ws_ld * sizeof(float) : 0;
+  a.cs_rows = want_cs ? a.nphase * (int)pl->grid.x : 0;
+  // split-K workspace: [tickets: CRDR_CONV_TICKETS ints, zero between launches][slabs]
+  pl->ws_bytes = bs > 1 ? (size_t)CRDR_CONV_TICKETS * sizeof(int) + (size_t)G * a.nphase * bs * a.M * a.ws_ld * sizeof(float) : 0;
   return 0;
 }
 
@@ -885,7 +955,9 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   if (int rc = build_plan(d, &pl, G)) return rc;
   IgemmArgs& a = pl.a;
   const crdr_conv_io* io = ios;
-  a.x = io->x; a.w = io->w; a.y = io->y; a.ws = (float*)ws;
+  a.x = io->x; a.w = io->w; a.y = io->y;
+  a.counters = (int*)ws;
+  a.ws = (float*)ws + CRDR_CONV_TICKETS;
   a.bias = io->bias; a.vec2 = io->vec2; a.res = io->res; a.scale = io->scale; a.shift = io->shift;
   a.gx = io->gx; a.gt = io->gt; a.sig = io->sig; a.pre = io->pre; a.mask = io->mask; a.cs = io->cs;
   if (a.M == 0) return 0;  // empty batch: nothing to compute (tensors may legitimately be null)
@@ -930,13 +1002,12 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   // a tile of BM <= 256 GEMM rows covers at most BM / GW + 2 grid rows, each of them `so` output rows of OW pixels
   const long long span_px = (256 / std::max(a.GW, 1) + 2) * (long long)std::max(a.so, 1) * a.OW + a.OW;
   const long long span = span_px * std::max(std::max(a.ldy, a.ldres), a.ldmask) * 4;
-  a.fast_epi = (v && a.Cout % 4 == 0 && a.nsplit == 1 && span < (1ll << 31) &&
-                !(a.flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM))) ? 1 : 0;
+  a.fast_epi = (v && a.Cout % 4 == 0 && span < (1ll << 31) && !(a.flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM))) ? 1 : 0;
   if (pl.stream >= 0 && !a.vec_epi && d->reserved == 0) {
     // the built-in choice assumed 16-byte aligned operands (it only knows the strides): take the tiled kernel instead
     Plan fb;
     if (int rc = build_plan(d, &fb, G, true)) return rc;
-    fb.a.x = a.x; fb.a.w = a.w; fb.a.y = a.y; fb.a.ws = a.ws; fb.a.bias = a.bias; fb.a.vec2 = a.vec2; fb.a.res = a.res;
+    fb.a.x = a.x; fb.a.w = a.w; fb.a.y = a.y; fb.a.ws = a.ws; fb.a.counters = a.counters; fb.a.bias = a.bias; fb.a.vec2 = a.vec2; fb.a.res = a.res;
     fb.a.scale = a.scale; fb.a.shift = a.shift; fb.a.gx = a.gx; fb.a.gt = a.gt; fb.a.sig = a.sig; fb.a.pre = a.pre;
     fb.a.mask = a.mask; fb.a.cs = a.cs; fb.a.vec_epi = 0; fb.a.fast_epi = 0;
     pl = fb;
@@ -960,13 +1031,6 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   hipLaunchKernelGGL(kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, pl.t, grp);
   CRDR_CHECK_LAUNCH("igemm_kernel");
   profile_end(0, G * crdr_conv2d_flops(d), prof, as_stream(s));  // kind 0 = the igemm kernel alone (what rocprofv3 lists)
-  if (a.nsplit > 1) {
-    void* prof2 = profile_begin(as_stream(s));
-    dim3 g(cdiv(a.Cout, 64), std::min(cdiv(a.M, 4), 2048), a.nphase * G);
-    hipLaunchKernelGGL(igemm_splitk_epilogue, g, dim3(256), 0, as_stream(s), a, pl.t, grp);
-    CRDR_CHECK_LAUNCH("igemm_splitk_epilogue");
-    profile_end(2, 0.0, prof2, as_stream(s));  // kind 2 = split-K epilogue launches
-  }
   return 0;
 }
 

@@ -21,6 +21,7 @@ struct IgemmArgs {
   float* sig;
   const float* pre;
   const float* mask;
+  int* counters;   // split-K: one ticket per (group, phase, M tile, N tile), zero between launches (head of the workspace)
   float* cs;       // CRDR_EPI_COLSUM: per-tile partial column sums [rows][2][cs_ld] (pre-mask, post-mask)
   int ldpre, ldmask;
   int cs_ld, cs_rows;

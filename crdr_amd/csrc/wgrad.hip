@@ -401,27 +401,73 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const crdr_pa
     const int r0 = (tl / ctiles) * 8, c0 = (tl % ctiles) * 32;
     const int T = it.T;
     const int sJ = it.srcJ ? it.srcJ : it.J;
-    if (it.mode == 0) {  // pack row = i, pack col = j : LDS [8 r][32 c][T]
+    const size_t dld = it.dld ? it.dld : it.cols;
+    const size_t tstride = it.tstride ? (size_t)it.tstride : (size_t)it.rows * it.cols;
+    // 16-byte accesses on both sides when every source run and every destination row segment is 16-byte aligned
+    const bool al = ((sJ * T) & 3) == 0 && (reinterpret_cast<uintptr_t>(it.src) & 15) == 0 && (reinterpret_cast<uintptr_t>(it.dst) & 15) == 0 &&
+                    (dld & 3) == 0 && (tstride & 3) == 0;
+    // LDS image: mode 0 [8 r][32 c][T], mode 1 [32 c][8 r][T]; each outer row padded by one float, which makes the strided
+    // reads of the write phase conflict free for the odd tap counts (1, 9, 25) these layers have
+    if (it.mode == 0) {  // pack row = i, pack col = j
       const int run = 32 * T;
-      for (int e = tid; e < 8 * run; e += 256) {
-        const int r = e / run, rest = e - r * run;
-        const int i = r0 + r, j = c0 + rest / T;
-        tile[e] = (i < it.I && j < it.J) ? it.src[((size_t)i * sJ + c0) * T + rest] : 0.f;
+      const bool vec = al && c0 + 32 <= it.J;   // whole runs inside the parameter row
+      if (vec) {
+        for (int e4 = tid; e4 < 8 * (run >> 2); e4 += 256) {
+          const int r = e4 / (run >> 2), rest = (e4 - r * (run >> 2)) << 2;
+          const int i = r0 + r;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (i < it.I) v = *reinterpret_cast<const f32x4*>(it.src + ((size_t)i * sJ + c0) * T + rest);
+          float* d = tile + r * (run + 1) + rest;
+          d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+      } else {
+        for (int e = tid; e < 8 * run; e += 256) {
+          const int r = e / run, rest = e - r * run;
+          const int i = r0 + r, j = c0 + rest / T;
+          tile[r * (run + 1) + rest] = (i < it.I && j < it.J) ? it.src[((size_t)i * sJ + c0) * T + rest] : 0.f;
+        }
       }
-    } else {             // pack row = j, pack col = i : LDS [32 c][8 r][T], each c padded by one float
+    } else {             // pack row = j, pack col = i
       const int run = 8 * T;
-      for (int e = tid; e < 32 * run; e += 256) {
-        const int c = e / run, rest = e - c * run;
-        const int i = c0 + c, j = r0 + rest / T;
-        tile[c * (run + 1) + rest] = (i < it.I && j < it.J) ? it.src[((size_t)i * sJ + r0) * T + rest] : 0.f;
+      const bool vec = al && r0 + 8 <= it.J;
+      if (vec) {
+        for (int e4 = tid; e4 < 32 * (run >> 2); e4 += 256) {
+          const int c = e4 / (run >> 2), rest = (e4 - c * (run >> 2)) << 2;
+          const int i = c0 + c;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (i < it.I) v = *reinterpret_cast<const f32x4*>(it.src + ((size_t)i * sJ + r0) * T + rest);
+          float* d = tile + c * (run + 1) + rest;
+          d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+      } else {
+        for (int e = tid; e < 32 * run; e += 256) {
+          const int c = e / run, rest = e - c * run;
+          const int i = c0 + c, j = r0 + rest / T;
+          tile[c * (run + 1) + rest] = (i < it.I && j < it.J) ? it.src[((size_t)i * sJ + r0) * T + rest] : 0.f;
+        }
       }
     }
     __syncthreads();
-    const int r = tid >> 5, c = tid & 31;
-    const float* sp = it.mode == 0 ? tile + (r * 32 + c) * T : tile + c * (8 * T + 1) + r * T;
-    float* dp = it.dst + ((size_t)(r0 + r)) * (it.dld ? it.dld : it.cols) + c0 + c;
-    const size_t tstride = it.tstride ? (size_t)it.tstride : (size_t)it.rows * it.cols;
-    for (int t = 0; t < T; ++t) dp[t * tstride] = sp[t];
+    if (al) {  // thread -> (tap lane tid >> 6, row (tid >> 3) & 7, four columns 4 (tid & 7)): one 128-byte row segment per 8 lanes
+      const int r = (tid >> 3) & 7, c4 = (tid & 7) << 2;
+      float* dp = it.dst + (size_t)(r0 + r) * dld + c0 + c4;
+      for (int t = tid >> 6; t < T; t += 4) {
+        f32x4 v;
+        if (it.mode == 0) {
+          const float* sp = tile + r * (32 * T + 1) + c4 * T + t;
+          v[0] = sp[0]; v[1] = sp[T]; v[2] = sp[2 * T]; v[3] = sp[3 * T];
+        } else {
+          const float* sp = tile + c4 * (8 * T + 1) + r * T + t;
+          v[0] = sp[0]; v[1] = sp[8 * T + 1]; v[2] = sp[2 * (8 * T + 1)]; v[3] = sp[3 * (8 * T + 1)];
+        }
+        *reinterpret_cast<f32x4*>(dp + (size_t)t * tstride) = v;
+      }
+    } else {
+      const int r = tid >> 5, c = tid & 31;
+      const float* sp = it.mode == 0 ? tile + r * (32 * T + 1) + c * T : tile + c * (8 * T + 1) + r * T;
+      float* dp = it.dst + ((size_t)(r0 + r)) * dld + c0 + c;
+      for (int t = 0; t < T; ++t) dp[t * tstride] = sp[t];
+    }
     __syncthreads();
   }
 }

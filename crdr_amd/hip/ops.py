@@ -161,11 +161,17 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def workspace(nbytes: int, device) -> Tuple[int, int]:
-    """Grow-only per-device scratch (kernels on one stream serialise, so one buffer is enough)."""
+_WS_HEAD = 4 * 16384  # bytes at the head of every scratch buffer: the split-K tickets of the conv kernels (CRDR_CONV_TICKETS int32)
+
+
+def workspace(nbytes: int, device, conv: bool = False) -> Tuple[int, int]:
+    """Grow-only per-device scratch (kernels on one stream serialise, so one buffer is enough).  The buffer is born zeroed and
+    its first _WS_HEAD bytes belong to the conv kernels' split-K tickets, which every launch leaves at zero (include/crdr_hip.h,
+    CRDR_CONV_TICKETS): conv launches (`conv=True`) get the buffer from its start, everything else the part behind the head."""
     global _ws_max
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
-    _ws_max = max(_ws_max, int(nbytes))
+    nbytes = int(nbytes) + (0 if conv else _WS_HEAD)
+    _ws_max = max(_ws_max, nbytes)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
@@ -174,9 +180,11 @@ def workspace(nbytes: int, device) -> Tuple[int, int]:
                                  f"need {nbytes} bytes, have {0 if buf is None else buf.numel()}")
         if buf is not None:
             _ws_keep.append(buf)
-        buf = torch.empty(max(int(_ws_max * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        buf = torch.zeros(max(int(_ws_max * 1.25), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
-    return buf.data_ptr(), buf.numel()
+    if conv:
+        return buf.data_ptr(), buf.numel()
+    return buf.data_ptr() + _WS_HEAD, buf.numel() - _WS_HEAD
 
 
 def reserve_workspace(device, stream: "torch.cuda.Stream") -> None:
@@ -189,7 +197,7 @@ def reserve_workspace(device, stream: "torch.cuda.Stream") -> None:
     if buf is None or buf.numel() < need:
         if buf is not None:
             _ws_keep.append(buf)
-        _ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+        _ws_cache[key] = torch.zeros(need, dtype=torch.uint8, device=dev)
 
 
 def _require_gpu(t: torch.Tensor):
@@ -317,12 +325,12 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
             def run(a):
                 d.reserved = a
                 nb = lib.crdr_conv2d_workspace(C.byref(d))
-                w_, wn_ = workspace(nb, x.device) if nb else (None, 0)
+                w_, wn_ = workspace(nb, x.device, conv=True) if nb else (None, 0)
                 return lib.crdr_conv2d(C.byref(d), C.byref(io), w_, wn_, _stream()) == 0
             algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids())
         d.reserved = algo
     nbytes = lib.crdr_conv2d_workspace(C.byref(d))
-    ws, ws_n = workspace(nbytes, x.device) if nbytes else (None, 0)
+    ws, ws_n = workspace(nbytes, x.device, conv=True) if nbytes else (None, 0)
     e0 = _prof_begin()
     L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), ws, ws_n, _stream()), "conv2d")
     _prof_end("igemm", 2.0 * n * (h * w if transposed else oh * ow) * c * oc * k[0] * k[1], e0,
@@ -618,12 +626,12 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
             def run(a):
                 d.reserved = a
                 nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
-                w_, wn_ = workspace(nb, device) if nb else (None, 0)
+                w_, wn_ = workspace(nb, device, conv=True) if nb else (None, 0)
                 return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
             algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids())
         d.reserved = algo
     nbytes = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
-    ws, ws_n = workspace(nbytes, device) if nbytes else (None, 0)
+    ws, ws_n = workspace(nbytes, device, conv=True) if nbytes else (None, 0)
     e0 = _prof_begin()
     L.check(lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream()), "conv2d_grouped")
     _prof_end("igemm", 2.0 * G * n * h * w * x0.c * oc * k[0] * k[1], e0,
@@ -908,7 +916,7 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
                     for g in range(G):
                         tio[g].cs = bufs[g]
                 nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
-                w_, wn_ = workspace(nb, device) if nb else (None, 0)
+                w_, wn_ = workspace(nb, device, conv=True) if nb else (None, 0)
                 return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
             algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids())
         d.reserved = algo
@@ -919,7 +927,7 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
             ios[g].cs = bufs[g]
         out = [(b, rows, ld) for b in bufs]
     nbytes = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
-    ws, ws_n = workspace(nbytes, device) if nbytes else (None, 0)
+    ws, ws_n = workspace(nbytes, device, conv=True) if nbytes else (None, 0)
     e0 = _prof_begin()
     L.check(lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream()), "conv2d_grouped")
     _prof_end("igemm", 2.0 * G * n * (h * w if transposed else oh * ow) * x0.c * oc * k[0] * k[1], e0,

@@ -70,6 +70,7 @@ int crdr_profile_read(int kind, double* flops, double* ms, long long* launches);
  * whose output gradient an input-gradient launch produces.  crdr_conv2d_colsum_layout gives the number of partial rows
  * and their stride; crdr_colsum_finish_batched adds them up in row order (deterministic). */
 #define CRDR_EPI_COLSUM 4096
+#define CRDR_CONV_NOSPLIT 8192 /* plan without split-K (the caller's workspace cannot hold the zeroed tickets, see CRDR_CONV_TICKETS) */
 
 typedef struct crdr_conv_desc {
   /* "in" tensor [N][H][W][C] (NHWC, pixel stride ldx) and "out" tensor [N][OH][OW][OC] (pixel stride ldy) */
@@ -94,6 +95,12 @@ typedef struct crdr_conv_desc {
   int32_t ldpre;    /* pixel stride of pre  (CRDR_EPI_PREADD)   */
   int32_t ldmask;   /* pixel stride of mask (CRDR_EPI_RELUMASK) */
 } crdr_conv_desc;
+
+/* Split-K plans (crdr_conv2d_workspace(d) > 0) reduce inside the launch: every K split publishes its partial tile, takes a
+ * ticket, and the workgroup that arrives last adds the slabs in split order and runs the epilogue.  The tickets are the first
+ * CRDR_CONV_TICKETS int32 of the workspace: they must be ZERO when the first launch that uses a workspace buffer starts, and
+ * every launch leaves them zero -- hand the same (initially zeroed) buffer to successive launches of one stream. */
+#define CRDR_CONV_TICKETS 16384
 
 typedef struct crdr_conv_io {
   const float* x;

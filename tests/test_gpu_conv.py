@@ -412,7 +412,7 @@ def test_streaming_1x1_variants(case):
             cs = torch.full((rows.value, 2, ld.value), float("nan"), device=dev)
             io.cs = cs.data_ptr()
         nb = lib.crdr_conv2d_workspace(C.byref(d))
-        ws = torch.empty(max(nb, 4) // 4, device=dev)
+        ws = torch.zeros(max(nb, 4) // 4, device=dev)   # split-K tickets at the head: zero on entry (CRDR_CONV_TICKETS)
         L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), ws.data_ptr(), nb, s), f"conv2d algo {algo} flags {flags}")
         torch.cuda.synchronize()
         return y, cs
@@ -483,7 +483,7 @@ def test_streaming_1x1_grouped():
             ios[g].x, ios[g].w, ios[g].y = X[g].data_ptr(), W[g].data_ptr(), ys[g].data_ptr()
             ios[g].bias, ios[g].res, ios[g].mask, ios[g].cs = B[g].data_ptr(), R[g].data_ptr(), K[g].data_ptr(), css[g].data_ptr()
         nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
-        ws = torch.empty(max(nb, 4) // 4, device=dev)
+        ws = torch.zeros(max(nb, 4) // 4, device=dev)   # split-K tickets at the head: zero on entry (CRDR_CONV_TICKETS)
         L.check(lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws.data_ptr(), nb, s), f"grouped algo {algo}")
         torch.cuda.synchronize()
         return ys, css
@@ -602,3 +602,80 @@ def test_column_sums_every_tile_config():
         pre = torch.nn.functional.conv2d(x.double().cpu(), wt.double(), padding=1).permute(0, 2, 3, 1).reshape(M, co).sum(0)
         _close(cs[:, 1, :co].sum(0), post, f"cfg {c}: column sums after the mask", rtol=1e-4)
         _close(cs[:, 0, :co].sum(0), pre, f"cfg {c}: column sums before the mask", rtol=1e-4)
+
+
+def test_splitk_in_launch_reduce_is_exact_deterministic_and_self_cleaning():
+    """Split-K plans reduce inside the launch (igemm.hip: write-through slabs, ticket, last arriver adds the slabs in split order):
+    every tile configuration x split depth on the Charm's 224->128 5x5 @16x16 shape, with every epilogue class (fast path,
+    PREADD + bias + ReLU, ACCUM, mask + column sums), against fp64; 12 back-to-back launches on ONE workspace are bit-identical
+    (the sum order is fixed, whoever arrives last) while a second stream keeps the chip unevenly loaded, and the tickets at the
+    head of the workspace are zero again after every launch."""
+    import ctypes as C
+    from crdr_amd.hip import ops, lib as L
+    dev = _dev()
+    lib = L.load()
+    n, ci, co, hh, k = 16, 224, 128, 16, 5
+    M = n * hh * hh
+    x = _rand(n, ci, hh, hh, seed=1)
+    wt = _rand(co, ci, k, k, seed=2, scale=(ci * k * k) ** -0.5)
+    b = _rand(co, seed=3)
+    ref = F.conv2d(x.double(), wt.double(), None, padding=2).permute(0, 2, 3, 1).reshape(M, co)
+    X = x.permute(0, 2, 3, 1).reshape(M, ci).contiguous().to(dev)
+    wp = ops.pack_weight(wt.to(dev), False)
+    bd = b.to(dev)
+    PRE = _rand(M, co, seed=8).to(dev)
+    MSK = _rand(M, co, seed=9).to(dev)
+    Y0 = _rand(M, co, seed=10).to(dev)
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    noise_a = torch.randn(4096, 4096, device=dev)
+    cases = {
+        "fast": (L.EPI_BIAS | L.EPI_RELU, lambda r: torch.relu(r + b.double())),
+        "preadd": (L.EPI_PREADD | L.EPI_BIAS | L.EPI_RELU, lambda r: torch.relu(r + PRE.cpu().double() + b.double())),
+        "accum": (L.EPI_ACCUM, lambda r: r + Y0.cpu().double()),
+        "mask+colsum": (L.EPI_RELUMASK | L.EPI_COLSUM, lambda r: torch.where(MSK.cpu() > 0, r, torch.zeros_like(r))),
+    }
+    ran = 0
+    for cfg in range(lib.crdr_conv2d_num_configs()):
+        for ls in (1, 2, 3, 4):
+            algo = (cfg + 1) | (ls << 8)
+            for cname, (flags, fref) in cases.items():
+                d = L.ConvDesc(N=n, H=hh, W=hh, C=ci, OH=hh, OW=hh, OC=co, kh=k, kw=k, stride=1, pad=2, transposed=0, ldx=ci, ldy=co,
+                               wrows=wp.shape[1], wcols=wp.shape[2], flags=flags, ldres=0, ldg=0, wlayout=0, reserved=algo, ldpre=co, ldmask=co)
+                nb = lib.crdr_conv2d_workspace(C.byref(d))
+                if nb == 0:
+                    continue   # the library rejects this combination (too few K tiles per split, too many tiles)
+                if (ls, cname) not in ((3, "fast"), (3, "preadd"), (2, "accum"), (4, "mask+colsum"), (1, "mask+colsum")) and cfg % 5:
+                    continue   # every configuration sees the main classes; the full cross product on every fifth
+                ws = torch.zeros(nb // 4, device=dev)
+                cs = None
+                outs = []
+                reps = 12 if cfg % 5 == 0 else 3
+                for rep in range(reps):
+                    y = Y0.clone()
+                    io = L.ConvIO(x=X.data_ptr(), w=wp.data_ptr(), y=y.data_ptr(), bias=bd.data_ptr(), pre=PRE.data_ptr(), mask=MSK.data_ptr())
+                    if flags & L.EPI_COLSUM:
+                        rows, ld = C.c_int(), C.c_int()
+                        L.check(lib.crdr_conv2d_colsum_layout(C.byref(d), 1, C.byref(rows), C.byref(ld)), "layout")
+                        cs = torch.full((rows.value, 2, ld.value), float("nan"), device=dev)
+                        io.cs = cs.data_ptr()
+                    if rep % 2:   # uneven load: a GEMM on another stream competes for some of the CUs
+                        with torch.cuda.stream(side):
+                            torch.mm(noise_a[: 512 * (1 + rep % 3)], noise_a)
+                    L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), ws.data_ptr(), nb, main.cuda_stream), f"conv2d cfg {cfg} split {1 << ls} {cname}")
+                    outs.append((y, cs))
+                torch.cuda.synchronize()
+                assert int(ws[:16384].view(torch.int32).abs().max()) == 0, f"tickets not back at zero (cfg {cfg} split {1 << ls} {cname})"
+                _close(outs[0][0], fref(ref), f"cfg {cfg} split {1 << ls} {cname}")
+                for y, c_ in outs[1:]:
+                    assert torch.equal(y, outs[0][0]), f"cfg {cfg} split {1 << ls} {cname}: launches differ"
+                    if c_ is not None:
+                        assert torch.equal(c_, outs[0][1])
+                if cs is not None:
+                    got = outs[0][1].double().cpu()
+                    want_pre, want_post = ref.sum(0), fref(ref).sum(0)
+                    scale = ref.abs().sum(0).max().item()
+                    assert (got[:, 0, :co].sum(0) - want_pre).abs().max().item() <= 2e-5 * scale
+                    assert (got[:, 1, :co].sum(0) - want_post).abs().max().item() <= 2e-5 * scale
+                ran += 1
+    assert ran >= 3 * lib.crdr_conv2d_num_configs(), ran
