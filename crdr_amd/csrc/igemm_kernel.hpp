@@ -1,0 +1,672 @@
+// Implicit-GEMM convolution on CDNA4 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+//   out[pix][oc] = epilogue( sum_{tap, c} in[gather(pix, tap)][c] * wpack[tap][oc][c] )
+//
+// One kernel covers Conv2d forward, ConvTranspose2d forward and both input gradients: a launch is a set of
+// "phases" (sub-pixel output grids); every phase owns the taps that can reach it, so a stride-2 transposed
+// conv does only the (k/2)^2-ish taps per output instead of zero-stuffing.
+//
+// Tiling: block = WM x WN waves (one wave per SIMD), wave tile = (32 MB) x (32 NB) made of 32x32 MFMA blocks,
+// K-tile = 32 input channels of one tap.  A (gathered activations) and B (packed weights) K-tiles are both
+// "rows of 128 B": staged global -> registers -> LDS (zero fill for padding taps), double buffered, one
+// barrier per K-tile.  Each lane reads 16 B (4 consecutive k) per 32-row fragment and feeds 4 MFMAs: lane half
+// h owns k = 4h..4h+3 of every 8-wide k group, identically for A and B, so the sum over k is complete.
+// Split-K (blockIdx.z): every split publishes its raw partial tile (write-through stores), takes a ticket on the tile's
+// counter, and the workgroup that arrives last adds the slabs in split order and runs the epilogue -- one launch, and the
+// result does not depend on which split came last.
+
+#include <algorithm>
+#include <atomic>
+#include <type_traits>
+
+#pragma once
+
+#include "common.hpp"
+#include "igemm_args.hpp"
+
+#ifndef CRDR_IGEMM_FETCH_FIRST
+#define CRDR_IGEMM_FETCH_FIRST 1
+#endif
+
+namespace crdr {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// epilogue on one element; opix = output pixel index, oc = channel
+__device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, int oc, float v, float& vpre, float& vpost) {
+  const int f = p.flags;
+  if (f & CRDR_EPI_PREADD) v += p.pre[opix * p.ldpre + oc];
+  if (f & CRDR_EPI_BIAS) v += p.bias[oc];
+  if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
+  if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
+  if (f & CRDR_EPI_VEC2) v += p.vec2[oc];
+  if (f & CRDR_EPI_RES) v += p.res[opix * p.ldres + oc];
+  if (f & CRDR_EPI_GATE) {
+    const float s = 1.0f / (1.0f + expf(-v));
+    p.sig[opix * p.ldg + oc] = s;
+    v = p.gx[opix * p.ldg + oc] + p.gt[opix * p.ldg + oc] * s;
+  }
+  if (f & CRDR_EPI_AFFINE) v = v * p.scale[oc] + p.shift[oc];
+  vpre = v;
+  if (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) {
+    const float mv = p.mask[opix * p.ldmask + oc] - ((f & CRDR_EPI_MASKOFF) ? p.vec2[oc] : 0.0f);
+    v = mv > 0.0f ? v : ((f & CRDR_EPI_LRELUMASK) ? 0.2f * v : 0.0f);
+  }
+  vpost = v;
+  float* dst = p.y + opix * p.ldy + oc;
+  if (f & CRDR_EPI_ACCUM) v += *dst;
+  *dst = v;
+}
+
+// Staging is LDS-DMA: `buffer_load_dwordx4 ... lds` moves 16 bytes per lane straight from global memory into LDS
+// (1 KiB = 8 tile rows per wave instruction, lane-linear destination), so the K loop carries no staging registers,
+// no ds_write pass and no zero-fill selects: rows / channel chunks / taps that fall outside the tensor get a byte
+// offset beyond the buffer descriptor's range and the hardware range check returns zeros for them.  The XOR swizzle
+// of the tile image (lds_off) is applied on the SOURCE side: the lane that fills slot s of row r fetches chunk
+// s ^ ((r >> 1) & 7).
+
+template <int WM, int WN, int MB, int NB, bool SMALLC>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
+  constexpr int BM = 32 * WM * MB, BN = 32 * WN * NB, NT = 64 * WM * WN;
+  constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;  // 16-byte pieces per thread per K-tile
+  static_assert(AV * NT == BM * 8 && BV * NT == BN * 8, "tile/threads mismatch");
+  constexpr int RPP = NT / 8;  // tile rows filled by one pass of the whole block
+  static_assert(RPP % 16 == 0, "the swizzle term must not depend on the pass");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                                        // [2][BM*32]
+  float* sB = smem + 2 * BM * 32;                          // [2][BN*32]
+  int* sTap = reinterpret_cast<int*>(smem + 2 * (BM + BN) * 32);  // [<=132] packed (dh, dw, widx) of this phase
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs (each with its own L2) in linear
+  // block-id order; remap so that every XCD walks a CONTIGUOUS range of tiles ordered (M tile, phase/split, N tile):
+  // the N tiles, phases and K splits that read the same activation rows then run back to back on one L2.
+  int tile_m, tile_n, tile_z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int nwg = gx * gy * gz, bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int cpx = nwg >> 3;
+    const int t = bid < cpx * 8 ? (bid & 7) * cpx + (bid >> 3) : bid;
+    if (p_.m_inner) {  // weights dominate the traffic: keep one weight tile in L2 while the M tiles stream past it
+      tile_m = t % gx;
+      tile_z = (t / gx) % gz;
+      tile_n = t / (gx * gz);
+    } else {
+      tile_n = t % gy;
+      tile_z = (t / gy) % gz;
+      tile_m = t / (gy * gz);
+    }
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // problem of a grouped launch (workgroup-uniform): its pointers replace the ones in the argument block
+  IgemmArgs p = p_;
+  const int zper = p.nphase * p.nsplit;
+  const int gidx = tile_z / zper;
+  tile_z -= gidx * zper;
+  if (p.ngroup > 1) {
+    p.x = grp.x[gidx]; p.w = grp.w[gidx]; p.y = grp.y[gidx];
+    p.bias = grp.bias[gidx]; p.pre = grp.pre[gidx]; p.mask = grp.mask[gidx]; p.res = grp.res[gidx]; p.cs = grp.cs[gidx];
+  }
+  const int phase = tile_z / p.nsplit, split = tile_z % p.nsplit;
+  const int tb = tp.tap_begin[phase], te = tp.tap_begin[phase + 1];
+  const int ntap = te - tb;
+  const int KT = SMALLC ? p.kchunks : ntap * p.kchunks;
+  const int it0 = (int)((long long)KT * split / p.nsplit), it1 = (int)((long long)KT * (split + 1) / p.nsplit);
+  const int poh = tp.poh[phase], pow_ = tp.pow[phase];
+  const int H = p.H, W = p.W, ldx = p.ldx, Cin = p.Cin, kchunks = p.kchunks;
+
+  int mintap = 0;  // most negative pixel offset any tap of this phase reaches (wave-uniform)
+  for (int t = 0; t < ntap; ++t) {  // wave-uniform index: scalar loads from the kernarg segment
+    const int v = tp.packed[tb + t];
+    if (tid == 0) sTap[t] = v;
+    mintap = min(mintap, (int)(signed char)(v & 0xff) * W + (int)(signed char)((v >> 8) & 0xff));
+  }
+  if (tid < 4) sTap[ntap + tid] = 0;  // the cursor may run one K-tile past the end (range-checked, never consumed)
+
+  // The input descriptor is re-based at the first pixel this workgroup can touch, so the 32-bit byte offsets below only
+  // have to span one tile (+ halo) and the tensor itself may be of any size.
+  long long base_pix;
+  {
+    const int hw0 = p.GH * p.GW;
+    const int nn = m0 / hw0, rem0 = m0 - nn * hw0, a0 = rem0 / p.GW, b0 = rem0 - a0 * p.GW;
+    base_pix = (long long)(nn * H + a0 * p.si) * W + b0 * p.si + mintap;
+    base_pix = base_pix < 0 ? 0 : base_pix;
+  }
+  const unsigned long long base_bytes = (unsigned long long)base_pix * ldx * 4ull;
+  const unsigned long long left = p.x_bytes - base_bytes;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x) + base_pix * ldx, 0, (unsigned)(left < 0x7fffffffull ? left : 0x7fffffffull), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  // ---- staging assignment: thread fills slot (tid & 7) of rows (tid >> 3) + j * RPP
+  const int srow = tid >> 3;
+  const int csrc = (tid & 7) ^ ((srow >> 1) & 7);  // source chunk landing in this thread's slot
+  unsigned a_off[AV];
+  int a_ih[AV], a_iw[AV];
+#pragma unroll
+  for (int j = 0; j < AV; ++j) {
+    const int m = m0 + srow + j * RPP;
+    const int hw = p.GH * p.GW;
+    const int n = m / hw, rem = m - n * hw, a = rem / p.GW, b = rem - a * p.GW;
+    const bool ok = (m < p.M) && (a * p.so + poh < p.OH) && (b * p.so + pow_ < p.OW);
+    a_ih[j] = ok ? a * p.si : -(1 << 24);  // a dead row fails every bounds test below
+    a_iw[j] = ok ? b * p.si : 0;
+    a_off[j] = ok ? (unsigned)(((long long)(n * H + a * p.si) * W + b * p.si - base_pix) * ldx + (SMALLC ? 0 : csrc * 4)) * 4u : 0u;
+  }
+  unsigned b_off[BV];
+#pragma unroll
+  for (int j = 0; j < BV; ++j) {
+    const int oc = n0 + srow + j * RPP;
+    b_off[j] = oc < p.wrows ? (unsigned)(oc * p.wcols + csrc * 4) * 4u : kOobOffset;
+  }
+  // per-column epilogue vectors of this N tile (neutral values where a flag is off or past Cout), read by the fast epilogue
+  constexpr int kG = NB < 4 ? NB : 4;
+  constexpr int kStagingFloats = 2 * (BM + BN) * 32 + 132;
+  constexpr int kEpiFloats = WM * WN * 32 * 32 * kG + WM * 2 * BN;
+  constexpr int kSvOff = ((kStagingFloats > kEpiFloats ? kStagingFloats : kEpiFloats) + 3) & ~3;
+  float* sV = smem + kSvOff;  // [4][BN]: bias, vec2, scale, shift
+  __syncthreads();  // sTap visible
+
+  // K-iteration cursor of the NEXT tile to fetch: tap index (relative to tb) and channel chunk
+  int lt = SMALLC ? 0 : it0 / kchunks, lc = SMALLC ? it0 : it0 - lt * kchunks;
+  auto fetch = [&](int buf) __attribute__((always_inline)) {
+    float* a = sA + buf * BM * 32 + wave * 8 * 32;
+    float* b = sB + buf * BN * 32 + wave * 8 * 32;
+    int dh, dw;
+    unsigned toff, woff;
+    bool cok;
+    if constexpr (SMALLC) {  // this thread's piece is tap (8 lc + csrc), channels 0..3
+      const int ti = lc * 8 + csrc;
+      cok = ti < ntap;
+      const int t = sTap[cok ? ti : 0];
+      dh = (int)(signed char)(t & 0xff); dw = (int)(signed char)((t >> 8) & 0xff);
+      toff = (unsigned)((dh * W + dw) * ldx) * 4u;
+      woff = (unsigned)(lc * 32) * 4u;
+    } else {
+      const int t = __builtin_amdgcn_readfirstlane(sTap[lt]);
+      dh = (int)(signed char)(t & 0xff); dw = (int)(signed char)((t >> 8) & 0xff);
+      const int wi = t >> 16;
+      cok = lc * 32 + csrc * 4 < Cin;
+      toff = (unsigned)((dh * W + dw) * ldx + lc * 32) * 4u;
+      woff = (unsigned)(wi * p.wrows * p.wcols + lc * 32) * 4u;
+    }
+#pragma unroll
+    for (int j = 0; j < AV; ++j) {
+      const int ih = a_ih[j] + dh, iw = a_iw[j] + dw;
+      const bool ok = cok & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(a + j * RPP * 32), 16, (int)(ok ? a_off[j] + toff : kOobOffset),
+                                               0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BV; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(b + j * RPP * 32), 16, (int)(b_off[j] + woff), 0, 0, 0);
+    if (++lc == kchunks && !SMALLC) { lc = 0; ++lt; }
+    __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the MFMA stream that hides its latency
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fh = lane >> 5;
+  const float* fa = sA + (wm * MB * 32) * 32;
+  const float* fb = sB + (wn * NB * 32) * 32;
+  int fo[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) fo[kk] = lds_off(frow, kk * 2 + fh);
+  // one K-tile: kk = [K0, K1) quarter steps of 8 K values each, out of LDS buffer `buf`
+  auto compute = [&](auto bufc, auto k0c, auto k1c) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value, K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+#pragma unroll
+    for (int kk = K0; kk < K1; ++kk) {
+      f32x4 af[MB], bf[NB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const f32x4*>(fa + fo[kk] + (buf * BM * 32 + i * 1024));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bf[j] = *reinterpret_cast<const f32x4*>(fb + fo[kk] + (buf * BN * 32 + j * 1024));
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  using std::integral_constant;
+  using I0 = integral_constant<int, 0>;
+  using I1 = integral_constant<int, 1>;
+  using I4 = integral_constant<int, 4>;
+  // a step = the MFMAs of one tile with the DMA of the next one issued behind the first quarter, so that its address
+  // arithmetic and issue slots run in the shadow of MFMAs already queued
+  auto step = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+#if CRDR_IGEMM_FETCH_FIRST
+    fetch(buf ^ 1);
+    compute(bufc, I0{}, I4{});
+#else
+    compute(bufc, I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(buf ^ 1);
+    compute(bufc, I1{}, I4{});
+#endif
+    __syncthreads();
+  };
+  if (it0 < it1) fetch(0);
+  // (behind the first DMA so that their latencies overlap; the barrier below publishes both)
+  if (p.fast_epi) {
+    const int f0 = p.flags;
+    for (int c = tid; c < BN; c += NT) {
+      const bool live = n0 + c < p.Cout;
+      sV[0 * BN + c] = (live && (f0 & CRDR_EPI_BIAS)) ? p.bias[n0 + c] : 0.f;
+      sV[1 * BN + c] = (live && (f0 & (CRDR_EPI_VEC2 | CRDR_EPI_MASKOFF))) ? p.vec2[n0 + c] : 0.f;
+      sV[2 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.scale[n0 + c] : 1.f;
+      sV[3 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[n0 + c] : 0.f;
+    }
+  }
+  __syncthreads();
+  int it = it0;
+  for (; it + 2 <= it1; it += 2) {
+    step(I0{});
+    step(I1{});
+  }
+  if (it < it1) {
+    compute(I0{}, I0{}, I4{});
+    __syncthreads();
+  }
+
+  // ---- epilogue.  The accumulators go through LDS (the staging buffers are free now) so that every lane handles
+  // 4 consecutive channels of one pixel: 16-byte residual / gate loads and 16-byte stores, 512 B contiguous per
+  // 32 lanes.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  constexpr int G = NB < 4 ? NB : 4;          // 32-column blocks staged per pass
+  constexpr int CLD = 32 * G;                 // floats per staged row
+  float* sC = smem + wave * (32 * CLD);       // per-wave [32][CLD]
+  const int f = p.flags;
+  const int hw = p.GH * p.GW;
+  const bool direct = (p.nphase == 1) && (p.so == 1);  // output pixel index == GEMM row
+  const bool vec = p.vec_epi != 0;
+
+  // ---- split-K inside the launch.  Slabs: ws[group][phase][split][M][ws_ld], this tile's part addressed through ONE buffer
+  // descriptor based at split 0 (build_plan keeps nsplit * M * ws_ld * 4 below 2 GiB).  Hand-off (MI355X_MICROARCH.md,
+  // "Workgroup dispatch, XCD placement & inter-workgroup visibility"): every slab byte is stored sc1 (write-through: no L2
+  // write-back needed), every storing wave drains vmcnt, the workgroup barrier, then ONE lane takes the ticket with an
+  // agent-scope atomic; the workgroup whose ticket is nsplit - 1 acquires (buffer_inv sc1) and reads all slabs with sc1 loads
+  // in split order.  Placement independent, no spinning: a workgroup either leaves or reduces.
+  const bool splitk = p.nsplit > 1;
+  const unsigned slab_bytes = splitk ? (unsigned)((size_t)p.M * p.ws_ld * 4u) : 0u;
+  __amdgpu_buffer_rsrc_t rws = rw;
+  if (splitk)
+    rws = __builtin_amdgcn_make_buffer_rsrc(
+        p.ws + (size_t)(gidx * p.nphase + phase) * p.nsplit * ((size_t)p.M * p.ws_ld) + (size_t)m0 * p.ws_ld + n0, 0, 0x7fffffff, 0x00020000);
+  // byte offset (relative to rws) of the 16-byte group that lane position q of pass (I, JG, GC) owns in split 0's slab
+  auto slab_off = [&](int I, int JG, int GC, int q) __attribute__((always_inline)) {
+    const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+    const int rr = (wm * MB + I) * 32 + row;
+    return (m0 + rr < p.M) ? (unsigned)(rr * p.ws_ld + (wn * NB + JG) * 32 + c4 * 4) * 4u : kOobOffset;
+  };
+  if (splitk) {
+    auto wpass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+      constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+#pragma unroll
+      for (int jj = 0; jj < GC; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
+      // sC is private to the wave: program order is enough
+#pragma unroll
+      for (int k = 0; k < 4 * GC; ++k) {
+        const int q = lane + 64 * k;
+        const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * CLD + c4 * 4);
+        const unsigned o = slab_off(I, JG, GC, q);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a4), rws, o == kOobOffset ? o : o + (unsigned)split * slab_bytes, 0,
+                                               16 /* sc1 */);
+      }
+    };
+    wpass(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+    if constexpr (NB > 4) wpass(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+    if constexpr (MB > 1) {
+      wpass(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+      if constexpr (NB > 4) wpass(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* sFlag = reinterpret_cast<int*>(smem + kSvOff + 4 * BN);
+    if (tid == 0) {
+      int* cnt = p.counters + ((gidx * p.nphase + phase) * (int)gridDim.x + tile_m) * (int)gridDim.y + tile_n;
+      const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == p.nsplit - 1;
+      if (last) {
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next launch finds zeros again
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      *sFlag = last;
+    }
+    __syncthreads();
+    if (!*sFlag) return;
+  }
+  // what the reducer of a split tile puts into sC instead of its accumulators: the sum of the slabs in split order
+  // (((s0 + s1) + s2) + ...), four splits of loads in flight at a time
+  auto rfill = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+    constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+#pragma unroll
+    for (int k = 0; k < 4 * GC; ++k) {
+      const int q = lane + 64 * k;
+      const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+      const unsigned o = slab_off(I, JG, GC, q);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < p.nsplit; s0 += 4) {
+        f32x4 l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          l[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rws, (o == kOobOffset || s0 + j >= p.nsplit) ? kOobOffset : o + (unsigned)(s0 + j) * slab_bytes, 0, 16));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += l[j];   // splits past nsplit read zeros: + 0.f is exact
+      }
+      *reinterpret_cast<f32x4*>(sC + row * CLD + c4 * 4) = v;
+    }
+  };
+  // CRDR_EPI_COLSUM: column sums of this tile's outputs (value before / after the ReLU mask), reduced lane -> wave ->
+  // workgroup in a fixed order and written as one partial row per (phase, M tile); crdr_colsum_finish adds the rows up.
+  // A lane must keep one 4-channel column group for a whole pass, which holds for passes of 1, 2 or 4 column blocks; a pass
+  // of 3 runs as three single-block passes when column sums are requested.
+  const bool do_cs = (f & CRDR_EPI_COLSUM) != 0;   // (of a split tile: by its reducer, from the summed values)
+  float* sS = smem + WM * WN * 32 * CLD;  // [WM][2][BN] behind the staged accumulators
+  // ---- fast epilogue (p.fast_epi): every global access is a buffer instruction issued by all lanes -- dead rows / column
+  // groups get an out-of-range offset, loads return 0 and stores are dropped -- relative to this tile's first output pixel;
+  // bias / vec2 / scale / shift come from sV.  The code is straight-line: no wait on a store anywhere, one wait per batch of
+  // four row groups on the res / mask operands.  Arithmetic and order are those of the general path below.
+  if (p.fast_epi) {
+    const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
+    long long opix0 = m0;
+    if (!direct) {
+      const int n = m0 / hw, rem = m0 - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
+      opix0 = ((long long)n * p.OH + ga * p.so + poh) * p.OW + gb * p.so + pow_;
+    }
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + opix0 * p.ldy, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? p.res + opix0 * p.ldres : p.y), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_mask ? p.mask + opix0 * p.ldmask : p.y), 0, 0x7fffffff, 0x00020000);
+    auto fpass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+      constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+      if (splitk) {
+        rfill(I_, JG_, GC_);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < GC; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
+      }
+      // sC is private to the wave: program order is enough
+      f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < GC; ++kb) {
+        f32x4 res4[4], msk4[4];
+        unsigned yoff[4];
+        int cc[4];
+        bool okk[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+          const int q = lane + 64 * (kb * 4 + kq);
+          const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+          const int m = m0 + (wm * MB + I) * 32 + row;
+          const int oc0 = n0 + (wn * NB + JG) * 32 + c4 * 4;
+          bool live_row = m < p.M;
+          unsigned rel = (unsigned)(m - m0);
+          if (!direct) {
+            const int mm = live_row ? m : m0;
+            const int n = mm / hw, rem = mm - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
+            const int oh = ga * p.so + poh, ow = gb * p.so + pow_;
+            live_row = live_row && (oh < p.OH) && (ow < p.OW);
+            rel = (unsigned)((((long long)n * p.OH + oh) * p.OW + ow) - opix0);
+          }
+          const bool ok = live_row && oc0 < p.Cout;
+          okk[kq] = ok;
+          cc[kq] = (wn * NB + JG) * 32 + c4 * 4;
+          yoff[kq] = ok ? (rel * p.ldy + oc0) * 4u : kOobOffset;
+          if (has_res)
+            res4[kq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? (rel * p.ldres + oc0) * 4u : kOobOffset, 0, 0));
+          if (has_mask)
+            msk4[kq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, ok ? (rel * p.ldmask + oc0) * 4u : kOobOffset, 0, 0));
+        }
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+          const int q = lane + 64 * (kb * 4 + kq);
+          const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * CLD + c4 * 4);
+          const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sV + 0 * BN + cc[kq]);
+          const f32x4 vec24 = *reinterpret_cast<const f32x4*>(sV + 1 * BN + cc[kq]);
+          const f32x4 scale4 = *reinterpret_cast<const f32x4*>(sV + 2 * BN + cc[kq]);
+          const f32x4 shift4 = *reinterpret_cast<const f32x4*>(sV + 3 * BN + cc[kq]);
+          const bool ok = okk[kq];
+          f32x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = a4[e];
+            if (f & CRDR_EPI_BIAS) v += bias4[e];
+            if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
+            if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
+            if (f & CRDR_EPI_VEC2) v += vec24[e];
+            if (has_res) v += res4[kq][e];
+            if (f & CRDR_EPI_AFFINE) v = v * scale4[e] + shift4[e];
+            if (do_cs) cpre[e] += ok ? v : 0.f;
+            if (has_mask) {
+              float mv = msk4[kq][e];
+              if (f & CRDR_EPI_MASKOFF) mv -= vec24[e];
+              v = mv > 0.0f ? v : ((f & CRDR_EPI_LRELUMASK) ? 0.2f * v : 0.0f);
+            }
+            if (do_cs) cpost[e] += ok ? v : 0.f;
+            o4[e] = v;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), ry, yoff[kq], 0, 0);
+        }
+      }
+      if (do_cs) {
+        if constexpr (GC == 1 || GC == 2 || GC == 4) {
+#pragma unroll
+          for (int off = 32; off >= 8 * GC; off >>= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              cpre[e] += __shfl_xor(cpre[e], off, 64);
+              cpost[e] += __shfl_xor(cpost[e], off, 64);
+            }
+          if (lane < 8 * GC) {
+            float* d0 = sS + (wm * 2 + 0) * BN + (wn * NB + JG) * 32 + lane * 4;
+            float* d1 = sS + (wm * 2 + 1) * BN + (wn * NB + JG) * 32 + lane * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if constexpr (I == 0) { d0[e] = cpre[e]; d1[e] = cpost[e]; }
+              else { d0[e] += cpre[e]; d1[e] += cpost[e]; }
+            }
+          }
+        }
+      }
+    };
+    // a pass of three column blocks cannot keep one column group per lane: with column sums it runs as three single-block passes
+    auto fgroup = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+      constexpr int JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+      if constexpr (GC == 3) {
+        if (do_cs) {
+          fpass(I_, integral_constant<int, JG>{}, integral_constant<int, 1>{});
+          fpass(I_, integral_constant<int, JG + 1>{}, integral_constant<int, 1>{});
+          fpass(I_, integral_constant<int, JG + 2>{}, integral_constant<int, 1>{});
+          return;
+        }
+      }
+      fpass(I_, JG_, GC_);
+    };
+    fgroup(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+    if constexpr (NB > 4) fgroup(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+    if constexpr (MB > 1) {
+      fgroup(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+      if constexpr (NB > 4) fgroup(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+    }
+    if (do_cs) {
+      __syncthreads();
+      float* dst = p.cs + ((size_t)(phase * gridDim.x + tile_m) * 2) * p.cs_ld;
+      for (int t = tid; t < 2 * BN; t += NT) {
+        const int which = t / BN, c = t - which * BN;
+        float v = sS[(0 * 2 + which) * BN + c];
+#pragma unroll
+        for (int w2 = 1; w2 < WM; ++w2) v += sS[(w2 * 2 + which) * BN + c];
+        if (n0 + c < p.Cout) dst[(size_t)which * p.cs_ld + n0 + c] = v;
+      }
+    }
+    return;
+  }
+  // one pass = GC column blocks [JG, JG+GC) of accumulator row-block I (all compile-time so acc stays in registers)
+  auto pass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+    constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+    if (splitk) {
+      rfill(I_, JG_, GC_);
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < GC; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sC[((r & 3) + 8 * (r >> 2) + 4 * fh) * CLD + jj * 32 + frow] = acc[I][JG + jj][r];
+    }
+    __syncthreads();
+    f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4 * GC; ++k) {
+      const int q = lane + 64 * k;
+      const int row = q / (8 * GC), c4 = q - row * (8 * GC);
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * CLD + c4 * 4);
+      const int m = m0 + (wm * MB + I) * 32 + row;
+      const int oc0 = n0 + (wn * NB + JG) * 32 + c4 * 4;
+      bool live_row = m < p.M;
+      {
+        size_t opix = (size_t)m;
+        if (!direct) {
+          const int mm = live_row ? m : 0;
+          const int n = mm / hw, rem = mm - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
+          const int oh = ga * p.so + poh, ow = gb * p.so + pow_;
+          live_row = live_row && (oh < p.OH) && (ow < p.OW);
+          opix = ((size_t)n * p.OH + oh) * p.OW + ow;
+        }
+        if (live_row && oc0 < p.Cout) {
+          const bool full = vec && (oc0 + 3 < p.Cout);
+          f32x4 res4 = {0.f, 0.f, 0.f, 0.f}, gx4 = res4, gt4 = res4, old4 = res4, pre4 = res4, msk4 = res4;
+          if (full) {
+            if (f & CRDR_EPI_PREADD) pre4 = *reinterpret_cast<const f32x4*>(p.pre + opix * p.ldpre + oc0);
+            if (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) msk4 = *reinterpret_cast<const f32x4*>(p.mask + opix * p.ldmask + oc0);
+            if (f & CRDR_EPI_RES) res4 = *reinterpret_cast<const f32x4*>(p.res + opix * p.ldres + oc0);
+            if (f & CRDR_EPI_GATE) {
+              gx4 = *reinterpret_cast<const f32x4*>(p.gx + opix * p.ldg + oc0);
+              gt4 = *reinterpret_cast<const f32x4*>(p.gt + opix * p.ldg + oc0);
+            }
+            if (f & CRDR_EPI_ACCUM) old4 = *reinterpret_cast<const f32x4*>(p.y + opix * p.ldy + oc0);
+          }
+          f32x4 o4, s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int oc = oc0 + e;
+            const bool live = oc < p.Cout;
+            float v = a4[e];
+            if (f & CRDR_EPI_PREADD) v += full ? pre4[e] : (live ? p.pre[opix * p.ldpre + oc] : 0.f);
+            if (f & CRDR_EPI_BIAS) v += live ? p.bias[oc] : 0.f;
+            if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
+            if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
+            if (f & CRDR_EPI_VEC2) v += live ? p.vec2[oc] : 0.f;
+            if (f & CRDR_EPI_RES) v += full ? res4[e] : (live ? p.res[opix * p.ldres + oc] : 0.f);
+            if (f & CRDR_EPI_GATE) {
+              const float sgm = 1.0f / (1.0f + expf(-v));
+              s4[e] = sgm;
+              const float gxv = full ? gx4[e] : (live ? p.gx[opix * p.ldg + oc] : 0.f);
+              const float gtv = full ? gt4[e] : (live ? p.gt[opix * p.ldg + oc] : 0.f);
+              v = gxv + gtv * sgm;
+            }
+            if (f & CRDR_EPI_AFFINE) v = live ? v * p.scale[oc] + p.shift[oc] : v;
+            if (do_cs && live) cpre[e] += v;
+            if (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) {
+              float mv = full ? msk4[e] : (live ? p.mask[opix * p.ldmask + oc] : 0.f);
+              if (f & CRDR_EPI_MASKOFF) mv -= live ? p.vec2[oc] : 0.f;
+              v = mv > 0.0f ? v : ((f & CRDR_EPI_LRELUMASK) ? 0.2f * v : 0.0f);
+            }
+            if (do_cs && live) cpost[e] += v;
+            if (f & CRDR_EPI_ACCUM) v += full ? old4[e] : (live ? p.y[opix * p.ldy + oc] : 0.f);
+            o4[e] = v;
+          }
+          if (full) {
+            *reinterpret_cast<f32x4*>(p.y + opix * p.ldy + oc0) = o4;
+            if (f & CRDR_EPI_GATE) *reinterpret_cast<f32x4*>(p.sig + opix * p.ldg + oc0) = s4;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (oc0 + e < p.Cout) {
+                p.y[opix * p.ldy + oc0 + e] = o4[e];
+                if (f & CRDR_EPI_GATE) p.sig[opix * p.ldg + oc0 + e] = s4[e];
+              }
+          }
+        }
+      }
+    }
+    if (do_cs) {
+      if constexpr (GC == 1 || GC == 2 || GC == 4) {
+        // lanes that share a column group differ in the lane bits >= 8 GC: fixed-order butterfly
+#pragma unroll
+        for (int off = 32; off >= 8 * GC; off >>= 1)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            cpre[e] += __shfl_xor(cpre[e], off, 64);
+            cpost[e] += __shfl_xor(cpost[e], off, 64);
+          }
+        if (lane < 8 * GC) {
+          float* d0 = sS + (wm * 2 + 0) * BN + (wn * NB + JG) * 32 + lane * 4;
+          float* d1 = sS + (wm * 2 + 1) * BN + (wn * NB + JG) * 32 + lane * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (I == 0) { d0[e] = cpre[e]; d1[e] = cpost[e]; }
+            else { d0[e] += cpre[e]; d1[e] += cpost[e]; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  };
+  auto group = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
+    constexpr int JG = decltype(JG_)::value, GC = decltype(GC_)::value;
+    if constexpr (GC == 3) {
+      if (do_cs) {  // (see the fast path)
+        pass(I_, integral_constant<int, JG>{}, integral_constant<int, 1>{});
+        pass(I_, integral_constant<int, JG + 1>{}, integral_constant<int, 1>{});
+        pass(I_, integral_constant<int, JG + 2>{}, integral_constant<int, 1>{});
+        return;
+      }
+    }
+    pass(I_, JG_, GC_);
+  };
+  group(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+  if constexpr (NB > 4) group(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+  if constexpr (MB > 1) {
+    group(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, G>{});
+    if constexpr (NB > 4) group(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, NB - 4>{});
+  }
+  static_assert(MB <= 2 && NB <= 8, "epilogue passes are written out for MB <= 2, NB <= 8");
+  if (do_cs) {  // (the last pass ended with a barrier) sum the WM row groups in order, one partial row per (phase, M tile)
+    float* dst = p.cs + ((size_t)(phase * gridDim.x + tile_m) * 2) * p.cs_ld;
+    for (int t = tid; t < 2 * BN; t += NT) {
+      const int which = t / BN, c = t - which * BN;
+      float v = sS[(0 * 2 + which) * BN + c];
+#pragma unroll
+      for (int w2 = 1; w2 < WM; ++w2) v += sS[(w2 * 2 + which) * BN + c];
+      if (n0 + c < p.Cout) dst[(size_t)which * p.cs_ld + n0 + c] = v;
+    }
+  }
+}
+
+}  // namespace crdr

@@ -282,11 +282,14 @@ class CharmRun:
     def bias(self, kind, i, layer):
         return self.p.conv(kind, i, layer).bias.data_ptr()
 
-    def _conv(self, xs, ws, ys, oc, k, *, wrows, wcols, biases=None, pres=None, relu=False, label=""):
-        for a, b in _chunks(len(xs)):
+    def _conv(self, xs, ws, ys, oc, k, *, wrows, wcols, biases=None, pres=None, relu=False, label="", ms=False):
+        """ms: a launch over mean (+ scale) transforms.  The mean-only pass (with_scale False) runs it with the plan the full
+        pass uses for twice the problems, so that mu -- hence y_hat -- comes out bit-identical in both."""
+        mult = 2 if (ms and not self.with_scale) else 1
+        for a, b in _chunks(len(xs), L.MAX_GROUP // mult):
             ops.conv_group(self.n, self.h, self.w, xs[a:b], ws[a:b], ys[a:b], oc, k, k[0] // 2, False, wrows=wrows, wcols=wcols,
                            biases=None if biases is None else biases[a:b], pres=None if pres is None else pres[a:b],
-                           flags=L.EPI_RELU if relu else 0, device=self.dev, label=label)
+                           flags=L.EPI_RELU if relu else 0, device=self.dev, label=label, plan_as=mult * (b - a) if mult > 1 else None)
 
     # ---- stages
     def stages(self):
@@ -304,14 +307,14 @@ class CharmRun:
             self._conv([self.h_sc], [self.addr["hyp_sc"]], [self.a1(P.n_mu, P.n_sc)], P.n_sc * P.C1, P.k1, wrows=P.n_sc * P.C1,
                        wcols=P.hm, label="charm.hoist")
 
-    def _l23(self, trs, outs, label):
+    def _l23(self, trs, outs, label, ms=False):
         """second and third layer of the transforms `trs` -> outs (V into MSL)"""
         P = self.p
         sl = [P.slot[t] for t in trs]
         self._conv([self.a1(s) for s in sl], [self.addr[(k, i, "l2")] for k, i in trs], [self.a2(s) for s in sl], P.C2, P.k2,
-                   wrows=P.C2, wcols=P.C1, biases=[self.bias(k, i, 1) for k, i in trs], relu=True, label=label + ".l2")
+                   wrows=P.C2, wcols=P.C1, biases=[self.bias(k, i, 1) for k, i in trs], relu=True, label=label + ".l2", ms=ms)
         self._conv([self.a2(s) for s in sl], [self.addr[(k, i, "l3")] for k, i in trs], outs, P.sc, P.k3,
-                   wrows=P.sc, wcols=P.C2, biases=[self.bias(k, i, 2) for k, i in trs], label=label + ".l3")
+                   wrows=P.sc, wcols=P.C2, biases=[self.bias(k, i, 2) for k, i in trs], label=label + ".l3", ms=ms)
 
     def mean_scale(self, st):
         """mu (and sigma) of the slices of stage `st` -> MSL"""
@@ -322,20 +325,20 @@ class CharmRun:
         if st[0] == 0:
             xs = [self.h_mu, self.h_sc][: len(kinds)]
             self._conv(xs, [self.addr[(k, 0, "l1")] for k in kinds], [self.a1(s) for s in sl], P.C1, P.k1, wrows=P.C1, wcols=P.hm,
-                       biases=[self.bias(k, 0, 0) for k in kinds], relu=True, label="charm.ms.l1")
+                       biases=[self.bias(k, 0, 0) for k in kinds], relu=True, label="charm.ms.l1", ms=True)
         else:
             s = P.sup(st[0])
             x = self.yh(0, s)
             self._conv([x] * len(trs), [self.addr[(k, i, "sup")] for k, i in trs], [self.a1(q) for q in sl], P.C1, P.k1,
                        wrows=P.C1, wcols=s, biases=[self.bias(k, i, 0) for k, i in trs], pres=[self.a1(q) for q in sl], relu=True,
-                       label="charm.ms.l1")
+                       label="charm.ms.l1", ms=True)
             if len(st) > 1:  # tail: the support part of the LRP transforms is known now as well (raw accumulate)
                 lt = [("lrp", i) for i in st]
                 ls = [self.a1(P.slot[t]) for t in lt]
                 self._conv([x] * len(lt), [self.addr[(k, i, "sup")] for k, i in lt], ls, P.C1, P.k1, wrows=P.C1, wcols=s, pres=ls,
                            label="charm.lrp.l1sup")
         outs = [self.msl(0 if k == "mean" else 1, i) for k, i in trs]
-        self._l23(trs, outs, "charm.ms")
+        self._l23(trs, outs, "charm.ms", ms=True)
 
     def quantize(self, st, y: Optional[V], noise: Optional[V], philox, lik_n, lik_q, bits_n, bits_q):
         """Gaussian conditional over the channels of stage `st`: Yh = Ypre = round(y - mu) + mu, likelihoods, bit sums."""

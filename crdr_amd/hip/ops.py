@@ -578,9 +578,12 @@ def view(buf: torch.Tensor, c0: int, c: int) -> V:
 
 
 def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, int], pad: int, transposed: bool, *,
-               wrows: int, wcols: int, biases=None, pres=None, masks=None, flags: int = 0, device=None, label: str = ""):
+               wrows: int, wcols: int, biases=None, pres=None, masks=None, flags: int = 0, device=None, label: str = "",
+               plan_as: Optional[int] = None):
     """G stride-1 'same' convolutions of one geometry in one launch (crdr_conv2d_grouped; G = 1: crdr_conv2d).
-    xs / ys / pres / masks: lists of V (equal ld and c within each list); wpacks / biases: lists of addresses."""
+    xs / ys / pres / masks: lists of V (equal ld and c within each list); wpacks / biases: lists of addresses.
+    plan_as: run with the tile configuration / split depth a launch of `plan_as` problems would get (same fp32 summation order
+    as that launch: the Charm's mean-only pass reproduces the mean transforms of the full pass bit for bit)."""
     lib = L.load()
     G = len(xs)
     x0, y0 = xs[0], ys[0]
@@ -603,10 +606,11 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
             io.pre = pres[g].ptr
         if masks is not None:
             io.mask = masks[g].ptr
+    GP = plan_as if plan_as else G
     if FORCED_CONV_ALGO:
         d.reserved = FORCED_CONV_ALGO
-    elif AUTOTUNE:
-        key = ("g", G, n, h, w, d.C, oc, k, pad, int(transposed), d.ldx, d.ldy, flags, d.ldpre, d.ldmask, wrows, wcols)
+    elif AUTOTUNE and (GP == G or ("g", GP, n, h, w, d.C, oc, k, pad, int(transposed), d.ldx, d.ldy, flags, d.ldpre, d.ldmask, wrows, wcols) in _algo_cache):
+        key = ("g", GP, n, h, w, d.C, oc, k, pad, int(transposed), d.ldx, d.ldy, flags, d.ldpre, d.ldmask, wrows, wcols)
         algo = _algo_cache.get(key)
         if algo is None:
             if flags & (L.EPI_ACCUM | L.EPI_PREADD):
@@ -630,6 +634,8 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
                 return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
             algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids())
         d.reserved = algo
+    elif GP != G:
+        d.reserved = lib.crdr_conv2d_choose_algo(C.byref(d), GP)
     nbytes = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
     ws, ws_n = workspace(nbytes, device, conv=True) if nbytes else (None, 0)
     e0 = _prof_begin()

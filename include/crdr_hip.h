@@ -121,6 +121,10 @@ typedef struct crdr_conv_io {
 
 /* number of tile configurations a forced algorithm may name */
 int crdr_conv2d_num_configs(void);
+/* the forced-algorithm id (crdr_conv_desc.reserved) of what the built-in heuristic picks for a launch of G problems of d
+ * (d->reserved is honoured if set); 0 on error.  Results of a launch depend on its tile configuration and split depth (fp32
+ * summation order): a caller that needs two launches of different group size to agree bit for bit forces one plan on both. */
+int crdr_conv2d_choose_algo(const crdr_conv_desc* d, int G);
 /* number of streaming 1x1 variants: forced algorithm ids crdr_conv2d_num_configs() + 1 + v, no split bits.  A persistent
  * workgroup keeps its weight tile in LDS and streams the activation rows through per-wave DMA rings (the 1x1 layers of
  * ResidualBottleneck, elic_layers.py:17-36, and of the NLAM branches, cheng_nlam.py); plain and grouped launches.  Rejected
