@@ -335,6 +335,8 @@ def main():
     ap.add_argument("--tune-log", default=None)
     ap.add_argument("--tune-db", default=None, help="perf database to preload (default: the one shipped in crdr_amd/hip); shapes it lacks are tuned live")
     ap.add_argument("--save-tune-db", default=None, help="write the tuner's choices after the run")
+    ap.add_argument("--seed-tune-db", default=None, help="KINDS:PATH -- preload only these key kinds (e.g. w,wm) from a database of another "
+                                                         "library version: a rebuild keeps the entries of kernels that did not change")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying captured HIP graphs")
     ap.add_argument("--profile-steps", type=int, default=5, help="eager steps after the timed region used for the per-kernel roofline")
     a = ap.parse_args()
@@ -358,6 +360,9 @@ def main():
     ops.AUTOTUNE = not a.no_autotune  # the reference runs with cudnn.benchmark = True (base_trainer.py:20)
     if ops.AUTOTUNE and a.tune_db != "none":
         ops.load_tune_cache(a.tune_db or ops.DEFAULT_TUNE_DB)
+    if ops.AUTOTUNE and a.seed_tune_db:
+        kinds, path = a.seed_tune_db.split(":", 1)
+        ops.load_tune_cache(path, only_kinds=tuple(kinds.split(",")), ignore_signature=True)
     main_run = run_stage(a, a.stage, a.bs, a.steps, a.warmup, a.profile_steps, a.shape_table)
     tr = main_run.pop("trainer")
     if rk == 0 and a.save_tune_db:

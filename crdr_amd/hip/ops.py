@@ -118,8 +118,10 @@ def save_tune_cache(path: str) -> None:
         json.dump({"signature": _tune_signature(), "algos": {repr(k): v for k, v in _algo_cache.items()}}, f, indent=0)
 
 
-def load_tune_cache(path: str) -> int:
-    """Load choices saved by save_tune_cache; ignored (returns 0) if the library's configuration list has changed."""
+def load_tune_cache(path: str, only_kinds=None, ignore_signature: bool = False) -> int:
+    """Load choices saved by save_tune_cache; ignored (returns 0) if the library's configuration list has changed.
+    only_kinds / ignore_signature: seed a rebuild of the database with the entries of kernel families that did not change
+    (key[0]: "c" / "g" / "m" conv launches, "w" / "wm" weight gradients)."""
     import ast
     import json
     import os
@@ -127,11 +129,16 @@ def load_tune_cache(path: str) -> int:
         return 0
     with open(path) as f:
         db = json.load(f)
-    if db.get("signature") != _tune_signature():
+    if db.get("signature") != _tune_signature() and not ignore_signature:
         return 0
+    n = 0
     for k, v in db["algos"].items():
-        _algo_cache.setdefault(ast.literal_eval(k), int(v))
-    return len(db["algos"])
+        key = ast.literal_eval(k)
+        if only_kinds is not None and key[0] not in only_kinds:
+            continue
+        _algo_cache.setdefault(key, int(v))
+        n += 1
+    return n
 
 
 # Optional per-launch timing (bench.py): {"igemm": [(flops, ev0, ev1), ...], "wgrad": [...]} or None.
