@@ -69,6 +69,16 @@ class RansDecoder:
                                                           out.ctypes.data), "rans decode_stream")
         return out
 
+    def decode_stream_into(self, indexes: np.ndarray, cdfs, cdf_sizes, offsets, out: np.ndarray) -> np.ndarray:
+        """decode_stream without allocations: `indexes` and `out` are caller-owned contiguous int32 arrays (pinned host staging)."""
+        assert indexes.dtype == np.int32 and out.dtype == np.int32 and indexes.flags.c_contiguous and out.flags.c_contiguous
+        assert out.size >= indexes.size
+        cdfs, sizes, offs = _tables(cdfs, cdf_sizes, offsets)
+        L.check(self._lib.crdr_rans_decoder_decode_stream(self._h, indexes.ctypes.data, indexes.size, cdfs.ctypes.data,
+                                                          cdfs.shape[1], sizes.ctypes.data, offs.ctypes.data, cdfs.shape[0],
+                                                          out.ctypes.data), "rans decode_stream")
+        return out
+
     def __del__(self):
         try:
             if self._h:

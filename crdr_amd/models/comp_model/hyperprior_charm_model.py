@@ -260,6 +260,39 @@ class HyperpriorCharmModel(BaseModel):
         self._tick("transforms", t)
         return fake, z_hat, y_hat
 
+    @torch.no_grad()
+    def decompress_many(self, string_lists, workers: int = 2, **cond):
+        """Generator over decompress() results for a sequence of [header, z, y] string lists, in order, with `workers` images in
+        flight: each is decoded by its own host thread on its own HIP stream, so the serial rANS decoder of one image (C, GIL
+        released) runs beside the GPU transforms of the others -- the decoder-side ping-pong of
+        minnen20_charm_context_model.py:192-240 (transform a slice, decode it on the host, feed it back) no longer leaves the GPU
+        idle.  Same bytes in, bit-identical y_hat / z_hat / image out as decompress() (deterministic kernels)."""
+        import threading
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        local = threading.local()
+        dev = torch.device(self.device)
+        ready = torch.cuda.Event()
+        ready.record()   # whatever prepared the model (codec_setup, weight packs) on the caller's stream
+
+        def work(strings):
+            st = getattr(local, "stream", None)
+            if st is None:
+                st = local.stream = torch.cuda.Stream(dev)
+            with torch.no_grad(), torch.cuda.stream(st):
+                st.wait_event(ready)
+                out = self.decompress(strings, **cond)
+                st.synchronize()
+            return out
+        pending = deque()
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            for strings in string_lists:
+                pending.append(pool.submit(work, strings))
+                while len(pending) > workers:
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
+
     # ---- validation (bpp / PSNR over a loader)
     def _validation_conditions(self, **kw) -> List[Tuple[str, Dict]]:
         return [("", {})]

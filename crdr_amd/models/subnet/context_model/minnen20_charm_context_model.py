@@ -177,6 +177,20 @@ class Minnen20CharmContextModel(BaseContextModel):
         return charm.charm_forward(self, y, hyper_out, None, None, entropy_model_y.scale_bound, entropy_model_y.likelihood_bound,
                                    True, False)
 
+    def _pinned_pair(self, shape):
+        """Two pinned int32 host buffers of (at least) `shape` elements, kept per thread (decompress_many decodes several images
+        concurrently, one thread and one stream each)."""
+        import threading
+        cache = self.__dict__.setdefault("_pin_cache", {})
+        key = threading.get_ident()
+        need = 1
+        for d in shape:
+            need *= int(d)
+        pair = cache.get(key)
+        if pair is None or pair[0].numel() < need:
+            pair = cache[key] = (torch.empty(need, dtype=torch.int32, pin_memory=True), torch.empty(need, dtype=torch.int32, pin_memory=True))
+        return pair
+
     @torch.no_grad()
     def forward_decompress(self, y_str: bytes, hyper_out: Tensor, entropy_model_y) -> Tuple[Tensor, Tensor]:
         """Decoder side (:189-240): the serial rANS decoder on the host alternates with the GPU transforms -- ms + 1 round
@@ -193,21 +207,36 @@ class Minnen20CharmContextModel(BaseContextModel):
         sc = self.slice_ch
         mu_all, sg_all = run.as_nchw(run.MSL, 0, run.Cy), run.as_nchw(run.MSL, run.Cy, run.Cy)
         yh_all, yp_all = run.as_nchw(run.Yh), run.as_nchw(run.Ypre)
-        syms = torch.empty((run.n, run.Cy, run.h, run.w), dtype=torch.int32, device=hyper_out.device)
+        dev = hyper_out.device
+        syms = torch.empty((run.n, run.Cy, run.h, run.w), dtype=torch.int32, device=dev)
+        # host <-> device staging of one stage (CDF indexes down, decoded symbols up) through pinned buffers, asynchronous
+        # copies on the caller's stream: the host waits only for the event behind the index copy, and the symbol upload is in
+        # flight while the next stage's launches are being issued
+        biggest = max(len(st) for st in run.stages()) * sc
+        pin_idx, pin_sym = self._pinned_pair((run.n, biggest, run.h, run.w))
+        ev = torch.cuda.Event()
         t = self._tick(None)
         for st in run.stages():
             run.mean_scale(st)
             t = self._tick("charm", t)
             # the stream holds the symbols in (channel, row, column) order: the channels of a stage are consecutive in it
             a, b = st[0] * sc, (st[-1] + 1) * sc
+            cnt = run.n * (b - a) * run.h * run.w
             _, idx = entropy_model_y.symbols_and_indexes(None, None, sg_all[:, a:b])
-            vals = dec.decode_stream(idx.cpu().numpy().reshape(-1), cdf, sizes, offs)
-            sym = torch.from_numpy(vals).view(run.n, b - a, run.h, run.w).to(hyper_out.device)
+            hi, hs = pin_idx.view(-1)[:cnt], pin_sym.view(-1)[:cnt]
+            hi.copy_(idx.view(-1), non_blocking=True)
+            ev.record()
+            ev.synchronize()
+            dec.decode_stream_into(hi.numpy(), cdf, sizes, offs, hs.numpy())
+            sym = torch.empty((run.n, b - a, run.h, run.w), dtype=torch.int32, device=dev)
+            sym.view(-1).copy_(hs, non_blocking=True)
             syms[:, a:b] = sym
             v = entropy_model_y.dequantize(sym, mu_all[:, a:b])
             yh_all[:, a:b] = v
             yp_all[:, a:b] = v
+            ev.record()   # the pinned symbol buffer is reused by the next stage: its upload must have been consumed by then
             t = self._tick("rans", t)
             run.lrp(st)
+            ev.synchronize()
         self._tick("charm", t)
         return yh_all, syms

@@ -19,3 +19,10 @@ def pytest_configure(config):
 def hip_lib():
     from crdr_amd.hip import lib
     return lib.load()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    path = os.environ.get("CRDR_PARITY_DUMP")
+    if path:
+        from tests import parity_margins
+        parity_margins.dump(path)

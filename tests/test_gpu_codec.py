@@ -104,3 +104,18 @@ def test_pipelined_sweep_equals_serial_compress():
         for a, b in zip(serial, piped):
             assert a["string_list"] == b["string_list"]
             assert torch.equal(a["y_hat"], b["y_hat"]) and a["pred_y_bit"] == b["pred_y_bit"]
+
+
+def test_pipelined_decode_equals_serial_decompress():
+    """decompress_many (one host thread + HIP stream per image in flight) returns, in order, exactly what decompress() returns."""
+    model, _ = _full_model(True)
+    model.eval()
+    model.codec_setup()
+    imgs = [seeded_input(f"dsweep{k}", (1, 3, 64 + 32 * (k % 3), 96 + 32 * (k % 2))) for k in range(6)]
+    strings = [model.compress(im, rate_ind=0.5 * k)["string_list"] for k, im in enumerate(imgs)]
+    serial = [model.decompress(sl, beta=2.0) for sl in strings]
+    for workers in (1, 3):
+        piped = list(model.decompress_many(strings, workers=workers, beta=2.0))
+        assert len(piped) == len(serial)
+        for (f0, z0, y0), (f1, z1, y1) in zip(serial, piped):
+            assert torch.equal(f0, f1) and torch.equal(z0, z1) and torch.equal(y0, y1)

@@ -33,15 +33,32 @@ def rel(a, b):
 
 
 def close(got, ref, what, rtol=2e-4):
+    """max |got - ref| <= rtol x max |ref|; the measured ratio is recorded (tests/parity_margins.py) and, once a measurement is
+    committed, the gate tightens to 3 x it."""
+    from tests import parity_margins as PM
     got, ref = torch.as_tensor(got).detach().cpu().double(), torch.as_tensor(ref).detach().cpu().double()
     got, ref = got.reshape(ref.shape) if got.numel() == ref.numel() else got, ref
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     scale = ref.abs().max().item() + 1e-12
     err = (got - ref).abs().max().item()
-    assert err <= rtol * scale, f"{what}: max err {err:.3e} scale {scale:.3e}"
+    PM.record("fwd:" + what, what, err / scale)
+    tol = PM.tolerance("fwd:" + what, rtol)
+    assert err <= tol * scale, f"{what}: max err {err:.3e} scale {scale:.3e} (rel {err / scale:.2e} > {tol:.2e})"
+
+
+def grad_close(got, ref, what, tol=2e-3):
+    """One gradient tensor (an input gradient) by relative L2 error, recorded and gated like check_grads."""
+    from tests import parity_margins as PM
+    e = rel(got, ref)
+    PM.record("dgrad:" + what, what, e)
+    t = PM.tolerance("dgrad:" + what, tol)
+    assert e <= t, f"{what}: relative L2 error {e:.3e} > {t:.3e}"
 
 
 def check_grads(module, prefix, ref_sd, what, tol=2e-3):
+    """Every parameter gradient against the oracle's by relative L2 error, gated per parameter group at 3 x the committed
+    measurement (profiles/r3_parity_margins.json) and never looser than `tol`."""
+    from tests import parity_margins as PM
     bad = []
     for k, p in module.named_parameters():
         r = ref_sd[prefix + k].grad
@@ -52,8 +69,11 @@ def check_grads(module, prefix, ref_sd, what, tol=2e-3):
             assert r.abs().max().item() == 0, f"{what}: {k} got no gradient but the oracle's is non-zero"
             continue
         e = rel(p.grad, r)
-        if e > tol:
-            bad.append((k, e))
+        g = "grad:" + PM.group_of(prefix + k)
+        PM.record(g, prefix + k, e)
+        t = PM.tolerance(g, tol)
+        if e > t:
+            bad.append((k, e, t))
     assert not bad, f"{what}: gradient mismatch {bad[:8]} ({len(bad)} tensors)"
 
 
@@ -76,7 +96,7 @@ def test_encoder_fwd_bwd():
     (O.encoder(sdg, xg, 1.5) * r).sum().backward()
     xd = x.to(dev()).requires_grad_(True)
     (m(xd, 1.5) * r.to(dev())).sum().backward()
-    assert rel(xd.grad, xg.grad) < 2e-3, rel(xd.grad, xg.grad)
+    grad_close(xd.grad, xg.grad, "dx")
     check_grads(m, "encoder.", sdg, "encoder")
 
 
@@ -96,7 +116,7 @@ def test_decoder_fwd_bwd():
     (O.decoder(sdg, yg, 1.5, 2.56) * r).sum().backward()
     yd = y.to(dev()).requires_grad_(True)
     (m(yd, 1.5, 2.56) * r.to(dev())).sum().backward()
-    assert rel(yd.grad, yg.grad) < 2e-3, rel(yd.grad, yg.grad)
+    grad_close(yd.grad, yg.grad, "dy")
     check_grads(m, "decoder.", sdg, "decoder")
 
 
@@ -232,7 +252,7 @@ def test_discriminator_fwd_bwd():
     out = D(xd, rate_ind=torch.tensor([3]))
     close(out, O.discriminator(sd, x, 3), "disc logits")
     (out * r.to(dev())).sum().backward()
-    assert rel(xd.grad, xg.grad) < 2e-3
+    grad_close(xd.grad, xg.grad, "dx")
     check_grads(D, "", sdg, "discriminator")
 
 

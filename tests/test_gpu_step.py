@@ -185,6 +185,8 @@ def test_stage3_step():
     close(log["aux"], O.eb_aux_loss(sd_g, "entropy_model_z"), "aux loss", 1e-4)
     close(log["qbpp"], out["qbpp"].mean(), "qbpp", 1e-4)
 
+    from tests import parity_margins as PM
+
     def cmp(cap_d, ref_sd, what, only=None, tol=5e-3):
         bad = []
         for n, g in cap_d.items():
@@ -196,8 +198,11 @@ def test_stage3_step():
                 assert g is None or g.abs().max().item() <= 1e-7, f"{what}: unexpected gradient for {n}"
                 continue
             e = rel(g, r)
-            if e > tol:
-                bad.append((n, e))
+            grp = f"grad:{what}:" + PM.group_of(n)
+            PM.record(grp, n, e)
+            t = PM.tolerance(grp, tol)
+            if e > t:
+                bad.append((n, e, t))
         assert not bad, f"{what}: {bad[:8]} ({len(bad)})"
     cmp(captured["g"], g_ref, "G grads", only=lambda n: not n.endswith(".quantiles"))
     cmp(captured["d"], d_ref, "D grads")
@@ -242,14 +247,18 @@ def test_stage1_step():
     losses["total"].backward()
     for k in ("distortion", "rate", "perceptual"):
         close(log[k], losses[k], f"loss {k}", 3e-4)
+    from tests import parity_margins as PM
     bad = []
     for n, g in captured.items():
         r = g_ref[n].grad
         if n.endswith(".quantiles") or r is None or r.abs().max() == 0:
             continue
         e = rel(g, r)
-        if e > 5e-3:
-            bad.append((n, e))
+        grp = "grad:G grads:" + PM.group_of(n)
+        PM.record(grp, n, e)
+        t = PM.tolerance(grp, 5e-3)
+        if e > t:
+            bad.append((n, e, t))
     assert not bad, bad[:8]
 
 

@@ -61,12 +61,27 @@ def main():
         torch.cuda.synchronize()
         res[workers] = time.perf_counter() - t
         assert piped == serial, "the pipelined sweep produced different bytes"
+    # decode sweep: decompress() per image vs decompress_many (one host thread + HIP stream per image in flight: the serial rANS
+    # decoder of one image beside the GPU transforms of the others)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    dser = [model.decompress(sl, beta=beta) for sl in serial]
+    torch.cuda.synchronize(); td_serial = time.perf_counter() - t
+    dres = {}
+    for workers in (2, 3, 4):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        dp = list(model.decompress_many(serial, workers=workers, beta=beta))
+        torch.cuda.synchronize()
+        dres[workers] = time.perf_counter() - t
+        for (f0, z0, y0), (f1, z1, y1) in zip(dser, dp):
+            assert torch.equal(f0, f1) and torch.equal(z0, z1) and torch.equal(y0, y1), "the pipelined decode differs"
     nbytes = sum(len(s) for s in out["string_list"]) + 12
     print(json.dumps({"size": [h, w], "q": q, "beta": beta, "bpp": round(nbytes * 8 / h / w, 4), "roundtrip_bit_exact": ok,
                       "one_image": {"compress_s": round(t1 - t0, 4), "decompress_s": round(t2 - t1, 4),
                                     "compress_split": {k: round(v, 4) for k, v in enc.items()}, "decompress_split": {k: round(v, 4) for k, v in dec.items()}},
                       "sweep": {"images": K, "serial_s": round(t_serial, 4), **{f"pipelined_{k}_workers_s": round(v, 4) for k, v in res.items()},
                                 "speedup_2_workers": round(t_serial / res[2], 3)},
+                      "decode_sweep": {"images": K, "serial_s": round(td_serial, 4), **{f"pipelined_{k}_workers_s": round(v, 4) for k, v in dres.items()},
+                                       "best_vs_serial": round(min(dres.values()) / td_serial, 3)},
                       "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
     assert ok and fake.shape == (1, 3, h, w)
 
