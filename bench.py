@@ -26,7 +26,7 @@ GFLOP_PER_IMG_STAGE3 = 631.2
 GFLOP_PER_IMG_STAGE1 = 434.0
 
 
-def build_trainer(stage: int, bs: int, size: int, device: str, graphs: bool = True):
+def build_trainer(stage: int, bs: int, size: int, device: str, graphs: bool = True, precision: str = "fp32"):
     import torch
     from crdr_amd.trainer import build_trainer as _bt
     from crdr_amd.utils.options import BaseConfig, ConfigDict
@@ -36,6 +36,7 @@ def build_trainer(stage: int, bs: int, size: int, device: str, graphs: bool = Tr
     cfg["dataset"] = {"batch_size": bs, "train_dataset": {"type": "SyntheticDataset", "image_size": size}}
     cfg["path"] = None
     cfg["hip_graphs"] = graphs
+    cfg["precision"] = precision
     if cfg.get("loss", {}).get("perceptual_loss"):  # throughput is weight-independent; stated in config.workload
         cfg["loss"]["perceptual_loss"]["allow_random_weights"] = True
     torch.manual_seed(0)
@@ -150,7 +151,7 @@ def _newest_profile(pattern: str):
     return fs[-1] if fs else None
 
 
-def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: int, shape_table=None) -> dict:
+def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: int, shape_table=None, precision: str = "fp32") -> dict:
     """Build the stage's trainer, warm up (autotune + graph capture per rate index), time `steps` iterations with the rate
     index CYCLED deterministically (q = iteration mod rate levels: the expectation over the uniform draw of the reference,
     interpca_hyperprior_model.py:28-29, without sampling noise in the step mix), then `profile_steps` eager iterations
@@ -162,7 +163,7 @@ def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: in
     from crdr_amd.trainer import dist as D
     ws = D.world_size()
     device = f"cuda:{torch.cuda.current_device()}"
-    tr = build_trainer(stage, bs, a.size, device, graphs=not a.no_graph)
+    tr = build_trainer(stage, bs, a.size, device, graphs=not a.no_graph, precision=precision)
     loader = iter(tr.train_loader)
     lib = __import__("crdr_amd.hip.lib", fromlist=["load"]).load()
     levels = getattr(tr.comp_model, "rate_level", 0)
@@ -337,6 +338,7 @@ def main():
     ap.add_argument("--save-tune-db", default=None, help="write the tuner's choices after the run")
     ap.add_argument("--seed-tune-db", default=None, help="KINDS:PATH -- preload only these key kinds (e.g. w,wm) from a database of another "
                                                          "library version: a rebuild keeps the entries of kernels that did not change")
+    ap.add_argument("--bf16x3", action="store_true", help="also time the step with precision: bf16x3 (second line `stage3_bf16x3`) even with --no-secondary")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying captured HIP graphs")
     ap.add_argument("--profile-steps", type=int, default=5, help="eager steps after the timed region used for the per-kernel roofline")
     a = ap.parse_args()
@@ -421,7 +423,7 @@ def main():
                                                                                           "colsum_finish", "gauss_cond_fwd", "gauss_cond_bwd", "igemm_splitk_epilogue")}}
         except Exception as e:  # the headline line must not depend on the secondary measurements
             roof["fused_ops"] = {"error": repr(e)[:300]}
-        del tr
+        tr = None
         torch.cuda.empty_cache()
         if a.stage == 3:
             try:
@@ -434,6 +436,27 @@ def main():
                                       "whole_step_frac": round(s1["value"] * GFLOP_PER_IMG_STAGE1 / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
             except Exception as e:
                 line["stage1_bs8"] = {"error": repr(e)[:300]}
+    if ws == 1 and a.stage == 3 and (a.bf16x3 or not a.no_secondary):
+        # second line, never the headline: the same step with `precision: bf16x3` (conv / weight-gradient products as split-bf16
+        # triples on the bf16 matrix path, <= 3 * 2^-16 relative error per product, fp32 accumulate; everything else as above)
+        try:
+            tr = None
+            torch.cuda.empty_cache()
+            bx = run_stage(a, 3, a.bs, a.steps, a.warmup, a.profile_steps, precision="bf16x3")
+            bx.pop("trainer")
+            big = bx["igemm"]
+            line["stage3_bf16x3"] = {
+                "metric": f"stage-3 training img/s at {a.size}x{a.size}", "value": round(bx["value"], 3), "unit": "img/s",
+                "ms_per_step": round(bx["ms_per_step"], 2), "steps": a.steps, "warmup": a.warmup, "dtype": "bf16x3 (fp32 accumulate)",
+                "config": {"workload": f"config/crdr_stage_3.yaml -b {a.bs} + precision: bf16x3"},
+                "roofline": {"bound": "mfma", "achieved": big["tflops"] if big else None, "peak": round(2500.0 / 3, 1), "unit": "TFLOP/s",
+                             "frac": round(big["tflops"] / (2500.0 / 3), 4) if big else None,
+                             "note": "conv forward / input-gradient family, dense fp32-equivalent FLOPs over HIP-event time; peak = dense bf16 "
+                                     "MFMA peak / 3 (three bf16 MFMAs per product term); the 1x1 streaming kernel and RGB-input layers run exact fp32"},
+                "wgrad_tflops": bx["wgrad"]["tflops"] if bx["wgrad"] else None,
+                "parity": "tests/test_gpu_bf16x3.py: kernels within 3 * 2^-16 * sum|a||b|, step losses <= 1e-3, gradients <= 5e-3 vs the oracle"}
+        except Exception as e:
+            line["stage3_bf16x3"] = {"error": repr(e)[:300]}
     if ws == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.stage, a.size)
     print(json.dumps(line), flush=True)

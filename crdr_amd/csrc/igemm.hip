@@ -8,42 +8,71 @@
 
 namespace crdr {
 
-extern template __global__ void igemm_kernel<4, 1, 1, 1, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 2, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 4, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 5, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 6, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 7, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 2, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 4, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 2, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 1, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 2, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 4, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 1, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 2, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 1, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 2, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 1, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 2, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 1, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 2, 1, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 2, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 1, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 1, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 2, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 2, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 2, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 1, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 2, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 1, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 2, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 2, 1, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+// BEGIN GENERATED (gen_igemm_parts.py)
+extern template __global__ void igemm_kernel<4, 1, 1, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 3, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 4, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 5, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 6, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 7, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 3, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 4, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 3, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 4, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 3, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 3, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 1, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 3, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 4, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 5, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 6, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 7, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 3, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 4, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 3, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 4, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 3, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 3, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+// END GENERATED
 
 // ------------------------------------------------------------------------------------------------------------
 // host side: geometry, config choice, launch
@@ -52,9 +81,10 @@ struct TileCfg {
   int wm, wn, mb, nb;
   void (*kern)(const IgemmArgs, const IgemmTaps, const IgemmGroup);
   void (*kern_smallc)(const IgemmArgs, const IgemmTaps, const IgemmGroup);  // tap-major variant (Cin <= 4), nullptr where not built
+  void (*kern_bf3)(const IgemmArgs, const IgemmTaps, const IgemmGroup);     // split-bf16 products (CRDR_CONV_BF16X3)
 };
-#define CFG(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false>, nullptr}
-#define CFGS(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false>, igemm_kernel<a, b, c, d, true>}
+#define CFG(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false, false>, nullptr, igemm_kernel<a, b, c, d, false, true>}
+#define CFGS(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false, false>, igemm_kernel<a, b, c, d, true, false>, igemm_kernel<a, b, c, d, false, true>}
 static const TileCfg kCfgs[] = {
     // BM=128 family (one 32-row strip per wave), BN = 32..224
     CFGS(4, 1, 1, 1), CFGS(4, 1, 1, 2), CFG(4, 1, 1, 3), CFG(4, 1, 1, 4), CFG(4, 1, 1, 5), CFG(4, 1, 1, 6),
@@ -190,7 +220,9 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
       if (ns > 1 && !splitk_ok(tiles * G, a.M, cdiv(d->OC, BN) * BN, ns)) break;
       const long long blocks = tiles * ns * G;
       // MFMA cycles of one workgroup per K-tile (waves beyond four share the SIMDs), scaled by the measured efficiency
-      const double per_iter = 16.0 * t.mb * t.nb * 64.0 * std::max(1.0, t.wm * t.wn / 4.0) * (133.0 / kCfgTflops[c]);
+      // (split-bf16 products: 6 MFMAs of 32 cycles per block and K-tile instead of 16 of 64, plus the operand splitting)
+      const double per_iter = 16.0 * t.mb * t.nb * 64.0 * std::max(1.0, t.wm * t.wn / 4.0) * (133.0 / kCfgTflops[c]) *
+                              ((d->flags & CRDR_CONV_BF16X3) && !a.smallc ? 0.3 : 1.0);
       const double waves = (double)cdiv64(blocks, 256);
       double cost = waves * ((double)cdiv(KT, ns) * per_iter + 3000.0);
       // in-launch reduce: publish + ticket + acquire (~3 us) and the last arriver's slab reads (~100 GB/s per workgroup)
@@ -279,6 +311,11 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
     a.m_inner = (G == 1 && B >= 32.0e6 && A * 4.0 <= B) ? 1 : 0;
   }
   a.ws_ld = pl->grid.y * BN;
+  {  // K order: experiment switch CRDR_K_CMAJOR = 0 (tap-major) / 1 (channel-major wherever it applies) / unset: built-in rule
+    static const int mode = [] { const char* e = getenv("CRDR_K_CMAJOR"); return e ? atoi(e) : -1; }();
+    const bool applies = !a.smallc && maxtaps > 1 && a.kchunks > 1;
+    a.k_cmajor = applies && (mode == 1 || (mode < 0 && d->C >= 1024)) ? 1 : 0;
+  }
   {
     // floats: K-loop staging (+ tap table) overlaid by the epilogue's transposed accumulators + column sums, then the
     // per-column vectors sV (kSvOff in the kernel)
@@ -408,11 +445,12 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
     return 0;
   }
   const TileCfg& t = kCfgs[pl.cfg];
-  auto kern = a.smallc ? t.kern_smallc : t.kern;
-  static std::atomic<bool> attr_done[2][64];
-  if (!attr_done[a.smallc][pl.cfg].load(std::memory_order_acquire)) {
+  const int variant = a.smallc ? 1 : ((d->flags & CRDR_CONV_BF16X3) ? 2 : 0);   // (RGB-input layers stay exact: K is tiny there)
+  auto kern = variant == 1 ? t.kern_smallc : (variant == 2 ? t.kern_bf3 : t.kern);
+  static std::atomic<bool> attr_done[3][64];
+  if (!attr_done[variant][pl.cfg].load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done[a.smallc][pl.cfg].store(true, std::memory_order_release);
+    attr_done[variant][pl.cfg].store(true, std::memory_order_release);
   }
   void* prof = profile_begin(as_stream(s));
   hipLaunchKernelGGL(kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, pl.t, grp);

@@ -39,6 +39,7 @@ struct IgemmArgs {
   int vec_epi;  // 1: y / res / gx / gt / sig rows are 16-byte aligned -> vector epilogue
   int m_inner;   // 1: consecutive workgroups walk the M tiles of one (N tile, phase/split) -- weight-heavy shapes (see build_plan)
   int fast_epi;  // 1: vec_epi, Cout % 4 == 0, unsplit, no gate / pre-add / accumulate: straight-line buffer-op epilogue
+  int k_cmajor;  // 1: K loop walks (channel chunk, tap) instead of (tap, channel chunk), see the kernel
   int smallc;   // 1: Cin <= 4 and the weight pack is tap-major ([rows][taps*4]): a K-tile covers 8 taps x 4 channels
   unsigned long long x_bytes;  // extent of the input tensor (the descriptor is re-based per workgroup, see kernel)
   unsigned w_bytes;            // extent of the weight pack's buffer descriptor

@@ -67,7 +67,9 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, 
 // of the tile image (lds_off) is applied on the SOURCE side: the lane that fills slot s of row r fetches chunk
 // s ^ ((r >> 1) & 7).
 
-template <int WM, int WN, int MB, int NB, bool SMALLC>
+// BF3: the products run as split-bf16 triples on the bf16 matrix path (common.hpp, split_bf16x8): same staging, same K order,
+// same epilogues -- only the fragment-to-MFMA step differs.
+template <int WM, int WN, int MB, int NB, bool SMALLC, bool BF3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
   constexpr int BM = 32 * WM * MB, BN = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;  // 16-byte pieces per thread per K-tile
@@ -172,13 +174,20 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   __syncthreads();  // sTap visible
 
   // K-iteration cursor of the NEXT tile to fetch: tap index (relative to tb) and channel chunk
-  int lt = SMALLC ? 0 : it0 / kchunks, lc = SMALLC ? it0 : it0 - lt * kchunks;
+  // K order (kmajor = p.k_cmajor): tap-major walks all channel chunks of one tap before the next tap; channel-major walks all
+  // taps of one 32-channel chunk first -- the ntap shifted reads of a chunk then hit the same few KB of pixel rows (L1 / L2)
+  // instead of re-streaming the whole activation tile once per tap.  Same products, different fp32 summation order.
+  // The cursor is kept as (inner, outer) counters -- which of them is the tap depends on the order -- so that it stays in registers.
+  const bool cmajor = !SMALLC && p.k_cmajor != 0;
+  const int inner_n = SMALLC ? (1 << 30) : (cmajor ? ntap : kchunks);
+  int ci = SMALLC ? it0 : it0 % inner_n, co = SMALLC ? 0 : it0 / inner_n;
   auto fetch = [&](int buf) __attribute__((always_inline)) {
     float* a = sA + buf * BM * 32 + wave * 8 * 32;
     float* b = sB + buf * BN * 32 + wave * 8 * 32;
     int dh, dw;
     unsigned toff, woff;
     bool cok;
+    const int lt = cmajor ? ci : co, lc = (SMALLC || !cmajor) ? ci : co;
     if constexpr (SMALLC) {  // this thread's piece is tap (8 lc + csrc), channels 0..3
       const int ti = lc * 8 + csrc;
       cok = ti < ntap;
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
 #pragma unroll
     for (int j = 0; j < BV; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(b + j * RPP * 32), 16, (int)(b_off[j] + woff), 0, 0, 0);
-    if (++lc == kchunks && !SMALLC) { lc = 0; ++lt; }
+    if (++ci == inner_n) { ci = 0; ++co; }
     __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the MFMA stream that hides its latency
   };
 
@@ -225,6 +234,34 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   // one K-tile: kk = [K0, K1) quarter steps of 8 K values each, out of LDS buffer `buf`
   auto compute = [&](auto bufc, auto k0c, auto k1c) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value, K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+    if constexpr (BF3) {
+      // one bf16 MFMA covers 16 k = the quarter steps kk, kk + 1: lane half h contributes the 4 + 4 floats it reads for them
+      // (the same k for A and B, so the sum over k is complete whatever their order inside the instruction)
+      static_assert(K0 % 2 == 0 && K1 % 2 == 0, "bf16x3 steps are pairs of quarter steps");
+#pragma unroll
+      for (int kk = K0; kk < K1; kk += 2) {
+        bf16x8 ah[MB], al[MB], bh[NB], bl[NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(fa + fo[kk] + (buf * BM * 32 + i * 1024));
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(fa + fo[kk + 1] + (buf * BM * 32 + i * 1024));
+          const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          split_bf16x8(x, ah[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(fb + fo[kk] + (buf * BN * 32 + j * 1024));
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(fb + fo[kk + 1] + (buf * BN * 32 + j * 1024));
+          const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          split_bf16x8(x, bh[j], bl[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] = mfma_bf16x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = K0; kk < K1; ++kk) {
       f32x4 af[MB], bf[NB];

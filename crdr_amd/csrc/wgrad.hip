@@ -60,7 +60,7 @@ struct WgradArgs {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 static constexpr unsigned kOob = 0x80000000u;  // >= any descriptor size accepted by build_wplan (< 2 GiB)
 
-template <int WM, int WN, int MB, int NB>
+template <int WM, int WN, int MB, int NB, bool BF3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p_, const WgradGroup grp) {
   constexpr int BI = 32 * WM * MB, BJ = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int PV = (8 * BI + NT - 1) / NT, QV = (8 * BJ + NT - 1) / NT;
@@ -154,6 +154,31 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p_,
   const float* fb = sQ + wn * NB * 32 + fcol + fh * BJ;
   auto compute = [&](auto bufc) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value;
+    if constexpr (BF3) {  // split-bf16 products (common.hpp): one bf16 MFMA covers the 16 pixels of eight fp32 steps
+#pragma unroll
+      for (int s0 = 0; s0 < 16; s0 += 8) {
+        bf16x8 ah[MB], al[MB], bh[NB], bl[NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fa[buf * 32 * BI + 2 * (s0 + e) * BI + i * 32];
+          split_bf16x8(x, ah[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fb[buf * 32 * BJ + 2 * (s0 + e) * BJ + j * 32];
+          split_bf16x8(x, bh[j], bl[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] = mfma_bf16x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       float af[MB], bf[NB];
@@ -486,8 +511,9 @@ __global__ __launch_bounds__(256) void pack_weight_scatter_kernel(const float* s
 struct WCfg {
   int wm, wn, mb, nb;
   void (*kern)(const WgradArgs, const WgradGroup);
+  void (*kern_bf3)(const WgradArgs, const WgradGroup);
 };
-#define CFG(a, b, c, d) {a, b, c, d, wgrad_kernel<a, b, c, d>}
+#define CFG(a, b, c, d) {a, b, c, d, wgrad_kernel<a, b, c, d, false>, wgrad_kernel<a, b, c, d, true>}
 static const WCfg kWCfgs[] = {
     CFG(1, 1, 1, 1),  // 32x32
     CFG(2, 2, 1, 1),  // 64x64
@@ -557,13 +583,13 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl, int G = 1) {
       if (ns > 1 && a.ntiles / ns < 4) break;
       const long long blocks = tiles * ns * G;
       const double slots = 256.0 * std::max(1, 4 / waves_per_block);  // blocks that run at full MFMA rate at once
-      const double per_tile = 16.0 * t.mb * t.nb * 64.0 + 400.0;
+      const double per_tile = 16.0 * t.mb * t.nb * 64.0 * ((d->algo & CRDR_WGRAD_BF16X3) ? 0.3 : 1.0) + 400.0;
       double cost = std::ceil(blocks / slots) * ((double)cdiv(a.ntiles, ns) * per_tile + 4000.0);
       cost += (double)ns * ntapg * d->PC * ncols * 4.0 / 1500.0;  // slab write + read
       if (cost < best) { best = cost; bc = c; bs = ns; }
     }
   }
-  if (d->algo != 0) {  // caller-forced algorithm (autotuner): (config index + 1) | log2(split) << 8
+  if ((d->algo & 0xffff) != 0) {  // caller-forced algorithm (autotuner): (config index + 1) | log2(split) << 8
     bc = (d->algo & 0xff) - 1;
     bs = 1 << ((d->algo >> 8) & 0xf);
     CRDR_REQUIRE(bc >= 0 && bc < kNumWCfgs, "wgrad: forced config %d out of range", bc);
@@ -607,12 +633,14 @@ static int launch_wgrad_slabs(const crdr_wgrad_desc* d, const float* const* ps, 
   }
   a.p = ps[0]; a.q = qs[0]; a.ws = (float*)ws;
   const WCfg& t = kWCfgs[pl.cfg];
-  static std::atomic<bool> attr_done[64];
-  if (!attr_done[pl.cfg].load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done[pl.cfg].store(true, std::memory_order_release);
+  const int bf3 = (d->algo & CRDR_WGRAD_BF16X3) ? 1 : 0;
+  auto kern = bf3 ? t.kern_bf3 : t.kern;
+  static std::atomic<bool> attr_done[2][64];
+  if (!attr_done[bf3][pl.cfg].load(std::memory_order_acquire)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done[bf3][pl.cfg].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(t.kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, grp);
+  hipLaunchKernelGGL(kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, grp);
   CRDR_CHECK_LAUNCH("wgrad_kernel");
   return 0;
 }

@@ -89,6 +89,7 @@ class GcDesc(C.Structure):
 
 EPI_BIAS, EPI_RELU, EPI_LRELU, EPI_VEC2, EPI_RES, EPI_GATE, EPI_AFFINE, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64, 128
 EPI_PREADD, EPI_RELUMASK, EPI_LRELUMASK, EPI_MASKOFF, EPI_COLSUM = 256, 512, 1024, 2048, 4096
+CONV_NOSPLIT, CONV_BF16X3, WGRAD_BF16X3 = 8192, 16384, 1 << 16
 MAX_GROUP = 16
 EB_PARAMS = 58
 

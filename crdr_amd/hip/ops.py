@@ -24,6 +24,19 @@ AUTOTUNE = False
 # + split, see crdr_conv_desc.reserved) instead of the tuner's or the cost model's choice.  The choice normally depends on the
 # problem size, and with it the fp32 summation order; tests that compare runs at different batch sizes bit for bit pin it.
 FORCED_CONV_ALGO = 0
+# Opt-in reduced-cost matrix mode ("bf16x3", include/crdr_hip.h CRDR_CONV_BF16X3): conv / weight-gradient products run as
+# split-bf16 triples on the bf16 MFMA path (per-product relative error <= 3 * 2^-16), everything else unchanged.  Set by the
+# trainers from the YAML key `precision: bf16x3` for the duration of a training step; the codec and every parity claim use
+# the exact fp32 default.
+MATRIX_BF16X3 = False
+
+
+def _cf() -> int:
+    return L.CONV_BF16X3 if MATRIX_BF16X3 else 0
+
+
+def _wa(algo: int) -> int:
+    return int(algo) | (L.WGRAD_BF16X3 if MATRIX_BF16X3 else 0)
 _algo_cache = {}
 TUNE_LOG = []
 
@@ -299,6 +312,7 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
     """One fused implicit-GEMM launch. `out` may be a channel slice of a wider NHWC tensor (written in place).
     The input may be of any size (the kernel re-bases its buffer descriptor per workgroup)."""
     lib = L.load()
+    flags |= _cf()
     x, ldx = nhwc(x)
     n, c, h, w = x.shape
     oh, ow = out_hw
@@ -368,17 +382,17 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
     qc4 = min((qc + 3) // 4 * 4, ldq)
     assert g.is_contiguous() and g.shape[0] <= pc4 and g.shape[1] <= qc4
     d = L.WgradDesc(N=n, PH=ph, PW=pw, PC=pc4, ldp=ldp, QH=qh, QW=qw, QC=qc4, ldq=ldq, kh=k[0], kw=k[1],
-                    stride=stride, pad=pad, gI=g.shape[0], gJ=g.shape[1], accumulate=int(accumulate), algo=0)
+                    stride=stride, pad=pad, gI=g.shape[0], gJ=g.shape[1], accumulate=int(accumulate), algo=_wa(0))
     if algo:
-        d.algo = algo
+        d.algo = _wa(algo)
     elif AUTOTUNE:
-        key = ("w", n, ph, pw, pc4, ldp, qh, qw, qc4, ldq, k, stride, pad, g.shape[0], g.shape[1])
+        key = ("w", n, ph, pw, pc4, ldp, qh, qw, qc4, ldq, k, stride, pad, g.shape[0], g.shape[1]) + ((1,) if MATRIX_BF16X3 else ())
         algo = _algo_cache.get(key)
         if algo is None:
             tmp = torch.empty_like(g)
 
             def run(a):
-                d.algo, d.accumulate = a, 0
+                d.algo, d.accumulate = _wa(a), 0
                 nb = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
                 if nb > (2 << 30):
                     return False
@@ -386,7 +400,7 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
                 return lib.crdr_conv2d_wgrad(C.byref(d), p.data_ptr(), q.data_ptr(), tmp.data_ptr(), w_, wn_, _stream()) == 0
             algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run)
             d.accumulate = int(accumulate)
-        d.algo = algo
+        d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
     e0 = _prof_begin()
     if defer and WGRAD_DEFER is not None and WGRAD_DEFER.device == p.device:
@@ -600,6 +614,7 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
         flags |= L.EPI_PREADD
     if masks is not None:
         flags |= L.EPI_RELUMASK
+    flags |= _cf()
     d = L.ConvDesc(N=n, H=h, W=w, C=x0.c, OH=h, OW=w, OC=oc, kh=k[0], kw=k[1], stride=1, pad=pad, transposed=int(transposed),
                    ldx=x0.ld, ldy=y0.ld, wrows=wrows, wcols=wcols, flags=flags, ldres=0, ldg=0, wlayout=0, reserved=0,
                    ldpre=pres[0].ld if pres is not None else 0, ldmask=masks[0].ld if masks is not None else 0)
@@ -663,10 +678,10 @@ def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[i
     G = len(ps)
     p0, q0 = ps[0], qs[0]
     d = L.WgradDesc(N=n, PH=h, PW=w, PC=p0.c, ldp=p0.ld, QH=h, QW=w, QC=q0.c, ldq=q0.ld, kh=k[0], kw=k[1], stride=1, pad=pad,
-                    gI=gi, gJ=gj, accumulate=int(accumulate), algo=0)
+                    gI=gi, gJ=gj, accumulate=int(accumulate), algo=_wa(0))
     pa, qa, ga = (C.c_void_p * G)(*[v.ptr for v in ps]), (C.c_void_p * G)(*[v.ptr for v in qs]), (C.c_void_p * G)(*[g[0] for g in gs])
     if AUTOTUNE:
-        key = ("wg", G, n, h, w, p0.c, p0.ld, q0.c, q0.ld, k, pad, gi, gj)
+        key = ("wg", G, n, h, w, p0.c, p0.ld, q0.c, q0.ld, k, pad, gi, gj) + ((1,) if MATRIX_BF16X3 else ())
         algo = _algo_cache.get(key)
         if algo is None:
             tmp = torch.empty(G * gi * gj * k[0] * k[1] + 64, dtype=torch.float32, device=device)
@@ -676,7 +691,7 @@ def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[i
             slab = [0]
 
             def run(a):
-                d.algo = a
+                d.algo = _wa(a)
                 nb = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
                 if nb == 0 or nb > (2 << 30):
                     return False
@@ -685,7 +700,7 @@ def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[i
                 return lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ta, G, w_, wn_, jobs_t, _stream()) == 0
             # + the batched reduce's read of these slabs at its measured 3.8 TB/s (profiles/r2_h_hbm_families.json)
             algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, penalty=lambda: slab[0] / 3.8e9)
-        d.algo = algo
+        d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
     jobs = (L.WgradJob * G)()
     e0 = _prof_begin()
@@ -706,15 +721,15 @@ def wgrad_split(n: int, h: int, w: int, p: V, q: V, parts, k: Tuple[int, int], p
     gJtot)]: rows [row0, row0 + rows) of the slab reduce into g[i][j0 + j][t], j < q.c."""
     lib = L.load()
     d = L.WgradDesc(N=n, PH=h, PW=w, PC=p.c, ldp=p.ld, QH=h, QW=w, QC=q.c, ldq=q.ld, kh=k[0], kw=k[1], stride=1, pad=pad,
-                    gI=p.c, gJ=q.c, accumulate=1, algo=0)
+                    gI=p.c, gJ=q.c, accumulate=1, algo=_wa(0))
     if AUTOTUNE:
-        key = ("ws", n, h, w, p.c, p.ld, q.c, q.ld, k, pad)
+        key = ("ws", n, h, w, p.c, p.ld, q.c, q.ld, k, pad) + ((1,) if MATRIX_BF16X3 else ())
         algo = _algo_cache.get(key)
         if algo is None:
             tmp = torch.empty(p.c * q.c * k[0] * k[1], dtype=torch.float32, device=device)
 
             def run(a):
-                d.algo, d.accumulate = a, 0
+                d.algo, d.accumulate = _wa(a), 0
                 nb = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
                 if nb == 0 or nb > (2 << 30):
                     return False
@@ -722,7 +737,7 @@ def wgrad_split(n: int, h: int, w: int, p: V, q: V, parts, k: Tuple[int, int], p
                 return lib.crdr_conv2d_wgrad(C.byref(d), p.ptr, q.ptr, tmp.data_ptr(), w_, wn_, _stream()) == 0
             algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run)
             d.accumulate = 1
-        d.algo = algo
+        d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
     job = L.WgradJob()
     e0 = _prof_begin()
@@ -869,6 +884,7 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
         flags |= L.EPI_AFFINE
     if colsum:
         flags |= L.EPI_COLSUM
+    flags |= _cf()
     cin = min((x0.c + 3) // 4 * 4, x0.ld)  # RGB / single-channel operands: the zeroed padding lanes ride along
     d = L.ConvDesc(N=n, H=h, W=w, C=cin, OH=oh, OW=ow, OC=oc, kh=k[0], kw=k[1], stride=stride, pad=pad, transposed=int(transposed),
                    ldx=x0.ld, ldy=y0.ld, wrows=wrows, wcols=wcols, flags=flags, ldres=ress[0].ld if ress is not None else 0, ldg=0,
@@ -959,10 +975,10 @@ def wgrad_multi(n: int, ph: int, pw: int, qh: int, qw: int, ps, qs, gs, gi: int,
     p0, q0 = ps[0], qs[0]
     pc, qc = min((p0.c + 3) // 4 * 4, p0.ld), min((q0.c + 3) // 4 * 4, q0.ld)
     d = L.WgradDesc(N=n, PH=ph, PW=pw, PC=pc, ldp=p0.ld, QH=qh, QW=qw, QC=qc, ldq=q0.ld, kh=k[0], kw=k[1], stride=stride, pad=pad,
-                    gI=gi, gJ=gj, accumulate=1, algo=0)
+                    gI=gi, gJ=gj, accumulate=1, algo=_wa(0))
     pa, qa, ga = (C.c_void_p * G)(*[v.ptr for v in ps]), (C.c_void_p * G)(*[v.ptr for v in qs]), (C.c_void_p * G)(*gs)
     if AUTOTUNE:
-        key = ("wm", G, n, ph, pw, pc, p0.ld, qh, qw, qc, q0.ld, k, stride, pad, gi, gj)
+        key = ("wm", G, n, ph, pw, pc, p0.ld, qh, qw, qc, q0.ld, k, stride, pad, gi, gj) + ((1,) if MATRIX_BF16X3 else ())
         algo = _algo_cache.get(key)
         if algo is None:
             tmp = torch.empty(G * gi * gj * k[0] * k[1] + 64, dtype=torch.float32, device=device)
@@ -972,7 +988,7 @@ def wgrad_multi(n: int, ph: int, pw: int, qh: int, qw: int, ps, qs, gs, gi: int,
             slab = [0]
 
             def run(a):
-                d.algo = a
+                d.algo = _wa(a)
                 nb = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
                 if nb == 0 or nb > (2 << 30):
                     return False
@@ -981,7 +997,7 @@ def wgrad_multi(n: int, ph: int, pw: int, qh: int, qw: int, ps, qs, gs, gi: int,
                 return lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ta, G, w_, wn_, jobs_t, _stream()) == 0
             # + the batched reduce's read of these slabs at its measured 3.8 TB/s (profiles/r2_h_hbm_families.json)
             algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, penalty=lambda: slab[0] / 3.8e9)
-        d.algo = algo
+        d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
     jobs = (L.WgradJob * G)()
     e0 = _prof_begin()

@@ -70,6 +70,11 @@ int crdr_profile_read(int kind, double* flops, double* ms, long long* launches);
  * whose output gradient an input-gradient launch produces.  crdr_conv2d_colsum_layout gives the number of partial rows
  * and their stride; crdr_colsum_finish_batched adds them up in row order (deterministic). */
 #define CRDR_EPI_COLSUM 4096
+#define CRDR_CONV_BF16X3 16384 /* opt-in reduced-cost products: operands split on the fly into (hi, lo) bf16 pairs, a b ~= ah bh + ah bl +
+                                * al bh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (per-product relative error <= 3 * 2^-16) at
+                                * 3/16 of the exact-fp32 MFMA cost.  Off = exact fp32 (the default, the codec path, every parity claim).
+                                * The reference's own GPU convolutions run TF32 (base_trainer.py:20 + torch 1.12 defaults), a coarser
+                                * format than this.  Ignored by the streaming 1x1 kernel and by RGB-input (tap-major) layers. */
 #define CRDR_CONV_NOSPLIT 8192 /* plan without split-K (the caller's workspace cannot hold the zeroed tickets, see CRDR_CONV_TICKETS) */
 
 typedef struct crdr_conv_desc {
@@ -178,8 +183,10 @@ typedef struct crdr_wgrad_desc {
   int32_t kh, kw, stride, pad;
   int32_t gI, gJ;     /* dims of g (<= PC, QC): channels beyond them are layout padding and are dropped */
   int32_t accumulate; /* 1: g += ; 0: g = */
-  int32_t algo;       /* 0: heuristic; else forced (config index + 1) | log2(pixel split) << 8 */
+  int32_t algo;       /* low 16 bits 0: heuristic; else forced (config index + 1) | log2(pixel split) << 8;
+                       * bit 16 (CRDR_WGRAD_BF16X3): split-bf16 products, see CRDR_CONV_BF16X3 */
 } crdr_wgrad_desc;
+#define CRDR_WGRAD_BF16X3 (1 << 16)
 int crdr_conv2d_wgrad_num_configs(void);
 size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d);
 int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* ws, size_t ws_bytes,

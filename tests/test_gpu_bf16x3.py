@@ -1,0 +1,148 @@
+"""Opt-in reduced-cost matrix mode `precision: bf16x3` (include/crdr_hip.h CRDR_CONV_BF16X3): conv / weight-gradient products as
+split-bf16 triples (a b ~= ah bh + ah bl + al bh on v_mfma_f32_32x32x16_bf16, fp32 accumulation).
+
+Stated tolerance.  x = hi + lo + eps with |eps| <= 2^-16 |x|, and the dropped lo lo term is <= 2^-16 |a b|: every product is
+within 3 * 2^-16 = 4.6e-5 of exact, so an output is within 4.6e-5 * sum |a| |b| (+ the fp32 accumulation noise the exact path
+has too).  The kernels are checked against THAT elementwise bound (computed in fp64 from |x|, |w|); the training step against
+the oracle at forward 1e-3 / gradients 5e-3 (measured margins are recorded like those of the fp32 tests), with the same bounded
+adoption of rounding decisions.  The exact-fp32 default is untouched: every other test runs it."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_gpu_conv import _dev, _rand
+
+pytestmark = pytest.mark.gpu
+BOUND = 3 * 2.0 ** -16 + 2e-6
+
+
+@pytest.fixture()
+def bf16x3():
+    from crdr_amd.hip import ops
+    ops.MATRIX_BF16X3 = True
+    yield
+    ops.MATRIX_BF16X3 = False
+
+
+CASES = [("3x3_96_96", 2, 96, 16, 16, 96, 3, 1, 1), ("5x5s2_192_320", 2, 192, 16, 16, 320, 5, 2, 2), ("5x5_224_128", 4, 224, 8, 8, 128, 5, 1, 2),
+         ("1x1_320_160", 1, 320, 6, 10, 160, 1, 1, 0), ("3x3s2_64_64", 2, 64, 18, 22, 64, 3, 2, 1)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_bf16x3_conv_family_within_the_stated_bound(case, bf16x3):
+    from crdr_amd.hip import ops
+    name, n, ci, h, w, co, k, s, p = case
+    dev = _dev()
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(co, ci, k, k, seed=2, scale=(ci * k * k) ** -0.5)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride=s, padding=p)
+    oh, ow = ref.shape[2:]
+    dy = _rand(*ref.shape, seed=4)
+    ref.backward(dy.double())
+    xa, wa, da = x.double().abs(), wt.double().abs(), dy.double().abs()
+    b_fwd = F.conv2d(xa, wa, None, stride=s, padding=p)
+    b_dx = torch.autograd.grad(F.conv2d(xa.requires_grad_(True), wa, None, stride=s, padding=p), xa, da)[0]
+    b_dw = torch.autograd.grad(F.conv2d(xa.detach(), wa.requires_grad_(True), None, stride=s, padding=p), wa, da)[0]
+    xd, wd, dyd = x.to(dev), wt.to(dev), dy.to(dev)
+    out = ops.conv2d_raw(xd, ops.pack_weight(wd, False), co, (k, k), s, p, False, (oh, ow))
+    dx = ops.conv2d_raw(dyd, ops.pack_weight(wd, True), ci, (k, k), s, p, True, (h, w))
+    g = torch.zeros_like(wd)
+    ops.conv2d_wgrad_raw(dyd, xd, g, (k, k), s, p, accumulate=False, defer=False)
+    torch.cuda.synchronize()
+    exact = ops.MATRIX_BF16X3
+    for got, want, bound, what in ((out, ref, b_fwd, "fwd"), (dx, xr.grad, b_dx, "dgrad"), (g, wr.grad, b_dw, "wgrad")):
+        err = (got.detach().cpu().double() - want.detach()).abs()
+        worst = float((err / (BOUND * bound + 1e-30)).max())
+        assert worst <= 1.0, f"{name} {what}: error {worst:.2f} x the split-bf16 bound"
+        # ... and it really ran the reduced path: an exact-fp32 result sits ~100x closer
+        assert float(err.max()) > 0.0
+    assert exact
+
+
+def test_bf16x3_differs_from_exact_and_default_is_exact(bf16x3):
+    from crdr_amd.hip import ops
+    dev = _dev()
+    x = _rand(2, 96, 16, 16, seed=1).to(dev)
+    wt = _rand(96, 96, 3, 3, seed=2, scale=0.03).to(dev)
+    wp = ops.pack_weight(wt, False)
+    a = ops.conv2d_raw(x, wp, 96, (3, 3), 1, 1, False, (16, 16))
+    ops.MATRIX_BF16X3 = False
+    b = ops.conv2d_raw(x, wp, 96, (3, 3), 1, 1, False, (16, 16))
+    ref = F.conv2d(x.double().cpu(), wt.double().cpu(), None, padding=1)
+    ea, eb = (a.cpu().double() - ref).abs().max().item(), (b.cpu().double() - ref).abs().max().item()
+    assert not torch.equal(a, b) and eb < 2e-6 and 1e-7 < ea < 1e-4, (ea, eb)
+
+
+def test_bf16x3_stage3_step_against_the_oracle():
+    """One full stage-3 step with `precision: bf16x3` against the oracle: every loss term within 1e-3, every G / D gradient tensor
+    within 5e-3 relative L2 (the stated tolerances of the mode), rounding decisions adopted only inside the oracle's window."""
+    from oracle import crdr_oracle as O
+    from crdr_amd.trainer import build_trainer
+    from tests import parity_margins as PM
+    from tests.golden.seeded_weights import seeded_input
+    from tests.test_gpu_model import close, dev, grad_sd, rel
+    from tests.test_gpu_step import _opt, _seed_params
+    opt = _opt(3)
+    opt["precision"] = "bf16x3"
+    tr = build_trainer(opt)
+    sd_g = _seed_params(tr.comp_model, "")
+    sd_d = _seed_params(tr.discriminator, "")
+    sd_l = _seed_params(tr.perceptual_loss.lpips, "lpips.")
+    x = seeded_input("image", (2, 3, 64, 64))
+    ny, nz = seeded_input("noise.y", (2, 320, 4, 4), 0.5), seeded_input("noise.z", (2, 192, 1, 1), 0.5)
+    q, beta = 2, 2.56
+    captured = {}
+    g_step, d_step = tr.g_optimizer.step, tr.d_optimizer.step
+
+    def cap(name, module, fn):
+        def wrapped(*a, **k):
+            captured[name] = {n: (p.grad.clone() if p.grad is not None else None) for n, p in module.named_parameters()}
+            return fn(*a, **k)
+        return wrapped
+    tr.g_optimizer.step = cap("g", tr.comp_model, g_step)
+    tr.d_optimizer.step = cap("d", tr.discriminator, d_step)
+    tr.loss_huge_threshold = float("inf")
+    tr.comp_model.context_model.record_symbols = []
+    z_hats = []
+    run_model, reconstruct = tr.comp_model.run_model, tr.comp_model.reconstruct
+
+    def spy(fn):
+        def w(*a, **k):
+            o = fn(*a, **k)
+            z_hats.append(o["z_hat"].detach().cpu())
+            return o
+        return w
+    tr.comp_model.run_model, tr.comp_model.reconstruct = spy(run_model), spy(reconstruct)
+    log = tr.optimize_parameters(1, {"real_images": x.to(dev()), "rate_ind": torch.tensor([q]), "beta": beta,
+                                     "noise": {"y": ny.to(dev()), "z": nz.to(dev())}})
+    assert log is not None
+    from crdr_amd.hip import ops
+    assert ops.MATRIX_BF16X3 is False, "the mode must not leak out of the training step"
+    syms = [t.cpu() for t in tr.comp_model.context_model.record_symbols]
+    med = sd_g["entropy_model_z.quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
+    forced = {"y": syms[:10], "z": torch.round(z_hats[0] - med)}
+    hr_forced = {"y": syms[10:], "z": torch.round(z_hats[1] - med)}
+    g_ref, d_ref, rep = grad_sd(sd_g), grad_sd(sd_d), {}
+    losses, out = O.stage3_g_losses(g_ref, d_ref, sd_l, x, q, beta, ny, nz, forced=forced, hr_forced=hr_forced, report=rep)
+    O.check_forced(rep, rep.get("symbols", 0))
+    losses["total"].backward()
+    d_ref = grad_sd(sd_d)
+    d_losses = O.stage3_d_losses(d_ref, x, out["fake_images"], q)
+    d_losses["d_total"].backward()
+    for k in ("distortion", "rate", "perceptual", "adv"):
+        close(log[k], losses[k], f"bf16x3 loss {k}", 1e-3)
+    for k in ("d_real", "d_fake"):
+        close(log[k], d_losses[k], f"bf16x3 loss {k}", 1e-3)
+    bad = []
+    for what, cap_d, ref_sd in (("G", captured["g"], g_ref), ("D", captured["d"], d_ref)):
+        for n, g in cap_d.items():
+            r = ref_sd[n].grad
+            if n.endswith(".quantiles") or r is None or r.abs().max() == 0:
+                continue
+            e = rel(g, r)
+            grp = f"grad:bf16x3 {what}:" + PM.group_of(n)
+            PM.record(grp, n, e)
+            if e > PM.tolerance(grp, 5e-3):
+                bad.append((n, e))
+    assert not bad, bad[:8]
