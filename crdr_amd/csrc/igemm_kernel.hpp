@@ -67,6 +67,11 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, 
 // of the tile image (lds_off) is applied on the SOURCE side: the lane that fills slot s of row r fetches chunk
 // s ^ ((r >> 1) & 7).
 
+// K-loop stages of a tile configuration (host and kernel agree through this): see the kernel.
+constexpr int igemm_stages(int BM, int BN, bool bf3) {
+  return !bf3 ? 2 : (((BM + BN) * 128 * 4 + 12 * 1024 <= 160 * 1024) ? 4 : 3);
+}
+
 // BF3: the products run as split-bf16 triples on the bf16 matrix path (common.hpp, split_bf16x8): same staging, same K order,
 // same epilogues -- only the fragment-to-MFMA step differs.
 template <int WM, int WN, int MB, int NB, bool SMALLC, bool BF3 = false>
@@ -77,10 +82,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   constexpr int RPP = NT / 8;  // tile rows filled by one pass of the whole block
   static_assert(RPP % 16 == 0, "the swizzle term must not depend on the pass");
 
+  // LDS stages of the K loop.  Exact fp32: two (the MFMAs of a tile take longer than its DMA).  Split-bf16: the MFMAs of a tile
+  // are ~5x shorter than an L2 round trip, so the ring is 3-4 deep with counted vmcnt waits and a raw barrier per tile (below).
+  constexpr int ST = igemm_stages(BM, BN, BF3);
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                                        // [2][BM*32]
-  float* sB = smem + 2 * BM * 32;                          // [2][BN*32]
-  int* sTap = reinterpret_cast<int*>(smem + 2 * (BM + BN) * 32);  // [<=132] packed (dh, dw, widx) of this phase
+  float* sA = smem;                                        // [ST][BM*32]
+  float* sB = smem + ST * BM * 32;                         // [ST][BN*32]
+  int* sTap = reinterpret_cast<int*>(smem + ST * (BM + BN) * 32);  // [<=132] packed (dh, dw, widx) of this phase
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   }
   // per-column epilogue vectors of this N tile (neutral values where a flag is off or past Cout), read by the fast epilogue
   constexpr int kG = NB < 4 ? NB : 4;
-  constexpr int kStagingFloats = 2 * (BM + BN) * 32 + 132;
+  constexpr int kStagingFloats = ST * (BM + BN) * 32 + 132;
   constexpr int kEpiFloats = WM * WN * 32 * 32 * kG + WM * 2 * BN;
   constexpr int kSvOff = ((kStagingFloats > kEpiFloats ? kStagingFloats : kEpiFloats) + 3) & ~3;
   float* sV = smem + kSvOff;  // [4][BN]: bias, vec2, scale, shift
@@ -299,6 +307,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     __syncthreads();
   };
   if (it0 < it1) fetch(0);
+  if constexpr (ST > 2) {   // ring prologue: tiles it0 .. it0 + ST - 2 in flight (past the end: range-checked, never consumed)
+    fetch(1);
+    if constexpr (ST > 3) fetch(2);
+  }
   // (behind the first DMA so that their latencies overlap; the barrier below publishes both)
   if (p.fast_epi) {
     const int f0 = p.flags;
@@ -310,14 +322,48 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
       sV[3 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[n0 + c] : 0.f;
     }
   }
-  __syncthreads();
   int it = it0;
-  for (; it + 2 <= it1; it += 2) {
-    step(I0{});
-    step(I1{});
-  }
-  if (it < it1) {
-    compute(I0{}, I0{}, I4{});
+  if constexpr (ST == 2) {
+    __syncthreads();
+    for (; it + 2 <= it1; it += 2) {
+      step(I0{});
+      step(I1{});
+    }
+    if (it < it1) {
+      compute(I0{}, I0{}, I4{});
+      __syncthreads();
+    }
+  } else {
+    // Ring of ST stages, ST - 1 tiles in flight.  vmcnt counts this wave's DMA pieces in issue order: with (ST - 2) tiles'
+    // worth still outstanding the oldest tile -- the one consumed next -- has landed for this wave, the barrier extends that to
+    // every wave and also says everyone is done reading the stage the next DMA overwrites.
+    constexpr int kWait = (ST - 2) * (AV + BV);
+    static_assert(kWait <= 63, "vmcnt immediate");
+    constexpr int kImm = 0x0F70 | (kWait & 15) | ((kWait >> 4) << 14);
+    auto rstep = [&](auto bufc) __attribute__((always_inline)) {
+      constexpr int buf = decltype(bufc)::value;
+      __builtin_amdgcn_s_waitcnt(kImm);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      fetch((buf + ST - 1) % ST);
+      compute(bufc, I0{}, I4{});
+    };
+    using I2 = integral_constant<int, 2>;
+    using I3 = integral_constant<int, 3>;
+    for (; it + ST <= it1; it += ST) {
+      rstep(I0{});
+      rstep(I1{});
+      rstep(I2{});
+      if constexpr (ST > 3) rstep(I3{});
+    }
+    const int rem = it1 - it;
+    if (rem > 0) rstep(I0{});
+    if (rem > 1) rstep(I1{});
+    if constexpr (ST > 3) {
+      if (rem > 2) rstep(I2{});
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0), lgkmcnt(0): the look-ahead pieces land before the epilogue reuses the stages
     __syncthreads();
   }
 
