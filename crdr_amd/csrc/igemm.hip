@@ -319,8 +319,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
   {
     // floats: K-loop staging (+ tap table) overlaid by the epilogue's transposed accumulators + column sums, then the
     // per-column vectors sV (kSvOff in the kernel)
-    const bool bf3 = (d->flags & CRDR_CONV_BF16X3) && !a.smallc;
-    const size_t staging = (size_t)igemm_stages(BM, BN, bf3) * (BM + BN) * 32 + 132;
+    const size_t staging = (size_t)2 * (BM + BN) * 32 + 132;
     const size_t epi = (size_t)t.wm * t.wn * 32 * 32 * std::min(t.nb, 4) + (size_t)t.wm * 2 * BN;
     const size_t sv_off = (std::max(staging, epi) + 3) & ~(size_t)3;
     pl->lds = (sv_off + (size_t)4 * BN + 4) * sizeof(float);   // (+ the reducer flag of a split launch)

@@ -68,10 +68,6 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, 
 // s ^ ((r >> 1) & 7).
 
 // K-loop stages of a tile configuration (host and kernel agree through this): see the kernel.
-constexpr int igemm_stages(int BM, int BN, bool bf3) {
-  return !bf3 ? 2 : (((BM + BN) * 128 * 4 + 12 * 1024 <= 160 * 1024) ? 4 : 3);
-}
-
 // BF3: the products run as split-bf16 triples on the bf16 matrix path (common.hpp, split_bf16x8): same staging, same K order,
 // same epilogues -- only the fragment-to-MFMA step differs.
 template <int WM, int WN, int MB, int NB, bool SMALLC, bool BF3 = false>
@@ -82,9 +78,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   constexpr int RPP = NT / 8;  // tile rows filled by one pass of the whole block
   static_assert(RPP % 16 == 0, "the swizzle term must not depend on the pass");
 
-  // LDS stages of the K loop.  Exact fp32: two (the MFMAs of a tile take longer than its DMA).  Split-bf16: the MFMAs of a tile
-  // are ~5x shorter than an L2 round trip, so the ring is 3-4 deep with counted vmcnt waits and a raw barrier per tile (below).
-  constexpr int ST = igemm_stages(BM, BN, BF3);
+  constexpr int ST = 2;   // LDS stages of the K loop (a 3-4 deep ring with counted vmcnt waits was measured slower, also for BF3)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                                        // [ST][BM*32]
   float* sB = smem + ST * BM * 32;                         // [ST][BN*32]
@@ -225,6 +219,28 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the MFMA stream that hides its latency
   };
 
+  // BF3: every thread splits the pieces IT staged, in place, once its DMA has landed (its own data: no barrier needed in
+  // between; the step's barrier then publishes the split image).  Each element is converted once per workgroup instead of once
+  // per wave that reads it, and the MFMA loop carries no VALU work.  Slot layout: {pk(hi0, hi1), pk(hi2, hi3), pk(lo0, lo1), pk(lo2, lo3)}.
+  auto presplit = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the stage have landed
+    asm volatile("" ::: "memory");
+    float* a = sA + buf * BM * 32 + wave * 8 * 32 + lane * 4;
+    float* b = sB + buf * BN * 32 + wave * 8 * 32 + lane * 4;
+#pragma unroll
+    for (int j = 0; j < AV + BV; ++j) {
+      float* q = j < AV ? a + j * RPP * 32 : b + (j - AV) * RPP * 32;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(q);
+      u32x4_t o;
+      unsigned h0, h1, l0, l1;
+      split_bf16x2(x[0], x[1], h0, l0);
+      split_bf16x2(x[2], x[3], h1, l1);
+      o[0] = h0; o[1] = h1; o[2] = l0; o[3] = l1;
+      *reinterpret_cast<u32x4_t*>(q) = o;
+    }
+  };
+
   f32x16 acc[MB][NB];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
@@ -243,25 +259,29 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   auto compute = [&](auto bufc, auto k0c, auto k1c) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value, K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
     if constexpr (BF3) {
-      // one bf16 MFMA covers 16 k = the quarter steps kk, kk + 1: lane half h contributes the 4 + 4 floats it reads for them
-      // (the same k for A and B, so the sum over k is complete whatever their order inside the instruction)
+      // one bf16 MFMA covers 16 k = the quarter steps kk, kk + 1.  The stage holds the PRE-SPLIT image (presplit below): every
+      // 16-byte slot is {bf16 hi of its 4 floats, bf16 lo of its 4 floats}, so a lane's 8 + 8 operand values are the first /
+      // second halves of the two slots it reads -- no conversion in the MFMA loop.  Lane half h contributes the same k for A
+      // and B, so the sum over k is complete whatever their order inside the instruction.
       static_assert(K0 % 2 == 0 && K1 % 2 == 0, "bf16x3 steps are pairs of quarter steps");
 #pragma unroll
       for (int kk = K0; kk < K1; kk += 2) {
         bf16x8 ah[MB], al[MB], bh[NB], bl[NB];
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
-          const f32x4 x0 = *reinterpret_cast<const f32x4*>(fa + fo[kk] + (buf * BM * 32 + i * 1024));
-          const f32x4 x1 = *reinterpret_cast<const f32x4*>(fa + fo[kk + 1] + (buf * BM * 32 + i * 1024));
-          const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-          split_bf16x8(x, ah[i], al[i]);
+          const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(fa + fo[kk] + (buf * BM * 32 + i * 1024));
+          const u32x4_t r1 = *reinterpret_cast<const u32x4_t*>(fa + fo[kk + 1] + (buf * BM * 32 + i * 1024));
+          const u32x4_t h = {r0[0], r0[1], r1[0], r1[1]}, l = {r0[2], r0[3], r1[2], r1[3]};
+          ah[i] = __builtin_bit_cast(bf16x8, h);
+          al[i] = __builtin_bit_cast(bf16x8, l);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          const f32x4 x0 = *reinterpret_cast<const f32x4*>(fb + fo[kk] + (buf * BN * 32 + j * 1024));
-          const f32x4 x1 = *reinterpret_cast<const f32x4*>(fb + fo[kk + 1] + (buf * BN * 32 + j * 1024));
-          const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-          split_bf16x8(x, bh[j], bl[j]);
+          const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(fb + fo[kk] + (buf * BN * 32 + j * 1024));
+          const u32x4_t r1 = *reinterpret_cast<const u32x4_t*>(fb + fo[kk + 1] + (buf * BN * 32 + j * 1024));
+          const u32x4_t h = {r0[0], r0[1], r1[0], r1[1]}, l = {r0[2], r0[3], r1[2], r1[3]};
+          bh[j] = __builtin_bit_cast(bf16x8, h);
+          bl[j] = __builtin_bit_cast(bf16x8, l);
         }
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -298,6 +318,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
 #if CRDR_IGEMM_FETCH_FIRST
     fetch(buf ^ 1);
     compute(bufc, I0{}, I4{});
+    if constexpr (BF3) presplit(integral_constant<int, buf ^ 1>{});
 #else
     compute(bufc, I0{}, I1{});
     __builtin_amdgcn_sched_barrier(0);
@@ -307,10 +328,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     __syncthreads();
   };
   if (it0 < it1) fetch(0);
-  if constexpr (ST > 2) {   // ring prologue: tiles it0 .. it0 + ST - 2 in flight (past the end: range-checked, never consumed)
-    fetch(1);
-    if constexpr (ST > 3) fetch(2);
-  }
   // (behind the first DMA so that their latencies overlap; the barrier below publishes both)
   if (p.fast_epi) {
     const int f0 = p.flags;
@@ -322,48 +339,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
       sV[3 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[n0 + c] : 0.f;
     }
   }
+  if constexpr (BF3) presplit(I0{});
+  __syncthreads();
   int it = it0;
-  if constexpr (ST == 2) {
-    __syncthreads();
-    for (; it + 2 <= it1; it += 2) {
-      step(I0{});
-      step(I1{});
-    }
-    if (it < it1) {
-      compute(I0{}, I0{}, I4{});
-      __syncthreads();
-    }
-  } else {
-    // Ring of ST stages, ST - 1 tiles in flight.  vmcnt counts this wave's DMA pieces in issue order: with (ST - 2) tiles'
-    // worth still outstanding the oldest tile -- the one consumed next -- has landed for this wave, the barrier extends that to
-    // every wave and also says everyone is done reading the stage the next DMA overwrites.
-    constexpr int kWait = (ST - 2) * (AV + BV);
-    static_assert(kWait <= 63, "vmcnt immediate");
-    constexpr int kImm = 0x0F70 | (kWait & 15) | ((kWait >> 4) << 14);
-    auto rstep = [&](auto bufc) __attribute__((always_inline)) {
-      constexpr int buf = decltype(bufc)::value;
-      __builtin_amdgcn_s_waitcnt(kImm);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      fetch((buf + ST - 1) % ST);
-      compute(bufc, I0{}, I4{});
-    };
-    using I2 = integral_constant<int, 2>;
-    using I3 = integral_constant<int, 3>;
-    for (; it + ST <= it1; it += ST) {
-      rstep(I0{});
-      rstep(I1{});
-      rstep(I2{});
-      if constexpr (ST > 3) rstep(I3{});
-    }
-    const int rem = it1 - it;
-    if (rem > 0) rstep(I0{});
-    if (rem > 1) rstep(I1{});
-    if constexpr (ST > 3) {
-      if (rem > 2) rstep(I2{});
-    }
-    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0), lgkmcnt(0): the look-ahead pieces land before the epilogue reuses the stages
+  for (; it + 2 <= it1; it += 2) {
+    step(I0{});
+    step(I1{});
+  }
+  if (it < it1) {
+    compute(I0{}, I0{}, I4{});
     __syncthreads();
   }
 

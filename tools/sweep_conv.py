@@ -62,7 +62,9 @@ def main():
     ap.add_argument("--wgrad", action="store_true")
     ap.add_argument("--shapes", default=None)
     ap.add_argument("--dump", action="store_true", help="print every unsplit tile configuration's TFLOP/s (cost-model fitting)")
+    ap.add_argument("--bf16x3", action="store_true", help="time the split-bf16 kernels (precision: bf16x3)")
     a = ap.parse_args()
+    ops.MATRIX_BF16X3 = a.bf16x3
     dev = torch.device("cuda:0")
     lib = L.load()
     ncfg = lib.crdr_conv2d_num_configs()
