@@ -184,6 +184,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   const int inner_n = SMALLC ? (1 << 30) : (cmajor ? ntap : kchunks);
   int ci = SMALLC ? it0 : it0 % inner_n, co = SMALLC ? 0 : it0 / inner_n;
   auto fetch = [&](int buf) __attribute__((always_inline)) {
+#ifdef EXP_NODMA   // experiment: the K loop re-reads whatever the stages hold (no global traffic after the prologue)
+    if (BF3 && buf >= 0) { if (++ci == inner_n) { ci = 0; ++co; } return; }
+#endif
     float* a = sA + buf * BM * 32 + wave * 8 * 32;
     float* b = sB + buf * BN * 32 + wave * 8 * 32;
     int dh, dw;
@@ -283,10 +286,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
           bh[j] = __builtin_bit_cast(bf16x8, h);
           bl[j] = __builtin_bit_cast(bf16x8, l);
         }
+#ifdef EXP_NOMFMA   // experiment: staging + fragment reads only (the accumulators get one cheap dependence on the fragments)
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j][0] += (float)ah[i][0] + (float)bl[j][0] + (float)al[i][1] + (float)bh[j][1];
+#else
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
           for (int j = 0; j < NB; ++j) acc[i][j] = mfma_bf16x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+#endif
       }
       return;
     }
