@@ -367,12 +367,14 @@ def main():
         ops.load_tune_cache(path, only_kinds=tuple(kinds.split(",")), ignore_signature=True)
     main_run = run_stage(a, a.stage, a.bs, a.steps, a.warmup, a.profile_steps, a.shape_table)
     tr = main_run.pop("trainer")
-    if rk == 0 and a.save_tune_db:
-        ops.save_tune_cache(a.save_tune_db)
-    if a.tune_log and rk == 0:
-        with open(a.tune_log, "w") as f:
-            for key, best, t0, t1 in ops.TUNE_LOG:
-                f.write(f"{t0 * 1e3:9.1f}us -> {t1 * 1e3:9.1f}us  algo cfg={(best & 0xff) - 1} split={1 << (best >> 8)}  {key}\n")
+    def save_tuning():   # (again at the end: the secondary runs tune their own shapes)
+        if rk == 0 and a.save_tune_db:
+            ops.save_tune_cache(a.save_tune_db)
+        if a.tune_log and rk == 0:
+            with open(a.tune_log, "w") as f:
+                for key, best, t0, t1 in ops.TUNE_LOG:
+                    f.write(f"{t0 * 1e3:9.1f}us -> {t1 * 1e3:9.1f}us  algo cfg={(best & 0xff) - 1} split={1 << ((best >> 8) & 0xf)}  {key}\n")
+    save_tuning()
     if rk != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -385,10 +387,18 @@ def main():
     tp = _newest_profile("r*_hbm_families.json")
     if a.stage == 3 and a.bs == 16 and a.size == 256 and tp:
         with open(tp) as f:
-            fams_ = json.load(f)["families"]
+            doc = json.load(f)
+        from crdr_amd.hip import lib as _L
+        ver = int(_L.load().crdr_version())
+        if doc.get("library_version") != ver:
+            # counters cannot be read inside this process; a committed measurement of another library build is not evidence
+            traffic_src = (f"STALE: {os.path.relpath(tp, ROOT)} was measured with library version {doc.get('library_version')}, this is {ver}: "
+                           f"re-run tools/pmc_round.sh (tools/pmc_step.py + tools/pmc_families.py) and commit the result")
+        else:
+            fams_ = doc["families"]
             traffic = round(fams_.get("conv_fwd_dgrad", fams_["igemm_kernel"])["hbm_bytes_per_launch"])
-        traffic_src = (f"HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step at q = 2 "
-                       f"({os.path.relpath(tp, ROOT)}); re-measure with tools/pmc_step.py + tools/pmc_families.py after kernel changes")
+            traffic_src = (f"HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step at q = 2 "
+                           f"with this library version ({os.path.relpath(tp, ROOT)})")
     roof = {"bound": "mfma", "achieved": ig["tflops"] if ig else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": round(main_run["alg_bytes_per_igemm_launch"]) if main_run["alg_bytes_per_igemm_launch"] else None,
@@ -459,6 +469,7 @@ def main():
             line["stage3_bf16x3"] = {"error": repr(e)[:300]}
     if ws == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.stage, a.size)
+    save_tuning()
     print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

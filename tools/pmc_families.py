@@ -14,7 +14,7 @@ import sys
 FAMILIES = [("igemm_kernel", "igemm_kernel"), ("gemm1x1_kernel", "gemm1x1_kernel"), ("wgrad_kernel", "wgrad_kernel"), ("wgrad_reduce_batched", "wgrad_reduce_batched_kernel"),
             ("igemm_splitk_epilogue", "igemm_splitk_epilogue"), ("ebwd", "ebwd_kernel"), ("adam_dyn", "adam_dyn_kernel"),
             ("pack_weights_batched", "pack_weights_batched_kernel"), ("colsum_finish", "colsum_finish_"), ("colsum", "colsum_kernel"),
-            ("gauss_cond_fwd", "gauss_cond_fwd_kernel"), ("gauss_cond_bwd", "gauss_cond_bwd_kernel"), ("eb", "eb_"),
+            ("gauss_cond_finish", "gauss_cond_finish_kernel"), ("gauss_cond_fwd", "gauss_cond_fwd_kernel"), ("gauss_cond_bwd", "gauss_cond_bwd_kernel"), ("eb", "eb_"),
             ("lrp", "lrp_"), ("col2im_rgb", "col2im_rgb_kernel"), ("lpips", "lpips_layer"), ("maxpool", "maxpool3s2"),
             ("reduce", "reduce_kernel"), ("aten", "at::native")]
 
@@ -48,7 +48,11 @@ def main():
         t["fetch_kib"] += float(a["Counter_Value"])
         t["write_kib"] += float(b["Counter_Value"])
         t["ns"] += int(a["End_Timestamp"]) - int(a["Start_Timestamp"])
-    out = {"note": "one eager stage-3 step (bs 16, 256x256, q = 2); hbm = (2*FETCH_SIZE + WRITE_SIZE) KiB; GB/s over the kernels' own durations in the FETCH pass",
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from crdr_amd.hip import lib as L
+    out = {"library_version": int(L.load().crdr_version()),
+           "note": "one eager stage-3 step (bs 16, 256x256, q = 2); hbm = (2*FETCH_SIZE + WRITE_SIZE) KiB; GB/s over the kernels' own durations in the FETCH pass",
            "kernels_in_step": len(fe), "families": {}}
     for fam, t in sorted(acc.items(), key=lambda kv: -kv[1]["ns"]):
         hbm = (2 * t["fetch_kib"] + t["write_kib"]) * 1024
