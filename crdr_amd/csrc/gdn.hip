@@ -13,6 +13,7 @@
 // transforms use ReLU bottlenecks -- so this is a registered optional op, parity-tested and profiled on its own.
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "common.hpp"
@@ -114,6 +115,140 @@ __global__ __launch_bounds__(256) void gdn_reparam_bwd_kernel(const float* dgamm
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Fused forward: ONE kernel reads x once and writes y once (8 B per element of HBM traffic; the four-kernel form above
+// moves 28 B).  A persistent workgroup (4 waves) takes tiles of 128 pixels x all channels: the x tile goes to LDS by
+// LDS-DMA as NB chunk images [128 rows][32 floats] (the igemm A-tile image: 128-byte rows, XOR-swizzled 16-byte slots),
+// gamma_eff streams through LDS in 32-channel K slabs [CP rows][32] (double buffered), A fragments are squared on the way
+// from LDS to the matrix cores (exact fp32 MFMA), and the epilogue -- n = acc + beta, y = x rsqrt(n) or x sqrt(n) -- takes
+// x from the LDS tile again, writes y over it in place and leaves with 16-byte stores of whole 128-byte row segments.
+// Roofline: 2 C^2 FLOP against 8 C bytes per pixel = C / 4 FLOP per byte: at C = 192 the exact-fp32 matrix peak
+// (157 TFLOP/s) caps the op at 3.3 TB/s = 0.41 of the HBM peak, at C = 128 it is HBM-bound.
+// mode 0: y = GDN / IGDN(x); mode 1: y = n (the norm, for the backward pass).  CP = 32 NB <= 192.
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* gdn_lds_ptr_t;
+struct GdnFusedArgs {
+  const float* x;
+  const float* pack;   // gamma_eff [CP][CP] (row = output channel, K-contiguous)
+  const float* beta;   // beta_eff [C]
+  float* y;
+  long long M;
+  int C, ldx, ldy, inverse, mode, tiles;
+  unsigned x_bytes, pack_bytes;
+};
+
+template <int NB>
+__global__ __launch_bounds__(256) void gdn_fused_fwd_kernel(const GdnFusedArgs p) {
+  constexpr int CP = 32 * NB, BM = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sX = smem;                    // [NB][BM * 32]
+  float* sG = smem + NB * BM * 32;     // [2][CP * 32]
+  float* sBeta = sG + 2 * CP * 32;     // [CP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 31, fh = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack), 0, p.pack_bytes, 0x00020000);
+  for (int c = tid; c < CP; c += 256) sBeta[c] = c < p.C ? p.beta[c] : 1.f;
+  // staging assignment (as igemm): thread fills slot (tid & 7) of rows (tid >> 3) + 32 j with source chunk slot ^ swizzle(row)
+  const int srow = tid >> 3;
+  const int csrc = (tid & 7) ^ ((srow >> 1) & 7);
+  int fo[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) fo[kk] = lds_off(frow, kk * 2 + fh);
+  auto fetch_g = [&](int kc, int buf) __attribute__((always_inline)) {   // gamma rows 0..CP-1, columns 32 kc .. +31
+    float* b = sG + buf * CP * 32 + wave * 8 * 32;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (gdn_lds_ptr_t)(b + j * 32 * 32), 16,
+                                               (int)(((unsigned)(srow + 32 * j) * CP + 32 * kc + csrc * 4) * 4u), 0, 0, 0);
+  };
+  for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
+    const long long m0 = (long long)t * BM;
+    const long long left = p.M - m0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x) + m0 * p.ldx, 0, (unsigned)std::min<long long>(((left < BM ? left : BM) - 1) * p.ldx * 4ll + p.C * 4ll, 0x7fffffffll), 0x00020000);
+    __syncthreads();   // the previous tile's epilogue is done with sX / sG
+    // x tile: chunk image kc, rows srow + 32 j (rows / channels past the tensor read zeros through the range check)
+#pragma unroll
+    for (int kc = 0; kc < NB; ++kc) {
+      float* a = sX + kc * BM * 32 + wave * 8 * 32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = srow + 32 * j, ch = 32 * kc + csrc * 4;
+        const bool ok = (row < left) && (ch < p.C);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (gdn_lds_ptr_t)(a + j * 32 * 32), 16, (int)(ok ? ((unsigned)row * p.ldx + ch) * 4u : 0x80000000u),
+                                                 0, 0, 0);
+      }
+    }
+    fetch_g(0, 0);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    __syncthreads();   // (waits for the DMA: x tile and slab 0 have landed)
+#pragma unroll 1
+    for (int kc = 0; kc < NB; ++kc) {
+      if (kc + 1 < NB) fetch_g(kc + 1, (kc + 1) & 1);
+      const float* fa = sX + kc * BM * 32 + wave * 32 * 32;
+      const float* fb = sG + (kc & 1) * CP * 32;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(fa + fo[kk]);
+        a = a * a;
+        f32x4 b[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b[j] = *reinterpret_cast<const f32x4*>(fb + fo[kk] + j * 1024);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[j][s2], acc[j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    // epilogue: accumulator element r of block j is (row (r & 3) + 8 (r >> 2) + 4 fh, column 32 j + frow) of this wave's 32 rows;
+    // x sits in chunk image j at slot frow >> 2 (swizzled), element frow & 3 -- rewritten in place with y
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float bta = sBeta[32 * j + frow];
+      float* img = sX + j * BM * 32 + wave * 32 * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        float* q = img + lds_off(row, frow >> 2) + (frow & 3);
+        const float n = acc[j][r] + bta;
+        const float xv = *q;
+        *q = p.mode ? n : (p.inverse ? xv * sqrtf(n) : xv / sqrtf(n));
+      }
+    }
+    // (the rows are private to the wave: program order is enough) 16-byte stores, 8 rows x 128 B per wave instruction
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + m0 * p.ldy, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float* img = sX + j * BM * 32 + wave * 32 * 32;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = (lane >> 3) + 8 * k, slot = lane & 7;
+        const int grow = wave * 32 + row, ch = 32 * j + ((slot ^ ((row >> 1) & 7)) << 2);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(img + row * 32 + slot * 4);
+        const bool ok = (grow < left) && (ch < p.C);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, ok ? ((unsigned)grow * p.ldy + ch) * 4u : 0x80000000u, 0, 0);
+      }
+    }
+  }
+}
+
+template <int NB>
+static void gdn_fused_launch(const GdnFusedArgs& a, hipStream_t s) {
+  constexpr int CP = 32 * NB;
+  const size_t lds = ((size_t)NB * 128 * 32 + 2 * CP * 32 + CP) * sizeof(float);
+  static std::atomic<bool> done{false};
+  if (!done.load(std::memory_order_acquire)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gdn_fused_fwd_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(gdn_fused_fwd_kernel<NB>, dim3(std::min(a.tiles, 256)), dim3(256), lds, s, a);
+}
+
 static inline int grid1(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(cdiv64(n, 256), 1), 8192); }
 
 struct GdnLayout {
@@ -160,6 +295,29 @@ static int gdn_layout(const crdr_gdn_desc* d, int backward, GdnLayout* L) {
   return 0;
 }
 
+static bool gdn_fused_ok(const crdr_gdn_desc* d, const GdnLayout& L) {
+  return L.CP <= 192 && (long long)128 * d->ldx * 4 < (1ll << 31) && (long long)128 * d->ldy * 4 < (1ll << 31);
+}
+
+// y (mode 0) or n (mode 1) by the fused kernel; gamma_eff / beta_eff must already be in the workspace
+static int gdn_fused(const crdr_gdn_desc* d, const GdnLayout& L, char* ws, const float* x, float* out, int ldo, int mode, crdr_stream_t s) {
+  GdnFusedArgs a;
+  a.x = x; a.pack = (const float*)(ws + L.pack_f); a.beta = (const float*)(ws + L.beta_eff); a.y = out;
+  a.M = d->M; a.C = d->C; a.ldx = d->ldx; a.ldy = ldo; a.inverse = d->inverse; a.mode = mode;
+  a.tiles = (int)((d->M + 127) / 128);
+  a.x_bytes = 0; a.pack_bytes = (unsigned)((size_t)L.CP * L.CP * 4);
+  switch (L.CP / 32) {
+    case 1: gdn_fused_launch<1>(a, as_stream(s)); break;
+    case 2: gdn_fused_launch<2>(a, as_stream(s)); break;
+    case 3: gdn_fused_launch<3>(a, as_stream(s)); break;
+    case 4: gdn_fused_launch<4>(a, as_stream(s)); break;
+    case 5: gdn_fused_launch<5>(a, as_stream(s)); break;
+    default: gdn_fused_launch<6>(a, as_stream(s)); break;
+  }
+  CRDR_CHECK_LAUNCH("gdn_fused_fwd");
+  return 0;
+}
+
 static int gdn_norm(const crdr_gdn_desc* d, const GdnLayout& L, char* ws, const float* x, const float* beta, const float* gamma,
                     crdr_stream_t s) {
   const float ped = d->reparam_offset * d->reparam_offset;
@@ -168,6 +326,7 @@ static int gdn_norm(const crdr_gdn_desc* d, const GdnLayout& L, char* ws, const 
   hipLaunchKernelGGL(gdn_reparam_kernel, dim3(grid1((int64_t)L.CP * L.CP)), dim3(256), 0, as_stream(s), beta, gamma, d->C, L.CP, bb, bg,
                      ped, beta_eff, (float*)(ws + L.pack_f), (float*)(ws + L.pack_b));
   CRDR_CHECK_LAUNCH("gdn_reparam");
+  if (gdn_fused_ok(d, L)) return gdn_fused(d, L, ws, x, (float*)(ws + L.norm), d->C, 1, s);   // n in one pass over x
   hipLaunchKernelGGL(gdn_square_kernel, dim3(grid1(d->M * (d->C / 4))), dim3(256), 0, as_stream(s), x, d->ldx, d->M, d->C / 4,
                      (float*)(ws + L.x2));
   CRDR_CHECK_LAUNCH("gdn_square");
@@ -198,6 +357,13 @@ extern "C" int crdr_gdn_fwd(const crdr_gdn_desc* d, const float* x, const float*
   CRDR_REQUIRE(ws_bytes >= L.end && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "gdn_fwd: workspace too small or misaligned (%zu < %zu)", ws_bytes, L.end);
   CRDR_REQUIRE(d->ldy % 4 == 0 && d->ldy >= d->C, "gdn_fwd: ldy");
   char* w8 = (char*)ws;
+  if (gdn_fused_ok(d, L)) {   // reparametrisation (C x C, tiny) + ONE pass over x
+    const float ped = d->reparam_offset * d->reparam_offset;
+    hipLaunchKernelGGL(gdn_reparam_kernel, dim3(grid1((int64_t)L.CP * L.CP)), dim3(256), 0, as_stream(s), beta, gamma, d->C, L.CP,
+                       sqrtf(d->beta_min + ped), d->reparam_offset, ped, (float*)(w8 + L.beta_eff), (float*)(w8 + L.pack_f), (float*)(w8 + L.pack_b));
+    CRDR_CHECK_LAUNCH("gdn_reparam");
+    return gdn_fused(d, L, w8, x, y, d->ldy, 0, s);
+  }
   if (int rc = gdn_norm(d, L, w8, x, beta, gamma, s)) return rc;
   hipLaunchKernelGGL(gdn_apply_kernel, dim3(grid1(d->M * (d->C / 4))), dim3(256), 0, as_stream(s), x, d->ldx, (const float*)(w8 + L.norm),
                      d->M, d->C / 4, d->inverse, y, d->ldy);
