@@ -399,6 +399,11 @@ extern "C" int crdr_gdn_bwd(const crdr_gdn_desc* d, const float* x, const float*
   wd.N = (int32_t)d->M; wd.PH = 1; wd.PW = 1; wd.PC = d->C; wd.ldp = d->C; wd.QH = 1; wd.QW = 1; wd.QC = d->C; wd.ldq = d->C;
   wd.kh = 1; wd.kw = 1; wd.stride = 1; wd.pad = 0; wd.gI = d->C; wd.gJ = d->C; wd.accumulate = 0;
   float *dg = (float*)(w8 + L.dg), *db = (float*)(w8 + L.db);
+  if (gdn_fused_ok(d, L)) {   // the fused norm pass squares on the fly: the weight gradient still wants x^2 in memory
+    hipLaunchKernelGGL(gdn_square_kernel, dim3(grid1(d->M * (d->C / 4))), dim3(256), 0, as_stream(s), x, d->ldx, d->M, d->C / 4,
+                       (float*)(w8 + L.x2));
+    CRDR_CHECK_LAUNCH("gdn_square");
+  }
   if (int rc = crdr_conv2d_wgrad(&wd, dn, (const float*)(w8 + L.x2), dg, w8 + L.conv_ws, L.conv_ws_bytes, s)) return rc;
   if (int rc = crdr_colsum(dn, d->C, d->M, d->C, db, 0, w8 + L.conv_ws, L.conv_ws_bytes, s)) return rc;
   const float ped = d->reparam_offset * d->reparam_offset;

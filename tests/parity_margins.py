@@ -43,6 +43,8 @@ def record(group: str, name: str, err: float) -> None:
 
 def tolerance(group: str, cap: float) -> float:
     global _committed
+    if os.environ.get("CRDR_PARITY_REMEASURE") == "1":   # tools/parity_margins.sh: gate at the stated bounds only, record afresh
+        return cap
     if _committed is None:
         _committed = json.load(open(COMMITTED))["tests"] if os.path.exists(COMMITTED) else {}
     m = _committed.get(_test_id(), {}).get(group)
