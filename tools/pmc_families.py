@@ -20,7 +20,8 @@ FAMILIES = [("igemm_kernel", "igemm_kernel"), ("gemm1x1_kernel", "gemm1x1_kernel
 
 
 def load(d, counter):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    import os
+    f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)   # gpurun_out accumulates old runs
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     marks = [i for i, r in enumerate(rows) if "adam_dyn_kernel" in r["Kernel_Name"]]

@@ -2,13 +2,13 @@
 import csv, glob, sys
 tag = sys.argv[1]; gflop = float(sys.argv[2]); mb = float(sys.argv[3])
 def last(d, counter):
-    f = glob.glob(f"gpurun_out/pmc_{tag}_{d}/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(f"gpurun_out/pmc_{tag}_{d}/**/*counter_collection.csv", recursive=True), key=__import__("os").path.getmtime)
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and ("igemm_kernel" in r["Kernel_Name"] or "gemm1x1_kernel" in r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     rows = rows[-10:]
     return sum(float(r["Counter_Value"]) for r in rows) / len(rows), rows[-1]
 def dur(d):
-    f = glob.glob(f"gpurun_out/pmc_{tag}_{d}/**/*kernel_trace.csv", recursive=True)[0]
+    f = max(glob.glob(f"gpurun_out/pmc_{tag}_{d}/**/*kernel_trace.csv", recursive=True), key=__import__("os").path.getmtime)
     rows = [r for r in csv.DictReader(open(f)) if ("igemm_kernel" in r["Kernel_Name"] or "gemm1x1_kernel" in r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     rows = rows[-10:]

@@ -10,7 +10,7 @@ import sys
 
 
 def per_kernel(d, counter, pat, n_last):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=__import__("os").path.getmtime)
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and pat in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     rows = rows[-n_last:]
