@@ -16,7 +16,10 @@ PARITY UNPINNED: the entropy-model arithmetic (GaussianConditional / EntropyBott
 rANS) lives in the third-party package compressai==1.2.4 (pyproject.toml:16) which is not installed and not
 vendored; it is restated here from that package's published behaviour as exercised by the reference's call
 sites (ste_gaussian_conditional.py:20-27, entropy_bottleneck.py:18-30, hyperprior_model.py:120-198,
-minnen20_charm_context_model.py:143-240) and checked only by analytic known answers and round trips.  The same
+minnen20_charm_context_model.py:143-240) and checked only by analytic known answers, round trips and an independent
+exact-rational CDF construction (tests/test_entropy_parity.py).  The end-to-end codec at the bottom of this file
+(compress / decompress: header, z string, y string) composes these pieces exactly as the reference's model classes do;
+the HIP path is held to it byte for byte (tests/test_gpu_codec_parity.py).  The same
 holds for LPIPS (lpips==0.1.4, perceptual_loss.py:23): architecture restated, weights not available offline.
 """
 from __future__ import annotations
