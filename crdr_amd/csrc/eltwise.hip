@@ -1068,6 +1068,50 @@ extern "C" int crdr_lrp_bwd(const float* dy, int lddy, const float* z, int ldz, 
   return 0;
 }
 
+// a[m][c0_k + c] = max(a[m][c0_k + c] + bias_k[c], 0) for up to CRDR_MAX_GROUP channel ranges ("slots") of one wide NHWC buffer:
+// the first-layer pre-activations of the Charm's transforms are accumulated by several launches (hoisted hyper-prior part,
+// one wide conv per decoded support slice); this finishes the slots that are complete.  16-byte accesses, 8 B per element.
+struct BiasReluArgs {
+  float* a;
+  long long M;
+  int ld, C, n;
+  int c0[CRDR_MAX_GROUP];
+  const float* bias[CRDR_MAX_GROUP];
+};
+__global__ __launch_bounds__(256) void bias_relu_slots_kernel(const BiasReluArgs p) {
+  const int C4 = p.C >> 2;
+  const long long per = p.M * C4, total = per * p.n;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int k = (int)(e / per);
+    const long long r = e - k * per;
+    const long long m = r / C4;
+    const int c = (int)(r - m * C4) << 2;
+    float* q = p.a + m * p.ld + p.c0[k] + c;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(q);
+    const float* b = p.bias[k] + c;   // (a parameter inside a flat buffer: 4-byte aligned only)
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(v[j] + b[j], 0.f);
+    *reinterpret_cast<f32x4*>(q) = o;
+  }
+}
+
+extern "C" int crdr_bias_relu_slots(float* a, int ld, int64_t M, int C, int n, const int32_t* c0, const float* const* bias, crdr_stream_t s) {
+  CRDR_REQUIRE(a && c0 && bias, "bias_relu_slots: null pointer");
+  CRDR_REQUIRE(n >= 1 && n <= CRDR_MAX_GROUP && C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0,
+               "bias_relu_slots: %d slots of %d channels (ld %d)", n, C, ld);
+  if (M * C == 0) return 0;
+  BiasReluArgs p;
+  p.a = a; p.M = M; p.ld = ld; p.C = C; p.n = n;
+  for (int k = 0; k < n; ++k) {
+    CRDR_REQUIRE(bias[k] && c0[k] % 4 == 0, "bias_relu_slots: slot %d misaligned", k);
+    p.c0[k] = c0[k]; p.bias[k] = bias[k];
+  }
+  hipLaunchKernelGGL(bias_relu_slots_kernel, dim3(grid_for(M * (C / 4) * n)), dim3(256), 0, as_stream(s), p);
+  CRDR_CHECK_LAUNCH("bias_relu_slots");
+  return 0;
+}
+
 extern "C" size_t crdr_reduce_workspace(int64_t n) { return (size_t)reduce_blocks(n) * sizeof(float); }
 
 template <int OP>

@@ -5,11 +5,16 @@ slice i the mean / scale / LRP transforms are conv5(->C1)-ReLU-conv5(->C2)-ReLU-
 [hyper-prior half, first min(i, ms) decoded slices(, y_hat_i)].  The reference runs 90 small convs in a 10-deep chain
 with concatenations in between; here the same arithmetic is re-scheduled:
 
- * HOIST.  The first conv of every transform is linear in its input channels, so its hyper-prior part (320 of 320..512
-   input channels = 72 % of the first-layer MACs, 56 % of the whole context model) does not depend on any decoded slice:
-   it is computed for all transforms up front by two wide convs (320 -> 19 x 224 from the mean half, 320 -> 9 x 224 from
-   the scale half; slice 0's own transforms have no other input and run directly).  The support part follows inside the
-   loop with the hoisted pre-activation added in the epilogue (CRDR_EPI_PREADD) before bias + ReLU.
+ * HOIST.  The first conv of every transform is linear in its input channels, so each part of it is computed by the
+   launch that has that part of the input.  The hyper-prior part (320 of 320..512 input channels = 72 % of the first-layer
+   MACs, 56 % of the whole context model) does not depend on any decoded slice: it is computed for all transforms up front by
+   two wide convs (320 -> 19 x 224 from the mean half, 320 -> 9 x 224 from the scale half; slice 0's own transforms have
+   no other input and run directly).  The SUPPORT part is scattered the same way (round 3): as soon as slice k is decoded,
+   ONE wide conv per half (32 -> 2 (S-1-k) x 224 and 32 -> (S-1-k) x 224, CRDR_EPI_ACCUM) adds its contribution to the
+   first-layer pre-activation of EVERY later transform -- 2 x ms efficient launches with N in the thousands instead of a
+   small conv per transform and stage whose K grows with the slice index.  A pre-activation that has received all its parts
+   is finished by crdr_bias_relu_slots (bias + ReLU in place); the LRP transforms get their last part -- the slice's own
+   pre-correction latent -- from a small conv that carries bias + ReLU in its epilogue (CRDR_EPI_PREADD).
  * TAIL.  From slice ms on the support stops growing (`y_hat_slice_list[:5]`, :104-105): the mean / scale transforms of
    ALL remaining slices are independent of each other and run as grouped launches (crdr_conv2d_grouped), then one
    Gaussian-conditional launch over all tail channels, then the LRP transforms as one group.  The sequential depth drops
@@ -18,14 +23,15 @@ with concatenations in between; here the same arithmetic is re-scheduled:
    A1 / A2 hold the first / second layer outputs of all 30 transforms ("slots"), MSL holds mu | sigma | lrp, Yh / Ypre
    the decoded latent after / before the LRP correction.
  * BACKWARD is written out by hand in reverse schedule order (no autograd graph inside): ReLU masks ride in the
-   input-gradient convs' epilogues (CRDR_EPI_RELUMASK), support gradients accumulate into one dY buffer
-   (CRDR_EPI_ACCUM), the hoisted parts get ONE input-gradient conv and ONE weight-gradient slab launch per half whose
-   rows are scattered to the 19 / 9 parameters by the batched reduce (crdr_wgrad_job.gJtot), and all bias gradients come
-   from three column-sum passes over the wide gradient buffers (crdr_colsum_scatter).
+   input-gradient convs' epilogues (CRDR_EPI_RELUMASK); the gradient of decoded slice k collects the first-layer gradients
+   of all its consumers through ONE K-concatenated input-gradient conv per half (CRDR_EPI_ACCUM into dY) and their weight
+   gradients through ONE slab launch per half whose rows the batched reduce scatters to the parameters
+   (crdr_wgrad_job.gJtot) -- the same two launches per half serve the hoisted hyper-prior parts -- and all bias gradients
+   come from three column-sum passes over the wide gradient buffers (crdr_colsum_scatter).
 
-Slot order (A1, A2 and their gradients): [lrp_0..ms-1 | mean_1..ms-1 | mean_ms..S-1 | lrp_ms..S-1] (reads the mean half)
-[scale_ms..S-1 | scale_1..ms-1] (reads the scale half) [mean_0, scale_0] -- the tail's 3 (S - ms) slots are contiguous
-so that their support gradient is one K-concatenated conv.
+Slot order (A1, A2 and their gradients): [mean_S-1, lrp_S-1, mean_S-2, lrp_S-2, ..., mean_1, lrp_1, lrp_0] (reads the mean
+half) [scale_S-1 ... scale_1] (reads the scale half) [mean_0, scale_0]: descending slice index, so the consumers of decoded
+slice k -- every transform of a later slice -- are a PREFIX of each half.
 """
 from __future__ import annotations
 
@@ -67,19 +73,16 @@ class CharmPlan:
         self.device = w1.device
         # ---- slots
         order: List[Tuple[str, int]] = []
-        order += [("lrp", i) for i in range(ms)]
-        order += [("mean", i) for i in range(1, ms)]
-        order += [("mean", i) for i in range(ms, S)]
-        order += [("lrp", i) for i in range(ms, S)]
+        for j in range(S - 1, 0, -1):
+            order += [("mean", j), ("lrp", j)]
+        order += [("lrp", 0)]
         self.n_mu = len(order)
-        order += [("scale", i) for i in range(ms, S)]
-        order += [("scale", i) for i in range(1, ms)]
+        order += [("scale", j) for j in range(S - 1, 0, -1)]
         self.n_sc = len(order) - self.n_mu
         order += [("mean", 0), ("scale", 0)]
         self.order = order
         self.slot = {t: k for k, t in enumerate(order)}
         self.NT = len(order)
-        self.tail0 = self.slot[("mean", ms)] if T else 0   # first of the 3 T contiguous tail slots
         self.signature = self._signature()
         self._fwd = None
         self._bwd = None
@@ -104,6 +107,16 @@ class CharmPlan:
         """support channels of slice i"""
         return self.sc * min(i, self.ms)
 
+    def ncons(self, k: int) -> int:
+        """later slices whose transforms read decoded slice k (0 for k >= ms: not a support slice)"""
+        return self.S - 1 - k if k < self.ms else 0
+
+    def consumers(self, k: int, half: str):
+        """(first slot, [(kind, j)...]) of the transforms that read slice k through the `half` ("mu" / "sc") of A1: a prefix"""
+        nc = self.ncons(k)
+        lo, cnt = (0, 2 * nc) if half == "mu" else (self.n_mu, nc)
+        return lo, self.order[lo:lo + cnt]
+
     # ---- packs
     def _alloc(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -123,6 +136,19 @@ class CharmPlan:
             for k in range(n):
                 kind, i = self.order[lo + k]
                 ents.append(HF.sub_pack(self.conv(kind, i, 0).weight, 0, hm, buf, k * C1 * hm, C1, hm, False, dld=hm, tstride=n * C1 * hm))
+        # support parts: decoded slice k -> every later transform, N-concatenated in slot order: [t1][n * C1][sc]
+        for k in range(ms):
+            for half in ("mu", "sc"):
+                lo, cons = self.consumers(k, half)
+                if not cons:
+                    continue
+                n = len(cons)
+                buf = self._alloc(t1, n * C1, sc)
+                keep.append(buf)
+                addr[("sup_" + half, k)] = buf.data_ptr()
+                for idx, (kind, j) in enumerate(cons):
+                    ents.append(HF.sub_pack(self.conv(kind, j, 0).weight, hm + k * sc, hm + (k + 1) * sc, buf, idx * C1 * sc, C1, sc, False,
+                                            dld=sc, tstride=n * C1 * sc))
         for kind in ("mean", "scale", "lrp"):
             for i in range(S):
                 w = self.conv(kind, i, 0).weight
@@ -131,20 +157,12 @@ class CharmPlan:
                     ents.append(HF.sub_pack(w, 0, hm, b, 0, C1, hm, False))
                     addr[(kind, 0, "l1")] = b.data_ptr()
                     keep.append(b)
-                else:
+                if kind == "lrp":                 # the slice's own pre-correction latent: the last part of its first conv
                     s = self.sup(i)
-                    if kind == "lrp" and i < ms:   # support + own slice, contiguous in Yh
-                        s += sc
-                    if s:
-                        b = self._alloc(t1, C1, s)
-                        ents.append(HF.sub_pack(w, hm, hm + s, b, 0, C1, s, False))
-                        addr[(kind, i, "sup")] = b.data_ptr()
-                        keep.append(b)
-                    if kind == "lrp" and i >= ms:  # own slice separately (not adjacent to the support in Yh)
-                        b = self._alloc(t1, C1, sc)
-                        ents.append(HF.sub_pack(w, hm + s, hm + s + sc, b, 0, C1, sc, False))
-                        addr[(kind, i, "own")] = b.data_ptr()
-                        keep.append(b)
+                    b = self._alloc(t1, C1, sc)
+                    ents.append(HF.sub_pack(w, hm + s, hm + s + sc, b, 0, C1, sc, False))
+                    addr[(kind, i, "own")] = b.data_ptr()
+                    keep.append(b)
                 w2, w3 = self.conv(kind, i, 1).weight, self.conv(kind, i, 2).weight
                 b2, b3 = self._alloc(t2, C2, C1), self._alloc(t3, sc, C2)
                 ents.append(HF.sub_pack(w2, 0, C1, b2, 0, C2, C1, False))
@@ -168,15 +186,19 @@ class CharmPlan:
             for k in range(n):
                 kind, i = self.order[lo + k]
                 ents.append(HF.sub_pack(self.conv(kind, i, 0).weight, 0, hm, buf, k * C1, hm, C1, True, dld=n * C1, tstride=hm * n * C1))
-        if T:   # tail support: K-concatenated over the 3 T tail transforms
-            s = self.sup(ms)
-            buf = self._alloc(t1, s, 3 * T * C1)
-            keep.append(buf)
-            addr["tail_sup"] = buf.data_ptr()
-            for k in range(3 * T):
-                kind, i = self.order[self.tail0 + k]
-                ents.append(HF.sub_pack(self.conv(kind, i, 0).weight, hm, hm + s, buf, k * C1, s, C1, True, dld=3 * T * C1,
-                                        tstride=s * 3 * T * C1))
+        # support parts, K-concatenated over the consumers of slice k: [t1][sc][n * C1]
+        for k in range(ms):
+            for half in ("mu", "sc"):
+                lo, cons = self.consumers(k, half)
+                if not cons:
+                    continue
+                n = len(cons)
+                buf = self._alloc(t1, sc, n * C1)
+                keep.append(buf)
+                addr[("sup_" + half, k)] = buf.data_ptr()
+                for idx, (kind, j) in enumerate(cons):
+                    ents.append(HF.sub_pack(self.conv(kind, j, 0).weight, hm + k * sc, hm + (k + 1) * sc, buf, idx * C1, sc, C1, True,
+                                            dld=n * C1, tstride=sc * n * C1))
         for kind in ("mean", "scale", "lrp"):
             for i in range(S):
                 w = self.conv(kind, i, 0).weight
@@ -185,14 +207,7 @@ class CharmPlan:
                     ents.append(HF.sub_pack(w, 0, hm, b, 0, hm, C1, True))
                     addr[(kind, 0, "l1")] = b.data_ptr()
                     keep.append(b)
-                elif i < ms:
-                    s = self.sup(i) + (sc if kind == "lrp" else 0)
-                    if s:
-                        b = self._alloc(t1, s, C1)
-                        ents.append(HF.sub_pack(w, hm, hm + s, b, 0, s, C1, True))
-                        addr[(kind, i, "sup")] = b.data_ptr()
-                        keep.append(b)
-                elif kind == "lrp":
+                if kind == "lrp":
                     s = self.sup(i)
                     b = self._alloc(t1, sc, C1)
                     ents.append(HF.sub_pack(w, hm + s, hm + s + sc, b, 0, sc, C1, True))
@@ -282,14 +297,15 @@ class CharmRun:
     def bias(self, kind, i, layer):
         return self.p.conv(kind, i, layer).bias.data_ptr()
 
-    def _conv(self, xs, ws, ys, oc, k, *, wrows, wcols, biases=None, pres=None, relu=False, label="", ms=False):
+    def _conv(self, xs, ws, ys, oc, k, *, wrows, wcols, biases=None, pres=None, relu=False, label="", ms=False, accum=False):
         """ms: a launch over mean (+ scale) transforms.  The mean-only pass (with_scale False) runs it with the plan the full
         pass uses for twice the problems, so that mu -- hence y_hat -- comes out bit-identical in both."""
         mult = 2 if (ms and not self.with_scale) else 1
         for a, b in _chunks(len(xs), L.MAX_GROUP // mult):
             ops.conv_group(self.n, self.h, self.w, xs[a:b], ws[a:b], ys[a:b], oc, k, k[0] // 2, False, wrows=wrows, wcols=wcols,
                            biases=None if biases is None else biases[a:b], pres=None if pres is None else pres[a:b],
-                           flags=L.EPI_RELU if relu else 0, device=self.dev, label=label, plan_as=mult * (b - a) if mult > 1 else None)
+                           flags=(L.EPI_RELU if relu else 0) | (L.EPI_ACCUM if accum else 0), device=self.dev, label=label,
+                           plan_as=mult * (b - a) if mult > 1 else None)
 
     # ---- stages
     def stages(self):
@@ -316,6 +332,15 @@ class CharmRun:
         self._conv([self.a2(s) for s in sl], [self.addr[(k, i, "l3")] for k, i in trs], outs, P.sc, P.k3,
                    wrows=P.sc, wcols=P.C2, biases=[self.bias(k, i, 2) for k, i in trs], label=label + ".l3", ms=ms)
 
+    def finish(self, trs):
+        """bias + ReLU in place on the first-layer pre-activations of `trs`, which have received all their parts"""
+        P = self.p
+        lib = L.load()
+        for a, b in _chunks(len(trs)):
+            c0 = (C.c_int32 * (b - a))(*[P.slot[t] * P.C1 for t in trs[a:b]])
+            bs = (C.c_void_p * (b - a))(*[self.bias(k, i, 0) for k, i in trs[a:b]])
+            L.check(lib.crdr_bias_relu_slots(self.A1.data_ptr(), self.A1.shape[1], self.M, P.C1, b - a, c0, bs, ops._stream()), "bias_relu_slots")
+
     def mean_scale(self, st):
         """mu (and sigma) of the slices of stage `st` -> MSL"""
         P = self.p
@@ -326,19 +351,22 @@ class CharmRun:
             xs = [self.h_mu, self.h_sc][: len(kinds)]
             self._conv(xs, [self.addr[(k, 0, "l1")] for k in kinds], [self.a1(s) for s in sl], P.C1, P.k1, wrows=P.C1, wcols=P.hm,
                        biases=[self.bias(k, 0, 0) for k in kinds], relu=True, label="charm.ms.l1", ms=True)
-        else:
-            s = P.sup(st[0])
-            x = self.yh(0, s)
-            self._conv([x] * len(trs), [self.addr[(k, i, "sup")] for k, i in trs], [self.a1(q) for q in sl], P.C1, P.k1,
-                       wrows=P.C1, wcols=s, biases=[self.bias(k, i, 0) for k, i in trs], pres=[self.a1(q) for q in sl], relu=True,
-                       label="charm.ms.l1", ms=True)
-            if len(st) > 1:  # tail: the support part of the LRP transforms is known now as well (raw accumulate)
-                lt = [("lrp", i) for i in st]
-                ls = [self.a1(P.slot[t]) for t in lt]
-                self._conv([x] * len(lt), [self.addr[(k, i, "sup")] for k, i in lt], ls, P.C1, P.k1, wrows=P.C1, wcols=s, pres=ls,
-                           label="charm.lrp.l1sup")
+        else:       # hoisted hyper-prior part + one part per support slice are in: finish
+            self.finish(trs)
         outs = [self.msl(0 if k == "mean" else 1, i) for k, i in trs]
         self._l23(trs, outs, "charm.ms", ms=True)
+
+    def push_support(self, k: int):
+        """decoded slice k (final: after its LRP correction) -> the first-layer pre-activations of every later transform"""
+        P = self.p
+        if not P.ncons(k):
+            return
+        x = self.yh(k * P.sc, P.sc)
+        for half in (("mu", "sc") if self.with_scale else ("mu",)):
+            lo, cons = P.consumers(k, half)
+            n = len(cons)
+            self._conv([x], [self.addr[("sup_" + half, k)]], [self.a1(lo, n)], n * P.C1, P.k1, wrows=n * P.C1, wcols=P.sc, accum=True,
+                       label="charm.sup")
 
     def quantize(self, st, y: Optional[V], noise: Optional[V], philox, lik_n, lik_q, bits_n, bits_q):
         """Gaussian conditional over the channels of stage `st`: Yh = Ypre = round(y - mu) + mu, likelihoods, bit sums."""
@@ -356,22 +384,19 @@ class CharmRun:
         HF.gauss_cond_fwd2(d, io, self.dev)
 
     def lrp(self, st):
-        """LRP transforms of stage `st` on the pre-correction latent in Yh, then Yh = Ypre + 0.5 tanh(.)"""
+        """LRP transforms of stage `st` on the pre-correction latent in Yh, then Yh = Ypre + 0.5 tanh(.); a sequential stage then
+        scatters its finished slice to the later transforms"""
         P = self.p
         lt = [("lrp", i) for i in st]
         sl = [self.a1(P.slot[t]) for t in lt]
-        if len(st) == 1:
-            i = st[0]
-            s = P.sup(i) + P.sc
-            self._conv([self.yh(0, s)], [self.addr[("lrp", i, "sup")]], sl, P.C1, P.k1, wrows=P.C1, wcols=s,
-                       biases=[self.bias("lrp", i, 0)], pres=sl, relu=True, label="charm.lrp.l1")
-        else:
-            self._conv([self.yh(i * P.sc, P.sc) for i in st], [self.addr[("lrp", i, "own")] for i in st], sl, P.C1, P.k1,
-                       wrows=P.C1, wcols=P.sc, biases=[self.bias("lrp", i, 0) for i in st], pres=sl, relu=True, label="charm.lrp.l1")
+        self._conv([self.yh(i * P.sc, P.sc) for i in st], [self.addr[("lrp", i, "own")] for i in st], sl, P.C1, P.k1,
+                   wrows=P.C1, wcols=P.sc, biases=[self.bias("lrp", i, 0) for i in st], pres=sl, relu=True, label="charm.lrp.l1")
         self._l23(lt, [self.msl(2, i) for i in st], "charm.lrp")
         c0, c = st[0] * P.sc, len(st) * P.sc
         L.check(L.load().crdr_lrp(self.yp(c0, c).ptr, self.Cy, self.msl(2, st[0]).ptr, self.MSL.shape[1], self.yh(c0, c).ptr, self.Cy,
                                   self.M, c, ops._stream()), "lrp")
+        if len(st) == 1:
+            self.push_support(st[0])
 
     # ---- whole pass
     def forward(self, y: torch.Tensor, noise: Optional[torch.Tensor], philox: Optional[int], scale_bound: float, lik_bound: float,
@@ -480,27 +505,30 @@ def charm_backward(run: CharmRun, dyhat: Optional[torch.Tensor], gbits: Optional
         for st in reversed(run.stages()):
             c0, c = st[0] * sc, len(st) * sc
             lt = [("lrp", i) for i in st]
+            if len(st) == 1 and P.ncons(st[0]):
+                # decoded slice k fed the first layer of every later transform: their (masked) first-layer gradients are final by
+                # now -- ONE K-concatenated input-gradient conv per half adds them to d Yh_k, ONE slab launch per half yields the
+                # weight gradients of those parts (rows scattered to the parameters' support columns by the batched reduce)
+                k = st[0]
+                for half in ("mu", "sc"):
+                    lo, cons = P.consumers(k, half)
+                    nc = len(cons)
+                    dgrad([da1(lo, nc)], [baddr[("sup_" + half, k)]], [dyv(k * sc, sc)], sc, P.k1, sc, nc * C1, accum=True, label="charm.sup")
+                    parts = []
+                    for idx, (kind, j) in enumerate(cons):
+                        gw = wg(kind, j, 0)
+                        parts.append((idx * C1, C1, gw.data_ptr() + 4 * (hm + k * sc) * t1, gw.shape[1]))
+                    ops.wgrad_split(n, h, w, da1(lo, nc), run.yh(k * sc, sc), parts, P.k1, pad1, device=dev, label="charm.sup")
             # Yh = Ypre + 0.5 tanh(lrp): d lrp
             L.check(lib.crdr_lrp_bwd(dyv(c0, c).ptr, Cy, run.msl(2, st[0]).ptr, 3 * Cy, g4(2, st[0]).ptr, 4 * Cy, M, c, ops._stream()),
                     "lrp_bwd")
             l32_bwd(lt, [g4(2, i) for i in st], "charm.lrp")
-            if len(st) == 1:
-                i = st[0]
-                s = P.sup(i) + sc
-                # dY[0 : s] += conv_T(dz1): the support slices' gradient AND (last sc channels) d Ypre_i on top of d Yh_i
-                dgrad([da1(P.slot[("lrp", i)])], [baddr[("lrp", i, "sup")]], [dyv(0, s)], s, P.k1, s, C1, accum=True, label="charm.lrp.l1")
-                gw = wg("lrp", i, 0)
-                if P.sup(i):
-                    wgrad([da1(P.slot[("lrp", i)])], [run.yh(0, P.sup(i))], [(gw.data_ptr() + 4 * hm * t1, gw.shape[1])], C1, P.sup(i), P.k1,
-                          label="charm.lrp.l1")
-                wgrad([da1(P.slot[("lrp", i)])], [run.yp(i * sc, sc)], [(gw.data_ptr() + 4 * (hm + P.sup(i)) * t1, gw.shape[1])], C1, sc,
-                      P.k1, label="charm.lrp.l1own")
-            else:
-                dgrad([da1(P.slot[t]) for t in lt], [baddr[("lrp", i, "own")] for i in st], [dyv(i * sc, sc) for i in st], sc, P.k1, sc, C1,
-                      accum=True, label="charm.lrp.l1own")
-                wgrad([da1(P.slot[t]) for t in lt], [run.yp(i * sc, sc) for i in st],
-                      [(wg("lrp", i, 0).data_ptr() + 4 * (hm + P.sup(i)) * t1, wg("lrp", i, 0).shape[1]) for i in st], C1, sc, P.k1,
-                      label="charm.lrp.l1own")
+            # the slice's own pre-correction latent: d Ypre_i on top of d Yh_i (Yh = Ypre + ...: the identity path shares dY)
+            dgrad([da1(P.slot[t]) for t in lt], [baddr[("lrp", i, "own")] for i in st], [dyv(i * sc, sc) for i in st], sc, P.k1, sc, C1,
+                  accum=True, label="charm.lrp.l1own")
+            wgrad([da1(P.slot[t]) for t in lt], [run.yp(i * sc, sc) for i in st],
+                  [(wg("lrp", i, 0).data_ptr() + 4 * (hm + P.sup(i)) * t1, wg("lrp", i, 0).shape[1]) for i in st], C1, sc, P.k1,
+                  label="charm.lrp.l1own")
             gc_bwd(st)
             trs = [(k, i) for k in ("mean", "scale") for i in st]
             l32_bwd(trs, [g4(0 if k == "mean" else 1, i) for k, i in trs], "charm.ms")
@@ -509,24 +537,6 @@ def charm_backward(run: CharmRun, dyhat: Optional[torch.Tensor], gbits: Optional
                       [V(dH.data_ptr(), 2 * hm, hm), V(dH.data_ptr() + 4 * hm, 2 * hm, hm)], hm, P.k1, hm, C1, label="charm.ms.l1")
                 wgrad([da1(P.slot[("mean", 0)]), da1(P.slot[("scale", 0)])], [run.h_mu, run.h_sc],
                       [(wg("mean", 0, 0).data_ptr(), 0), (wg("scale", 0, 0).data_ptr(), 0)], C1, hm, P.k1, label="charm.ms.l1")
-            elif len(st) == 1:
-                i = st[0]
-                s = P.sup(i)
-                for k in ("mean", "scale"):   # both accumulate into the same support gradient: two launches, fixed order
-                    dgrad([da1(P.slot[(k, i)])], [baddr[(k, i, "sup")]], [dyv(0, s)], s, P.k1, s, C1, accum=True, label="charm.ms.l1")
-                wgrad([da1(P.slot[(k, i)]) for k in ("mean", "scale")], [run.yh(0, s)] * 2,
-                      [(wg(k, i, 0).data_ptr() + 4 * hm * t1, wg(k, i, 0).shape[1]) for k in ("mean", "scale")], C1, s, P.k1,
-                      label="charm.ms.l1")
-            else:
-                s = P.sup(ms)
-                nt = 3 * T
-                dgrad([da1(P.tail0, nt)], [baddr["tail_sup"]], [dyv(0, s)], s, P.k1, s, nt * C1, accum=True, label="charm.tail.l1")
-                parts = []
-                for k in range(nt):
-                    kind, i = P.order[P.tail0 + k]
-                    gw = wg(kind, i, 0)
-                    parts.append((k * C1, C1, gw.data_ptr() + 4 * hm * t1, gw.shape[1]))
-                ops.wgrad_split(n, h, w, da1(P.tail0, nt), run.yh(0, s), parts, P.k1, pad1, device=dev, label="charm.tail.l1")
         # hoisted hyper-prior parts
         for name, lo, cnt, hv, c0 in (("hyp_mu", 0, P.n_mu, run.h_mu, 0), ("hyp_sc", P.n_mu, P.n_sc, run.h_sc, hm)):
             dgrad([da1(lo, cnt)], [baddr[name]], [V(dH.data_ptr() + 4 * c0, 2 * hm, hm)], hm, P.k1, hm, cnt * C1, accum=True,

@@ -147,6 +147,7 @@ SIGNATURES = {
     "crdr_colsum": (_I, [_P, _I, _I64, _I, _P, _I, _P, _SZ, _P]),
     "crdr_interp_ca_params": (_I, [_P, _P, _I, _I, _F, _P, _P, _P]),
     "crdr_interp_ca_params_bwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _P, _P]),
+    "crdr_bias_relu_slots": (_I, [_P, _I, _I64, _I, _I, _P, _P, _P]),
     "crdr_lrp": (_I, [_P, _I, _P, _I, _P, _I, _I64, _I, _P]),
     "crdr_lrp_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I64, _I, _P]),
     "crdr_gauss_cond_fwd": (_I, [C.POINTER(GcDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -350,6 +350,12 @@ int crdr_interp_ca_params(const float* W, const float* B, int L, int C, float q,
 int crdr_interp_ca_params_bwd(const float* W, int L, int C, float q, const float* dscale, const float* dshift,
                               float* dW, float* dB, crdr_stream_t s);
 
+/* a[m][c0[k] + c] = max(a[m][c0[k] + c] + bias[k][c], 0), k < n <= CRDR_MAX_GROUP channel ranges of C channels of one NHWC
+ * buffer with pixel stride ld (host arrays c0 / bias; a and the c0 are 16-byte aligned): finishes first-layer pre-activations that several
+ * launches accumulated (the Charm's SliceTransform first convs, minnen20_charm_context_model.py:26-38, whose input is the
+ * concatenation [hyper, support slices] -- the conv is linear in it, so each part is added by the launch that has it) */
+int crdr_bias_relu_slots(float* a, int ld, int64_t M, int C, int n, const int32_t* c0, const float* const* bias, crdr_stream_t s);
+
 /* y = a + 0.5*tanh(z)  (latent residual prediction, minnen20_charm_context_model.py:127-131) and its backward */
 int crdr_lrp(const float* a, int lda, const float* z, int ldz, float* y, int ldy, int64_t M, int C, crdr_stream_t s);
 int crdr_lrp_bwd(const float* dy, int lddy, const float* z, int ldz, float* dz, int lddz, int64_t M, int C,
