@@ -614,9 +614,14 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
         flags |= L.EPI_PREADD
     if masks is not None:
         flags |= L.EPI_RELUMASK
+    # a pure accumulation y += conv(x) is the residual epilogue with the output as its own residual operand (the same single
+    # add, bit for bit): that form takes the straight-line buffer-op epilogue, CRDR_EPI_ACCUM the general one
+    self_res = flags == L.EPI_ACCUM
+    if self_res:
+        flags = L.EPI_RES
     flags |= _cf()
     d = L.ConvDesc(N=n, H=h, W=w, C=x0.c, OH=h, OW=w, OC=oc, kh=k[0], kw=k[1], stride=1, pad=pad, transposed=int(transposed),
-                   ldx=x0.ld, ldy=y0.ld, wrows=wrows, wcols=wcols, flags=flags, ldres=0, ldg=0, wlayout=0, reserved=0,
+                   ldx=x0.ld, ldy=y0.ld, wrows=wrows, wcols=wcols, flags=flags, ldres=y0.ld if self_res else 0, ldg=0, wlayout=0, reserved=0,
                    ldpre=pres[0].ld if pres is not None else 0, ldmask=masks[0].ld if masks is not None else 0)
     ios = (L.ConvIO * G)()
     for g in range(G):
@@ -628,6 +633,8 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
             io.pre = pres[g].ptr
         if masks is not None:
             io.mask = masks[g].ptr
+        if self_res:
+            io.res = ys[g].ptr
     GP = plan_as if plan_as else G
     if FORCED_CONV_ALGO:
         d.reserved = FORCED_CONV_ALGO
@@ -635,7 +642,7 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
         key = ("g", GP, n, h, w, d.C, oc, k, pad, int(transposed), d.ldx, d.ldy, flags, d.ldpre, d.ldmask, wrows, wcols)
         algo = _algo_cache.get(key)
         if algo is None:
-            if flags & (L.EPI_ACCUM | L.EPI_PREADD):
+            if (flags & (L.EPI_ACCUM | L.EPI_PREADD)) or self_res:
                 # timing runs would accumulate into live data: tune on scratch outputs with the same strides
                 span = (n * h * w - 1) * y0.ld + oc
                 scratch = torch.empty(G * span + 64, dtype=torch.float32, device=device)
@@ -646,6 +653,8 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
                     tio[g].y = scratch.data_ptr() + 4 * g * span
                     if pres is not None and pres[g].ptr == ys[g].ptr:
                         tio[g].pre = tio[g].y
+                    if self_res:
+                        tio[g].res = tio[g].y
             else:
                 tio = ios
 
