@@ -5,6 +5,7 @@
 #include <type_traits>
 
 #include "igemm_kernel.hpp"
+#include "wino.hpp"
 
 namespace crdr {
 
@@ -121,6 +122,7 @@ struct Plan {
   IgemmTaps t;
   int cfg;
   int stream;  // index into kStreamCfgs, or -1: the tiled kernel
+  int wino;    // 1: the Winograd kernel (wino.hip); cfg and stream are -1
   StreamArgs sa;
   dim3 grid;
   size_t lds;
@@ -231,6 +233,21 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
     }
   }
   pl->stream = -1;
+  pl->wino = 0;
+  if (d->reserved != 0 && (d->reserved & 0xff) - 1 == kNumCfgs + stream_num_variants()) {  // forced: the Winograd F(2x2, 3x3) kernel (wino.hip)
+    CRDR_REQUIRE(!fallback && wino_eligible(d, G), "conv2d: forced Winograd kernel: not a 3x3 stride-1 convolution it takes");
+    CRDR_REQUIRE(((d->reserved >> 8) & 0xf) == 0, "conv2d: the Winograd kernel has no split-K");
+    pl->wino = 1;
+    pl->cfg = -1;
+    a.nsplit = 1;
+    a.ws_ld = 0;
+    pl->grid = dim3(1, 1, 1);
+    pl->lds = 0;
+    a.cs_ld = round_up(d->OC, 32);
+    a.cs_rows = want_cs ? wino_colsum_rows(d) : 0;
+    pl->ws_bytes = (size_t)CRDR_CONV_TICKETS * sizeof(int) + wino_workspace(d, G);
+    return 0;
+  }
   int auto_sv = -1;
   if (d->reserved == 0 && !fallback && !want_cs && !a.smallc && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 &&
       d->C % 32 == 0 && d->OC % 4 == 0 && !(d->flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM)) &&
@@ -337,6 +354,7 @@ using namespace crdr;
 
 extern "C" int crdr_conv2d_num_configs(void) { return kNumCfgs; }
 extern "C" int crdr_conv2d_num_stream_configs(void) { return stream_num_variants(); }
+extern "C" int crdr_conv2d_num_wino_configs(void) { return 1; }
 
 extern "C" size_t crdr_conv2d_workspace(const crdr_conv_desc* d) {
   Plan pl;
@@ -362,6 +380,7 @@ extern "C" int crdr_conv2d_colsum_layout(const crdr_conv_desc* d, int G, int* ro
 extern "C" int crdr_conv2d_choose_algo(const crdr_conv_desc* d, int G) {
   Plan pl;
   if (!d || build_plan(d, &pl, G)) return 0;
+  if (pl.wino) return kNumCfgs + 1 + stream_num_variants();
   if (pl.stream >= 0) return kNumCfgs + 1 + pl.stream;
   int ls = 0;
   while ((1 << ls) < pl.a.nsplit) ++ls;
@@ -427,6 +446,12 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   const long long span_px = (256 / std::max(a.GW, 1) + 2) * (long long)std::max(a.so, 1) * a.OW + a.OW;
   const long long span = span_px * std::max(std::max(a.ldy, a.ldres), a.ldmask) * 4;
   a.fast_epi = (v && a.Cout % 4 == 0 && span < (1ll << 31) && !(a.flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM))) ? 1 : 0;
+  if (pl.wino) {
+    void* prof = profile_begin(as_stream(s));
+    if (int rc = wino_launch(d, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
+    profile_end(0, G * crdr_conv2d_flops(d), prof, as_stream(s));   // (direct-convolution flop count: the figure is an effective rate)
+    return 0;
+  }
   if (pl.stream >= 0 && !a.vec_epi && d->reserved == 0) {
     // the built-in choice assumed 16-byte aligned operands (it only knows the strides): take the tiled kernel instead
     Plan fb;

@@ -1,0 +1,13 @@
+// Winograd F(2x2, 3x3) path of crdr_conv2d (wino.hip), planned and launched from igemm.hip.
+#pragma once
+#include "common.hpp"
+#include "igemm_args.hpp"
+
+namespace crdr {
+
+bool wino_eligible(const crdr_conv_desc* d, int G);
+size_t wino_workspace(const crdr_conv_desc* d, int G);   // bytes of transformed filters
+int wino_colsum_rows(const crdr_conv_desc* d);
+int wino_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s);
+
+}  // namespace crdr

@@ -103,6 +103,7 @@ SIGNATURES = {
     "crdr_profile_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "crdr_conv2d_num_configs": (_I, []),
     "crdr_conv2d_num_stream_configs": (_I, []),
+    "crdr_conv2d_num_wino_configs": (_I, []),
     "crdr_conv2d_wgrad_num_configs": (_I, []),
     "crdr_conv2d_workspace": (_SZ, [C.POINTER(ConvDesc)]),
     "crdr_conv2d_choose_algo": (_I, [C.POINTER(ConvDesc), _I]),

@@ -87,11 +87,15 @@ def _time_call(fn, reps: int = 2) -> float:
     return best
 
 
+WINOGRAD = __import__("os").environ.get("CRDR_WINOGRAD", "1") != "0"   # 0: the tuner never offers the Winograd kernel
+
+
 def _stream_ids():
-    """Forced-algorithm ids of the streaming 1x1 variants (the library rejects them for other shapes)."""
+    """Forced-algorithm ids of the streaming 1x1 variants and of the Winograd 3x3 kernel (the library rejects them for other shapes)."""
     lib = L.load()
     n = lib.crdr_conv2d_num_configs()
-    return [n + 1 + v for v in range(lib.crdr_conv2d_num_stream_configs())]
+    ns = lib.crdr_conv2d_num_stream_configs()
+    return [n + 1 + v for v in range(ns)] + ([n + 1 + ns + v for v in range(lib.crdr_conv2d_num_wino_configs())] if WINOGRAD else [])
 
 
 def _autotune(key, ncfg: int, max_log2_split: int, run, extra=(), penalty=None) -> int:
@@ -121,7 +125,7 @@ DEFAULT_TUNE_DB = __import__("os").path.join(__import__("os").path.dirname(__fil
 def _tune_signature() -> str:
     lib = L.load()
     return (f"v{lib.crdr_version()}-c{lib.crdr_conv2d_num_configs()}-s{lib.crdr_conv2d_num_stream_configs()}"
-            f"-w{lib.crdr_conv2d_wgrad_num_configs()}")
+            f"-w{lib.crdr_conv2d_wgrad_num_configs()}-n{lib.crdr_conv2d_num_wino_configs()}")
 
 
 def save_tune_cache(path: str) -> None:
@@ -131,7 +135,7 @@ def save_tune_cache(path: str) -> None:
         json.dump({"signature": _tune_signature(), "algos": {repr(k): v for k, v in _algo_cache.items()}}, f, indent=0)
 
 
-def load_tune_cache(path: str, only_kinds=None, ignore_signature: bool = False) -> int:
+def load_tune_cache(path: str, only_kinds=None, ignore_signature: bool = False, skip=None) -> int:
     """Load choices saved by save_tune_cache; ignored (returns 0) if the library's configuration list has changed.
     only_kinds / ignore_signature: seed a rebuild of the database with the entries of kernel families that did not change
     (key[0]: "c" / "g" / "m" conv launches, "w" / "wm" weight gradients)."""
@@ -148,6 +152,8 @@ def load_tune_cache(path: str, only_kinds=None, ignore_signature: bool = False) 
     for k, v in db["algos"].items():
         key = ast.literal_eval(k)
         if only_kinds is not None and key[0] not in only_kinds:
+            continue
+        if skip is not None and skip(key):   # (entries the caller wants timed again, e.g. shapes a new kernel applies to)
             continue
         _algo_cache.setdefault(key, int(v))
         n += 1

@@ -137,6 +137,14 @@ int crdr_conv2d_choose_algo(const crdr_conv_desc* d, int G);
  * 16-byte aligned rows, no GATE / PREADD / ACCUM epilogue and a weight tile that fits LDS.  Results are bit-identical to
  * the unsplit tile configurations; CRDR_EPI_COLSUM rows are per 128- or 256-row tile (crdr_conv2d_colsum_layout) */
 int crdr_conv2d_num_stream_configs(void);
+/* number of Winograd variants (1): forced algorithm id crdr_conv2d_num_configs() + 1 + crdr_conv2d_num_stream_configs() + v, no
+ * split bits.  F(2x2, 3x3) minimal filtering on the exact-fp32 matrix cores for 3x3 stride-1 convolutions and their input
+ * gradients (2.25x fewer multiply-accumulates than the implicit GEMM; what cuDNN's WINOGRAD algorithms do for the reference,
+ * base_trainer.py:20 cudnn.benchmark).  fp32 arithmetic throughout (data transform +-1, filter transform halves); the sums are
+ * associated differently from the direct form.  Rejected unless kh = kw = 3, stride 1, C % 4 == 0 and the epilogue has no GATE /
+ * PREADD (grouped: nor VEC2 / AFFINE / MASKOFF).  The transformed filters are rebuilt from the weight pack into the workspace by
+ * every launch (crdr_conv2d_workspace with the same `reserved`); CRDR_EPI_COLSUM rows are per 16x16-pixel output patch. */
+int crdr_conv2d_num_wino_configs(void);
 /* bytes of workspace crdr_conv2d needs for this problem (split-K partial slabs; may be 0) */
 size_t crdr_conv2d_workspace(const crdr_conv_desc* d);
 int crdr_conv2d(const crdr_conv_desc* d, const crdr_conv_io* io, void* ws, size_t ws_bytes, crdr_stream_t s);

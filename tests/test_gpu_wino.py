@@ -1,0 +1,99 @@
+"""Winograd F(2x2, 3x3) kernel (csrc/wino.hip, forced algorithm id) against fp64 torch and against the implicit-GEMM kernel:
+forward and input gradient of 3x3 stride-1 convolutions, ragged sizes (partial 16x16 patches, odd H / W), channel counts that
+are not multiples of 8 / 32 / 64, channel-slice strides, and the fused epilogues.  fp32 arithmetic with a different association
+of the sums: the deviation from fp64 is held to the same bound as the direct kernel's (rtol 2e-4 of the output scale) and the
+measured ratio of the two kernels' errors is printed."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_gpu_conv import _close, _dev, _rand
+
+pytestmark = pytest.mark.gpu
+
+
+def _wino_id():
+    from crdr_amd.hip import lib as L
+    lib = L.load()
+    return lib.crdr_conv2d_num_configs() + 1 + lib.crdr_conv2d_num_stream_configs()
+
+
+CASES = [
+    # name, N, Cin, H, W, Cout, pad
+    ("96_96_16", 2, 96, 16, 16, 96, 1),
+    ("128_128_ragged", 1, 128, 34, 38, 128, 1),
+    ("64_160_odd", 2, 64, 15, 15, 160, 1),
+    ("36_40_c4", 1, 36, 20, 20, 40, 1),
+    ("256_512_32", 1, 256, 32, 32, 512, 1),
+    ("32_64_valid", 1, 32, 18, 21, 64, 0),
+    ("8_8_tiny", 1, 8, 5, 3, 8, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_winograd_fwd_dgrad(case):
+    from crdr_amd.hip import ops
+    name, n, ci, h, w, co, p = case
+    dev = _dev()
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(co, ci, 3, 3, seed=2, scale=(ci * 9) ** -0.5)
+    b = _rand(co, seed=3)
+    xr = x.double().requires_grad_(True)
+    ref = F.conv2d(xr, wt.double(), b.double(), padding=p)
+    oh, ow = ref.shape[2:]
+    dy = _rand(*ref.shape, seed=4)
+    ref.backward(dy.double())
+    xd, wd, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
+    wp = ops.pack_weight(wd, transpose=False)
+    direct = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=1)
+    out = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=_wino_id())
+    torch.cuda.synchronize()
+    _close(out, ref, name + " fwd")
+    e_w = (out.cpu().double() - ref.detach()).abs().max().item()
+    e_d = (direct.cpu().double() - ref.detach()).abs().max().item()
+    print(f"{name}: fwd max err winograd {e_w:.2e} direct {e_d:.2e} (scale {ref.abs().max().item():.2e})")
+    wq = ops.pack_weight(wd, transpose=True)
+    dx = ops.conv2d_raw(dyd, wq, ci, (3, 3), 1, p, True, (h, w), algo=_wino_id())
+    _close(dx, xr.grad, name + " dgrad")
+    # deterministic
+    out2 = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=_wino_id())
+    assert torch.equal(out, out2)
+
+
+def test_winograd_epilogues_and_slices():
+    """bias + ReLU + vec2 + residual + affine, output written into a channel slice of a wider tensor, input read from one."""
+    from crdr_amd.hip import lib as L
+    from crdr_amd.hip import ops
+    dev = _dev()
+    n, ci, h, w, co = 2, 64, 24, 20, 96
+    wide = _rand(n, ci + 32, h, w, seed=5).to(dev).contiguous(memory_format=torch.channels_last)
+    x = wide[:, 16:16 + ci]
+    wt = _rand(co, ci, 3, 3, seed=6, scale=(ci * 9) ** -0.5).to(dev)
+    b, v2, sc, sh = (_rand(co, seed=s).to(dev) for s in (7, 8, 9, 10))
+    res = _rand(n, co, h, w, seed=11).to(dev).contiguous(memory_format=torch.channels_last)
+    wp = ops.pack_weight(wt, transpose=False)
+    flags = L.EPI_BIAS | L.EPI_RELU | L.EPI_VEC2 | L.EPI_RES | L.EPI_AFFINE
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1).relu() + v2.double().view(1, -1, 1, 1) + res.double()
+    ref = ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    owide = torch.zeros(n, co + 40, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+    out = ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (h, w), bias=b, flags=flags, vec2=v2, res=res, scale=sc, shift=sh,
+                         out=owide[:, 8:8 + co], algo=_wino_id())
+    torch.cuda.synchronize()
+    _close(out, ref, "epilogues")
+    assert float(owide[:, :8].abs().max()) == 0.0 and float(owide[:, 8 + co:].abs().max()) == 0.0
+    # LeakyReLU
+    out = ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (h, w), bias=b, flags=L.EPI_BIAS | L.EPI_LRELU, algo=_wino_id())
+    _close(out, F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1), 0.2), "lrelu")
+
+
+def test_winograd_rejects_other_shapes():
+    from crdr_amd.hip import lib as L
+    from crdr_amd.hip import ops
+    dev = _dev()
+    x = _rand(1, 32, 8, 8, seed=1).to(dev)
+    w5 = ops.pack_weight(_rand(32, 32, 5, 5, seed=2).to(dev), transpose=False)
+    with pytest.raises(L.CrdrHipError):
+        ops.conv2d_raw(x, w5, 32, (5, 5), 1, 2, False, (8, 8), algo=_wino_id())
+    w3 = ops.pack_weight(_rand(32, 32, 3, 3, seed=2).to(dev), transpose=False)
+    with pytest.raises(L.CrdrHipError):
+        ops.conv2d_raw(x, w3, 32, (3, 3), 2, 1, False, (4, 4), algo=_wino_id())

@@ -1,0 +1,45 @@
+"""Winograd F(2x2, 3x3) kernel against the tuned implicit-GEMM kernel on the 3x3 stride-1 shapes of the stage-3 step (bs 16):
+python tools/bench_wino.py [--cold]"""
+import argparse
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from crdr_amd.hip import lib as L  # noqa: E402
+from crdr_amd.hip import ops  # noqa: E402
+
+SHAPES = [(128, 128, 128), (96, 96, 128), (64, 128, 128), (128, 64, 128), (128, 128, 64), (96, 96, 64), (128, 256, 64), (256, 128, 64),
+          (256, 512, 32), (512, 256, 32), (128, 128, 32), (96, 96, 32), (160, 160, 16), (320, 320, 16)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cold", action="store_true")
+    ap.add_argument("--bs", type=int, default=16)
+    a = ap.parse_args()
+    ops.TUNE_COLD = a.cold
+    ops.TUNE_ROUNDS = 3
+    lib = L.load()
+    wid = lib.crdr_conv2d_num_configs() + 1 + lib.crdr_conv2d_num_stream_configs()
+    dev = torch.device("cuda:0")
+    for ci, co, hw in SHAPES:
+        x = torch.randn(a.bs, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+        wt = torch.randn(co, ci, 3, 3, device=dev) * (ci * 9) ** -0.5
+        b = torch.randn(co, device=dev)
+        wp = ops.pack_weight(wt, transpose=False)
+        best = (1e9, 0)
+        for cfg in range(lib.crdr_conv2d_num_configs()):
+            try:
+                t = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (hw, hw), bias=b, flags=3, algo=cfg + 1), reps=3)
+            except L.CrdrHipError:
+                continue
+            best = min(best, (t, cfg))
+        tw = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (hw, hw), bias=b, flags=3, algo=wid), reps=3)
+        fl = 2.0 * a.bs * hw * hw * ci * co * 9
+        print(f"{ci:4d}->{co:4d} @{hw:3d}: direct {best[0] * 1e3:8.1f} us ({fl / best[0] / 1e9:6.1f} TF, cfg {best[1]})   winograd {tw * 1e3:8.1f} us "
+              f"({fl / tw / 1e9:6.1f} TF-eq)   x{best[0] / tw:.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
