@@ -212,16 +212,26 @@ def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: in
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    def fam(kind):
+    def raw(kind):
         fl, ms, n = C.c_double(), C.c_double(), C.c_longlong()
         lib.crdr_profile_read(kind, C.byref(fl), C.byref(ms), C.byref(n))
-        if n.value == 0 or ms.value <= 0:
+        return fl.value, ms.value, n.value
+
+    def fam(fl, ms, n):
+        if n == 0 or ms <= 0:
             return None
         ps = max(profile_steps, 1)
-        return {"launches_per_step": round(n.value / ps, 1), "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
-                "avg_gflop_per_launch": round(fl.value / n.value / 1e9, 3), "tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
-                "ms_per_step": round(ms.value / ps, 2)}
-    ig, wg, sk = fam(0), fam(1), fam(2)
+        return {"launches_per_step": round(n / ps, 1), "avg_launch_us": round(ms * 1e3 / n, 2),
+                "avg_gflop_per_launch": round(fl / n / 1e9, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                "ms_per_step": round(ms / ps, 2)}
+    r0, r3 = raw(0), raw(3)   # implicit-GEMM / streaming launches, Winograd launches (both counted with the direct convolution's flops)
+    ig, wg, sk = fam(r0[0] + r3[0], r0[1] + r3[1], r0[2] + r3[2]), fam(*raw(1)), fam(*raw(2))
+    if ig is not None and r3[2]:
+        # what the matrix cores execute: a Winograd F(2x2, 3x3) launch does 16 multiply-accumulates per 2x2 outputs and channel pair
+        # instead of 36 -- its effective rate may exceed the MFMA peak, its executed rate may not
+        ig["winograd"] = dict(fam(*r3), executed_tflops=round(r3[0] / 2.25 / (r3[1] * 1e-3) / 1e12, 2))
+        ig["direct"] = fam(*r0)
+        ig["executed_mfma_tflops"] = round((r0[0] + r3[0] / 2.25) / ((r0[1] + r3[1]) * 1e-3) / 1e12, 2)
     if ig is not None and sk is not None:
         ig["splitk_epilogue"] = {"launches_per_step": sk["launches_per_step"], "avg_launch_us": sk["avg_launch_us"], "ms_per_step": sk["ms_per_step"]}
     alg_bytes = None
@@ -408,9 +418,15 @@ def main():
             "algorithmic_bytes_per_launch": round(main_run["alg_bytes_per_igemm_launch"]) if main_run["alg_bytes_per_igemm_launch"] else None,
             "flop_convention": "dense: 2 * Cin * Cout * kh * kw per output pixel (input pixel for transposed convs), zero-padding taps at "
                                "the borders included (5x5 at 16x16: 14 % of the counted taps multiply padding)",
-            "kernel": "igemm_kernel<*> + gemm1x1_kernel<*> (conv / convT forward + input-gradient launches incl. grouped ones: tiled "
-                      "implicit GEMM and the streaming 1x1 kernel, v_mfma_f32_32x32x2_f32; split-K epilogue launches timed separately "
-                      "under detail.splitk_epilogue)",
+            "kernel": "igemm_kernel<*> + gemm1x1_kernel<*> + wino_kernel (conv / convT forward + input-gradient launches incl. grouped ones: "
+                      "tiled implicit GEMM, the streaming 1x1 kernel and, where the tuner found it faster, the Winograd F(2x2,3x3) kernel with "
+                      "its filter transform; all v_mfma_f32_32x32x2_f32)",
+            "effective_rate_note": "`achieved` / `frac` price the ALGORITHMIC (direct-convolution) flops of every launch against the fp32 MFMA "
+                                   "peak, as SURVEY 8(d) defines the unit; a Winograd launch executes 2.25x fewer multiply-accumulates than it is "
+                                   "credited with, so this is an effective rate (a single Winograd launch may exceed 1.0). What the matrix cores "
+                                   "actually execute is detail.executed_mfma_tflops (frac_executed below); detail.direct / detail.winograd split "
+                                   "the family.",
+            "frac_executed": round(ig["executed_mfma_tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig and "executed_mfma_tflops" in ig else None,
             "measured_over": f"{a.profile_steps} eager steps after the timed region, rate index cycled (HIP events around each launch, on its stream)",
             "detail": ig, "wgrad_kernel": wg,
             "whole_step": {"algorithmic_gflop_per_img": gflop, "achieved": round(value / ws * gflop / 1e3, 2),

@@ -449,7 +449,7 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   if (pl.wino) {
     void* prof = profile_begin(as_stream(s));
     if (int rc = wino_launch(d, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
-    profile_end(0, G * crdr_conv2d_flops(d), prof, as_stream(s));   // (direct-convolution flop count: the figure is an effective rate)
+    profile_end(3, G * crdr_conv2d_flops(d), prof, as_stream(s));   // kind 3: filter transform + Winograd kernel, direct-convolution flop count
     return 0;
   }
   if (pl.stream >= 0 && !a.vec_epi && d->reserved == 0) {

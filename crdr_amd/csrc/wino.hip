@@ -9,12 +9,12 @@
 //   wave (ph, wm, wn): transform rows xi in {2 ph, 2 ph + 1} (8 of the 16 positions), tile columns 4 wm .. 4 wm + 3 (8 rows x 4
 //   columns = 32 tiles = the 32 MFMA rows), output channels 32 wn .. 32 wn + 31: 8 accumulator blocks of 32 x 32 = 128 AGPRs,
 //   two waves per SIMD.
-// K loop: 8 input channels per stage, double-buffered LDS filled by LDS-DMA:
+// K loop: sub-steps of 8 input channels, operands double buffered in LDS and filled by LDS-DMA:
 //   * the raw 18 x 18 x 8 input patch, stored by pixel parity class so that the 32 tiles' reads of patch pixel (i, j) are
 //     consecutive 16-B slots: [half h = channels 4h..4h+3][class (i&1, j&1)][9 rows][12 slots (9 used)]; with 8 x 4 tiles per
 //     wave a row pitch of 12 slots makes every 16-lane group of a ds_read_b128 hit 16 different slots mod 16 (conflict free);
 //     pixels outside the image (padding) and channels past Cin read zeros through the buffer range check;
-//   * the transformed filters of the stage, one contiguous 32 KiB block in memory and in LDS: [position 16][h][oc 64][4].
+//   * the transformed filters of the sub-step, one contiguous 32 KiB block in memory and in LDS: [position 16][h][oc 64][4].
 //   Every wave builds B^T d B for its 8 positions in registers from 12 ds_read_b128 (lane = tile, half-wave = channel half, the
 //   operand layout of the implicit-GEMM kernel), reads 8 filter fragments and issues 32 MFMAs per stage.
 // Epilogue: the two waves of a (wm, wn) pair each hold half of the xi sum; each forms its part of A^T M A for both output rows,
@@ -32,10 +32,12 @@ namespace crdr {
 
 namespace {
 
-constexpr int kInUsed = 2 * 4 * 9 * 12;     // 16-byte slots of the input patch image per stage ...
-constexpr int kInSlots = 896;               // ... rounded up to whole 64-lane DMA instructions
-constexpr int kUSlots = 16 * 2 * 64;        // of the filter block
-constexpr int kStageFloats = (kInSlots + kUSlots) * 4;
+constexpr int kInUsed = 2 * 4 * 9 * 12;     // 16-byte slots of the input patch image per stage: [h][class][9 rows][12 slots, 9 used] ...
+constexpr int kInSlots = 1024;              // ... rounded up to 4 DMA instructions for each of the 4 issuing waves
+constexpr int kUSlots = 16 * 2 * 64;        // of one filter block (8 channels): 8 DMA instructions per issuing wave
+constexpr int kInFloats = kInSlots * 4, kUFloats = kUSlots * 4;
+constexpr int kStageFloats = kInFloats + kUFloats;
+constexpr int kStagingFloats = 2 * kStageFloats;
 constexpr int kNT = 512;
 
 // in-place 1-D data transform of four f32x4 (B^T rows applied along one axis): (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
@@ -43,11 +45,18 @@ __device__ __forceinline__ void bt4(const f32x4 d0, const f32x4 d1, const f32x4 
   o[0] = d0 - d2; o[1] = d1 + d2; o[2] = d2 - d1; o[3] = d1 - d3;
 }
 
-template <int PH>
+// K loop of one wave.  The two waves of a SIMD (ROLE 0: waves 0-3, ROLE 1: waves 4-7) run half a sub-step apart -- while one
+// reads its raw pixels and filter fragments from LDS and transforms the pixels (latency-bound LDS / VALU work), the other issues
+// its 32 MFMAs from registers -- so the matrix pipe of the SIMD always has one wave feeding it.  Two barriers per sub-step k
+// (8 channels): A(k) (its operands have landed) and B(k); phase [A(k), B(k)): role 0 loads k, role 1 multiplies k - 1; phase
+// [B(k), A(k + 1)): role 0 multiplies k, role 1 loads k.  The role-1 waves issue ALL the DMA of sub-step k + 1 between their
+// MFMAs of phase [A(k), B(k)) (where an issue slot is nearly free) and drain it before A(k + 1); the stage it overwrites was last
+// read in phase [B(k - 1), A(k)).  B barriers hand no data over: a bare s_barrier that does not drain the DMA in flight.
+template <int PH, int ROLE>
 __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const __amdgpu_buffer_rsrc_t rx, const __amdgpu_buffer_rsrc_t ru,
-                                          const unsigned (&a_off)[2], const bool (&a_ok)[2], const int a_h[2], unsigned u_off0,
-                                          int tid, int lane, int wave, int wm, int wn, f32x16 (&acc)[8]) {
-  const int KC = p.kchunks;
+                                          const unsigned (&a_off)[4], const unsigned a_okmask, unsigned u_off0,
+                                          int lane, int wave, int wm, int wn, f32x16 (&acc)[8]) {
+  const int K8 = p.kchunks;
   const int m = lane & 31, fh = lane >> 5;
   const int ty = m >> 2, tx = (m & 3) + 4 * wm;
   // float offsets of this lane's 12 raw reads (rows PH .. PH + 2 of the 4 x 4 patch, all 4 columns) inside a stage
@@ -60,32 +69,42 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
       const int cls = (i & 1) * 2 + (j & 1);
       ro[a][j] = (fh * 432 + cls * 108 + (ty + (i >> 1)) * 12 + tx + (j >> 1)) * 4;
     }
-  const int bo = kInSlots * 4 + ((2 * PH * 4 * 2 + fh) * 64 + wn * 32 + m) * 4;  // position p = (2 PH + a) * 4 + nu: + (a * 4 + nu) * 512
+  const int bo = kInFloats + ((2 * PH * 4 * 2 + fh) * 64 + wn * 32 + m) * 4;  // position p = (2 PH + a) * 4 + nu: + (a * 4 + nu) * 512
+  const int w1 = wave & 3;
 
-  auto fetch = [&](int buf, int kc) __attribute__((always_inline)) {
-    float* st = smem + buf * kStageFloats;
-    const unsigned cb = (unsigned)kc * 32u;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j == 1 && wave * 64 + 512 >= kInSlots) break;   // (wave-uniform: the second pass covers slots 512..863)
-      const bool ok = a_ok[j] && (kc * 8 + a_h[j] * 4 < p.Cin);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(st + (j * 512 + wave * 64) * 4), 16, (int)(ok ? a_off[j] + cb : kOobOffset), 0, 0, 0);
+  // DMA instruction idx (0..11) of this (role-1) wave for sub-step k8: 0..3 input (slots (4 idx + w1) * 64 + lane), 4..11 filters
+  auto issue = [&](int k8, int idx) __attribute__((always_inline)) {
+#ifdef WINO_EXP_NODMA
+    if (k8 > 0) return;
+#endif
+    float* st = smem + (k8 & 1) * kStageFloats;
+    if (idx < 4) {
+      const bool ok = ((a_okmask >> idx) & 1u) && (k8 * 8 + (int)((a_okmask >> (8 + idx)) & 1u) * 4 < p.Cin);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(st + ((4 * idx + w1) * 64) * 4), 16, (int)(ok ? a_off[idx] + (unsigned)k8 * 32u : kOobOffset), 0, 0, 0);
+    } else {
+      const int j = idx - 4;
+      const unsigned ub = u_off0 + (unsigned)k8 * (kUSlots * 16u) + (unsigned)((4 * j + w1) * 64 + lane) * 16u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(st + kInFloats + ((4 * j + w1) * 64) * 4), 16, (int)ub, 0, 0, 0);
     }
-    const unsigned ub = u_off0 + (unsigned)kc * (kUSlots * 16u);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(st + (kInSlots + j * 512 + wave * 64) * 4), 16, (int)(ub + (unsigned)(j * 512 + tid) * 16u), 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
   };
 
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const float* st = smem + buf * kStageFloats;
+  f32x4 v[2][4], bfr[8];   // B^T d B and the filter fragments of the sub-step: everything its MFMAs read
+  auto loads = [&](int k8) __attribute__((always_inline)) {
+    const float* st = smem + (k8 & 1) * kStageFloats;
     f32x4 d[3][4];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[a][j] = *reinterpret_cast<const f32x4*>(st + ro[a][j]);
-    f32x4 t[2][4], v[2][4];
+      for (int j = 0; j < 4; ++j) {
+#ifdef WINO_EXP_NORAW
+        d[a][j] = f32x4{(float)k8, 1.f, 2.f, (float)(a + j)};
+#else
+        d[a][j] = *reinterpret_cast<const f32x4*>(st + ro[a][j]);
+#endif
+      }
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) bfr[q8] = *reinterpret_cast<const f32x4*>(st + bo + q8 * 512);
+    f32x4 t[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (PH == 0) { t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; }   // xi = 0, 1 from rows 0, 1, 2
@@ -93,24 +112,58 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a) bt4(t[a][0], t[a][1], t[a][2], t[a][3], v[a]);
+  };
+  // the 32 MFMAs of a sub-step from v and bfr; kd >= 0: the DMA of sub-step kd is issued between them
+  auto mfmas = [&](int kd) __attribute__((always_inline)) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) {
-        const f32x4 bf = *reinterpret_cast<const f32x4*>(st + bo + (a * 4 + nu) * 512);
+        const f32x4 bf = bfr[a * 4 + nu];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s) {
+#ifdef WINO_EXP_NOMFMA
+          acc[a * 4 + nu][s] += v[a][nu][s] * bf[s];
+#else
           acc[a * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[a][nu][s], bf[s], acc[a * 4 + nu], 0, 0, 0);
+#endif
+          if constexpr (ROLE == 1) {
+            const int g = (a * 4 + nu) * 4 + s;   // one DMA instruction behind every second MFMA of the first 24
+            if ((g & 1) && g < 24 && kd >= 0) issue(kd, g >> 1);
+          }
+        }
       }
   };
+  auto pbarrier = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
 
-  fetch(0, 0);
-  __syncthreads();
-  for (int kc = 0; kc < KC; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < KC) fetch(buf ^ 1, kc + 1);
-    compute(buf);
-    __syncthreads();
+  if constexpr (ROLE == 0) {
+    __syncthreads();   // A(0): sub-step 0 has landed (issued by the role-1 waves)
+    for (int k8 = 0; k8 < K8; ++k8) {
+      loads(k8);
+      pbarrier();        // B(k8)
+      mfmas(-1);
+      __syncthreads();   // A(k8 + 1)
+    }
+  } else {
+#pragma unroll
+    for (int idx = 0; idx < 12; ++idx) issue(0, idx);
+    __syncthreads();   // A(0)
+    for (int k8 = 0; k8 < K8; ++k8) {
+      const int kd = k8 + 1 < K8 ? k8 + 1 : -1;
+      if (k8 > 0) mfmas(kd);
+      else if (kd >= 0) {
+#pragma unroll
+        for (int idx = 0; idx < 12; ++idx) issue(kd, idx);
+      }
+      pbarrier();        // B(k8)
+      loads(k8);
+      __syncthreads();   // A(k8 + 1) (with the DMA of sub-step k8 + 1 drained)
+    }
+    mfmas(-1);
   }
 }
 
@@ -149,18 +202,18 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
   const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (size_t)gidx * ublock, 0, (unsigned)(ublock * 4), 0x00020000);
   const unsigned u_off0 = (unsigned)tile_n * (unsigned)p.kchunks * (kUSlots * 16u);
 
-  // input staging: slot s = tid + 512 j -> (h, class, r, c) -> patch pixel (2 r + pi, 2 c + pj)
-  unsigned a_off[2];
-  bool a_ok[2];
-  int a_h[2];
+  // input staging (waves 4-7): DMA instruction i of wave 4 + w1 fills slots (4 i + w1) * 64 + lane -> (h, class, r, c) -> patch
+  // pixel (2 r + pi, 2 c + pj), channels 4h .. 4h + 3 of the sub-step
+  unsigned a_off[4], a_okmask = 0;   // bits 0..3: slot holds a pixel of the image; bits 8..11: its channel half h
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int s = tid + 512 * j;
-    const int h = s / 432, rem = s - h * 432, cls = rem / 108, r2 = rem - cls * 108, r = r2 / 12, c = r2 - r * 12;
+  for (int i = 0; i < 4; ++i) {
+    const int S = (4 * i + (wave & 3)) * 64 + lane;
+    const int h = S / 432, rem = S - h * 432, cls = rem / 108, r2 = rem - cls * 108, r = r2 / 12, c = r2 - r * 12;
     const int ih = ih0 + 2 * r + (cls >> 1), iw = iw0 + 2 * c + (cls & 1);
-    a_ok[j] = s < kInUsed && c < 9 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-    a_h[j] = h;
-    a_off[j] = a_ok[j] ? (unsigned)(((ih * W + iw) * ldx + 4 * h) * 4) : 0u;
+    const bool ok = S < kInUsed && c < 9 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    a_okmask |= (ok ? 1u : 0u) << i;
+    a_okmask |= (h ? 1u : 0u) << (8 + i);
+    a_off[i] = ok ? (unsigned)(((ih * W + iw) * ldx + 4 * h) * 4) : 0u;
   }
 
   f32x16 acc[8];
@@ -170,7 +223,7 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   // per-column epilogue vectors (behind the two stages)
-  float* sV = smem + 2 * kStageFloats;        // [4][64]: bias, vec2, scale, shift
+  float* sV = smem + kStagingFloats;          // [4][64]: bias, vec2, scale, shift
   float* sS = sV + 4 * 64;                    // [8 waves][2][32] column sums
   {
     const int f0 = p.flags;
@@ -182,9 +235,14 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
       sV[3 * 64 + tid] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[n0 + tid] : 0.f;
     }
   }
-  if (ph == 0) wino_loop<0>(p, smem, rx, ru, a_off, a_ok, a_h, u_off0, tid, lane, wave, wm, wn, acc);
-  else wino_loop<1>(p, smem, rx, ru, a_off, a_ok, a_h, u_off0, tid, lane, wave, wm, wn, acc);
-  // (the loop ends with a barrier: the stages are free)
+  if (wave < 4) {
+    if (ph == 0) wino_loop<0, 0>(p, smem, rx, ru, a_off, a_okmask, u_off0, lane, wave, wm, wn, acc);
+    else wino_loop<1, 0>(p, smem, rx, ru, a_off, a_okmask, u_off0, lane, wave, wm, wn, acc);
+  } else {
+    if (ph == 0) wino_loop<0, 1>(p, smem, rx, ru, a_off, a_okmask, u_off0, lane, wave, wm, wn, acc);
+    else wino_loop<1, 1>(p, smem, rx, ru, a_off, a_okmask, u_off0, lane, wave, wm, wn, acc);
+  }
+  __syncthreads();   // every wave is past its last LDS read: the staging area is free
 
   // ---- output transform.  This wave holds M[xi][nu] for xi = 2 ph, 2 ph + 1.  Row sums of A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]:
   //   ph 0: s0 = M0 + M1, s1 = M1;   ph 1: s0 = M2, s1 = -M2 - M3;   then along nu: (s[0] + s[1] + s[2], s[1] - s[2] - s[3]).
@@ -391,7 +449,7 @@ int wino_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, con
   a.GW = cdiv(d->OW, 16);
   a.si = -dmin;   // the patch starts `si` pixels above / left of its first output pixel
   a.cs_rows = wino_colsum_rows(d);
-  const size_t lds = (size_t)(2 * kStageFloats + 4 * 64 + 8 * 2 * 32) * sizeof(float);
+  const size_t lds = (size_t)(kStagingFloats + 4 * 64 + 8 * 2 * 32) * sizeof(float);
   static std::atomic<bool> attr_done{false};
   if (!attr_done.load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -90,6 +90,23 @@ def _time_call(fn, reps: int = 2) -> float:
 WINOGRAD = __import__("os").environ.get("CRDR_WINOGRAD", "1") != "0"   # 0: the tuner never offers the Winograd kernel
 
 
+# Tests: every convolution the Winograd kernel accepts takes it (without the tuner, whose choice is per shape and speed): the
+# model-level parity tests run once more through it.
+PREFER_WINOGRAD = False
+
+
+def _prefer_wino(d, G: int = 1) -> int:
+    """-> the Winograd algorithm id if PREFER_WINOGRAD is set and the library accepts it for this launch, else 0."""
+    if not PREFER_WINOGRAD or (d.kh, d.kw, d.stride) != (3, 3, 1):
+        return 0
+    lib = L.load()
+    keep = d.reserved
+    d.reserved = lib.crdr_conv2d_num_configs() + 1 + lib.crdr_conv2d_num_stream_configs()
+    ok = lib.crdr_conv2d_choose_algo(C.byref(d), G) == d.reserved
+    algo, d.reserved = (d.reserved if ok else 0), keep
+    return algo
+
+
 def _stream_ids():
     """Forced-algorithm ids of the streaming 1x1 variants and of the Winograd 3x3 kernel (the library rejects them for other shapes)."""
     lib = L.load()
@@ -345,6 +362,8 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
         io.gx, io.gt, io.sig = gate_x.data_ptr(), gate_t.data_ptr(), sig_out.data_ptr()
     if algo or FORCED_CONV_ALGO:
         d.reserved = algo or FORCED_CONV_ALGO
+    elif _prefer_wino(d):
+        d.reserved = _prefer_wino(d)
     elif AUTOTUNE and not (flags & L.EPI_ACCUM):
         key = ("c", n, h, w, d.C, oh, ow, oc, k, stride, pad, int(transposed), ldx, ldy, flags, d.ldres, d.ldg, wlayout)
         algo = _algo_cache.get(key)
@@ -644,6 +663,8 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
     GP = plan_as if plan_as else G
     if FORCED_CONV_ALGO:
         d.reserved = FORCED_CONV_ALGO
+    elif _prefer_wino(d, G):
+        d.reserved = _prefer_wino(d, G)
     elif AUTOTUNE and (GP == G or ("g", GP, n, h, w, d.C, oc, k, pad, int(transposed), d.ldx, d.ldy, flags, d.ldpre, d.ldmask, wrows, wcols) in _algo_cache):
         key = ("g", GP, n, h, w, d.C, oc, k, pad, int(transposed), d.ldx, d.ldy, flags, d.ldpre, d.ldmask, wrows, wcols)
         algo = _algo_cache.get(key)
@@ -934,6 +955,8 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
         return [q.alloc(nf) for _ in range(G)], rows.value, ld.value, None
     if FORCED_CONV_ALGO:
         d.reserved = FORCED_CONV_ALGO
+    elif _prefer_wino(d, G):
+        d.reserved = _prefer_wino(d, G)
     elif AUTOTUNE:
         key = ("m", G, n, h, w, oh, ow, d.C, oc, k, stride, pad, int(transposed), d.ldx, d.ldy, flags, d.ldres, d.ldpre, d.ldmask,
                wrows, wcols, wlayout)

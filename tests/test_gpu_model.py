@@ -204,6 +204,22 @@ def _full_model(stage3=True):
 
 @pytest.mark.parametrize("stage3", [True, False], ids=["stage3", "stage1"])
 def test_generator_forward_backward(stage3):
+    _generator_forward_backward(stage3)
+
+
+@pytest.mark.parametrize("stage3", [True, False], ids=["stage3", "stage1"])
+def test_generator_forward_backward_winograd(stage3):
+    """the same comparison with every 3x3 stride-1 convolution and input gradient on the Winograd F(2x2, 3x3) kernel (csrc/wino.hip;
+    in production the autotuner picks it per shape)"""
+    from crdr_amd.hip import ops
+    ops.PREFER_WINOGRAD = True
+    try:
+        _generator_forward_backward(stage3)
+    finally:
+        ops.PREFER_WINOGRAD = False
+
+
+def _generator_forward_backward(stage3):
     from oracle import crdr_oracle as O
     model, sd = _full_model(stage3)
     x = seeded_input("image", (2, 3, 64, 64))

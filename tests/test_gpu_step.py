@@ -117,6 +117,21 @@ def test_adam_partitions_skip_unused_modules_like_torch(device_counters):
 
 
 def test_stage3_step():
+    _stage3_step()
+
+
+def test_stage3_step_winograd():
+    """the stage-3 step with every 3x3 stride-1 convolution / input gradient (generator bottlenecks, NLAM, discriminator) on the
+    Winograd kernel: same oracle, same gates"""
+    from crdr_amd.hip import ops
+    ops.PREFER_WINOGRAD = True
+    try:
+        _stage3_step()
+    finally:
+        ops.PREFER_WINOGRAD = False
+
+
+def _stage3_step():
     from oracle import crdr_oracle as O
     from crdr_amd.trainer import build_trainer
     tr = build_trainer(_opt(3))

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cold", action="store_true")
     ap.add_argument("--bs", type=int, default=16)
+    ap.add_argument("--wino-only", action="store_true")
     a = ap.parse_args()
     ops.TUNE_COLD = a.cold
     ops.TUNE_ROUNDS = 3
@@ -29,7 +30,7 @@ def main():
         b = torch.randn(co, device=dev)
         wp = ops.pack_weight(wt, transpose=False)
         best = (1e9, 0)
-        for cfg in range(lib.crdr_conv2d_num_configs()):
+        for cfg in range(0 if a.wino_only else lib.crdr_conv2d_num_configs()):
             try:
                 t = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (hw, hw), bias=b, flags=3, algo=cfg + 1), reps=3)
             except L.CrdrHipError:
