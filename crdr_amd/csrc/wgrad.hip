@@ -13,49 +13,9 @@
 #include <atomic>
 
 #include "common.hpp"
+#include "wgrad_args.hpp"
 
 namespace crdr {
-
-struct FastDiv {  // unsigned division by a runtime constant: n / d == umulhi(n, mul) >> sh   (n < 2^31)
-  unsigned mul, sh, d;
-};
-static FastDiv make_fastdiv(unsigned d) {
-  FastDiv f; f.d = d;
-  if (d == 1) { f.mul = 0; f.sh = 0; return f; }
-  unsigned l = 0; while ((1u << l) < d) ++l;               // ceil(log2 d)
-  const unsigned long long m = ((1ull << (32 + l)) + d - 1) / d;  // in (2^32, 2^33)
-  f.mul = (unsigned)(m - (1ull << 32)); f.sh = l;
-  return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
-  if (f.d == 1) return n;
-  const unsigned t = __umulhi(n, f.mul);
-  return (t + ((n - t) >> 1)) >> (f.sh - 1);
-}
-
-struct WgradGroup {  // per-problem operands of a grouped launch; indexed with the workgroup-uniform problem index only
-  const float* p[CRDR_MAX_GROUP];
-  const float* q[CRDR_MAX_GROUP];
-};
-
-struct WgradArgs {
-  const float* p;
-  const float* q;
-  float* ws;
-  int ngroup;
-  long long slab_elems;  // floats of one problem's slab
-  int N, PH, PW, PC, ldp;
-  int QH, QW, QC, ldq;
-  int kw, stride, pad, T;
-  int M;        // N*PH*PW
-  int ntiles;   // pixel tiles of 32
-  int nsplit;
-  int jtiles;
-  FastDiv d_hw, d_w;
-  unsigned p_bytes, q_bytes;  // extents of the two buffer descriptors (range-checked loads)
-  int smallj;  // 1: QC <= 4 (RGB operand): the taps are folded into the GEMM columns, column = 4 tap + channel, so one
-               // launch covers all taps instead of one 32-column (>= 87 % padding) GEMM per tap
-};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 static constexpr unsigned kOob = 0x80000000u;  // >= any descriptor size accepted by build_wplan (< 2 GiB)
@@ -545,6 +505,7 @@ static const int kNumWCfgs = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
 struct WPlan {
   WgradArgs a;
   int cfg;
+  int wino;   // 1: the Winograd slab kernel (cfg = -1)
   dim3 grid;
   size_t lds, ws_bytes;
 };
@@ -589,6 +550,22 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl, int G = 1) {
       if (cost < best) { best = cost; bc = c; bs = ns; }
     }
   }
+  pl->wino = 0;
+  if ((d->algo & 0xff) - 1 == kNumWCfgs) {  // forced: the Winograd F(3x3, 2x2) slab kernel (wino_wgrad.hip), strips split 2^k ways
+    CRDR_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && !a.smallj && !(d->algo & CRDR_WGRAD_BF16X3) && d->pad >= 0 && d->pad <= 2,
+                 "wgrad: the Winograd kernel takes 3x3 stride-1 weight gradients with QC > 4 (exact fp32 only)");
+    bs = 1 << ((d->algo >> 8) & 0xf);
+    const long long strips = (long long)d->N * ((d->PH + 1) / 2) * ((d->PW + 15) / 16);
+    CRDR_REQUIRE(strips / bs >= 1, "wgrad: forced split %d too deep for %lld strips", bs, strips);
+    pl->wino = 1; pl->cfg = -1;
+    a.nsplit = bs; a.jtiles = cdiv(d->QC, 64);
+    pl->grid = dim3(cdiv(d->PC, 64) * a.jtiles, bs, G);
+    pl->lds = 0;
+    a.ngroup = G;
+    a.slab_elems = (long long)bs * a.T * d->PC * d->QC;
+    pl->ws_bytes = (size_t)G * bs * a.T * d->PC * d->QC * sizeof(float);
+    return 0;
+  }
   if ((d->algo & 0xffff) != 0) {  // caller-forced algorithm (autotuner): (config index + 1) | log2(split) << 8
     bc = (d->algo & 0xff) - 1;
     bs = 1 << ((d->algo >> 8) & 0xf);
@@ -611,7 +588,7 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl, int G = 1) {
 
 using namespace crdr;
 
-extern "C" int crdr_conv2d_wgrad_num_configs(void) { return kNumWCfgs; }
+extern "C" int crdr_conv2d_wgrad_num_configs(void) { return kNumWCfgs + 1; }   // (+ the Winograd slab kernel, last)
 
 extern "C" size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d) {
   WPlan pl;
@@ -632,6 +609,11 @@ static int launch_wgrad_slabs(const crdr_wgrad_desc* d, const float* const* ps, 
     grp.p[g] = ps[g]; grp.q[g] = qs[g];
   }
   a.p = ps[0]; a.q = qs[0]; a.ws = (float*)ws;
+  if (pl.wino) {
+    wino_wgrad_launch(a, grp, pl.grid, as_stream(s));
+    CRDR_CHECK_LAUNCH("wino_wgrad_kernel");
+    return 0;
+  }
   const WCfg& t = kWCfgs[pl.cfg];
   const int bf3 = (d->algo & CRDR_WGRAD_BF16X3) ? 1 : 0;
   auto kern = bf3 ? t.kern_bf3 : t.kern;

@@ -196,6 +196,9 @@ typedef struct crdr_wgrad_desc {
                        * bit 16 (CRDR_WGRAD_BF16X3): split-bf16 products, see CRDR_CONV_BF16X3 */
 } crdr_wgrad_desc;
 #define CRDR_WGRAD_BF16X3 (1 << 16)
+/* number of forced configurations; the LAST one (index crdr_conv2d_wgrad_num_configs() - 1) is the Winograd F(3x3, 2x2) slab kernel
+ * (csrc/wino_wgrad.hip: 16 products per 2x2 tile of P and tap set instead of 36; same slabs, same deferred reduce), accepted for
+ * kh = kw = 3, stride 1, QC > 4, exact fp32; its split bits divide the strips of 8 tiles instead of the 32-pixel tiles */
 int crdr_conv2d_wgrad_num_configs(void);
 size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d);
 int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* ws, size_t ws_bytes,

@@ -97,3 +97,50 @@ def test_winograd_rejects_other_shapes():
     w3 = ops.pack_weight(_rand(32, 32, 3, 3, seed=2).to(dev), transpose=False)
     with pytest.raises(L.CrdrHipError):
         ops.conv2d_raw(x, w3, 32, (3, 3), 2, 1, False, (4, 4), algo=_wino_id())
+
+
+WG_CASES = [
+    # name, N, Cin, H, W, Cout, pad, log2 split
+    ("96_96_16", 2, 96, 16, 16, 96, 1, 0),
+    ("128_128_ragged", 1, 128, 34, 38, 128, 1, 2),
+    ("64_160_odd", 2, 64, 15, 15, 160, 1, 1),
+    ("36_40_c4", 1, 36, 20, 20, 40, 1, 0),
+    ("32_64_valid", 1, 32, 18, 21, 64, 0, 3),
+    ("8_8_tiny", 1, 8, 5, 3, 8, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_winograd_wgrad(case):
+    """weight gradient through the Winograd F(3x3, 2x2) slab kernel (the last forced wgrad configuration) vs fp64 torch, for the
+    Conv2d and the ConvTranspose2d operand order, with and without accumulation"""
+    from crdr_amd.hip import lib as L
+    from crdr_amd.hip import ops
+    name, n, ci, h, w, co, p, ls = case
+    dev = _dev()
+    algo = L.load().crdr_conv2d_wgrad_num_configs() | (ls << 8)
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(co, ci, 3, 3, seed=2, scale=(ci * 9) ** -0.5)
+    xr, wr = x.double(), wt.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, padding=p)
+    dy = _rand(*ref.shape, seed=4)
+    ref.backward(dy.double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    g = torch.zeros(co, ci, 3, 3, device=dev)
+    ops.conv2d_wgrad_raw(dyd, xd, g, (3, 3), 1, p, accumulate=False, algo=algo)
+    _close(g, wr.grad, name + " wgrad")
+    gd = torch.zeros_like(g)
+    ops.conv2d_wgrad_raw(dyd, xd, gd, (3, 3), 1, p, accumulate=False, algo=1)
+    e_w = (g.cpu().double() - wr.grad).abs().max().item()
+    e_d = (gd.cpu().double() - wr.grad).abs().max().item()
+    print(f"{name}: wgrad max err winograd {e_w:.2e} direct {e_d:.2e} (scale {wr.grad.abs().max().item():.2e})")
+    ops.conv2d_wgrad_raw(dyd, xd, g, (3, 3), 1, p, accumulate=True, algo=algo)
+    _close(g, 2 * wr.grad, name + " wgrad accumulate")
+    if p == 1:   # ConvTranspose2d 3x3 s1: P = x, Q = dy
+        wT = _rand(ci, co, 3, 3, seed=5, scale=(ci * 9) ** -0.5).double().requires_grad_(True)
+        rT = F.conv_transpose2d(xr, wT, None, padding=1)
+        dyT = _rand(*rT.shape, seed=6)
+        rT.backward(dyT.double())
+        gT = torch.zeros(ci, co, 3, 3, device=dev)
+        ops.conv2d_wgrad_raw(xd, dyT.to(dev), gT, (3, 3), 1, 1, accumulate=False, algo=algo)
+        _close(gT, wT.grad, name + " convT wgrad")

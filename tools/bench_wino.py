@@ -18,12 +18,35 @@ def main():
     ap.add_argument("--cold", action="store_true")
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--wino-only", action="store_true")
+    ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient kernels instead (direct slab kernel vs Winograd F(3x3, 2x2))")
     a = ap.parse_args()
     ops.TUNE_COLD = a.cold
     ops.TUNE_ROUNDS = 3
     lib = L.load()
     wid = lib.crdr_conv2d_num_configs() + 1 + lib.crdr_conv2d_num_stream_configs()
     dev = torch.device("cuda:0")
+    if a.wgrad:
+        nw = lib.crdr_conv2d_wgrad_num_configs()
+        for ci, co, hw in SHAPES:
+            x = torch.randn(a.bs, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+            dy = torch.randn(a.bs, co, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+            g = torch.zeros(co, ci, 3, 3, device=dev)
+            res = {}
+            for name, cfgs in (("direct", range(0 if a.wino_only else nw - 1)), ("winograd", [nw - 1])):
+                best = (1e9, 0, 0)
+                for cfg in cfgs:
+                    for ls in range(9):
+                        try:
+                            t = ops._time_call(lambda: ops.conv2d_wgrad_raw(dy, x, g, (3, 3), 1, 1, False, algo=(cfg + 1) | (ls << 8), defer=False), reps=3)
+                        except (L.CrdrHipError, AssertionError):
+                            continue
+                        best = min(best, (t, cfg, ls))
+                res[name] = best
+            fl = 2.0 * a.bs * hw * hw * ci * co * 9
+            d, w = res["direct"], res["winograd"]
+            print(f"wgrad {co:4d}x{ci:4d} @{hw:3d}: direct {d[0] * 1e3:8.1f} us ({fl / d[0] / 1e9:6.1f} TF, cfg {d[1]} split {1 << d[2]})   winograd {w[0] * 1e3:8.1f} us "
+                  f"({fl / w[0] / 1e9:6.1f} TF-eq, split {1 << w[2]})   x{d[0] / w[0]:.2f}", flush=True)
+        return
     for ci, co, hw in SHAPES:
         x = torch.randn(a.bs, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
         wt = torch.randn(co, ci, 3, 3, device=dev) * (ci * 9) ** -0.5
