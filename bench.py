@@ -378,7 +378,7 @@ def main():
         kinds, path = a.seed_tune_db.split(":", 1)
         ops.load_tune_cache(path, only_kinds=tuple(kinds.split(",")), ignore_signature=True)
     if ops.AUTOTUNE and a.retune_k3:
-        ops.load_tune_cache(a.retune_k3, ignore_signature=True, skip=lambda key: (3, 3) in key)   # (conv launches and weight gradients alike)
+        ops.load_tune_cache(a.retune_k3, ignore_signature=True, skip=lambda key: (3, 3) in key or (5, 5) in key)   # (conv launches and weight gradients alike)
     main_run = run_stage(a, a.stage, a.bs, a.steps, a.warmup, a.profile_steps, a.shape_table)
     tr = main_run.pop("trainer")
     def save_tuning():   # (again at the end: the secondary runs tune their own shapes)

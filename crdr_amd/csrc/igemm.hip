@@ -235,7 +235,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
   pl->stream = -1;
   pl->wino = 0;
   if (d->reserved != 0 && (d->reserved & 0xff) - 1 == kNumCfgs + stream_num_variants()) {  // forced: the Winograd F(2x2, 3x3) kernel (wino.hip)
-    CRDR_REQUIRE(!fallback && wino_eligible(d, G), "conv2d: forced Winograd kernel: not a 3x3 stride-1 convolution it takes");
+    CRDR_REQUIRE(!fallback && wino_eligible(d, G), "conv2d: forced Winograd kernel: not a 3x3 / 5x5 stride-1 convolution it takes");
     CRDR_REQUIRE(((d->reserved >> 8) & 0xf) == 0, "conv2d: the Winograd kernel has no split-K");
     pl->wino = 1;
     pl->cfg = -1;

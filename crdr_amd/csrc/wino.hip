@@ -5,22 +5,30 @@
 // transform has +-1 coefficients only, the filter transform halves (exact), so the arithmetic stays fp32 throughout; the
 // association of the sums differs from the direct form (typical deviation a few 1e-7 of the output scale, tests/test_gpu_conv.py).
 //
-// One workgroup = 8 waves = 16 x 16 output pixels (8 x 8 Winograd tiles) of one image x 64 output channels.
-//   wave (ph, wm, wn): transform rows xi in {2 ph, 2 ph + 1} (8 of the 16 positions), tile columns 4 wm .. 4 wm + 3 (8 rows x 4
-//   columns = 32 tiles = the 32 MFMA rows), output channels 32 wn .. 32 wn + 31: 8 accumulator blocks of 32 x 32 = 128 AGPRs,
-//   two waves per SIMD.
-// K loop: sub-steps of 8 input channels, operands double buffered in LDS and filled by LDS-DMA:
+// A 5x5 stride-1 kernel (Charm transforms) runs as 2 x 2 sub-filters of 3x3 (the outer ones zero padded), each reading the patch 3
+// pixels further down / right: 4 x 16 = 64 products per 2x2 outputs instead of 100, same transforms, the sub-filters are just more
+// reduction steps.  (Measured: not faster than the implicit GEMM on the 16x16 Charm shapes -- few patches, 2.56x larger filter
+// blocks -- so the tuner rarely takes it there; tools/bench_wino.py --k5.)
+//
+// One output tile = 16 x 16 output pixels (8 x 8 Winograd tiles) of one image x 64 output channels, computed by 8 waves:
+//   wave (ph, wn, wm): transform rows xi in {2 ph, 2 ph + 1} (8 of the 16 positions), tile columns 4 wm .. 4 wm + 3 (8 rows x 4
+//   columns = 32 tiles = the 32 MFMA rows), output channels 32 wn .. 32 wn + 31: 8 accumulator blocks of 32 x 32, two waves per SIMD.
+// The launch is persistent (one workgroup per CU walks the tiles in an XCD-aware order); before the epilogue of a tile the
+// waves already issue the first sub-step of the next one.
+// K loop: sub-steps of 8 input channels (of one sub-filter), one barrier each, operands double buffered in LDS and filled by LDS-DMA:
 //   * the raw 18 x 18 x 8 input patch, stored by pixel parity class so that the 32 tiles' reads of patch pixel (i, j) are
 //     consecutive 16-B slots: [half h = channels 4h..4h+3][class (i&1, j&1)][9 rows][12 slots (9 used)]; with 8 x 4 tiles per
 //     wave a row pitch of 12 slots makes every 16-lane group of a ds_read_b128 hit 16 different slots mod 16 (conflict free);
 //     pixels outside the image (padding) and channels past Cin read zeros through the buffer range check;
 //   * the transformed filters of the sub-step, one contiguous 32 KiB block in memory and in LDS: [position 16][h][oc 64][4].
 //   Every wave builds B^T d B for its 8 positions in registers from 12 ds_read_b128 (lane = tile, half-wave = channel half, the
-//   operand layout of the implicit-GEMM kernel), reads 8 filter fragments and issues 32 MFMAs per stage.
+//   operand layout of the implicit-GEMM kernel), reads 8 filter fragments and issues 32 MFMAs per sub-step.
+//   (Measured alternatives at the same speed, +-1 %: 32-channel input chunks staged as full 128-B lines with an XOR swizzle; the
+//   two waves of a SIMD half a sub-step apart, one loading while the other multiplies; all DMA issued between the MFMAs of one role.)
 // Epilogue: the two waves of a (wm, wn) pair each hold half of the xi sum; each forms its part of A^T M A for both output rows,
 //   hands the part of the partner's row over through LDS and finishes its own row (ph = output row inside the tile), then runs
-//   the element-wise epilogue of the implicit-GEMM kernel (same order of operations) with dword buffer stores: 32 lanes = 32
-//   consecutive channels of one pixel.
+//   the element-wise epilogue of the implicit-GEMM kernel (same order of operations) with dword buffer accesses whose per-element
+//   offset is a scalar: 32 lanes = 32 consecutive channels of one pixel.
 #include <algorithm>
 #include <atomic>
 
@@ -38,6 +46,16 @@ constexpr int kUSlots = 16 * 2 * 64;        // of one filter block (8 channels):
 constexpr int kInFloats = kInSlots * 4, kUFloats = kUSlots * 4;
 constexpr int kStageFloats = kInFloats + kUFloats;
 constexpr int kStagingFloats = 2 * kStageFloats;
+constexpr int kXFloats = 8 * 32 * 64;       // epilogue hand-over area, placed behind stage 0 (which then already receives the next tile)
+constexpr int kLdsTileFloats = kStageFloats + kXFloats > kStagingFloats ? kStageFloats + kXFloats : kStagingFloats;
+
+// workgroup barrier that publishes LDS writes but does not wait for DMA / global stores in flight
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) (vmcnt, expcnt untouched)
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
 constexpr int kNT = 512;
 
 // in-place 1-D data transform of four f32x4 (B^T rows applied along one axis): (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
@@ -52,11 +70,42 @@ __device__ __forceinline__ void bt4(const f32x4 d0, const f32x4 d1, const f32x4 
 // [B(k), A(k + 1)): role 0 multiplies k, role 1 loads k.  The role-1 waves issue ALL the DMA of sub-step k + 1 between their
 // MFMAs of phase [A(k), B(k)) (where an issue slot is nearly free) and drain it before A(k + 1); the stage it overwrites was last
 // read in phase [B(k - 1), A(k)).  B barriers hand no data over: a bare s_barrier that does not drain the DMA in flight.
-template <int PH, int ROLE>
-__device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const __amdgpu_buffer_rsrc_t rx, const __amdgpu_buffer_rsrc_t ru,
-                                          const unsigned (&a_off)[4], const unsigned a_okmask, unsigned u_off0,
+// what the DMA of one output tile needs: descriptors of its image and filter blocks, and this lane's two input slots
+struct WinoIO {
+  __amdgpu_buffer_rsrc_t rx, ru;
+  unsigned a_off[2];   // byte offset of slot j's pixel (sub-filter 0, chunk 0) in the image; may wrap where the pixel is outside: used only where ok
+  unsigned okmask;     // bits 2 sub + j: slot j holds a pixel of the image for sub-filter sub; bits 16, 17: its channel half h
+  unsigned u_off0;     // byte offset of the N tile's first filter block
+};
+
+// the DMA of sub-step k8, this wave's share: input instructions 2 wave + j (slots (2 wave + j) * 64 + lane), filter instructions 4 wave + j
+__device__ __forceinline__ void wino_issue(const IgemmArgs& p, float* smem, const WinoIO& io, int k8, int lane, int wave) {
+#ifdef WINO_EXP_NODMA
+  if (k8 > 0) return;
+#endif
+  float* st = smem + (k8 & 1) * kStageFloats;
+  // sub-filter (sa, sb) of a 5x5 kernel reads the patch 3 sa rows / 3 sb columns further down / right
+  const int KC = p.kchunks;
+  const int sub = k8 / KC, kc = k8 - sub * KC, sa = sub / p.so, sb = sub - sa * p.so;
+  const unsigned delta = (unsigned)(((3 * sa * p.W + 3 * sb) * p.ldx + kc * 8) * 4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bool ok = ((io.okmask >> (2 * sub + j)) & 1u) && (kc * 8 + (int)((io.okmask >> (16 + j)) & 1u) * 4 < p.Cin);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rx, (lds_ptr_t)(st + ((2 * wave + j) * 64) * 4), 16, (int)(ok ? io.a_off[j] + delta : kOobOffset), 0, 0, 0);
+  }
+  const unsigned ub = io.u_off0 + (unsigned)k8 * (kUSlots * 16u) + (unsigned)(4 * wave * 64 + lane) * 16u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(io.ru, (lds_ptr_t)(st + kInFloats + ((4 * wave + j) * 64) * 4), 16, (int)(ub + (unsigned)j * 1024u), 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// K loop of one wave: one barrier per sub-step k (8 channels of one sub-filter); the DMA of sub-step k + 1 is issued first, then
+// the wave reads its 12 raw pixels, transforms them, and issues its 32 MFMAs, reading one filter fragment per position.
+template <int PH>
+__device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const WinoIO& io, bool stage0_issued,
                                           int lane, int wave, int wm, int wn, f32x16 (&acc)[8]) {
-  const int K8 = p.kchunks;
+  const int K8 = p.kchunks * p.nphase;   // sub-steps: (sub-filter, 8-channel chunk), sub-filter outermost
   const int m = lane & 31, fh = lane >> 5;
   const int ty = m >> 2, tx = (m & 3) + 4 * wm;
   // float offsets of this lane's 12 raw reads (rows PH .. PH + 2 of the 4 x 4 patch, all 4 columns) inside a stage
@@ -70,41 +119,21 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
       ro[a][j] = (fh * 432 + cls * 108 + (ty + (i >> 1)) * 12 + tx + (j >> 1)) * 4;
     }
   const int bo = kInFloats + ((2 * PH * 4 * 2 + fh) * 64 + wn * 32 + m) * 4;  // position p = (2 PH + a) * 4 + nu: + (a * 4 + nu) * 512
-  const int w1 = wave & 3;
 
-  // DMA instruction idx (0..11) of this (role-1) wave for sub-step k8: 0..3 input (slots (4 idx + w1) * 64 + lane), 4..11 filters
-  auto issue = [&](int k8, int idx) __attribute__((always_inline)) {
-#ifdef WINO_EXP_NODMA
-    if (k8 > 0) return;
-#endif
-    float* st = smem + (k8 & 1) * kStageFloats;
-    if (idx < 4) {
-      const bool ok = ((a_okmask >> idx) & 1u) && (k8 * 8 + (int)((a_okmask >> (8 + idx)) & 1u) * 4 < p.Cin);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(st + ((4 * idx + w1) * 64) * 4), 16, (int)(ok ? a_off[idx] + (unsigned)k8 * 32u : kOobOffset), 0, 0, 0);
-    } else {
-      const int j = idx - 4;
-      const unsigned ub = u_off0 + (unsigned)k8 * (kUSlots * 16u) + (unsigned)((4 * j + w1) * 64 + lane) * 16u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(st + kInFloats + ((4 * j + w1) * 64) * 4), 16, (int)ub, 0, 0, 0);
-    }
-  };
-
-  f32x4 v[2][4], bfr[8];   // B^T d B and the filter fragments of the sub-step: everything its MFMAs read
-  auto loads = [&](int k8) __attribute__((always_inline)) {
-    const float* st = smem + (k8 & 1) * kStageFloats;
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const float* st = smem + buf * kStageFloats;
     f32x4 d[3][4];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #ifdef WINO_EXP_NORAW
-        d[a][j] = f32x4{(float)k8, 1.f, 2.f, (float)(a + j)};
+        d[a][j] = f32x4{(float)buf, 1.f, 2.f, (float)(a + j)};
 #else
         d[a][j] = *reinterpret_cast<const f32x4*>(st + ro[a][j]);
 #endif
       }
-#pragma unroll
-    for (int q8 = 0; q8 < 8; ++q8) bfr[q8] = *reinterpret_cast<const f32x4*>(st + bo + q8 * 512);
-    f32x4 t[2][4];
+    f32x4 t[2][4], v[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (PH == 0) { t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; }   // xi = 0, 1 from rows 0, 1, 2
@@ -112,109 +141,109 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a) bt4(t[a][0], t[a][1], t[a][2], t[a][3], v[a]);
-  };
-  // the 32 MFMAs of a sub-step from v and bfr; kd >= 0: the DMA of sub-step kd is issued between them
-  auto mfmas = [&](int kd) __attribute__((always_inline)) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) {
-        const f32x4 bf = bfr[a * 4 + nu];
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(st + bo + (a * 4 + nu) * 512);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 4; ++s)
 #ifdef WINO_EXP_NOMFMA
           acc[a * 4 + nu][s] += v[a][nu][s] * bf[s];
 #else
           acc[a * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[a][nu][s], bf[s], acc[a * 4 + nu], 0, 0, 0);
 #endif
-          if constexpr (ROLE == 1) {
-            const int g = (a * 4 + nu) * 4 + s;   // one DMA instruction behind every second MFMA of the first 24
-            if ((g & 1) && g < 24 && kd >= 0) issue(kd, g >> 1);
-          }
-        }
       }
-  };
-  auto pbarrier = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
   };
 
-  if constexpr (ROLE == 0) {
-    __syncthreads();   // A(0): sub-step 0 has landed (issued by the role-1 waves)
-    for (int k8 = 0; k8 < K8; ++k8) {
-      loads(k8);
-      pbarrier();        // B(k8)
-      mfmas(-1);
-      __syncthreads();   // A(k8 + 1)
-    }
-  } else {
-#pragma unroll
-    for (int idx = 0; idx < 12; ++idx) issue(0, idx);
-    __syncthreads();   // A(0)
-    for (int k8 = 0; k8 < K8; ++k8) {
-      const int kd = k8 + 1 < K8 ? k8 + 1 : -1;
-      if (k8 > 0) mfmas(kd);
-      else if (kd >= 0) {
-#pragma unroll
-        for (int idx = 0; idx < 12; ++idx) issue(kd, idx);
-      }
-      pbarrier();        // B(k8)
-      loads(k8);
-      __syncthreads();   // A(k8 + 1) (with the DMA of sub-step k8 + 1 drained)
-    }
-    mfmas(-1);
+  if (!stage0_issued) wino_issue(p, smem, io, 0, lane, wave);
+  __syncthreads();
+  for (int k8 = 0; k8 < K8; ++k8) {
+    if (k8 + 1 < K8) wino_issue(p, smem, io, k8 + 1, lane, wave);
+    compute(k8 & 1);
+    __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const IgemmGroup grp) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ph = wave & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
-  // XCD-aware order (see igemm_kernel): every XCD walks a contiguous range of (patch, N tile) pairs, the N tiles of a patch
-  // back to back on one L2
-  int patch, tile_n, gidx;
-  {
-    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
-    const int nwg = gx * gy * gz, bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const int cpx = nwg >> 3;
-    const int t = bid < cpx * 8 ? (bid & 7) * cpx + (bid >> 3) : bid;
-    tile_n = t % gy;
-    patch = (t / gy) % gx;
-    gidx = t / (gx * gy);
+// where an output tile (virtual block id vb of the tile grid gx x gy x gz) lies
+struct WinoTile { int patch, tile_n, gidx, n, oh0, ow0, n0; };
+__device__ __forceinline__ WinoTile wino_tile(const IgemmArgs& p, int vb, int gx, int gy, int gz) {
+  // XCD-aware order (see igemm_kernel): the hardware deals workgroups round-robin over the 8 XCDs; every XCD walks a contiguous
+  // range of (patch, N tile) pairs, the N tiles of a patch back to back on one L2.  The persistent grid is a multiple of 8
+  // workgroups, so vb & 7 is still the XCD of the workgroup that runs tile vb.
+  WinoTile t;
+  const int nwg = gx * gy * gz, cpx = nwg >> 3;
+  const int q = vb < cpx * 8 ? (vb & 7) * cpx + (vb >> 3) : vb;
+  if (p.m_inner) {   // filters dominate the traffic (Charm hoists): the patches of one N tile run together and share its filter blocks in L2
+    t.patch = q % gx;
+    t.tile_n = (q / gx) % gy;
+  } else {
+    t.tile_n = q % gy;
+    t.patch = (q / gy) % gx;
   }
+  t.gidx = q / (gx * gy);
+  const int ppi = p.GH * p.GW;
+  t.n = t.patch / ppi;
+  const int prem = t.patch - t.n * ppi, by = prem / p.GW, bx = prem - by * p.GW;
+  t.oh0 = by * 16; t.ow0 = bx * 16; t.n0 = t.tile_n * 64;
+  return t;
+}
+
+__device__ __forceinline__ WinoIO wino_io(const IgemmArgs& p, const IgemmGroup& grp, const WinoTile& t, int gy, int wave, int lane) {
+  WinoIO io;
+  const int H = p.H, W = p.W, ldx = p.ldx;
+  const float* x = p.ngroup > 1 ? grp.x[t.gidx] : p.x;
+  io.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)t.n * H * W * ldx, 0,
+                                            (unsigned)(((unsigned long long)(H * W - 1) * ldx + p.Cin) * 4ull), 0x00020000);
+  // transformed filters of group gidx: [N tile][sub-filter][chunk][2048 slots of 16 B]
+  const size_t ublock = (size_t)gy * p.nphase * p.kchunks * kUSlots * 4;   // floats per group
+  io.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (size_t)t.gidx * ublock, 0, (unsigned)(ublock * 4), 0x00020000);
+  io.u_off0 = (unsigned)t.tile_n * (unsigned)(p.nphase * p.kchunks) * (kUSlots * 16u);
+  // input staging: DMA instruction j of wave w fills slots (2 w + j) * 64 + lane -> (h, class, r, c) -> patch pixel
+  // (2 r + pi, 2 c + pj), channels 4h .. 4h + 3 of the sub-step
+  const int ih0 = t.oh0 - p.si, iw0 = t.ow0 - p.si;
+  io.okmask = 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int S = (2 * wave + j) * 64 + lane;
+    const int h = S / 432, rem = S - h * 432, cls = rem / 108, r2 = rem - cls * 108, r = r2 / 12, c = r2 - r * 12;
+    const int ih = ih0 + 2 * r + (cls >> 1), iw = iw0 + 2 * c + (cls & 1);
+    for (int sub = 0; sub < p.nphase; ++sub) {
+      const int sa = sub / p.so, sb = sub - sa * p.so;
+      const bool ok = S < kInUsed && c < 9 && (unsigned)(ih + 3 * sa) < (unsigned)H && (unsigned)(iw + 3 * sb) < (unsigned)W;
+      io.okmask |= (ok ? 1u : 0u) << (2 * sub + j);
+    }
+    io.okmask |= (h ? 1u : 0u) << (16 + j);
+    io.a_off[j] = (unsigned)(((ih * W + iw) * ldx + 4 * h) * 4);
+  }
+  return io;
+}
+
+// Persistent: the launch has at most one workgroup per CU, each walks the tiles vb = blockIdx.x, + gridDim.x, ...  Before the
+// epilogue of a tile the waves already issue the first sub-step of the next one, so its DMA latency (and the dispatch of a
+// fresh workgroup) is hidden behind the output transform and the stores.
+__global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gy, int gz) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int total = gx * gy * gz;
+  float* sV = smem + kLdsTileFloats;          // [4][64]: bias, vec2, scale, shift
+  float* sS = sV + 4 * 64;                    // [8 waves][2][32] column sums
+  bool stage0_issued = false;
+  for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+  // (per-lane constants of the K loop are re-derived per tile instead of staying live across the register-hungry epilogue)
+  int lane = lane_, wave = wave_;
+  asm volatile("" : "+v"(lane));
+  asm volatile("" : "+s"(wave));
+  const int tid = wave * 64 + lane;
+  const int ph = wave & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
+  const WinoTile tl = wino_tile(p_, vb, gx, gy, gz);
+  const WinoIO io = wino_io(p_, grp, tl, gy, wave, lane);
   IgemmArgs p = p_;
+  const int gidx = tl.gidx;
   if (p.ngroup > 1) {
     p.x = grp.x[gidx]; p.y = grp.y[gidx]; p.bias = grp.bias[gidx]; p.mask = grp.mask[gidx]; p.res = grp.res[gidx]; p.cs = grp.cs[gidx];
   }
-  const int ppi = p.GH * p.GW;
-  const int n = patch / ppi, prem = patch - n * ppi, by = prem / p.GW, bx = prem - by * p.GW;
-  const int oh0 = by * 16, ow0 = bx * 16, ih0 = oh0 - p.si, iw0 = ow0 - p.si;
-  const int n0 = tile_n * 64;
-  const int H = p.H, W = p.W, ldx = p.ldx;
-
-  const unsigned long long img = (unsigned long long)H * W * ldx * 4ull;   // bytes of one image (< 2 GiB: wino_plan)
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + (size_t)n * H * W * ldx, 0,
-                                                                      (unsigned)(((unsigned long long)(H * W - 1) * ldx + p.Cin) * 4ull), 0x00020000);
-  (void)img;
-  // transformed filters of group gidx: [N tile][chunk][2048 slots of 16 B]
-  const size_t ublock = (size_t)gridDim.y * p.kchunks * kUSlots * 4;   // floats per group
-  const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (size_t)gidx * ublock, 0, (unsigned)(ublock * 4), 0x00020000);
-  const unsigned u_off0 = (unsigned)tile_n * (unsigned)p.kchunks * (kUSlots * 16u);
-
-  // input staging (waves 4-7): DMA instruction i of wave 4 + w1 fills slots (4 i + w1) * 64 + lane -> (h, class, r, c) -> patch
-  // pixel (2 r + pi, 2 c + pj), channels 4h .. 4h + 3 of the sub-step
-  unsigned a_off[4], a_okmask = 0;   // bits 0..3: slot holds a pixel of the image; bits 8..11: its channel half h
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int S = (4 * i + (wave & 3)) * 64 + lane;
-    const int h = S / 432, rem = S - h * 432, cls = rem / 108, r2 = rem - cls * 108, r = r2 / 12, c = r2 - r * 12;
-    const int ih = ih0 + 2 * r + (cls >> 1), iw = iw0 + 2 * c + (cls & 1);
-    const bool ok = S < kInUsed && c < 9 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-    a_okmask |= (ok ? 1u : 0u) << i;
-    a_okmask |= (h ? 1u : 0u) << (8 + i);
-    a_off[i] = ok ? (unsigned)(((ih * W + iw) * ldx + 4 * h) * 4) : 0u;
-  }
+  const int n = tl.n, oh0 = tl.oh0, ow0 = tl.ow0, n0 = tl.n0, patch = tl.patch;
 
   f32x16 acc[8];
 #pragma unroll
@@ -222,9 +251,7 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  // per-column epilogue vectors (behind the two stages)
-  float* sV = smem + kStagingFloats;          // [4][64]: bias, vec2, scale, shift
-  float* sS = sV + 4 * 64;                    // [8 waves][2][32] column sums
+  // per-column epilogue vectors (the previous tile's epilogue ended with a barrier; the K loop's barriers publish them)
   {
     const int f0 = p.flags;
     if (tid < 64) {
@@ -235,14 +262,18 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
       sV[3 * 64 + tid] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[n0 + tid] : 0.f;
     }
   }
-  if (wave < 4) {
-    if (ph == 0) wino_loop<0, 0>(p, smem, rx, ru, a_off, a_okmask, u_off0, lane, wave, wm, wn, acc);
-    else wino_loop<1, 0>(p, smem, rx, ru, a_off, a_okmask, u_off0, lane, wave, wm, wn, acc);
-  } else {
-    if (ph == 0) wino_loop<0, 1>(p, smem, rx, ru, a_off, a_okmask, u_off0, lane, wave, wm, wn, acc);
-    else wino_loop<1, 1>(p, smem, rx, ru, a_off, a_okmask, u_off0, lane, wave, wm, wn, acc);
+  if (ph == 0) wino_loop<0>(p, smem, io, stage0_issued, lane, wave, wm, wn, acc);
+  else wino_loop<1>(p, smem, io, stage0_issued, lane, wave, wm, wn, acc);
+  // (the loop ends with a barrier: every wave is past its last LDS read, the stages are free)
+  // the next tile's first sub-step goes out now (stage 0; the epilogue below works in the region behind it)
+  stage0_issued = false;
+  if (vb + (int)gridDim.x < total) {   // (recomputed at the top of the next iteration: nothing of it stays live across the epilogue)
+    const WinoTile tn = wino_tile(p_, vb + (int)gridDim.x, gx, gy, gz);
+    const WinoIO ion = wino_io(p_, grp, tn, gy, wave, lane);
+    wino_issue(p_, smem, ion, 0, lane, wave);
+    stage0_issued = true;
   }
-  __syncthreads();   // every wave is past its last LDS read: the staging area is free
+  float* sXb = smem + kStageFloats;   // hand-over area of the epilogue: [8 waves][32][64 lanes] behind stage 0
 
   // ---- output transform.  This wave holds M[xi][nu] for xi = 2 ph, 2 ph + 1.  Row sums of A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]:
   //   ph 0: s0 = M0 + M1, s1 = M1;   ph 1: s0 = M2, s1 = -M2 - M3;   then along nu: (s[0] + s[1] + s[2], s[1] - s[2] - s[3]).
@@ -263,13 +294,13 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
     own[0][r] = ph == 0 ? y00 : y10; own[1][r] = ph == 0 ? y01 : y11;
     give[0][r] = ph == 0 ? y10 : y00; give[1][r] = ph == 0 ? y11 : y01;
   }
-  float* sX = smem + wave * (32 * 64);   // [32][64 lanes]
+  float* sX = sXb + wave * (32 * 64);   // [32][64 lanes]
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sX[(jj * 16 + r) * 64 + lane] = give[jj][r];
-  __syncthreads();
-  const float* sP = smem + (wave ^ 1) * (32 * 64);
+  lds_barrier();   // (not __syncthreads: the next tile's DMA stays in flight)
+  const float* sP = sXb + (wave ^ 1) * (32 * 64);
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -278,41 +309,52 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
       own[jj][r] = ph == 0 ? own[jj][r] + o : o + own[jj][r];   // (part of xi 0, 1) + (part of xi 2, 3)
     }
 
-  // ---- element-wise epilogue + stores (order of operations: epilogue_store of igemm_kernel.hpp)
+  // ---- element-wise epilogue + stores (order of operations: epilogue_store of igemm_kernel.hpp).
+  // This lane's 32 outputs: channel cn of pixels (oh0 + 4 (r >> 2) + 2 fh + ph, ow0 + 2 (r & 3) + 8 wm + jj), r < 16, jj < 2.  The descriptors
+  // are based at the tile's first pixel and channel; the per-lane part of the offset is fixed and the (r, jj) part is uniform, so
+  // it travels in the instruction's scalar offset: no per-element address arithmetic.  Pixels past the image / channels past Cout
+  // get an out-of-range lane offset (rows past OH fall off the end of the image-sized descriptor by themselves).
   const int f = p.flags;
   const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
   const bool do_cs = (f & CRDR_EPI_COLSUM) != 0, accum = (f & CRDR_EPI_ACCUM) != 0;
-  const size_t opix_img = (size_t)n * p.OH * p.OW;
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + opix_img * p.ldy, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rr =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? p.res + opix_img * p.ldres : p.y), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rm =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_mask ? p.mask + opix_img * p.ldmask : p.y), 0, 0x7fffffff, 0x00020000);
-  const int cn = wn * 32 + (lane & 31), oc = n0 + cn, fh = lane >> 5;
-  const bool oc_ok = oc < p.Cout;
+  const int fh = lane >> 5, cn = wn * 32 + (lane & 31);
+  const bool oc_ok = n0 + cn < p.Cout;
+  const size_t pix0 = ((size_t)n * p.OH + oh0) * p.OW + ow0;             // first pixel of the tile
+  const unsigned rows_left = (unsigned)(p.OH - oh0);                     // image rows from the tile's first one
+  auto desc = [&](const float* base, int ld) __attribute__((always_inline)) {
+    const unsigned long long bytes = ((unsigned long long)rows_left * p.OW - ow0) * (unsigned long long)ld * 4ull;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + pix0 * ld + n0, 0, (unsigned)(bytes < 0x7fffffffull ? bytes : 0x7fffffffull), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t ry = desc(p.y, p.ldy);
+  const __amdgpu_buffer_rsrc_t rr = has_res ? desc(p.res, p.ldres) : ry;
+  const __amdgpu_buffer_rsrc_t rm = has_mask ? desc(p.mask, p.ldmask) : ry;
+  const int lrow = 2 * fh + ph, lcol = 8 * wm;                           // lane part of the pixel position inside the tile
+  const bool full_w = ow0 + 16 <= p.OW;                                  // (uniform) no column of the tile hangs over the image
+  auto lane_off = [&](int ld) __attribute__((always_inline)) { return oc_ok ? (unsigned)(((lrow * p.OW + lcol) * ld + cn) * 4) : kOobOffset; };
+  const unsigned vy = lane_off(p.ldy), vr = lane_off(p.ldres), vm = lane_off(p.ldmask);
   const float bias = sV[0 * 64 + cn], vec2 = sV[1 * 64 + cn], scale = sV[2 * 64 + cn], shift = sV[3 * 64 + cn];
   float cpre = 0.f, cpost = 0.f;
 #pragma unroll
   for (int rb = 0; rb < 4; ++rb) {   // batches of 4 accumulator registers x 2 columns = 8 pixels: loads first, then the stores
     float resv[8], mskv[8], oldv[8];
-    unsigned yo[8];
     bool okk[8];
+    // uniform part of the batch's offsets, in pixels: 4 rb rows down, then 2 (q >> 1) + (q & 1) columns right
+    const int prow = 4 * rb * p.OW;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int r = rb * 4 + (q >> 1), jj = q & 1;
-      const int trow = (r & 3) + 8 * (r >> 2) + 4 * fh;   // MFMA row = tile of the wave's 8 x 4 block
-      const int oh = oh0 + 2 * (trow >> 2) + ph, ow = ow0 + 2 * ((trow & 3) + 4 * wm) + jj;
-      const bool ok = oc_ok && oh < p.OH && ow < p.OW;
-      const unsigned pix = (unsigned)(oh * p.OW + ow);
-      okk[q] = ok;
-      yo[q] = ok ? (pix * (unsigned)p.ldy + (unsigned)oc) * 4u : kOobOffset;
-      if (has_res) resv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, ok ? (pix * (unsigned)p.ldres + (unsigned)oc) * 4u : kOobOffset, 0, 0));
-      if (has_mask) mskv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, ok ? (pix * (unsigned)p.ldmask + (unsigned)oc) * 4u : kOobOffset, 0, 0));
-      if (accum) oldv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yo[q], 0, 0));
+      const int pixs = prow + 2 * (q >> 1) + (q & 1);
+      // a column past the image would alias the next row: mask it by lane (only tiles on the right edge of a ragged image)
+      const bool col_ok = full_w || ow0 + lcol + 2 * (q >> 1) + (q & 1) < p.OW;
+      okk[q] = oc_ok && col_ok && oh0 + 4 * rb + lrow < p.OH;
+      if (has_res) resv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, col_ok ? vr : kOobOffset, pixs * p.ldres * 4, 0));
+      if (has_mask) mskv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, col_ok ? vm : kOobOffset, pixs * p.ldmask * 4, 0));
+      if (accum) oldv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, col_ok ? vy : kOobOffset, pixs * p.ldy * 4, 0));
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int r = rb * 4 + (q >> 1), jj = q & 1;
+      const int pixs = prow + 2 * (q >> 1) + (q & 1);
+      const bool col_ok = full_w || ow0 + lcol + 2 * (q >> 1) + (q & 1) < p.OW;
       float v = own[jj][r];
       if (f & CRDR_EPI_BIAS) v += bias;
       if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
@@ -328,7 +370,7 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
       }
       if (do_cs) cpost += okk[q] ? v : 0.f;
       if (accum) v += oldv[q];
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, yo[q], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, col_ok ? vy : kOobOffset, pixs * p.ldy * 4, 0);
     }
   }
   if (do_cs) {   // lane -> wave (the two half-waves hold different tiles of the same channel) -> workgroup, fixed order
@@ -347,22 +389,26 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
       if (n0 + c < p.Cout) p.cs[((size_t)patch * 2 + which) * p.cs_ld + n0 + c] = v;
     }
   }
+  lds_barrier();   // the hand-over area, sV and sS are free for the next tile
+  }  // tile loop
 }
 
 // Filter transform U = G g G^T, G = [[1, 0, 0], [1/2, 1/2, 1/2], [1/2, -1/2, 1/2], [0, 0, 1]], from the implicit-GEMM weight pack
 // (tap-major [tap][wrows][wcols]) into the stage-block layout of wino_kernel: [N tile][chunk of 8 channels][position 16][h 2][oc 64][4].
 // One thread per (N tile, chunk, h, oc): 9 x 16 B in, 16 x 16 B out (consecutive threads = consecutive oc: coalesced both ways).
-struct WinoTaps { int widx[9]; };   // weight index of tap (a, b) = patch offset (a, b) relative to the first tap
+struct WinoTaps { int widx[36]; };   // weight index of kernel offset (a, b) on the (3 ks) x (3 ks) grid, -1 outside the kernel
 __global__ void wino_filter_kernel(const IgemmGroup grp, int ngroup, const float* w0, float* u, int Cin, int Cout, int wrows, int wcols, int kchunks,
-                                   int ntile, WinoTaps tp) {
-  const long long total = (long long)ntile * kchunks * 128;
+                                   int ntile, int ks, WinoTaps tp) {
+  const int nsub = ks * ks;
+  const long long total = (long long)ntile * nsub * kchunks * 128;
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= total) return;
   const int g = blockIdx.y;
   const float* w = ngroup > 1 ? grp.w[g] : w0;
   const int oc64 = (int)(id & 63), h = (int)((id >> 6) & 1);
-  const long long blk = id >> 7;   // (N tile, chunk)
-  const int kc = (int)(blk % kchunks), ct = (int)(blk / kchunks);
+  const long long blk = id >> 7;   // (N tile, sub-filter, chunk)
+  const int kc = (int)(blk % kchunks), sub = (int)((blk / kchunks) % nsub), ct = (int)(blk / ((long long)kchunks * nsub));
+  const int sa = sub / ks, sb = sub - sa * ks;
   const int oc = ct * 64 + oc64, c0 = kc * 8 + h * 4;
   f32x4 g9[3][3];
   const bool live = oc < Cout && c0 < Cin;
@@ -371,7 +417,8 @@ __global__ void wino_filter_kernel(const IgemmGroup grp, int ngroup, const float
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (live) v = *reinterpret_cast<const f32x4*>(w + ((size_t)tp.widx[a * 3 + b] * wrows + oc) * wcols + c0);
+      const int wi = tp.widx[(3 * sa + a) * (3 * ks) + 3 * sb + b];
+      if (live && wi >= 0) v = *reinterpret_cast<const f32x4*>(w + ((size_t)wi * wrows + oc) * wcols + c0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (c0 + e >= Cin) v[e] = 0.f;
@@ -385,7 +432,7 @@ __global__ void wino_filter_kernel(const IgemmGroup grp, int ngroup, const float
     t[2][b] = 0.5f * (g9[0][b] - g9[1][b] + g9[2][b]);
     t[3][b] = g9[2][b];
   }
-  float* dst = u + ((size_t)g * ntile * kchunks + (size_t)blk) * (kUSlots * 4) + ((size_t)h * 64 + oc64) * 4;
+  float* dst = u + ((size_t)g * ntile * nsub * kchunks + (size_t)blk) * (kUSlots * 4) + ((size_t)h * 64 + oc64) * 4;
 #pragma unroll
   for (int xi = 0; xi < 4; ++xi) {
     f32x4 o[4];
@@ -400,62 +447,78 @@ __global__ void wino_filter_kernel(const IgemmGroup grp, int ngroup, const float
 
 }  // namespace
 
+static int wino_ks(const crdr_conv_desc* d) { return d->kh == 5 ? 2 : 1; }   // sub-filters per axis
+
 bool wino_eligible(const crdr_conv_desc* d, int G) {
-  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->wlayout != 0) return false;
-  const int grow = d->transposed ? 2 - 2 * d->pad : 2 * d->pad - 2;   // (a stride-1 transposed conv = a conv with pad 2 - pad)
+  if (!((d->kh == 3 && d->kw == 3) || (d->kh == 5 && d->kw == 5)) || d->stride != 1 || d->wlayout != 0) return false;
+  const int k = d->kh;
+  const int grow = d->transposed ? (k - 1) - 2 * d->pad : 2 * d->pad - (k - 1);   // (a stride-1 transposed conv = a conv with pad k - 1 - pad)
   if (d->OH != d->H + grow || d->OW != d->W + grow) return false;
-  if (d->pad < 0 || d->pad > 2) return false;
+  if (d->pad < 0 || d->pad > k - 1) return false;
   if (d->C % 4 != 0 || d->ldx % 4 != 0) return false;
   if (d->flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_CONV_BF16X3)) return false;
   if (G > 1 && (d->flags & (CRDR_EPI_VEC2 | CRDR_EPI_AFFINE | CRDR_EPI_MASKOFF))) return false;
-  const long long img = (long long)d->H * d->W * d->ldx * 4;
+  const long long img = (long long)(d->H + 8) * d->W * d->ldx * 4;
   const long long oimg = (long long)d->OH * d->OW * std::max(std::max(d->ldy, d->ldres), d->ldmask) * 4;
   if (img >= (1ll << 31) || oimg >= (1ll << 31)) return false;
-  const long long ub = (long long)cdiv(d->OC, 64) * cdiv(d->C, 8) * kUSlots * 16;
-  if (ub >= (1ll << 31)) return false;
+  if ((long long)wino_workspace(d, G) / G >= (1ll << 31)) return false;
   return true;
 }
 
 size_t wino_workspace(const crdr_conv_desc* d, int G) {
-  return (size_t)G * cdiv(d->OC, 64) * cdiv(d->C, 8) * kUSlots * 16;
+  return (size_t)G * cdiv(d->OC, 64) * wino_ks(d) * wino_ks(d) * cdiv(d->C, 8) * kUSlots * 16;
 }
 
 int wino_colsum_rows(const crdr_conv_desc* d) { return d->N * cdiv(d->OH, 16) * cdiv(d->OW, 16); }
 
 // a: the argument block of the implicit-GEMM plan with every pointer / stride / flag filled in; taps: the plan's tap table
 int wino_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s) {
-  CRDR_REQUIRE(wino_eligible(d, G), "conv2d: the Winograd kernel takes 3x3 stride-1 convolutions (C %% 4 == 0, no gate / pre-add epilogue)");
+  CRDR_REQUIRE(wino_eligible(d, G), "conv2d: the Winograd kernel takes 3x3 / 5x5 stride-1 convolutions (C %% 4 == 0, no gate / pre-add epilogue)");
+  const int ks = wino_ks(d), kk = d->kh, nt = kk * kk;
   WinoTaps wt;
   int dmin = 127;
-  for (int t = 0; t < 9; ++t) dmin = std::min(dmin, (int)(signed char)(taps.packed[t] & 0xff));
-  for (int t = 0; t < 9; ++t) wt.widx[t] = -1;
-  for (int t = 0; t < 9; ++t) {
+  for (int t = 0; t < nt; ++t) dmin = std::min(dmin, (int)(signed char)(taps.packed[t] & 0xff));
+  for (int t = 0; t < 36; ++t) wt.widx[t] = -1;
+  for (int t = 0; t < nt; ++t) {
     const int v = taps.packed[t];
     const int dh = (int)(signed char)(v & 0xff) - dmin, dw = (int)(signed char)((v >> 8) & 0xff) - dmin;
-    CRDR_REQUIRE(dh >= 0 && dh < 3 && dw >= 0 && dw < 3, "conv2d: Winograd: tap offsets are not a 3x3 window");
-    wt.widx[dh * 3 + dw] = v >> 16;
+    CRDR_REQUIRE(dh >= 0 && dh < kk && dw >= 0 && dw < kk, "conv2d: Winograd: tap offsets are not a %dx%d window", kk, kk);
+    wt.widx[dh * (3 * ks) + dw] = v >> 16;
   }
-  for (int t = 0; t < 9; ++t) CRDR_REQUIRE(wt.widx[t] >= 0, "conv2d: Winograd: incomplete 3x3 window");
+  for (int a2 = 0; a2 < kk; ++a2)
+    for (int b2 = 0; b2 < kk; ++b2) CRDR_REQUIRE(wt.widx[a2 * (3 * ks) + b2] >= 0, "conv2d: Winograd: incomplete %dx%d window", kk, kk);
   const int ntile = cdiv(d->OC, 64), kchunks = cdiv(d->C, 8);
   {
-    const long long total = (long long)ntile * kchunks * 128;
+    const long long total = (long long)ntile * ks * ks * kchunks * 128;
     hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)cdiv64(total, 256), G), dim3(256), 0, s, grp, G, a.w, u, d->C, d->OC, d->wrows, d->wcols, kchunks,
-                       ntile, wt);
+                       ntile, ks, wt);
     CRDR_CHECK_LAUNCH("wino_filter_kernel");
   }
   a.w = u;
   a.kchunks = kchunks;
+  {
+    const double A = (double)d->N * d->H * d->W * d->C * 4.0, B = (double)wino_workspace(d, 1);
+    a.m_inner = (G == 1 && B >= 32.0e6 && A * 4.0 <= B) ? 1 : 0;
+  }
+  a.nphase = ks * ks;   // sub-filters (a 5x5 kernel = 2 x 2 sub-filters of 3x3, the outer ones zero padded, 3 pixels apart)
+  a.so = ks;
   a.GH = cdiv(d->OH, 16);
   a.GW = cdiv(d->OW, 16);
   a.si = -dmin;   // the patch starts `si` pixels above / left of its first output pixel
   a.cs_rows = wino_colsum_rows(d);
-  const size_t lds = (size_t)(kStagingFloats + 4 * 64 + 8 * 2 * 32) * sizeof(float);
+  const size_t lds = (size_t)(kLdsTileFloats + 4 * 64 + 8 * 2 * 32) * sizeof(float);
   static std::atomic<bool> attr_done{false};
   if (!attr_done.load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(wino_kernel, dim3(d->N * a.GH * a.GW, ntile, G), dim3(kNT), lds, s, a, grp);
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    return n / 8 * 8;
+  }();
+  const int gx = d->N * a.GH * a.GW, total = gx * ntile * G;
+  hipLaunchKernelGGL(wino_kernel, dim3(std::min(total, ncu)), dim3(kNT), lds, s, a, grp, gx, ntile, G);
   CRDR_CHECK_LAUNCH("wino_kernel");
   return 0;
 }

@@ -19,7 +19,7 @@ def _wino_id():
 
 
 CASES = [
-    # name, N, Cin, H, W, Cout, pad
+    # name, N, Cin, H, W, Cout, pad[, k]
     ("96_96_16", 2, 96, 16, 16, 96, 1),
     ("128_128_ragged", 1, 128, 34, 38, 128, 1),
     ("64_160_odd", 2, 64, 15, 15, 160, 1),
@@ -27,16 +27,22 @@ CASES = [
     ("256_512_32", 1, 256, 32, 32, 512, 1),
     ("32_64_valid", 1, 32, 18, 21, 64, 0),
     ("8_8_tiny", 1, 8, 5, 3, 8, 1),
+    # 5x5 = 2 x 2 sub-filters of 3x3 (Charm transforms, minnen20_charm_context_model.py:29-35)
+    ("k5_320_224_16", 2, 320, 16, 16, 224, 2, 5),
+    ("k5_32_96_ragged", 1, 32, 19, 23, 96, 2, 5),
+    ("k5_36_40_valid", 1, 36, 12, 9, 40, 0, 5),
+    ("k5_64_64_pad1", 1, 64, 10, 10, 64, 1, 5),
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_winograd_fwd_dgrad(case):
     from crdr_amd.hip import ops
-    name, n, ci, h, w, co, p = case
+    name, n, ci, h, w, co, p = case[:7]
+    k = case[7] if len(case) > 7 else 3
     dev = _dev()
     x = _rand(n, ci, h, w, seed=1)
-    wt = _rand(co, ci, 3, 3, seed=2, scale=(ci * 9) ** -0.5)
+    wt = _rand(co, ci, k, k, seed=2, scale=(ci * k * k) ** -0.5)
     b = _rand(co, seed=3)
     xr = x.double().requires_grad_(True)
     ref = F.conv2d(xr, wt.double(), b.double(), padding=p)
@@ -45,18 +51,18 @@ def test_winograd_fwd_dgrad(case):
     ref.backward(dy.double())
     xd, wd, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
     wp = ops.pack_weight(wd, transpose=False)
-    direct = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=1)
-    out = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=_wino_id())
+    direct = ops.conv2d_raw(xd, wp, co, (k, k), 1, p, False, (oh, ow), bias=bd, flags=1, algo=1)
+    out = ops.conv2d_raw(xd, wp, co, (k, k), 1, p, False, (oh, ow), bias=bd, flags=1, algo=_wino_id())
     torch.cuda.synchronize()
     _close(out, ref, name + " fwd")
     e_w = (out.cpu().double() - ref.detach()).abs().max().item()
     e_d = (direct.cpu().double() - ref.detach()).abs().max().item()
     print(f"{name}: fwd max err winograd {e_w:.2e} direct {e_d:.2e} (scale {ref.abs().max().item():.2e})")
     wq = ops.pack_weight(wd, transpose=True)
-    dx = ops.conv2d_raw(dyd, wq, ci, (3, 3), 1, p, True, (h, w), algo=_wino_id())
+    dx = ops.conv2d_raw(dyd, wq, ci, (k, k), 1, p, True, (h, w), algo=_wino_id())
     _close(dx, xr.grad, name + " dgrad")
     # deterministic
-    out2 = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=_wino_id())
+    out2 = ops.conv2d_raw(xd, wp, co, (k, k), 1, p, False, (oh, ow), bias=bd, flags=1, algo=_wino_id())
     assert torch.equal(out, out2)
 
 
@@ -91,9 +97,9 @@ def test_winograd_rejects_other_shapes():
     from crdr_amd.hip import ops
     dev = _dev()
     x = _rand(1, 32, 8, 8, seed=1).to(dev)
-    w5 = ops.pack_weight(_rand(32, 32, 5, 5, seed=2).to(dev), transpose=False)
+    w7 = ops.pack_weight(_rand(32, 32, 7, 7, seed=2).to(dev), transpose=False)
     with pytest.raises(L.CrdrHipError):
-        ops.conv2d_raw(x, w5, 32, (5, 5), 1, 2, False, (8, 8), algo=_wino_id())
+        ops.conv2d_raw(x, w7, 32, (7, 7), 1, 3, False, (8, 8), algo=_wino_id())
     w3 = ops.pack_weight(_rand(32, 32, 3, 3, seed=2).to(dev), transpose=False)
     with pytest.raises(L.CrdrHipError):
         ops.conv2d_raw(x, w3, 32, (3, 3), 2, 1, False, (4, 4), algo=_wino_id())

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--cold", action="store_true")
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--wino-only", action="store_true")
+    ap.add_argument("--k5", action="store_true", help="the 5x5 stride-1 shapes of the Charm at 16x16 instead")
     ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient kernels instead (direct slab kernel vs Winograd F(3x3, 2x2))")
     a = ap.parse_args()
     ops.TUNE_COLD = a.cold
@@ -47,20 +48,22 @@ def main():
             print(f"wgrad {co:4d}x{ci:4d} @{hw:3d}: direct {d[0] * 1e3:8.1f} us ({fl / d[0] / 1e9:6.1f} TF, cfg {d[1]} split {1 << d[2]})   winograd {w[0] * 1e3:8.1f} us "
                   f"({fl / w[0] / 1e9:6.1f} TF-eq, split {1 << w[2]})   x{d[0] / w[0]:.2f}", flush=True)
         return
-    for ci, co, hw in SHAPES:
+    kk, shapes = (5, [(320, 4256, 16), (320, 2016, 16), (32, 4032, 16), (32, 2240, 16), (224, 128, 16), (320, 224, 16), (128, 224, 16)]) if a.k5 else (3, SHAPES)
+    for ci, co, hw in shapes:
         x = torch.randn(a.bs, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
-        wt = torch.randn(co, ci, 3, 3, device=dev) * (ci * 9) ** -0.5
+        wt = torch.randn(co, ci, kk, kk, device=dev) * (ci * kk * kk) ** -0.5
         b = torch.randn(co, device=dev)
         wp = ops.pack_weight(wt, transpose=False)
         best = (1e9, 0)
         for cfg in range(0 if a.wino_only else lib.crdr_conv2d_num_configs()):
             try:
-                t = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (hw, hw), bias=b, flags=3, algo=cfg + 1), reps=3)
+                t = min(ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (kk, kk), 1, kk // 2, False, (hw, hw), bias=b, flags=3, algo=(cfg + 1) | (ls << 8)), reps=3)
+                        for ls in (range(3) if a.k5 else range(1)))
             except L.CrdrHipError:
                 continue
             best = min(best, (t, cfg))
-        tw = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (hw, hw), bias=b, flags=3, algo=wid), reps=3)
-        fl = 2.0 * a.bs * hw * hw * ci * co * 9
+        tw = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (kk, kk), 1, kk // 2, False, (hw, hw), bias=b, flags=3, algo=wid), reps=3)
+        fl = 2.0 * a.bs * hw * hw * ci * co * kk * kk
         print(f"{ci:4d}->{co:4d} @{hw:3d}: direct {best[0] * 1e3:8.1f} us ({fl / best[0] / 1e9:6.1f} TF, cfg {best[1]})   winograd {tw * 1e3:8.1f} us "
               f"({fl / tw / 1e9:6.1f} TF-eq)   x{best[0] / tw:.2f}", flush=True)
 
