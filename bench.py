@@ -225,7 +225,12 @@ def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: in
                 "avg_gflop_per_launch": round(fl / n / 1e9, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                 "ms_per_step": round(ms / ps, 2)}
     r0, r3 = raw(0), raw(3)   # implicit-GEMM / streaming launches, Winograd launches (both counted with the direct convolution's flops)
-    ig, wg, sk = fam(r0[0] + r3[0], r0[1] + r3[1], r0[2] + r3[2]), fam(*raw(1)), fam(*raw(2))
+    r1, r4 = raw(1), raw(4)   # weight-gradient slab launches: direct, Winograd F(3x3, 2x2)
+    ig, wg, sk = fam(r0[0] + r3[0], r0[1] + r3[1], r0[2] + r3[2]), fam(r1[0] + r4[0], r1[1] + r4[1], r1[2] + r4[2]), fam(*raw(2))
+    if wg is not None and r4[2]:
+        wg["winograd"] = dict(fam(*r4), executed_tflops=round(r4[0] / 2.25 / (r4[1] * 1e-3) / 1e12, 2))
+        wg["direct"] = fam(*r1)
+        wg["executed_mfma_tflops"] = round((r1[0] + r4[0] / 2.25) / ((r1[1] + r4[1]) * 1e-3) / 1e12, 2)
     if ig is not None and r3[2]:
         # what the matrix cores execute: a Winograd F(2x2, 3x3) launch does 16 multiply-accumulates per 2x2 outputs and channel pair
         # instead of 36 -- its effective rate may exceed the MFMA peak, its executed rate may not

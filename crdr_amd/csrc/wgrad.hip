@@ -639,7 +639,7 @@ extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const
   hipLaunchKernelGGL(wgrad_reduce, dim3(blocks), dim3(256), 0, as_stream(s), (const float*)ws, g, d->PC, d->QC, d->gI,
                      d->gJ, a.T, a.nsplit, d->accumulate, a.smallj);
   CRDR_CHECK_LAUNCH("wgrad_reduce");
-  profile_end(1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
+  profile_end(pl.wino ? 4 : 1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
   return 0;
 }
 
@@ -653,7 +653,7 @@ extern "C" int crdr_conv2d_wgrad_partial(const crdr_wgrad_desc* d, const float* 
   job->slab = (const float*)slab; job->g = g;
   job->PC = d->PC; job->QC = d->QC; job->gI = d->gI; job->gJ = d->gJ; job->T = a.T; job->nsplit = a.nsplit;
   job->smallj = a.smallj; job->accumulate = d->accumulate; job->gJtot = 0; job->reserved = 0;
-  profile_end(1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
+  profile_end(pl.wino ? 4 : 1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
   return 0;
 }
 
@@ -679,7 +679,7 @@ extern "C" int crdr_conv2d_wgrad_partial_grouped(const crdr_wgrad_desc* d, const
     job->PC = d->PC; job->QC = d->QC; job->gI = d->gI; job->gJ = d->gJ; job->T = a.T; job->nsplit = a.nsplit;
     job->smallj = a.smallj; job->accumulate = d->accumulate; job->gJtot = 0; job->reserved = 0;
   }
-  profile_end(1, 2.0 * (double)G * a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
+  profile_end(pl.wino ? 4 : 1, 2.0 * (double)G * a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
   return 0;
 }
 
