@@ -44,7 +44,7 @@ constexpr int kInUsed = 2 * 4 * 9 * 12;     // 16-byte slots of the input patch 
 constexpr int kInSlots = 1024;              // ... rounded up to 4 DMA instructions for each of the 4 issuing waves
 constexpr int kUSlots = 16 * 2 * 64;        // of one filter block (8 channels): 8 DMA instructions per issuing wave
 constexpr int kInFloats = kInSlots * 4, kUFloats = kUSlots * 4;
-constexpr int kStageFloats = kInFloats + kUFloats;
+constexpr int kStageFloats = 2 * kInFloats + kUFloats;   // [input patch A][input patch B (pair tiles only)][filters]
 constexpr int kStagingFloats = 2 * kStageFloats;
 constexpr int kXFloats = 8 * 32 * 64;       // epilogue hand-over area, placed behind stage 0 (which then already receives the next tile)
 constexpr int kLdsTileFloats = kStageFloats + kXFloats > kStagingFloats ? kStageFloats + kXFloats : kStagingFloats;
@@ -73,9 +73,9 @@ __device__ __forceinline__ void bt4(const f32x4 d0, const f32x4 d1, const f32x4 
 // what the DMA of one output tile needs: descriptors of its image and filter blocks, and this lane's two input slots
 struct WinoIO {
   __amdgpu_buffer_rsrc_t rx, ru;
-  unsigned a_off[2];   // byte offset of slot j's pixel (sub-filter 0, chunk 0) in the image; may wrap where the pixel is outside: used only where ok
-  unsigned okmask;     // bits 2 sub + j: slot j holds a pixel of the image for sub-filter sub; bits 16, 17: its channel half h
-  unsigned u_off0;     // byte offset of the N tile's first filter block
+  unsigned a_off[2][2];  // [patch A / B][j]: byte offset of slot j's pixel (sub-filter 0, chunk 0) in the tensor; may wrap where the pixel is outside: used only where ok
+  unsigned okmask;       // bits 8 patch + 2 sub + j: slot j holds a pixel of the image for sub-filter sub; bits 16, 17: its channel half h; bit 18: pair tile
+  unsigned u_off0;       // byte offset of the N tile's first filter block
 };
 
 // the DMA of sub-step k8, this wave's share: input instructions 2 wave + j (slots (2 wave + j) * 64 + lane), filter instructions 4 wave + j
@@ -89,14 +89,19 @@ __device__ __forceinline__ void wino_issue(const IgemmArgs& p, float* smem, cons
   const int sub = k8 / KC, kc = k8 - sub * KC, sa = sub / p.so, sb = sub - sa * p.so;
   const unsigned delta = (unsigned)(((3 * sa * p.W + 3 * sb) * p.ldx + kc * 8) * 4);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const bool ok = ((io.okmask >> (2 * sub + j)) & 1u) && (kc * 8 + (int)((io.okmask >> (16 + j)) & 1u) * 4 < p.Cin);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rx, (lds_ptr_t)(st + ((2 * wave + j) * 64) * 4), 16, (int)(ok ? io.a_off[j] + delta : kOobOffset), 0, 0, 0);
+  for (int pb = 0; pb < 2; ++pb) {
+    if (pb == 1 && !((io.okmask >> 18) & 1u)) break;   // (uniform) the second patch of a pair tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = ((io.okmask >> (8 * pb + 2 * sub + j)) & 1u) && (kc * 8 + (int)((io.okmask >> (16 + j)) & 1u) * 4 < p.Cin);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rx, (lds_ptr_t)(st + pb * kInFloats + ((2 * wave + j) * 64) * 4), 16,
+                                               (int)(ok ? io.a_off[pb][j] + delta : kOobOffset), 0, 0, 0);
+    }
   }
   const unsigned ub = io.u_off0 + (unsigned)k8 * (kUSlots * 16u) + (unsigned)(4 * wave * 64 + lane) * 16u;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(io.ru, (lds_ptr_t)(st + kInFloats + ((4 * wave + j) * 64) * 4), 16, (int)(ub + (unsigned)j * 1024u), 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(io.ru, (lds_ptr_t)(st + 2 * kInFloats + ((4 * wave + j) * 64) * 4), 16, (int)(ub + (unsigned)j * 1024u), 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -108,6 +113,7 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
   const int K8 = p.kchunks * p.nphase;   // sub-steps: (sub-filter, 8-channel chunk), sub-filter outermost
   const int m = lane & 31, fh = lane >> 5;
   const int ty = m >> 2, tx = (m & 3) + 4 * wm;
+  const bool pair = (io.okmask >> 18) & 1u;
   // float offsets of this lane's 12 raw reads (rows PH .. PH + 2 of the 4 x 4 patch, all 4 columns) inside a stage
   int ro[3][4];
 #pragma unroll
@@ -116,9 +122,10 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
     for (int j = 0; j < 4; ++j) {
       const int i = PH + a;
       const int cls = (i & 1) * 2 + (j & 1);
-      ro[a][j] = (fh * 432 + cls * 108 + (ty + (i >> 1)) * 12 + tx + (j >> 1)) * 4;
+      ro[a][j] = (pair && wn ? kInFloats : 0) + (fh * 432 + cls * 108 + (ty + (i >> 1)) * 12 + tx + (j >> 1)) * 4;
     }
-  const int bo = kInFloats + ((2 * PH * 4 * 2 + fh) * 64 + wn * 32 + m) * 4;  // position p = (2 PH + a) * 4 + nu: + (a * 4 + nu) * 512
+  // position p = (2 PH + a) * 4 + nu: + (a * 4 + nu) * 512; in a pair tile both wn take the tile's first 32 channels (of two patches)
+  const int bo = 2 * kInFloats + ((2 * PH * 4 * 2 + fh) * 64 + (pair ? 0 : wn * 32) + m) * 4;
 
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const float* st = smem + buf * kStageFloats;
@@ -165,27 +172,39 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
   }
 }
 
-// where an output tile (virtual block id vb of the tile grid gx x gy x gz) lies
-struct WinoTile { int patch, tile_n, gidx, n, oh0, ow0, n0; };
-__device__ __forceinline__ WinoTile wino_tile(const IgemmArgs& p, int vb, int gx, int gy, int gz) {
+// where an output tile (virtual block id vb) lies.  A group's tiles: gx patches x gyn N tiles of 64 channels, then -- when the
+// channel count leaves a tail of <= 32 -- npair PAIR tiles: the tail's 32 channels for TWO patches (2 i, 2 i + 1), the wn waves
+// taking one patch each instead of one 32-channel half each, so that a 96-channel layer costs 1.5 tiles per patch, not 2.
+struct WinoTile { int patch, tile_n, gidx, n, oh0, ow0, n0; int pair, nB, oh0B, ow0B, patchB; };
+__device__ __forceinline__ WinoTile wino_tile(const IgemmArgs& p, int vb, int gx, int gyn, int npair, int gz) {
   // XCD-aware order (see igemm_kernel): the hardware deals workgroups round-robin over the 8 XCDs; every XCD walks a contiguous
   // range of (patch, N tile) pairs, the N tiles of a patch back to back on one L2.  The persistent grid is a multiple of 8
   // workgroups, so vb & 7 is still the XCD of the workgroup that runs tile vb.
   WinoTile t;
-  const int nwg = gx * gy * gz, cpx = nwg >> 3;
+  const int T = gx * gyn + npair, nwg = T * gz, cpx = nwg >> 3;
   const int q = vb < cpx * 8 ? (vb & 7) * cpx + (vb >> 3) : vb;
-  if (p.m_inner) {   // filters dominate the traffic (Charm hoists): the patches of one N tile run together and share its filter blocks in L2
-    t.patch = q % gx;
-    t.tile_n = (q / gx) % gy;
-  } else {
-    t.tile_n = q % gy;
-    t.patch = (q / gy) % gx;
-  }
-  t.gidx = q / (gx * gy);
+  t.gidx = q / T;
+  const int r = q - t.gidx * T;
   const int ppi = p.GH * p.GW;
+  t.pair = r >= gx * gyn;
+  if (t.pair) {
+    t.patch = 2 * (r - gx * gyn);
+    t.tile_n = gyn;
+  } else if (p.m_inner) {   // filters dominate the traffic (Charm hoists): the patches of one N tile run together and share its filter blocks in L2
+    t.patch = r % gx;
+    t.tile_n = r / gx;
+  } else {
+    t.tile_n = r % gyn;
+    t.patch = r / gyn;
+  }
   t.n = t.patch / ppi;
   const int prem = t.patch - t.n * ppi, by = prem / p.GW, bx = prem - by * p.GW;
   t.oh0 = by * 16; t.ow0 = bx * 16; t.n0 = t.tile_n * 64;
+  t.patchB = t.patch + 1;
+  t.nB = t.patchB / ppi;
+  const int premB = t.patchB - t.nB * ppi, byB = premB / p.GW, bxB = premB - byB * p.GW;
+  t.oh0B = byB * 16; t.ow0B = bxB * 16;
+  if (!t.pair || t.patchB >= gx) t.patchB = -1;   // no second patch (odd patch count): every access of it falls out of range
   return t;
 }
 
@@ -193,28 +212,31 @@ __device__ __forceinline__ WinoIO wino_io(const IgemmArgs& p, const IgemmGroup& 
   WinoIO io;
   const int H = p.H, W = p.W, ldx = p.ldx;
   const float* x = p.ngroup > 1 ? grp.x[t.gidx] : p.x;
-  io.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)t.n * H * W * ldx, 0,
-                                            (unsigned)(((unsigned long long)(H * W - 1) * ldx + p.Cin) * 4ull), 0x00020000);
+  io.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)((((unsigned long long)p.N * H * W - 1) * ldx + p.Cin) * 4ull), 0x00020000);
   // transformed filters of group gidx: [N tile][sub-filter][chunk][2048 slots of 16 B]
   const size_t ublock = (size_t)gy * p.nphase * p.kchunks * kUSlots * 4;   // floats per group
   io.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (size_t)t.gidx * ublock, 0, (unsigned)(ublock * 4), 0x00020000);
   io.u_off0 = (unsigned)t.tile_n * (unsigned)(p.nphase * p.kchunks) * (kUSlots * 16u);
   // input staging: DMA instruction j of wave w fills slots (2 w + j) * 64 + lane -> (h, class, r, c) -> patch pixel
   // (2 r + pi, 2 c + pj), channels 4h .. 4h + 3 of the sub-step
-  const int ih0 = t.oh0 - p.si, iw0 = t.ow0 - p.si;
-  io.okmask = 0;
+  io.okmask = t.pair ? (1u << 18) : 0u;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int S = (2 * wave + j) * 64 + lane;
     const int h = S / 432, rem = S - h * 432, cls = rem / 108, r2 = rem - cls * 108, r = r2 / 12, c = r2 - r * 12;
-    const int ih = ih0 + 2 * r + (cls >> 1), iw = iw0 + 2 * c + (cls & 1);
-    for (int sub = 0; sub < p.nphase; ++sub) {
-      const int sa = sub / p.so, sb = sub - sa * p.so;
-      const bool ok = S < kInUsed && c < 9 && (unsigned)(ih + 3 * sa) < (unsigned)H && (unsigned)(iw + 3 * sb) < (unsigned)W;
-      io.okmask |= (ok ? 1u : 0u) << (2 * sub + j);
-    }
     io.okmask |= (h ? 1u : 0u) << (16 + j);
-    io.a_off[j] = (unsigned)(((ih * W + iw) * ldx + 4 * h) * 4);
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int nn = pb ? t.nB : t.n, ih0 = (pb ? t.oh0B : t.oh0) - p.si, iw0 = (pb ? t.ow0B : t.ow0) - p.si;
+      const bool live = pb ? t.patchB >= 0 : true;
+      const int ih = ih0 + 2 * r + (cls >> 1), iw = iw0 + 2 * c + (cls & 1);
+      for (int sub = 0; sub < p.nphase; ++sub) {
+        const int sa = sub / p.so, sb = sub - sa * p.so;
+        const bool ok = live && S < kInUsed && c < 9 && (unsigned)(ih + 3 * sa) < (unsigned)H && (unsigned)(iw + 3 * sb) < (unsigned)W;
+        io.okmask |= (ok ? 1u : 0u) << (8 * pb + 2 * sub + j);
+      }
+      io.a_off[pb][j] = (unsigned)((((nn * H + ih) * W + iw) * ldx + 4 * h) * 4);
+    }
   }
   return io;
 }
@@ -222,10 +244,10 @@ __device__ __forceinline__ WinoIO wino_io(const IgemmArgs& p, const IgemmGroup& 
 // Persistent: the launch has at most one workgroup per CU, each walks the tiles vb = blockIdx.x, + gridDim.x, ...  Before the
 // epilogue of a tile the waves already issue the first sub-step of the next one, so its DMA latency (and the dispatch of a
 // fresh workgroup) is hidden behind the output transform and the stores.
-__global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gy, int gz) {
+__global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gyn, int npair, int gz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int total = gx * gy * gz;
+  const int total = (gx * gyn + npair) * gz, gy = gyn + (npair ? 1 : 0);   // gy: filter tiles per group
   float* sV = smem + kLdsTileFloats;          // [4][64]: bias, vec2, scale, shift
   float* sS = sV + 4 * 64;                    // [8 waves][2][32] column sums
   bool stage0_issued = false;
@@ -236,14 +258,17 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
   asm volatile("" : "+s"(wave));
   const int tid = wave * 64 + lane;
   const int ph = wave & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
-  const WinoTile tl = wino_tile(p_, vb, gx, gy, gz);
+  const WinoTile tl = wino_tile(p_, vb, gx, gyn, npair, gz);
   const WinoIO io = wino_io(p_, grp, tl, gy, wave, lane);
   IgemmArgs p = p_;
   const int gidx = tl.gidx;
   if (p.ngroup > 1) {
     p.x = grp.x[gidx]; p.y = grp.y[gidx]; p.bias = grp.bias[gidx]; p.mask = grp.mask[gidx]; p.res = grp.res[gidx]; p.cs = grp.cs[gidx];
   }
-  const int n = tl.n, oh0 = tl.oh0, ow0 = tl.ow0, n0 = tl.n0, patch = tl.patch;
+  // (a pair tile: the wn = 1 waves work on the tile's second patch)
+  const bool second = tl.pair && wn;
+  const int n = second ? tl.nB : tl.n, oh0 = second ? tl.oh0B : tl.oh0, ow0 = second ? tl.ow0B : tl.ow0, n0 = tl.n0;
+  const int patch = second ? tl.patchB : tl.patch;   // (-1: no such patch)
 
   f32x16 acc[8];
 #pragma unroll
@@ -268,7 +293,7 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
   // the next tile's first sub-step goes out now (stage 0; the epilogue below works in the region behind it)
   stage0_issued = false;
   if (vb + (int)gridDim.x < total) {   // (recomputed at the top of the next iteration: nothing of it stays live across the epilogue)
-    const WinoTile tn = wino_tile(p_, vb + (int)gridDim.x, gx, gy, gz);
+    const WinoTile tn = wino_tile(p_, vb + (int)gridDim.x, gx, gyn, npair, gz);
     const WinoIO ion = wino_io(p_, grp, tn, gy, wave, lane);
     wino_issue(p_, smem, ion, 0, lane, wave);
     stage0_issued = true;
@@ -317,12 +342,12 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
   const int f = p.flags;
   const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
   const bool do_cs = (f & CRDR_EPI_COLSUM) != 0, accum = (f & CRDR_EPI_ACCUM) != 0;
-  const int fh = lane >> 5, cn = wn * 32 + (lane & 31);
+  const int fh = lane >> 5, cn = (tl.pair ? 0 : wn * 32) + (lane & 31);
   const bool oc_ok = n0 + cn < p.Cout;
   const size_t pix0 = ((size_t)n * p.OH + oh0) * p.OW + ow0;             // first pixel of the tile
   const unsigned rows_left = (unsigned)(p.OH - oh0);                     // image rows from the tile's first one
   auto desc = [&](const float* base, int ld) __attribute__((always_inline)) {
-    const unsigned long long bytes = ((unsigned long long)rows_left * p.OW - ow0) * (unsigned long long)ld * 4ull;
+    const unsigned long long bytes = patch < 0 ? 0ull : ((unsigned long long)rows_left * p.OW - ow0) * (unsigned long long)ld * 4ull;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + pix0 * ld + n0, 0, (unsigned)(bytes < 0x7fffffffull ? bytes : 0x7fffffffull), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t ry = desc(p.y, p.ldy);
@@ -386,7 +411,9 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
         const int wv = (q & 1) + 2 * w2 + 4 * (q >> 1);
         v += sS[(wv * 2 + which) * 32 + cc];
       }
-      if (n0 + c < p.Cout) p.cs[((size_t)patch * 2 + which) * p.cs_ld + n0 + c] = v;
+      // plain tile: the wn = w2 waves hold channels 32 w2 + cc of the tile's patch; pair tile: channels cc of patch A / B
+      const int prow = tl.pair ? (w2 ? tl.patchB : tl.patch) : tl.patch, col = n0 + (tl.pair ? cc : c);
+      if (prow >= 0 && col < p.Cout) p.cs[((size_t)prow * 2 + which) * p.cs_ld + col] = v;
     }
   }
   lds_barrier();   // the hand-over area, sV and sS are free for the next tile
@@ -458,7 +485,7 @@ bool wino_eligible(const crdr_conv_desc* d, int G) {
   if (d->C % 4 != 0 || d->ldx % 4 != 0) return false;
   if (d->flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_CONV_BF16X3)) return false;
   if (G > 1 && (d->flags & (CRDR_EPI_VEC2 | CRDR_EPI_AFFINE | CRDR_EPI_MASKOFF))) return false;
-  const long long img = (long long)(d->H + 8) * d->W * d->ldx * 4;
+  const long long img = ((long long)d->N * d->H + 8) * d->W * d->ldx * 4;   // one descriptor spans the whole input tensor
   const long long oimg = (long long)d->OH * d->OW * std::max(std::max(d->ldy, d->ldres), d->ldmask) * 4;
   if (img >= (1ll << 31) || oimg >= (1ll << 31)) return false;
   if ((long long)wino_workspace(d, G) / G >= (1ll << 31)) return false;
@@ -517,8 +544,12 @@ int wino_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, con
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
     return n / 8 * 8;
   }();
-  const int gx = d->N * a.GH * a.GW, total = gx * ntile * G;
-  hipLaunchKernelGGL(wino_kernel, dim3(std::min(total, ncu)), dim3(kNT), lds, s, a, grp, gx, ntile, G);
+  // N tiles: full 64-channel ones, then either one padded tile for the tail or -- tail <= 32 -- pair tiles (two patches each)
+  const int gx = d->N * a.GH * a.GW, tail = d->OC % 64;
+  const bool pairs = tail > 0 && tail <= 32 && gx > 1;
+  const int gyn = pairs ? d->OC / 64 : ntile, npair = pairs ? (gx + 1) / 2 : 0;
+  const int total = (gx * gyn + npair) * G;
+  hipLaunchKernelGGL(wino_kernel, dim3(std::min(total, ncu)), dim3(kNT), lds, s, a, grp, gx, gyn, npair, G);
   CRDR_CHECK_LAUNCH("wino_kernel");
   return 0;
 }

@@ -27,6 +27,8 @@ CASES = [
     ("256_512_32", 1, 256, 32, 32, 512, 1),
     ("32_64_valid", 1, 32, 18, 21, 64, 0),
     ("8_8_tiny", 1, 8, 5, 3, 8, 1),
+    ("64_96_9patches", 1, 64, 34, 38, 96, 1),     # channel tail of 32: pair tiles, odd patch count (the last pair has one patch)
+    ("32_224_pairs", 3, 32, 16, 16, 224, 1),
     # 5x5 = 2 x 2 sub-filters of 3x3 (Charm transforms, minnen20_charm_context_model.py:29-35)
     ("k5_320_224_16", 2, 320, 16, 16, 224, 2, 5),
     ("k5_32_96_ragged", 1, 32, 19, 23, 96, 2, 5),
