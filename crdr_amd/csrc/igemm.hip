@@ -122,7 +122,7 @@ struct Plan {
   IgemmTaps t;
   int cfg;
   int stream;  // index into kStreamCfgs, or -1: the tiled kernel
-  int wino;    // 1: the Winograd kernel (wino.hip); cfg and stream are -1
+  int wino;    // 1 + variant: the Winograd kernel (wino.hip); cfg and stream are -1
   StreamArgs sa;
   dim3 grid;
   size_t lds;
@@ -234,10 +234,12 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
   }
   pl->stream = -1;
   pl->wino = 0;
-  if (d->reserved != 0 && (d->reserved & 0xff) - 1 == kNumCfgs + stream_num_variants()) {  // forced: the Winograd F(2x2, 3x3) kernel (wino.hip)
+  const int wino_variant = d->reserved != 0 ? (d->reserved & 0xff) - 1 - kNumCfgs - stream_num_variants() : -1;
+  if (wino_variant >= 0 && wino_variant < 2) {  // forced: the Winograd F(2x2, 3x3) kernel (wino.hip); variant 1 = pair tiles for a channel tail <= 32
     CRDR_REQUIRE(!fallback && wino_eligible(d, G), "conv2d: forced Winograd kernel: not a 3x3 / 5x5 stride-1 convolution it takes");
+    CRDR_REQUIRE(wino_variant == 0 || wino_pairs_ok(d), "conv2d: Winograd pair-tile variant: needs a channel tail of 1..32 and more than one patch");
     CRDR_REQUIRE(((d->reserved >> 8) & 0xf) == 0, "conv2d: the Winograd kernel has no split-K");
-    pl->wino = 1;
+    pl->wino = 1 + wino_variant;
     pl->cfg = -1;
     a.nsplit = 1;
     a.ws_ld = 0;
@@ -354,7 +356,7 @@ using namespace crdr;
 
 extern "C" int crdr_conv2d_num_configs(void) { return kNumCfgs; }
 extern "C" int crdr_conv2d_num_stream_configs(void) { return stream_num_variants(); }
-extern "C" int crdr_conv2d_num_wino_configs(void) { return 1; }
+extern "C" int crdr_conv2d_num_wino_configs(void) { return 2; }
 
 extern "C" size_t crdr_conv2d_workspace(const crdr_conv_desc* d) {
   Plan pl;
@@ -380,7 +382,7 @@ extern "C" int crdr_conv2d_colsum_layout(const crdr_conv_desc* d, int G, int* ro
 extern "C" int crdr_conv2d_choose_algo(const crdr_conv_desc* d, int G) {
   Plan pl;
   if (!d || build_plan(d, &pl, G)) return 0;
-  if (pl.wino) return kNumCfgs + 1 + stream_num_variants();
+  if (pl.wino) return kNumCfgs + 1 + stream_num_variants() + (pl.wino - 1);
   if (pl.stream >= 0) return kNumCfgs + 1 + pl.stream;
   int ls = 0;
   while ((1 << ls) < pl.a.nsplit) ++ls;
@@ -448,7 +450,7 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   a.fast_epi = (v && a.Cout % 4 == 0 && span < (1ll << 31) && !(a.flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM))) ? 1 : 0;
   if (pl.wino) {
     void* prof = profile_begin(as_stream(s));
-    if (int rc = wino_launch(d, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
+    if (int rc = wino_launch(d, pl.wino - 1, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
     profile_end(3, G * crdr_conv2d_flops(d), prof, as_stream(s));   // kind 3: filter transform + Winograd kernel, direct-convolution flop count
     return 0;
   }

@@ -44,10 +44,13 @@ constexpr int kInUsed = 2 * 4 * 9 * 12;     // 16-byte slots of the input patch 
 constexpr int kInSlots = 1024;              // ... rounded up to 4 DMA instructions for each of the 4 issuing waves
 constexpr int kUSlots = 16 * 2 * 64;        // of one filter block (8 channels): 8 DMA instructions per issuing wave
 constexpr int kInFloats = kInSlots * 4, kUFloats = kUSlots * 4;
-constexpr int kStageFloats = 2 * kInFloats + kUFloats;   // [input patch A][input patch B (pair tiles only)][filters]
-constexpr int kStagingFloats = 2 * kStageFloats;
-constexpr int kXFloats = 8 * 32 * 64;       // epilogue hand-over area, placed behind stage 0 (which then already receives the next tile)
-constexpr int kLdsTileFloats = kStageFloats + kXFloats > kStagingFloats ? kStageFloats + kXFloats : kStagingFloats;
+// stage = [input patch A][input patch B (kernel variant with pair tiles only)][filters]
+template <bool PAIRS> struct WinoLds {
+  static constexpr int kNIn = PAIRS ? 2 : 1;
+  static constexpr int kStageFloats = kNIn * kInFloats + kUFloats;
+  static constexpr int kXFloats = 8 * 32 * 64;       // epilogue hand-over area, placed behind stage 0 (which then already receives the next tile)
+  static constexpr int kTileFloats = kStageFloats + kXFloats > 2 * kStageFloats ? kStageFloats + kXFloats : 2 * kStageFloats;
+};
 
 // workgroup barrier that publishes LDS writes but does not wait for DMA / global stores in flight
 __device__ __forceinline__ void lds_barrier() {
@@ -79,7 +82,9 @@ struct WinoIO {
 };
 
 // the DMA of sub-step k8, this wave's share: input instructions 2 wave + j (slots (2 wave + j) * 64 + lane), filter instructions 4 wave + j
+template <bool PAIRS>
 __device__ __forceinline__ void wino_issue(const IgemmArgs& p, float* smem, const WinoIO& io, int k8, int lane, int wave) {
+  constexpr int kStageFloats = WinoLds<PAIRS>::kStageFloats, kNIn = WinoLds<PAIRS>::kNIn;
 #ifdef WINO_EXP_NODMA
   if (k8 > 0) return;
 #endif
@@ -89,7 +94,7 @@ __device__ __forceinline__ void wino_issue(const IgemmArgs& p, float* smem, cons
   const int sub = k8 / KC, kc = k8 - sub * KC, sa = sub / p.so, sb = sub - sa * p.so;
   const unsigned delta = (unsigned)(((3 * sa * p.W + 3 * sb) * p.ldx + kc * 8) * 4);
 #pragma unroll
-  for (int pb = 0; pb < 2; ++pb) {
+  for (int pb = 0; pb < kNIn; ++pb) {
     if (pb == 1 && !((io.okmask >> 18) & 1u)) break;   // (uniform) the second patch of a pair tile
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -101,19 +106,20 @@ __device__ __forceinline__ void wino_issue(const IgemmArgs& p, float* smem, cons
   const unsigned ub = io.u_off0 + (unsigned)k8 * (kUSlots * 16u) + (unsigned)(4 * wave * 64 + lane) * 16u;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(io.ru, (lds_ptr_t)(st + 2 * kInFloats + ((4 * wave + j) * 64) * 4), 16, (int)(ub + (unsigned)j * 1024u), 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(io.ru, (lds_ptr_t)(st + kNIn * kInFloats + ((4 * wave + j) * 64) * 4), 16, (int)(ub + (unsigned)j * 1024u), 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
 }
 
 // K loop of one wave: one barrier per sub-step k (8 channels of one sub-filter); the DMA of sub-step k + 1 is issued first, then
 // the wave reads its 12 raw pixels, transforms them, and issues its 32 MFMAs, reading one filter fragment per position.
-template <int PH>
+template <int PH, bool PAIRS>
 __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const WinoIO& io, bool stage0_issued,
                                           int lane, int wave, int wm, int wn, f32x16 (&acc)[8]) {
   const int K8 = p.kchunks * p.nphase;   // sub-steps: (sub-filter, 8-channel chunk), sub-filter outermost
   const int m = lane & 31, fh = lane >> 5;
   const int ty = m >> 2, tx = (m & 3) + 4 * wm;
-  const bool pair = (io.okmask >> 18) & 1u;
+  constexpr int kStageFloats = WinoLds<PAIRS>::kStageFloats, kNIn = WinoLds<PAIRS>::kNIn;
+  const bool pair = PAIRS && ((io.okmask >> 18) & 1u);
   // float offsets of this lane's 12 raw reads (rows PH .. PH + 2 of the 4 x 4 patch, all 4 columns) inside a stage
   int ro[3][4];
 #pragma unroll
@@ -125,7 +131,7 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
       ro[a][j] = (pair && wn ? kInFloats : 0) + (fh * 432 + cls * 108 + (ty + (i >> 1)) * 12 + tx + (j >> 1)) * 4;
     }
   // position p = (2 PH + a) * 4 + nu: + (a * 4 + nu) * 512; in a pair tile both wn take the tile's first 32 channels (of two patches)
-  const int bo = 2 * kInFloats + ((2 * PH * 4 * 2 + fh) * 64 + (pair ? 0 : wn * 32) + m) * 4;
+  const int bo = kNIn * kInFloats + ((2 * PH * 4 * 2 + fh) * 64 + (pair ? 0 : wn * 32) + m) * 4;
 
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const float* st = smem + buf * kStageFloats;
@@ -163,10 +169,10 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
       }
   };
 
-  if (!stage0_issued) wino_issue(p, smem, io, 0, lane, wave);
+  if (!stage0_issued) wino_issue<PAIRS>(p, smem, io, 0, lane, wave);
   __syncthreads();
   for (int k8 = 0; k8 < K8; ++k8) {
-    if (k8 + 1 < K8) wino_issue(p, smem, io, k8 + 1, lane, wave);
+    if (k8 + 1 < K8) wino_issue<PAIRS>(p, smem, io, k8 + 1, lane, wave);
     compute(k8 & 1);
     __syncthreads();
   }
@@ -200,14 +206,18 @@ __device__ __forceinline__ WinoTile wino_tile(const IgemmArgs& p, int vb, int gx
   t.n = t.patch / ppi;
   const int prem = t.patch - t.n * ppi, by = prem / p.GW, bx = prem - by * p.GW;
   t.oh0 = by * 16; t.ow0 = bx * 16; t.n0 = t.tile_n * 64;
-  t.patchB = t.patch + 1;
-  t.nB = t.patchB / ppi;
-  const int premB = t.patchB - t.nB * ppi, byB = premB / p.GW, bxB = premB - byB * p.GW;
-  t.oh0B = byB * 16; t.ow0B = bxB * 16;
-  if (!t.pair || t.patchB >= gx) t.patchB = -1;   // no second patch (odd patch count): every access of it falls out of range
+  t.patchB = -1; t.nB = 0; t.oh0B = 0; t.ow0B = 0;
+  if (t.pair) {
+    const int pb = t.patch + 1;
+    t.nB = pb / ppi;
+    const int premB = pb - t.nB * ppi, byB = premB / p.GW, bxB = premB - byB * p.GW;
+    t.oh0B = byB * 16; t.ow0B = bxB * 16;
+    t.patchB = pb < gx ? pb : -1;   // no second patch (odd patch count): every access of it falls out of range
+  }
   return t;
 }
 
+template <bool PAIRS>
 __device__ __forceinline__ WinoIO wino_io(const IgemmArgs& p, const IgemmGroup& grp, const WinoTile& t, int gy, int wave, int lane) {
   WinoIO io;
   const int H = p.H, W = p.W, ldx = p.ldx;
@@ -227,6 +237,7 @@ __device__ __forceinline__ WinoIO wino_io(const IgemmArgs& p, const IgemmGroup& 
     io.okmask |= (h ? 1u : 0u) << (16 + j);
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
+      if (pb == 1 && (!PAIRS || !t.pair)) { io.a_off[1][j] = 0; break; }   // (uniform)
       const int nn = pb ? t.nB : t.n, ih0 = (pb ? t.oh0B : t.oh0) - p.si, iw0 = (pb ? t.ow0B : t.ow0) - p.si;
       const bool live = pb ? t.patchB >= 0 : true;
       const int ih = ih0 + 2 * r + (cls >> 1), iw = iw0 + 2 * c + (cls & 1);
@@ -244,7 +255,9 @@ __device__ __forceinline__ WinoIO wino_io(const IgemmArgs& p, const IgemmGroup& 
 // Persistent: the launch has at most one workgroup per CU, each walks the tiles vb = blockIdx.x, + gridDim.x, ...  Before the
 // epilogue of a tile the waves already issue the first sub-step of the next one, so its DMA latency (and the dispatch of a
 // fresh workgroup) is hidden behind the output transform and the stores.
+template <bool PAIRS>
 __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gyn, int npair, int gz) {
+  constexpr int kStageFloats = WinoLds<PAIRS>::kStageFloats, kLdsTileFloats = WinoLds<PAIRS>::kTileFloats;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int total = (gx * gyn + npair) * gz, gy = gyn + (npair ? 1 : 0);   // gy: filter tiles per group
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
   const int tid = wave * 64 + lane;
   const int ph = wave & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
   const WinoTile tl = wino_tile(p_, vb, gx, gyn, npair, gz);
-  const WinoIO io = wino_io(p_, grp, tl, gy, wave, lane);
+  const WinoIO io = wino_io<PAIRS>(p_, grp, tl, gy, wave, lane);
   IgemmArgs p = p_;
   const int gidx = tl.gidx;
   if (p.ngroup > 1) {
@@ -287,15 +300,15 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
       sV[3 * 64 + tid] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[n0 + tid] : 0.f;
     }
   }
-  if (ph == 0) wino_loop<0>(p, smem, io, stage0_issued, lane, wave, wm, wn, acc);
-  else wino_loop<1>(p, smem, io, stage0_issued, lane, wave, wm, wn, acc);
+  if (ph == 0) wino_loop<0, PAIRS>(p, smem, io, stage0_issued, lane, wave, wm, wn, acc);
+  else wino_loop<1, PAIRS>(p, smem, io, stage0_issued, lane, wave, wm, wn, acc);
   // (the loop ends with a barrier: every wave is past its last LDS read, the stages are free)
   // the next tile's first sub-step goes out now (stage 0; the epilogue below works in the region behind it)
   stage0_issued = false;
   if (vb + (int)gridDim.x < total) {   // (recomputed at the top of the next iteration: nothing of it stays live across the epilogue)
     const WinoTile tn = wino_tile(p_, vb + (int)gridDim.x, gx, gyn, npair, gz);
-    const WinoIO ion = wino_io(p_, grp, tn, gy, wave, lane);
-    wino_issue(p_, smem, ion, 0, lane, wave);
+    const WinoIO ion = wino_io<PAIRS>(p_, grp, tn, gy, wave, lane);
+    wino_issue<PAIRS>(p_, smem, ion, 0, lane, wave);
     stage0_issued = true;
   }
   float* sXb = smem + kStageFloats;   // hand-over area of the epilogue: [8 waves][32][64 lanes] behind stage 0
@@ -498,8 +511,14 @@ size_t wino_workspace(const crdr_conv_desc* d, int G) {
 
 int wino_colsum_rows(const crdr_conv_desc* d) { return d->N * cdiv(d->OH, 16) * cdiv(d->OW, 16); }
 
+// variant 1 (pair tiles): the channel count leaves a tail of <= 32 and there is more than one patch to pair
+bool wino_pairs_ok(const crdr_conv_desc* d) {
+  const int tail = d->OC % 64;
+  return tail > 0 && tail <= 32 && d->N * cdiv(d->OH, 16) * cdiv(d->OW, 16) > 1;
+}
+
 // a: the argument block of the implicit-GEMM plan with every pointer / stride / flag filled in; taps: the plan's tap table
-int wino_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s) {
+int wino_launch(const crdr_conv_desc* d, int variant, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s) {
   CRDR_REQUIRE(wino_eligible(d, G), "conv2d: the Winograd kernel takes 3x3 / 5x5 stride-1 convolutions (C %% 4 == 0, no gate / pre-add epilogue)");
   const int ks = wino_ks(d), kk = d->kh, nt = kk * kk;
   WinoTaps wt;
@@ -533,23 +552,30 @@ int wino_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, con
   a.GW = cdiv(d->OW, 16);
   a.si = -dmin;   // the patch starts `si` pixels above / left of its first output pixel
   a.cs_rows = wino_colsum_rows(d);
-  const size_t lds = (size_t)(kLdsTileFloats + 4 * 64 + 8 * 2 * 32) * sizeof(float);
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done.store(true, std::memory_order_release);
-  }
   static const int ncu = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
     return n / 8 * 8;
   }();
-  // N tiles: full 64-channel ones, then either one padded tile for the tail or -- tail <= 32 -- pair tiles (two patches each)
-  const int gx = d->N * a.GH * a.GW, tail = d->OC % 64;
-  const bool pairs = tail > 0 && tail <= 32 && gx > 1;
+  // N tiles: full 64-channel ones, then either one padded tile for the tail (variant 0) or pair tiles (variant 1, two patches each)
+  const int gx = d->N * a.GH * a.GW;
+  const bool pairs = variant == 1;
+  CRDR_REQUIRE(!pairs || wino_pairs_ok(d), "conv2d: Winograd pair-tile variant: needs a channel tail of 1..32 and more than one patch");
   const int gyn = pairs ? d->OC / 64 : ntile, npair = pairs ? (gx + 1) / 2 : 0;
   const int total = (gx * gyn + npair) * G;
-  hipLaunchKernelGGL(wino_kernel, dim3(std::min(total, ncu)), dim3(kNT), lds, s, a, grp, gx, gyn, npair, G);
+  static std::atomic<bool> attr_done[2];
+  if (!attr_done[variant].load(std::memory_order_acquire)) {
+    (void)hipFuncSetAttribute(pairs ? reinterpret_cast<const void*>(wino_kernel<true>) : reinterpret_cast<const void*>(wino_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done[variant].store(true, std::memory_order_release);
+  }
+  if (pairs) {
+    const size_t lds = (size_t)(WinoLds<true>::kTileFloats + 4 * 64 + 8 * 2 * 32) * sizeof(float);
+    hipLaunchKernelGGL(wino_kernel<true>, dim3(std::min(total, ncu)), dim3(kNT), lds, s, a, grp, gx, gyn, npair, G);
+  } else {
+    const size_t lds = (size_t)(WinoLds<false>::kTileFloats + 4 * 64 + 8 * 2 * 32) * sizeof(float);
+    hipLaunchKernelGGL(wino_kernel<false>, dim3(std::min(total, ncu)), dim3(kNT), lds, s, a, grp, gx, gyn, npair, G);
+  }
   CRDR_CHECK_LAUNCH("wino_kernel");
   return 0;
 }

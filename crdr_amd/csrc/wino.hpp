@@ -8,6 +8,7 @@ namespace crdr {
 bool wino_eligible(const crdr_conv_desc* d, int G);
 size_t wino_workspace(const crdr_conv_desc* d, int G);   // bytes of transformed filters
 int wino_colsum_rows(const crdr_conv_desc* d);
-int wino_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s);
+bool wino_pairs_ok(const crdr_conv_desc* d);   // variant 1 applies
+int wino_launch(const crdr_conv_desc* d, int variant, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s);
 
 }  // namespace crdr

@@ -100,10 +100,14 @@ def _prefer_wino(d, G: int = 1) -> int:
     if not PREFER_WINOGRAD or (d.kh, d.kw, d.stride) not in ((3, 3, 1), (5, 5, 1)):
         return 0
     lib = L.load()
-    keep = d.reserved
-    d.reserved = lib.crdr_conv2d_num_configs() + 1 + lib.crdr_conv2d_num_stream_configs()
-    ok = lib.crdr_conv2d_choose_algo(C.byref(d), G) == d.reserved
-    algo, d.reserved = (d.reserved if ok else 0), keep
+    keep, algo = d.reserved, 0
+    base = lib.crdr_conv2d_num_configs() + 1 + lib.crdr_conv2d_num_stream_configs()
+    for v in reversed(range(lib.crdr_conv2d_num_wino_configs())):   # (the pair-tile variant where it applies)
+        d.reserved = base + v
+        if lib.crdr_conv2d_choose_algo(C.byref(d), G) == d.reserved:
+            algo = d.reserved
+            break
+    d.reserved = keep
     return algo
 
 

@@ -139,7 +139,8 @@ int crdr_conv2d_choose_algo(const crdr_conv_desc* d, int G);
  * 16-byte aligned rows, no GATE / PREADD / ACCUM epilogue and a weight tile that fits LDS.  Results are bit-identical to
  * the unsplit tile configurations; CRDR_EPI_COLSUM rows are per 128- or 256-row tile (crdr_conv2d_colsum_layout) */
 int crdr_conv2d_num_stream_configs(void);
-/* number of Winograd variants (1): forced algorithm id crdr_conv2d_num_configs() + 1 + crdr_conv2d_num_stream_configs() + v, no
+/* number of Winograd variants (2; v = 1 covers a channel tail of <= 32 with PAIR tiles -- the tail's channels of two 16x16 patches per
+ * workgroup -- so that e.g. 96 channels cost 1.5 tiles per patch, not 2): forced algorithm id crdr_conv2d_num_configs() + 1 + crdr_conv2d_num_stream_configs() + v, no
  * split bits.  F(2x2, 3x3) minimal filtering on the exact-fp32 matrix cores for 3x3 stride-1 convolutions and their input
  * gradients (2.25x fewer multiply-accumulates than the implicit GEMM; what cuDNN's WINOGRAD algorithms do for the reference,
  * base_trainer.py:20 cudnn.benchmark).  fp32 arithmetic throughout (data transform +-1, filter transform halves); the sums are

@@ -66,6 +66,16 @@ def test_winograd_fwd_dgrad(case):
     # deterministic
     out2 = ops.conv2d_raw(xd, wp, co, (k, k), 1, p, False, (oh, ow), bias=bd, flags=1, algo=_wino_id())
     assert torch.equal(out, out2)
+    # variant 1 (pair tiles for a channel tail of <= 32): same products in the same order, bit for bit the same result
+    from crdr_amd.hip import lib as L
+    patches = lambda a, b: n * ((a + 15) // 16) * ((b + 15) // 16)
+    for what, cc, hw, run, want in (("fwd", co, (oh, ow), lambda a: ops.conv2d_raw(xd, wp, co, (k, k), 1, p, False, (oh, ow), bias=bd, flags=1, algo=a), out),
+                                    ("dgrad", ci, (h, w), lambda a: ops.conv2d_raw(dyd, wq, ci, (k, k), 1, p, True, (h, w), algo=a), dx)):
+        if 0 < cc % 64 <= 32 and patches(*hw) > 1:
+            assert torch.equal(run(_wino_id() + 1), want), f"{name} {what}: pair-tile variant differs"
+        else:
+            with pytest.raises(L.CrdrHipError):
+                run(_wino_id() + 1)
 
 
 def test_winograd_epilogues_and_slices():
