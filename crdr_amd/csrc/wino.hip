@@ -83,15 +83,15 @@ struct WinoIO {
 
 // the DMA of sub-step k8, this wave's share: input instructions 2 wave + j (slots (2 wave + j) * 64 + lane), filter instructions 4 wave + j
 template <bool PAIRS>
-__device__ __forceinline__ void wino_issue(const IgemmArgs& p, float* smem, const WinoIO& io, int k8, int lane, int wave) {
+__device__ __forceinline__ void wino_issue(const IgemmArgs& p, float* smem, const WinoIO& io, int k8, int sub, int kc, int lane, int wave) {
   constexpr int kStageFloats = WinoLds<PAIRS>::kStageFloats, kNIn = WinoLds<PAIRS>::kNIn;
 #ifdef WINO_EXP_NODMA
   if (k8 > 0) return;
 #endif
   float* st = smem + (k8 & 1) * kStageFloats;
-  // sub-filter (sa, sb) of a 5x5 kernel reads the patch 3 sa rows / 3 sb columns further down / right
-  const int KC = p.kchunks;
-  const int sub = k8 / KC, kc = k8 - sub * KC, sa = sub / p.so, sb = sub - sa * p.so;
+  // k8 = sub * kchunks + kc (the caller keeps both counters: no division in the loop).  Sub-filter (sa, sb) of a 5x5 kernel
+  // (2 x 2 of them) reads the patch 3 sa rows / 3 sb columns further down / right
+  const int sa = sub >> 1, sb = sub & 1;
   const unsigned delta = (unsigned)(((3 * sa * p.W + 3 * sb) * p.ldx + kc * 8) * 4);
 #pragma unroll
   for (int pb = 0; pb < kNIn; ++pb) {
@@ -169,10 +169,12 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
       }
   };
 
-  if (!stage0_issued) wino_issue<PAIRS>(p, smem, io, 0, lane, wave);
+  if (!stage0_issued) wino_issue<PAIRS>(p, smem, io, 0, 0, 0, lane, wave);
   __syncthreads();
+  int sub = 0, kc = 0;   // of sub-step k8 + 1
   for (int k8 = 0; k8 < K8; ++k8) {
-    if (k8 + 1 < K8) wino_issue<PAIRS>(p, smem, io, k8 + 1, lane, wave);
+    if (++kc == p.kchunks) { kc = 0; ++sub; }
+    if (k8 + 1 < K8) wino_issue<PAIRS>(p, smem, io, k8 + 1, sub, kc, lane, wave);
     compute(k8 & 1);
     __syncthreads();
   }
@@ -242,7 +244,7 @@ __device__ __forceinline__ WinoIO wino_io(const IgemmArgs& p, const IgemmGroup& 
       const bool live = pb ? t.patchB >= 0 : true;
       const int ih = ih0 + 2 * r + (cls >> 1), iw = iw0 + 2 * c + (cls & 1);
       for (int sub = 0; sub < p.nphase; ++sub) {
-        const int sa = sub / p.so, sb = sub - sa * p.so;
+        const int sa = sub >> 1, sb = sub & 1;
         const bool ok = live && S < kInUsed && c < 9 && (unsigned)(ih + 3 * sa) < (unsigned)H && (unsigned)(iw + 3 * sb) < (unsigned)W;
         io.okmask |= (ok ? 1u : 0u) << (8 * pb + 2 * sub + j);
       }
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
   if (vb + (int)gridDim.x < total) {   // (recomputed at the top of the next iteration: nothing of it stays live across the epilogue)
     const WinoTile tn = wino_tile(p_, vb + (int)gridDim.x, gx, gyn, npair, gz);
     const WinoIO ion = wino_io<PAIRS>(p_, grp, tn, gy, wave, lane);
-    wino_issue<PAIRS>(p_, smem, ion, 0, lane, wave);
+    wino_issue<PAIRS>(p_, smem, ion, 0, 0, 0, lane, wave);
     stage0_issued = true;
   }
   float* sXb = smem + kStageFloats;   // hand-over area of the epilogue: [8 waves][32][64 lanes] behind stage 0
