@@ -92,21 +92,41 @@ __device__ __forceinline__ void wino_issue(const IgemmArgs& p, float* smem, cons
   // k8 = sub * kchunks + kc (the caller keeps both counters: no division in the loop).  Sub-filter (sa, sb) of a 5x5 kernel
   // (2 x 2 of them) reads the patch 3 sa rows / 3 sb columns further down / right
   const int sa = sub >> 1, sb = sub & 1;
-  const unsigned delta = (unsigned)(((3 * sa * p.W + 3 * sb) * p.ldx + kc * 8) * 4);
+  // Every non-MFMA instruction costs matrix time, so the per-piece address work is kept minimal: the chunk / sub-filter
+  // displacement is uniform and travels in the instruction's SCALAR offset, a slot outside the image has an out-of-range lane
+  // offset for the whole tile (io.a_off, set up once per tile and sub-filter), and the channel-tail test only runs in the last chunk.
+  const unsigned dsp = (unsigned)(((3 * sa * p.W + 3 * sb) * p.ldx) * 4), dch = (unsigned)(kc * 32);
+  const bool tail = kc * 8 + 8 > p.Cin;   // (uniform) the chunk's upper half lies past Cin
+  if (p.nphase == 1 && !tail) {   // (uniform) the common case: nothing to decide per lane
 #pragma unroll
-  for (int pb = 0; pb < kNIn; ++pb) {
-    if (pb == 1 && !((io.okmask >> 18) & 1u)) break;   // (uniform) the second patch of a pair tile
+    for (int pb = 0; pb < kNIn; ++pb) {
+      if (pb == 1 && !((io.okmask >> 18) & 1u)) break;   // (uniform) the second patch of a pair tile
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const bool ok = ((io.okmask >> (8 * pb + 2 * sub + j)) & 1u) && (kc * 8 + (int)((io.okmask >> (16 + j)) & 1u) * 4 < p.Cin);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rx, (lds_ptr_t)(st + pb * kInFloats + ((2 * wave + j) * 64) * 4), 16,
-                                               (int)(ok ? io.a_off[pb][j] + delta : kOobOffset), 0, 0, 0);
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rx, (lds_ptr_t)(st + pb * kInFloats + ((2 * wave + j) * 64) * 4), 16, (int)io.a_off[pb][j], (int)dch, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int pb = 0; pb < kNIn; ++pb) {
+      if (pb == 1 && !((io.okmask >> 18) & 1u)) break;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // (several sub-filters: a_off may have wrapped below zero for a slot that only a displaced sub-filter brings into the
+        // image, so the displacement is added in the lane offset there; the range check does not see the scalar offset wrap)
+        unsigned off = p.nphase == 1 ? io.a_off[pb][j] : (((io.okmask >> (8 * pb + 2 * sub + j)) & 1u) ? io.a_off[pb][j] + dsp : kOobOffset);
+        if (tail && ((io.okmask >> (16 + j)) & 1u)) off = kOobOffset;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rx, (lds_ptr_t)(st + pb * kInFloats + ((2 * wave + j) * 64) * 4), 16, (int)off, (int)dch, 0, 0);
+      }
     }
   }
-  const unsigned ub = io.u_off0 + (unsigned)k8 * (kUSlots * 16u) + (unsigned)(4 * wave * 64 + lane) * 16u;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(io.ru, (lds_ptr_t)(st + kNIn * kInFloats + ((4 * wave + j) * 64) * 4), 16, (int)(ub + (unsigned)j * 1024u), 0, 0, 0);
+  const unsigned ub = io.u_off0 + (unsigned)k8 * (kUSlots * 16u);
+  const unsigned ul = (unsigned)(4 * wave * 64 + lane) * 16u;
+  // four consecutive KiB: the instruction's immediate offset (a literal) advances the global AND the LDS address, so one M0 serves all four
+  float* su = st + kNIn * kInFloats + (4 * wave * 64) * 4;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(io.ru, (lds_ptr_t)su, 16, (int)ul, (int)ub, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(io.ru, (lds_ptr_t)su, 16, (int)ul, (int)ub, 1024, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(io.ru, (lds_ptr_t)su, 16, (int)ul, (int)ub, 2048, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(io.ru, (lds_ptr_t)su, 16, (int)ul, (int)ub, 3072, 0);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -133,9 +153,12 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
   // position p = (2 PH + a) * 4 + nu: + (a * 4 + nu) * 512; in a pair tile both wn take the tile's first 32 channels (of two patches)
   const int bo = kNIn * kInFloats + ((2 * PH * 4 * 2 + fh) * 64 + (pair ? 0 : wn * 32) + m) * 4;
 
+  // One sub-step.  Every instruction beside the MFMAs costs matrix time, hazard no-ops and waits included, so the
+  // three parts are kept apart: all LDS reads of the first half, the whole data transform, then the 32 MFMAs back to back with
+  // the second half of the filter fragments read behind the first MFMAs.
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const float* st = smem + buf * kStageFloats;
-    f32x4 d[3][4];
+    f32x4 d[3][4], bfa[4], bfb[4];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -146,6 +169,9 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
         d[a][j] = *reinterpret_cast<const f32x4*>(st + ro[a][j]);
 #endif
       }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bfa[q] = *reinterpret_cast<const f32x4*>(st + bo + q * 512);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 t[2][4], v[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -154,19 +180,18 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a) bt4(t[a][0], t[a][1], t[a][2], t[a][3], v[a]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int q = 0; q < 4; ++q) bfb[q] = *reinterpret_cast<const f32x4*>(st + bo + (4 + q) * 512);
 #pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        const f32x4 bf = *reinterpret_cast<const f32x4*>(st + bo + (a * 4 + nu) * 512);
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#ifdef WINO_EXP_NOMFMA
-          acc[a * 4 + nu][s] += v[a][nu][s] * bf[s];
-#else
-          acc[a * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[a][nu][s], bf[s], acc[a * 4 + nu], 0, 0, 0);
-#endif
-      }
+      for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[0][q][s], bfa[q][s], acc[q], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[1][q][s], bfb[q][s], acc[4 + q], 0, 0, 0);
   };
 
   if (!stage0_issued) wino_issue<PAIRS>(p, smem, io, 0, 0, 0, lane, wave);
@@ -249,6 +274,7 @@ __device__ __forceinline__ WinoIO wino_io(const IgemmArgs& p, const IgemmGroup& 
         io.okmask |= (ok ? 1u : 0u) << (8 * pb + 2 * sub + j);
       }
       io.a_off[pb][j] = (unsigned)((((nn * H + ih) * W + iw) * ldx + 4 * h) * 4);
+      if (p.nphase == 1 && !((io.okmask >> (8 * pb + j)) & 1u)) io.a_off[pb][j] = kOobOffset;   // (one sub-filter: decided once per tile)
     }
   }
   return io;

@@ -54,22 +54,54 @@ __device__ __forceinline__ void wino_wgrad_loop(const WgradArgs& p, float* smem,
     s_row[j] = isp ? px >> 4 : px / 18;
     s_col[j] = isp ? px & 15 : px - (px / 18) * 18;
   }
-  auto fetch = [&](int buf, int strip) __attribute__((always_inline)) {
-    const int n = strip / (TR * SC), rem = strip - n * (TR * SC), tr = rem / SC, sc = rem - tr * SC;
+  // per-thread constants of the staging: lane part of the byte offsets (strip (n, tr, sc) = (0, 0, 0)) and whether the piece's
+  // channels exist.  The strip's displacement is uniform and travels in the instruction's scalar offset; bounds are only
+  // tested for strips that touch an image border (every non-MFMA instruction of the loop costs matrix time).
+  unsigned s_off[kPasses];
+  bool s_chok[kPasses];
+#pragma unroll
+  for (int j = 0; j < kPasses; ++j) {
+    if (s_isp[j]) {
+      s_chok[j] = i0 + s_ch[j] < p.PC;
+      s_off[j] = (unsigned)(((s_row[j] * p.PW + s_col[j]) * p.ldp + i0 + s_ch[j]) * 4);
+    } else {
+      s_chok[j] = j0 + s_ch[j] < p.QC;
+      s_off[j] = (unsigned)((((s_row[j] - p.pad) * p.QW + s_col[j] - p.pad) * p.ldq + j0 + s_ch[j]) * 4);   // (may wrap: added to the strip's displacement below)
+    }
+    if (!s_chok[j]) s_off[j] = kOob;
+  }
+  // strip counters (n, tr, sc) of the NEXT strip to fetch: no division in the loop
+  int f_n, f_tr, f_sc;
+  {
+    const int n = s0 / (TR * SC), rem = s0 - n * (TR * SC);
+    f_n = n; f_tr = rem / SC; f_sc = rem - f_tr * SC;
+  }
+  auto fetch = [&](int buf) __attribute__((always_inline)) {
+    const int n = f_n, tr = f_tr, sc = f_sc;
+    if (++f_sc == SC) { f_sc = 0; if (++f_tr == TR) { f_tr = 0; ++f_n; } }
     float* st = smem + buf * kStage;
+    const unsigned dp = (unsigned)((((n * p.PH + 2 * tr) * p.PW + 16 * sc) * p.ldp) * 4);
+    const unsigned dq = (unsigned)((((n * p.QH + 2 * tr) * p.QW + 16 * sc) * p.ldq) * 4);
+    // interior strip: its 2 x 16 pixels of P and the 4 x 18 pixels of Q around them all lie inside the images
+    const bool inner = 2 * tr + 2 <= p.PH && 16 * sc + 16 <= p.PW && 2 * tr - p.pad >= 0 && 2 * tr - p.pad + 4 <= p.QH &&
+                       16 * sc - p.pad >= 0 && 16 * sc - p.pad + 18 <= p.QW;
 #pragma unroll
     for (int j = 0; j < kPasses; ++j) {
       if (j * 512 + wave * 64 >= kPieces) break;   // (wave-uniform)
-      unsigned off = kOob;
-      if (s_isp[j]) {
-        const int a = 2 * tr + s_row[j], b = 16 * sc + s_col[j], ch = i0 + s_ch[j];
-        if (a < p.PH && b < p.PW && ch < p.PC) off = (unsigned)((((n * p.PH + a) * p.PW + b) * p.ldp + ch) * 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr_t)(st + (j * 512 + wave * 64) * 4), 16, (int)off, 0, 0, 0);
-      } else {
-        const int a = 2 * tr - p.pad + s_row[j], b = 16 * sc - p.pad + s_col[j], ch = j0 + s_ch[j];
-        if ((unsigned)a < (unsigned)p.QH && (unsigned)b < (unsigned)p.QW && ch < p.QC) off = (unsigned)((((n * p.QH + a) * p.QW + b) * p.ldq + ch) * 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr_t)(st + (j * 512 + wave * 64) * 4), 16, (int)off, 0, 0, 0);
+      unsigned off = s_off[j];
+      if (!inner) {
+        if (s_isp[j]) {
+          const int a = 2 * tr + s_row[j], b = 16 * sc + s_col[j];
+          if (!(a < p.PH && b < p.PW)) off = kOob;
+        } else {
+          const int a = 2 * tr - p.pad + s_row[j], b = 16 * sc - p.pad + s_col[j];
+          if (!((unsigned)a < (unsigned)p.QH && (unsigned)b < (unsigned)p.QW)) off = kOob;
+        }
       }
+      // (Q's lane offset may have wrapped below zero for pad > 0: lane offset and displacement are added before the range check
+      // only in the vector operand, so the sum goes there)
+      if (s_isp[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr_t)(st + (j * 512 + wave * 64) * 4), 16, (int)off, (int)dp, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr_t)(st + (j * 512 + wave * 64) * 4), 16, (int)(off == kOob ? kOob : off + dq), 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -117,11 +149,11 @@ __device__ __forceinline__ void wino_wgrad_loop(const WgradArgs& p, float* smem,
         for (int nu = 0; nu < 4; ++nu) acc[a * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[a][nu], v[a][nu], acc[a * 4 + nu], 0, 0, 0);
     }
   };
-  if (s0 < s1) fetch(0, s0);
+  if (s0 < s1) fetch(0);
   __syncthreads();
   for (int s = s0; s < s1; ++s) {
     const int buf = (s - s0) & 1;
-    if (s + 1 < s1) fetch(buf ^ 1, s + 1);
+    if (s + 1 < s1) fetch(buf ^ 1);
     compute(buf);
     __syncthreads();
   }
