@@ -280,6 +280,142 @@ __device__ __forceinline__ WinoIO wino_io(const IgemmArgs& p, const IgemmGroup& 
   return io;
 }
 
+// Everything after the K loop of one wave, compiled per PH (no per-element selects on the wave's role) and organised as one pass
+// over the wave's 32 outputs per epilogue flag (a flag is tested once per tile, not once per element): every instruction here is
+// matrix time lost, and this part used to be a third of a 16-sub-step tile.
+//   Output transform: this wave holds M[xi][nu] for xi = 2 PH, 2 PH + 1.  Row sums of A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]:
+//   PH 0: s0 = M0 + M1, s1 = M1;   PH 1: s0 = M2, s1 = -M2 - M3;   then along nu: (s[0] + s[1] + s[2], s[1] - s[2] - s[3]).
+//   The wave finishes output row i = PH of its tiles and hands its part of row 1 - PH to the partner wave through LDS.
+template <int PH>
+__device__ __forceinline__ void wino_finish(const IgemmArgs& p, bool pair, int patch, int n, int oh0, int ow0, int n0, float* sXb, const float* sV,
+                                            int lane, int wave, int wm, int wn, f32x16 (&acc)[8], float& cpre, float& cpost) {
+  float own[32], give[32];   // index jj * 16 + r: column jj of the tile of accumulator register r
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float s0[4], s1[4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      const float ma = acc[nu][r], mb = acc[4 + nu][r];
+      if constexpr (PH == 0) { s0[nu] = ma + mb; s1[nu] = mb; }
+      else { s0[nu] = ma; s1[nu] = -ma - mb; }
+    }
+    const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+    const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+    if constexpr (PH == 0) { own[r] = y00; own[16 + r] = y01; give[r] = y10; give[16 + r] = y11; }
+    else { own[r] = y10; own[16 + r] = y11; give[r] = y00; give[16 + r] = y01; }
+  }
+  float* sX = sXb + wave * (32 * 64);   // [32][64 lanes]
+#pragma unroll
+  for (int q = 0; q < 32; ++q) sX[q * 64 + lane] = give[q];
+  lds_barrier();   // (not __syncthreads: the next tile's DMA stays in flight)
+  const float* sP = sXb + (wave ^ 1) * (32 * 64);
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const float o = sP[q * 64 + lane];
+    own[q] = PH == 0 ? own[q] + o : o + own[q];   // (part of xi 0, 1) + (part of xi 2, 3)
+  }
+
+  // ---- element-wise epilogue + stores (order of operations: epilogue_store of igemm_kernel.hpp).
+  // This lane's 32 outputs: channel cn of pixels (oh0 + 4 (r >> 2) + 2 fh + PH, ow0 + 2 (r & 3) + 8 wm + jj), r < 16, jj < 2.  The descriptors
+  // are based at the tile's first pixel and channel; the per-lane part of the offset is fixed and the (r, jj) part is uniform, so
+  // it travels in the instruction's scalar offset: no per-element address arithmetic.  Pixels past the image / channels past Cout
+  // get an out-of-range lane offset (rows past OH fall off the end of the image-sized descriptor by themselves).
+  const int f = p.flags;
+  const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
+  const bool do_cs = (f & CRDR_EPI_COLSUM) != 0, accum = (f & CRDR_EPI_ACCUM) != 0;
+  const int fh = lane >> 5, cn = (pair ? 0 : wn * 32) + (lane & 31);
+  const bool oc_ok = n0 + cn < p.Cout;
+  const size_t pix0 = ((size_t)n * p.OH + oh0) * p.OW + ow0;             // first pixel of the tile
+  const unsigned rows_left = (unsigned)(p.OH - oh0);                     // image rows from the tile's first one
+  auto desc = [&](const float* base, int ld) __attribute__((always_inline)) {
+    const unsigned long long bytes = patch < 0 ? 0ull : ((unsigned long long)rows_left * p.OW - ow0) * (unsigned long long)ld * 4ull;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + pix0 * ld + n0, 0, (unsigned)(bytes < 0x7fffffffull ? bytes : 0x7fffffffull), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t ry = desc(p.y, p.ldy);
+  const int lrow = 2 * fh + PH, lcol = 8 * wm;                           // lane part of the pixel position inside the tile
+  const bool full_w = ow0 + 16 <= p.OW;                                  // (uniform) no column of the tile hangs over the image
+  // element q = jj * 16 + r sits 4 (r >> 2) rows down and 2 (r & 3) + jj columns right of the lane's first pixel
+  auto pixs = [&](int q) __attribute__((always_inline)) { return 4 * ((q & 15) >> 2) * p.OW + 2 * (q & 3) + (q >> 4); };
+  // lane offsets per element: the fixed lane part, or out of range (a column past the image would alias the next row: only tiles
+  // on the right edge of a ragged image test per element)
+  auto lane_off = [&](int ld, int q) __attribute__((always_inline)) {
+    const unsigned v = oc_ok ? (unsigned)(((lrow * p.OW + lcol) * ld + cn) * 4) : kOobOffset;
+    return (full_w || ow0 + lcol + 2 * (q & 3) + (q >> 4) < p.OW) ? v : kOobOffset;
+  };
+  const float bias = sV[0 * 64 + cn], vec2 = sV[1 * 64 + cn], scale = sV[2 * 64 + cn], shift = sV[3 * 64 + cn];
+  // (rows past OH / columns past OW / channels past Cout must not enter the column sums; everything else about them is harmless)
+  auto live = [&](int q) __attribute__((always_inline)) {
+    return oc_ok && (full_w || ow0 + lcol + 2 * (q & 3) + (q >> 4) < p.OW) && oh0 + 4 * ((q & 15) >> 2) + lrow < p.OH;
+  };
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {   // the two tile columns jj, 16 outputs each (keeps the operand arrays small)
+    float* o = own + hb * 16;
+    float resv[16], mskv[16];
+    if (has_res) {
+      const __amdgpu_buffer_rsrc_t rr = desc(p.res, p.ldres);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) resv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lane_off(p.ldres, hb * 16 + r), pixs(hb * 16 + r) * p.ldres * 4, 0));
+    }
+    if (has_mask) {
+      const __amdgpu_buffer_rsrc_t rm = desc(p.mask, p.ldmask);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mskv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, lane_off(p.ldmask, hb * 16 + r), pixs(hb * 16 + r) * p.ldmask * 4, 0));
+    }
+    if (f & CRDR_EPI_BIAS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] += bias;
+    }
+    if (f & CRDR_EPI_RELU) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = fmaxf(o[r], 0.0f);
+    }
+    if (f & CRDR_EPI_LRELU) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = o[r] > 0.0f ? o[r] : 0.2f * o[r];
+    }
+    if (f & CRDR_EPI_VEC2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] += vec2;
+    }
+    if (has_res) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] += resv[r];
+    }
+    if (f & CRDR_EPI_AFFINE) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = o[r] * scale + shift;
+    }
+    if (do_cs) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cpre += live(hb * 16 + r) ? o[r] : 0.f;
+    }
+    if (has_mask) {
+      const float moff = (f & CRDR_EPI_MASKOFF) ? vec2 : 0.f;
+      if (f & CRDR_EPI_LRELUMASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = (mskv[r] - moff) > 0.0f ? o[r] : 0.2f * o[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = (mskv[r] - moff) > 0.0f ? o[r] : 0.0f;
+      }
+    }
+    if (do_cs) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cpost += live(hb * 16 + r) ? o[r] : 0.f;
+    }
+    if (accum) {
+      float oldv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oldv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, lane_off(p.ldy, hb * 16 + r), pixs(hb * 16 + r) * p.ldy * 4, 0));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] += oldv[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[r]), ry, lane_off(p.ldy, hb * 16 + r), pixs(hb * 16 + r) * p.ldy * 4, 0);
+  }
+}
+
 // Persistent: the launch has at most one workgroup per CU, each walks the tiles vb = blockIdx.x, + gridDim.x, ...  Before the
 // epilogue of a tile the waves already issue the first sub-step of the next one, so its DMA latency (and the dispatch of a
 // fresh workgroup) is hidden behind the output transform and the stores.
@@ -339,105 +475,15 @@ __global__ __launch_bounds__(kNT) void wino_kernel(const IgemmArgs p_, const Ige
     wino_issue<PAIRS>(p_, smem, ion, 0, 0, 0, lane, wave);
     stage0_issued = true;
   }
-  float* sXb = smem + kStageFloats;   // hand-over area of the epilogue: [8 waves][32][64 lanes] behind stage 0
 
-  // ---- output transform.  This wave holds M[xi][nu] for xi = 2 ph, 2 ph + 1.  Row sums of A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]:
-  //   ph 0: s0 = M0 + M1, s1 = M1;   ph 1: s0 = M2, s1 = -M2 - M3;   then along nu: (s[0] + s[1] + s[2], s[1] - s[2] - s[3]).
-  // yp[i][jj][r]: this wave's part of output row i, column jj of the tile of accumulator register r.
-  float own[2][16], give[2][16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float s0[4], s1[4];
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      const float ma = acc[nu][r], mb = acc[4 + nu][r];
-      if (ph == 0) { s0[nu] = ma + mb; s1[nu] = mb; }
-      else { s0[nu] = ma; s1[nu] = -ma - mb; }
-    }
-    const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
-    const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-    // this wave finishes output row i = ph and hands row 1 - ph to its partner
-    own[0][r] = ph == 0 ? y00 : y10; own[1][r] = ph == 0 ? y01 : y11;
-    give[0][r] = ph == 0 ? y10 : y00; give[1][r] = ph == 0 ? y11 : y01;
-  }
-  float* sX = sXb + wave * (32 * 64);   // [32][64 lanes]
-#pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sX[(jj * 16 + r) * 64 + lane] = give[jj][r];
-  lds_barrier();   // (not __syncthreads: the next tile's DMA stays in flight)
-  const float* sP = sXb + (wave ^ 1) * (32 * 64);
-#pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float o = sP[(jj * 16 + r) * 64 + lane];
-      own[jj][r] = ph == 0 ? own[jj][r] + o : o + own[jj][r];   // (part of xi 0, 1) + (part of xi 2, 3)
-    }
-
-  // ---- element-wise epilogue + stores (order of operations: epilogue_store of igemm_kernel.hpp).
-  // This lane's 32 outputs: channel cn of pixels (oh0 + 4 (r >> 2) + 2 fh + ph, ow0 + 2 (r & 3) + 8 wm + jj), r < 16, jj < 2.  The descriptors
-  // are based at the tile's first pixel and channel; the per-lane part of the offset is fixed and the (r, jj) part is uniform, so
-  // it travels in the instruction's scalar offset: no per-element address arithmetic.  Pixels past the image / channels past Cout
-  // get an out-of-range lane offset (rows past OH fall off the end of the image-sized descriptor by themselves).
+  // ---- output transform, hand-over between the two waves of a pair, element-wise epilogue and stores (wino_finish below)
   const int f = p.flags;
-  const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
-  const bool do_cs = (f & CRDR_EPI_COLSUM) != 0, accum = (f & CRDR_EPI_ACCUM) != 0;
-  const int fh = lane >> 5, cn = (tl.pair ? 0 : wn * 32) + (lane & 31);
-  const bool oc_ok = n0 + cn < p.Cout;
-  const size_t pix0 = ((size_t)n * p.OH + oh0) * p.OW + ow0;             // first pixel of the tile
-  const unsigned rows_left = (unsigned)(p.OH - oh0);                     // image rows from the tile's first one
-  auto desc = [&](const float* base, int ld) __attribute__((always_inline)) {
-    const unsigned long long bytes = patch < 0 ? 0ull : ((unsigned long long)rows_left * p.OW - ow0) * (unsigned long long)ld * 4ull;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + pix0 * ld + n0, 0, (unsigned)(bytes < 0x7fffffffull ? bytes : 0x7fffffffull), 0x00020000);
-  };
-  const __amdgpu_buffer_rsrc_t ry = desc(p.y, p.ldy);
-  const __amdgpu_buffer_rsrc_t rr = has_res ? desc(p.res, p.ldres) : ry;
-  const __amdgpu_buffer_rsrc_t rm = has_mask ? desc(p.mask, p.ldmask) : ry;
-  const int lrow = 2 * fh + ph, lcol = 8 * wm;                           // lane part of the pixel position inside the tile
-  const bool full_w = ow0 + 16 <= p.OW;                                  // (uniform) no column of the tile hangs over the image
-  auto lane_off = [&](int ld) __attribute__((always_inline)) { return oc_ok ? (unsigned)(((lrow * p.OW + lcol) * ld + cn) * 4) : kOobOffset; };
-  const unsigned vy = lane_off(p.ldy), vr = lane_off(p.ldres), vm = lane_off(p.ldmask);
-  const float bias = sV[0 * 64 + cn], vec2 = sV[1 * 64 + cn], scale = sV[2 * 64 + cn], shift = sV[3 * 64 + cn];
+  const bool do_cs = (f & CRDR_EPI_COLSUM) != 0;
   float cpre = 0.f, cpost = 0.f;
-#pragma unroll
-  for (int rb = 0; rb < 4; ++rb) {   // batches of 4 accumulator registers x 2 columns = 8 pixels: loads first, then the stores
-    float resv[8], mskv[8], oldv[8];
-    bool okk[8];
-    // uniform part of the batch's offsets, in pixels: 4 rb rows down, then 2 (q >> 1) + (q & 1) columns right
-    const int prow = 4 * rb * p.OW;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int pixs = prow + 2 * (q >> 1) + (q & 1);
-      // a column past the image would alias the next row: mask it by lane (only tiles on the right edge of a ragged image)
-      const bool col_ok = full_w || ow0 + lcol + 2 * (q >> 1) + (q & 1) < p.OW;
-      okk[q] = oc_ok && col_ok && oh0 + 4 * rb + lrow < p.OH;
-      if (has_res) resv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, col_ok ? vr : kOobOffset, pixs * p.ldres * 4, 0));
-      if (has_mask) mskv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, col_ok ? vm : kOobOffset, pixs * p.ldmask * 4, 0));
-      if (accum) oldv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, col_ok ? vy : kOobOffset, pixs * p.ldy * 4, 0));
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = rb * 4 + (q >> 1), jj = q & 1;
-      const int pixs = prow + 2 * (q >> 1) + (q & 1);
-      const bool col_ok = full_w || ow0 + lcol + 2 * (q >> 1) + (q & 1) < p.OW;
-      float v = own[jj][r];
-      if (f & CRDR_EPI_BIAS) v += bias;
-      if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
-      if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
-      if (f & CRDR_EPI_VEC2) v += vec2;
-      if (has_res) v += resv[q];
-      if (f & CRDR_EPI_AFFINE) v = v * scale + shift;
-      if (do_cs) cpre += okk[q] ? v : 0.f;
-      if (has_mask) {
-        float mv = mskv[q];
-        if (f & CRDR_EPI_MASKOFF) mv -= vec2;
-        v = mv > 0.0f ? v : ((f & CRDR_EPI_LRELUMASK) ? 0.2f * v : 0.0f);
-      }
-      if (do_cs) cpost += okk[q] ? v : 0.f;
-      if (accum) v += oldv[q];
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, col_ok ? vy : kOobOffset, pixs * p.ldy * 4, 0);
-    }
+  {
+    float* sXb = smem + kStageFloats;
+    if (ph == 0) wino_finish<0>(p, tl.pair, patch, n, oh0, ow0, n0, sXb, sV, lane, wave, wm, wn, acc, cpre, cpost);
+    else wino_finish<1>(p, tl.pair, patch, n, oh0, ow0, n0, sXb, sV, lane, wave, wm, wn, acc, cpre, cpost);
   }
   if (do_cs) {   // lane -> wave (the two half-waves hold different tiles of the same channel) -> workgroup, fixed order
     cpre += __shfl_xor(cpre, 32, 64);

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--cold", action="store_true")
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--wino-only", action="store_true")
+    ap.add_argument("--shapes", default=None, help="ci,co,hw;ci,co,hw;... instead of the built-in list")
     ap.add_argument("--k5", action="store_true", help="the 5x5 stride-1 shapes of the Charm at 16x16 instead")
     ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient kernels instead (direct slab kernel vs Winograd F(3x3, 2x2))")
     a = ap.parse_args()
@@ -48,6 +49,8 @@ def main():
             print(f"wgrad {co:4d}x{ci:4d} @{hw:3d}: direct {d[0] * 1e3:8.1f} us ({fl / d[0] / 1e9:6.1f} TF, cfg {d[1]} split {1 << d[2]})   winograd {w[0] * 1e3:8.1f} us "
                   f"({fl / w[0] / 1e9:6.1f} TF-eq, split {1 << w[2]})   x{d[0] / w[0]:.2f}", flush=True)
         return
+    if a.shapes:
+        SHAPES[:] = [tuple(int(v) for v in t.split(",")) for t in a.shapes.split(";")]
     kk, shapes = (5, [(320, 4256, 16), (320, 2016, 16), (32, 4032, 16), (32, 2240, 16), (224, 128, 16), (320, 224, 16), (128, 224, 16)]) if a.k5 else (3, SHAPES)
     for ci, co, hw in shapes:
         x = torch.randn(a.bs, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
