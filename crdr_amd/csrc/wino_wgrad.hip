@@ -121,16 +121,18 @@ __device__ __forceinline__ void wino_wgrad_loop(const WgradArgs& p, float* smem,
       for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) d[a][b] = st[qo + (((PH + a) * 18) + 2 * tc + b) * 64];
-      // P side: rows xi = 2 PH, 2 PH + 1 of G p G^T
+      // P side: rows xi = 2 PH, 2 PH + 1 of G p G^T -- WITHOUT G's halves: positions (xi, nu) with xi in {1, 2} and / or nu in
+      // {1, 2} are accumulated 2x / 4x too large and scaled once per workgroup in the output transform (a power of two commutes
+      // with every rounding of the sum), which takes 24 multiplies out of every k-step
       float zr[2][2], z[2][4];
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        if constexpr (PH == 0) { zr[0][jj] = dy[0][jj]; zr[1][jj] = 0.5f * (dy[0][jj] + dy[1][jj]); }
-        else { zr[0][jj] = 0.5f * (dy[0][jj] - dy[1][jj]); zr[1][jj] = dy[1][jj]; }
+        if constexpr (PH == 0) { zr[0][jj] = dy[0][jj]; zr[1][jj] = dy[0][jj] + dy[1][jj]; }
+        else { zr[0][jj] = dy[0][jj] - dy[1][jj]; zr[1][jj] = dy[1][jj]; }
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        z[a][0] = zr[a][0]; z[a][1] = 0.5f * (zr[a][0] + zr[a][1]); z[a][2] = 0.5f * (zr[a][0] - zr[a][1]); z[a][3] = zr[a][1];
+        z[a][0] = zr[a][0]; z[a][1] = zr[a][0] + zr[a][1]; z[a][2] = zr[a][0] - zr[a][1]; z[a][3] = zr[a][1];
       }
       // Q side: rows xi = 2 PH, 2 PH + 1 of B^T q B (raw rows PH .. PH + 2)
       float t[2][4], v[2][4];
@@ -197,7 +199,9 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p_, con
       float sv[4];
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) {
-        const float ua = acc[nu][r], ub = acc[4 + nu][r];
+        // G's halves, left out of the K loop: row xi = 2 ph + a carries 1/2 for xi in {1, 2} (a = 1 of ph 0, a = 0 of ph 1), column nu likewise
+        const float fc = (nu == 1 || nu == 2) ? 0.5f : 1.0f;
+        const float ua = acc[nu][r] * (ph == 0 ? fc : 0.5f * fc), ub = acc[4 + nu][r] * (ph == 0 ? 0.5f * fc : fc);
         if (ph == 0) sv[nu] = a == 0 ? ua + ub : ub;
         else sv[nu] = a == 0 ? ua : (a == 1 ? -ua : ua + ub);
       }

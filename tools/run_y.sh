@@ -1,4 +1,4 @@
 set -x
 timeout 600 python -m pytest tests/test_gpu_wino.py -x -q -m gpu > gpurun_out/y_tests.log 2>&1; echo "rc=$?" >> gpurun_out/y_tests.log
 tail -4 gpurun_out/y_tests.log
-timeout 900 python tools/bench_wino.py --wino-only 2>&1 | grep -v amdgpu.ids | head -10 | cut -c1-20,75-140
+timeout 900 python tools/bench_wino.py --wgrad --wino-only 2>&1 | grep -v amdgpu.ids | head -8 | cut -c1-24,80-150
