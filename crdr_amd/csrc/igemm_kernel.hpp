@@ -378,7 +378,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   // write-back needed), every storing wave drains vmcnt, the workgroup barrier, then ONE lane takes the ticket with an
   // agent-scope atomic; the workgroup whose ticket is nsplit - 1 acquires (buffer_inv sc1) and reads all slabs with sc1 loads
   // in split order.  Placement independent, no spinning: a workgroup either leaves or reduces.
+#ifdef IGEMM_FAST_ONLY   // experiment: only the straight-line epilogue is compiled (code size / instruction-cache effect)
+  const bool splitk = false;
+  if (!p.fast_epi || p.nsplit > 1) return;
+#else
   const bool splitk = p.nsplit > 1;
+#endif
   const unsigned slab_bytes = splitk ? (unsigned)((size_t)p.M * p.ws_ld * 4u) : 0u;
   __amdgpu_buffer_rsrc_t rws = rw;
   if (splitk)
@@ -604,6 +609,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     }
     return;
   }
+#ifndef IGEMM_FAST_ONLY
   // one pass = GC column blocks [JG, JG+GC) of accumulator row-block I (all compile-time so acc stays in registers)
   auto pass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
     constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
@@ -744,6 +750,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
       if (n0 + c < p.Cout) dst[(size_t)which * p.cs_ld + n0 + c] = v;
     }
   }
+#endif
 }
 
 }  // namespace crdr
