@@ -524,37 +524,77 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
           if (has_mask)
             msk4[kq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, ok ? (rel * p.ldmask + oc0) * 4u : kOobOffset, 0, 0));
         }
+        // One pass over the batch's 16 outputs per epilogue flag: a flag is tested once per batch, not once per element (per-element
+        // tests compile to a select each, and every non-MFMA instruction costs matrix time -- DESIGN 4e).  Same operations in the
+        // same order per element.
+        f32x4 o[4];
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
           const int q = lane + 64 * (kb * 4 + kq);
           const int row = q / (8 * GC), c4 = q - row * (8 * GC);
-          const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * CLD + c4 * 4);
-          const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sV + 0 * BN + cc[kq]);
-          const f32x4 vec24 = *reinterpret_cast<const f32x4*>(sV + 1 * BN + cc[kq]);
-          const f32x4 scale4 = *reinterpret_cast<const f32x4*>(sV + 2 * BN + cc[kq]);
-          const f32x4 shift4 = *reinterpret_cast<const f32x4*>(sV + 3 * BN + cc[kq]);
-          const bool ok = okk[kq];
-          f32x4 o4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = a4[e];
-            if (f & CRDR_EPI_BIAS) v += bias4[e];
-            if (f & CRDR_EPI_RELU) v = fmaxf(v, 0.0f);
-            if (f & CRDR_EPI_LRELU) v = v > 0.0f ? v : 0.2f * v;
-            if (f & CRDR_EPI_VEC2) v += vec24[e];
-            if (has_res) v += res4[kq][e];
-            if (f & CRDR_EPI_AFFINE) v = v * scale4[e] + shift4[e];
-            if (do_cs) cpre[e] += ok ? v : 0.f;
-            if (has_mask) {
-              float mv = msk4[kq][e];
-              if (f & CRDR_EPI_MASKOFF) mv -= vec24[e];
-              v = mv > 0.0f ? v : ((f & CRDR_EPI_LRELUMASK) ? 0.2f * v : 0.0f);
-            }
-            if (do_cs) cpost[e] += ok ? v : 0.f;
-            o4[e] = v;
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), ry, yoff[kq], 0, 0);
+          o[kq] = *reinterpret_cast<const f32x4*>(sC + row * CLD + c4 * 4);
         }
+        if (f & CRDR_EPI_BIAS) {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) o[kq] += *reinterpret_cast<const f32x4*>(sV + 0 * BN + cc[kq]);
+        }
+        if (f & CRDR_EPI_RELU) {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[kq][e] = fmaxf(o[kq][e], 0.0f);
+        }
+        if (f & CRDR_EPI_LRELU) {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[kq][e] = o[kq][e] > 0.0f ? o[kq][e] : 0.2f * o[kq][e];
+        }
+        if (f & CRDR_EPI_VEC2) {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) o[kq] += *reinterpret_cast<const f32x4*>(sV + 1 * BN + cc[kq]);
+        }
+        if (has_res) {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) o[kq] += res4[kq];
+        }
+        if (f & CRDR_EPI_AFFINE) {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) {
+            const f32x4 scale4 = *reinterpret_cast<const f32x4*>(sV + 2 * BN + cc[kq]);
+            const f32x4 shift4 = *reinterpret_cast<const f32x4*>(sV + 3 * BN + cc[kq]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[kq][e] = o[kq][e] * scale4[e] + shift4[e];
+          }
+        }
+        if (do_cs) {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cpre[e] += okk[kq] ? o[kq][e] : 0.f;
+        }
+        if (has_mask) {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) {
+            f32x4 mv = msk4[kq];
+            if (f & CRDR_EPI_MASKOFF) mv -= *reinterpret_cast<const f32x4*>(sV + 1 * BN + cc[kq]);
+            if (f & CRDR_EPI_LRELUMASK) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[kq][e] = mv[e] > 0.0f ? o[kq][e] : 0.2f * o[kq][e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[kq][e] = mv[e] > 0.0f ? o[kq][e] : 0.0f;
+            }
+          }
+        }
+        if (do_cs) {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cpost[e] += okk[kq] ? o[kq][e] : 0.f;
+        }
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[kq]), ry, yoff[kq], 0, 0);
       }
       if (do_cs) {
         if constexpr (GC == 1 || GC == 2 || GC == 4) {
