@@ -1,3 +1,6 @@
+#!/bin/bash
+# Rebuild the shipped perf database on the GPU box (run from the repo root): the 3x3 / 5x5 launches are timed again (cold caches,
+# best of 3) on top of the shipped entries, then one confirmation run; copy gpurun_out/tune_*.json to crdr_amd/hip/tune_gfx950.json.
 set -x
 export TMPDIR=/tmp
 export CRDR_TUNE_ROUNDS=3 CRDR_TUNE_COLD=1

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round-end validation on the GPU box (run from the repo root): the whole GPU test suite, the smoke entry, then
+# tools/evidence_round.sh (bench lines, rocprofv3 stats, per-shape table, PMC passes, codec sweep) -> gpurun_out/evidence/.
 set -x
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/b_tests.log 2>&1; echo "rc=$?" >> gpurun_out/b_tests.log; tail -5 gpurun_out/b_tests.log
