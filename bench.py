@@ -355,6 +355,7 @@ def main():
                                                          "library version: a rebuild keeps the entries of kernels that did not change")
     ap.add_argument("--retune-k3", default=None, help="PATH -- preload a database of another library version except the 3x3 launches "
                                                       "(timed again: the Winograd kernels are new candidates for them)")
+    ap.add_argument("--retune-k1", action="store_true", help="with --retune-k3: time the 1x1 launches again as well")
     ap.add_argument("--bf16x3", action="store_true", help="also time the step with precision: bf16x3 (second line `stage3_bf16x3`) even with --no-secondary")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying captured HIP graphs")
     ap.add_argument("--profile-steps", type=int, default=5, help="eager steps after the timed region used for the per-kernel roofline")
@@ -383,7 +384,7 @@ def main():
         kinds, path = a.seed_tune_db.split(":", 1)
         ops.load_tune_cache(path, only_kinds=tuple(kinds.split(",")), ignore_signature=True)
     if ops.AUTOTUNE and a.retune_k3:
-        ops.load_tune_cache(a.retune_k3, ignore_signature=True, skip=lambda key: (3, 3) in key or (5, 5) in key)   # (conv launches and weight gradients alike)
+        ops.load_tune_cache(a.retune_k3, ignore_signature=True, skip=lambda key: (3, 3) in key or (5, 5) in key or (a.retune_k1 and (1, 1) in key))   # (conv launches and weight gradients alike)
     main_run = run_stage(a, a.stage, a.bs, a.steps, a.warmup, a.profile_steps, a.shape_table)
     tr = main_run.pop("trainer")
     def save_tuning():   # (again at the end: the secondary runs tune their own shapes)

@@ -4,7 +4,7 @@
 set -x
 export TMPDIR=/tmp
 export CRDR_TUNE_ROUNDS=3 CRDR_TUNE_COLD=1
-timeout 2400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --bf16x3 --tune-db none --retune-k3 crdr_amd/hip/tune_gfx950.json --save-tune-db gpurun_out/tune_r3_n.json --tune-log gpurun_out/tune_r3_n.log --shape-table gpurun_out/r3_a_shapes.txt > gpurun_out/bench_a.log 2> gpurun_out/bench_a.err
+timeout 2400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --bf16x3 --tune-db none --retune-k3 crdr_amd/hip/tune_gfx950.json --retune-k1 --save-tune-db gpurun_out/tune_r3_o.json --tune-log gpurun_out/tune_r3_o.log --shape-table gpurun_out/r3_a_shapes.txt > gpurun_out/bench_a.log 2> gpurun_out/bench_a.err
 cut -c1-300 gpurun_out/bench_a.log; tail -2 gpurun_out/bench_a.err
-timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary --tune-db gpurun_out/tune_r3_n.json > gpurun_out/bench_a2.log 2>> gpurun_out/bench_a.err
+timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary --tune-db gpurun_out/tune_r3_o.json > gpurun_out/bench_a2.log 2>> gpurun_out/bench_a.err
 cut -c1-300 gpurun_out/bench_a2.log
