@@ -493,6 +493,31 @@ def main():
                 "parity": "tests/test_gpu_bf16x3.py: kernels within 3 * 2^-16 * sum|a||b|, step losses <= 1e-3, gradients <= 5e-3 vs the oracle"}
         except Exception as e:
             line["stage3_bf16x3"] = {"error": repr(e)[:300]}
+    if ws == 1 and a.stage == 3 and not a.no_secondary:
+        # third line, for the record: the same fp32 step with the Winograd kernels taken out of the tuner's candidates (every conv on
+        # the implicit-GEMM / streaming kernels, every weight gradient on the direct slab kernel) -- what the headline would be
+        # without minimal filtering.  The 3x3 choices of the last database built before those kernels existed are preloaded.
+        try:
+            tr = None
+            torch.cuda.empty_cache()
+            lib_ = __import__("crdr_amd.hip.lib", fromlist=["x"]).load()
+            wbase = lib_.crdr_conv2d_num_configs() + 1 + lib_.crdr_conv2d_num_stream_configs()
+            wlast = lib_.crdr_conv2d_wgrad_num_configs()
+            saved, saved_flag = dict(ops._algo_cache), ops.WINOGRAD
+            ops.WINOGRAD = False
+            for k_, v_ in list(ops._algo_cache.items()):
+                is_w = k_[0] in ("w", "wg", "ws", "wm")
+                if (is_w and (v_ & 0xff) == wlast) or (not is_w and (v_ & 0xff) >= wbase):
+                    del ops._algo_cache[k_]
+            ops.load_tune_cache(os.path.join(ROOT, "tools", "data", "tune_r3_f.json"), ignore_signature=True)
+            dx = run_stage(a, 3, a.bs, min(a.steps, 20), a.warmup, 0)
+            dx.pop("trainer")
+            line["stage3_direct_only"] = {"metric": f"stage-3 training img/s at {a.size}x{a.size}", "value": round(dx["value"], 3), "unit": "img/s",
+                                          "ms_per_step": round(dx["ms_per_step"], 2), "steps": min(a.steps, 20), "warmup": a.warmup, "dtype": "fp32",
+                                          "config": {"workload": f"config/crdr_stage_3.yaml -b {a.bs}, CRDR_WINOGRAD=0 (no minimal-filtering kernels)"}}
+            ops._algo_cache.clear(); ops._algo_cache.update(saved); ops.WINOGRAD = saved_flag
+        except Exception as e:
+            line["stage3_direct_only"] = {"error": repr(e)[:300]}
     if ws == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.stage, a.size)
     save_tuning()
