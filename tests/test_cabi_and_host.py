@@ -314,3 +314,35 @@ def test_eval_grid_csv_layout_and_gate(tmp_path):
                 "kodak,4.0,0.0,1.0503268771701388,37.640484422314252,0.03,0.04\nkodak,2.0,0.0,0.4,32.9,0.1,0.1\n")
     cmp = E.compare_with_reference(rows, str(ref))
     assert [(c[0], c[1], c[4]) for c in cmp] == [(0.0, 3.84, True), (4.0, 0.0, False)]
+
+
+def test_shipped_perf_database_matches_the_library():
+    """crdr_amd/hip/tune_gfx950.json is keyed by the library version and its configuration counts: a database of another build is
+    silently ignored at start-up (every shape would be tuned live), so a stale one must not be committed; its algorithm ids must
+    also be ids this library knows."""
+    import json
+    from crdr_amd.hip import lib as L
+    from crdr_amd.hip import ops
+    db = json.load(open(ops.DEFAULT_TUNE_DB))
+    assert db["signature"] == ops._tune_signature(), (db["signature"], ops._tune_signature())
+    lib = L.load()
+    nconv = lib.crdr_conv2d_num_configs() + lib.crdr_conv2d_num_stream_configs() + lib.crdr_conv2d_num_wino_configs()
+    nw = lib.crdr_conv2d_wgrad_num_configs()
+    assert len(db["algos"]) > 300
+    for k, v in db["algos"].items():
+        kind = k[2:k.index("'", 2)]
+        cfg = v & 0xff
+        assert 0 <= cfg <= (nw if kind in ("w", "wg", "ws", "wm") else nconv), (k, v)
+
+
+def test_committed_traffic_measurement_is_of_this_library():
+    """bench.py prices roofline.traffic with the newest profiles/r*_hbm_families.json and refuses one measured with another
+    crdr_version(): the committed one must be of the committed library."""
+    import glob
+    import json
+    from crdr_amd.hip import lib as L
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_families.json")))
+    assert fs, "no PMC family file committed"
+    doc = json.load(open(fs[-1]))
+    assert doc.get("library_version") == int(L.load().crdr_version()), (fs[-1], doc.get("library_version"))
+    assert "conv_fwd_dgrad" in doc["families"]
