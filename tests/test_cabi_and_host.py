@@ -346,3 +346,50 @@ def test_committed_traffic_measurement_is_of_this_library():
     doc = json.load(open(fs[-1]))
     assert doc.get("library_version") == int(L.load().crdr_version()), (fs[-1], doc.get("library_version"))
     assert "conv_fwd_dgrad" in doc["families"]
+
+
+def test_winograd_ids_are_planned_only_for_the_shapes_they_take(lib):
+    """Host-side planning of the Winograd variants (no GPU needed): the forced ids are accepted for 3x3 / 5x5 stride-1 convolutions
+    and their stride-1 transposed twins, rejected otherwise; the pair-tile variant needs a channel tail of 1..32 and more than one
+    16x16 patch; the workspace holds the tickets + 16 positions x (sub-filters) x padded OC x padded C floats; the last
+    weight-gradient configuration is planned for 3x3 stride 1 only."""
+    import ctypes as C
+    from crdr_amd.hip import lib as L
+    base = lib.crdr_conv2d_num_configs() + 1 + lib.crdr_conv2d_num_stream_configs()
+    assert lib.crdr_conv2d_num_wino_configs() == 2
+
+    def desc(c, oc, h, k, stride=1, pad=None, transposed=0, n=2):
+        pad = k // 2 if pad is None else pad
+        oh = (h - 1) * stride - 2 * pad + k if transposed else (h + 2 * pad - k) // stride + 1
+        cols = (c + 31) // 32 * 32
+        return L.ConvDesc(N=n, H=h, W=h, C=c, OH=oh, OW=oh, OC=oc, kh=k, kw=k, stride=stride, pad=pad, transposed=transposed, ldx=c, ldy=oc,
+                          wrows=oc, wcols=cols, flags=0, ldres=0, ldg=0, wlayout=0, reserved=0, ldpre=0, ldmask=0)
+
+    def plan(d, algo, g=1):
+        d.reserved = algo
+        return lib.crdr_conv2d_choose_algo(C.byref(d), g)
+
+    assert plan(desc(96, 96, 32, 3), base) == base
+    assert plan(desc(96, 96, 32, 3), base + 1) == base + 1            # tail 32, 2 x 4 patches
+    assert plan(desc(128, 128, 32, 3), base + 1) == 0                 # no channel tail
+    assert plan(desc(96, 104, 32, 3), base + 1) == 0                  # tail 40 > 32
+    assert plan(desc(96, 96, 16, 3, n=1), base + 1) == 0              # a single patch: nothing to pair
+    assert plan(desc(96, 96, 32, 3, transposed=1), base) == base      # stride-1 transposed = input gradient
+    assert plan(desc(320, 224, 16, 5), base) == base                  # 5x5 as 2 x 2 sub-filters
+    assert plan(desc(96, 96, 32, 3, stride=2), base) == 0
+    assert plan(desc(96, 96, 32, 1), base) == 0
+    assert plan(desc(96, 96, 32, 7), base) == 0
+    d = desc(100, 96, 32, 3)
+    d.reserved = base
+    tickets = 16384 * 4
+    assert lib.crdr_conv2d_workspace(C.byref(d)) == tickets + 2 * 13 * 16 * 2 * 64 * 16   # 2 N tiles x 13 chunks of 8 channels x 2048 slots of 16 B
+    d5 = desc(32, 64, 16, 5)
+    d5.reserved = base
+    assert lib.crdr_conv2d_workspace(C.byref(d5)) == tickets + 1 * 4 * 4 * 16 * 2 * 64 * 16
+    nw = lib.crdr_conv2d_wgrad_num_configs()
+
+    def wdesc(k, stride):
+        return L.WgradDesc(N=2, PH=32, PW=32, PC=96, ldp=96, QH=32, QW=32, QC=64, ldq=64, kh=k, kw=k, stride=stride, pad=k // 2, gI=96, gJ=64, accumulate=0, algo=nw)
+    assert lib.crdr_conv2d_wgrad_workspace(C.byref(wdesc(3, 1))) == 9 * 96 * 64 * 4      # unsplit: one slab of 9 taps
+    assert lib.crdr_conv2d_wgrad_workspace(C.byref(wdesc(5, 1))) == 0                     # rejected (0 = planning failed)
+    assert lib.crdr_conv2d_wgrad_workspace(C.byref(wdesc(3, 2))) == 0
