@@ -190,11 +190,25 @@ def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: in
     for _ in range(warmup):
         step()
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]   # per-step device timestamps (no extra syncs): the median
+    marks[0].record()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for k in range(steps):
         step()
+        marks[k + 1].record()   # the step's stream scope has made the current stream wait for the trainer's stream
     barrier()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
+    median_ms = (per_step[(steps - 1) // 2] + per_step[steps // 2]) / 2 if steps else None
+    # communication overlap (data parallel): timing events around every gradient all-reduce, over `comm_steps` extra graph-replayed
+    # steps (the collectives run between the captured graphs, on the communication stream)
+    comm = None
+    if D.is_dist():
+        D.TRACE = []
+        for _ in range(min(10, max(steps, 1))):
+            step()
+        barrier()
+        comm, D.TRACE = D.trace_summary(D.TRACE), None
     # per-kernel roofline: HIP events bracket every conv launch inside the library (they cannot be recorded inside a
     # graph replay), over `profile_steps` eager iterations of the same step mix right after the timed region
     graphs_on = tr.graphs.enabled
@@ -251,8 +265,8 @@ def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: in
         with open(shape_table, "w") as f:
             for (kind, label), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"{ms / max(profile_steps, 1):8.3f} ms/step  {cnt / max(profile_steps, 1):6.1f} calls/step  {fl / (ms * 1e-3) / 1e12:6.1f} TF  {kind:5s} {label}\n")
-    out = {"value": ws * bs * steps / dt, "ms_per_step": dt / steps * 1e3, "igemm": ig, "wgrad": wg, "alg_bytes_per_igemm_launch": alg_bytes,
-           "graphs": bool(graphs_on), "trainer": tr}
+    out = {"value": ws * bs * steps / dt, "ms_per_step": dt / steps * 1e3, "median_ms": median_ms, "comm": comm, "igemm": ig, "wgrad": wg,
+           "alg_bytes_per_igemm_launch": alg_bytes, "graphs": bool(graphs_on), "trainer": tr}
     return out
 
 
@@ -439,6 +453,8 @@ def main():
                            "frac": round(value / ws * gflop / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}}
     line = {"metric": f"stage-{a.stage} training img/s at {a.size}x{a.size}", "value": round(value, 3), "unit": "img/s",
             "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(main_run["ms_per_step"], 2),
+            "ms_per_step_median": round(main_run["median_ms"], 2) if main_run["median_ms"] else None,
+            "value_at_median": round(ws * a.bs / main_run["median_ms"] * 1e3, 3) if main_run["median_ms"] else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
             "autotune": bool(ops.AUTOTUNE), "hip_graphs": main_run["graphs"], "rccl_ranks": rccl,
             "peak_device_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
@@ -446,6 +462,8 @@ def main():
                                    f"rate index cycled 0..4" if a.stage == 3 else f"config/crdr_stage_1.yaml -b {a.bs}: R-D step (+LPIPS-Alex, random-init weights)",
                        "global_batch": ws * a.bs, "crop": a.size, "parallelism": f"dp{ws}"},
             "roofline": roof}
+    if main_run.get("comm") is not None:
+        line["comm_overlap"] = main_run["comm"]
     if ws == 1 and not a.no_secondary:
         try:
             roof["fused_ops"] = fused_ops_roofline(tr)

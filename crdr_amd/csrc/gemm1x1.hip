@@ -1,9 +1,7 @@
 // Streaming 1x1 convolution kernel of the implicit-GEMM family (see igemm.hip for the tiled kernels and the host side).
 //
-// Experiment switches (make EXTRA=-DEXP_..., load the result with CRDR_HIP_LIB; never set in the shipped build): EXP_NOFETCH
-// (ring not refilled), EXP_NOSTORE (results not stored), EXP_NOEPI (no epilogue), EXP_SAMETILE / EXP_SAMEOUT (every tile
-// reads / writes the workgroup's first tile: L2-resident traffic), CRDR_STORE_AUX=2 (non-temporal stores).  They are how
-// DESIGN.md 4c's cost breakdown was measured.
+// The throw-away build switches DESIGN.md 4c's cost breakdown was measured with (ring not refilled, results not stored, no epilogue,
+// L2-resident tiles) live in tools/experiments/kernel_experiment_switches.patch, not here.  CRDR_STORE_AUX=2: non-temporal stores.
 
 #include <atomic>
 
@@ -81,11 +79,7 @@ __global__ __launch_bounds__(64 * NW) void gemm1x1_kernel(const IgemmArgs p_, co
   int f_t = 0, f_kc = 0, f_slot = 0;
   auto fetch = [&]() __attribute__((always_inline)) {
     const bool live = f_t < my_tiles;
-#ifdef EXP_SAMETILE
-    const long long m0 = (long long)mlane * BM;
-#else
     const long long m0 = (long long)(mlane + f_t * nlanes) * BM;
-#endif
     const unsigned long long base_bytes = live ? (unsigned long long)m0 * ldx * 4ull : 0ull;
     const unsigned long long left = live ? p.x_bytes - base_bytes : 0ull;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -170,9 +164,7 @@ __global__ __launch_bounds__(64 * NW) void gemm1x1_kernel(const IgemmArgs p_, co
 #pragma unroll
           for (int j = 0; j < NB; ++j)
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][s2], bf[kk & 1][j][s2], acc[j], 0, 0, 0);
-#ifndef EXP_NOFETCH
         if (kk == 0) fetch();                       // issued in the shadow of the first MFMAs
-#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if (++c_slot == S) c_slot = 0;
@@ -181,22 +173,7 @@ __global__ __launch_bounds__(64 * NW) void gemm1x1_kernel(const IgemmArgs p_, co
     // global access is a buffer instruction issued by all lanes (rows past M / column groups past Cout get an out-of-range
     // offset: loads return 0, stores are dropped), so the code is straight-line, the compiler's vmcnt waits are exact and
     // the operands of pass j + 1 are in flight while pass j is computed and stored.
-#ifdef EXP_NOEPI
-    {
-      float sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += acc[j][r];
-      if (sum == 1.2345f) p.y[0] = sum;
-      continue;
-    }
-#endif
-#ifdef EXP_SAMEOUT
-    const int mt = mlane;
-#else
     const int mt = mlane + t * nlanes;
-#endif
     // the ring slot consumed last is free until the next fetch: it stages this wave's transposed accumulators
     float* sC = sA + (c_slot == 0 ? S - 1 : c_slot - 1) * BM * 32 + wave * 1024;
     const long long mw = (long long)mt * BM + wave * 32;  // first row of this wave
@@ -300,12 +277,10 @@ __global__ __launch_bounds__(64 * NW) void gemm1x1_kernel(const IgemmArgs p_, co
 #pragma unroll
           for (int e = 0; e < 4; ++e) cpost[e] += okk[k] ? o[k][e] : 0.f;
       }
-#ifndef EXP_NOSTORE
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[k]), ry,
                                                okk[k] ? (unsigned)((rbase + 8 * k) * p.ldy + oc0) * 4u : kOobOffset, 0, CRDR_STORE_AUX);
-#endif
       if (do_cs) {
 #pragma unroll
         for (int off = 32; off >= 8; off >>= 1)

@@ -24,9 +24,6 @@
 #include "common.hpp"
 #include "igemm_args.hpp"
 
-#ifndef CRDR_IGEMM_FETCH_FIRST
-#define CRDR_IGEMM_FETCH_FIRST 1
-#endif
 
 namespace crdr {
 
@@ -184,9 +181,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   const int inner_n = SMALLC ? (1 << 30) : (cmajor ? ntap : kchunks);
   int ci = SMALLC ? it0 : it0 % inner_n, co = SMALLC ? 0 : it0 / inner_n;
   auto fetch = [&](int buf) __attribute__((always_inline)) {
-#ifdef EXP_NODMA   // experiment: the K loop re-reads whatever the stages hold (no global traffic after the prologue)
-    if (BF3 && buf >= 0) { if (++ci == inner_n) { ci = 0; ++co; } return; }
-#endif
     float* a = sA + buf * BM * 32 + wave * 8 * 32;
     float* b = sB + buf * BN * 32 + wave * 8 * 32;
     int dh, dw;
@@ -286,17 +280,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
           bh[j] = __builtin_bit_cast(bf16x8, h);
           bl[j] = __builtin_bit_cast(bf16x8, l);
         }
-#ifdef EXP_NOMFMA   // experiment: staging + fragment reads only (the accumulators get one cheap dependence on the fragments)
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j) acc[i][j][0] += (float)ah[i][0] + (float)bl[j][0] + (float)al[i][1] + (float)bh[j][1];
-#else
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
           for (int j = 0; j < NB; ++j) acc[i][j] = mfma_bf16x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
-#endif
       }
       return;
     }
@@ -325,16 +312,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   // arithmetic and issue slots run in the shadow of MFMAs already queued
   auto step = [&](auto bufc) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value;
-#if CRDR_IGEMM_FETCH_FIRST
     fetch(buf ^ 1);
     compute(bufc, I0{}, I4{});
     if constexpr (BF3) presplit(integral_constant<int, buf ^ 1>{});
-#else
-    compute(bufc, I0{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(buf ^ 1);
-    compute(bufc, I1{}, I4{});
-#endif
     __syncthreads();
   };
   if (it0 < it1) fetch(0);
@@ -378,12 +358,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   // write-back needed), every storing wave drains vmcnt, the workgroup barrier, then ONE lane takes the ticket with an
   // agent-scope atomic; the workgroup whose ticket is nsplit - 1 acquires (buffer_inv sc1) and reads all slabs with sc1 loads
   // in split order.  Placement independent, no spinning: a workgroup either leaves or reduces.
-#ifdef IGEMM_FAST_ONLY   // experiment: only the straight-line epilogue is compiled (code size / instruction-cache effect)
-  const bool splitk = false;
-  if (!p.fast_epi || p.nsplit > 1) return;
-#else
   const bool splitk = p.nsplit > 1;
-#endif
   const unsigned slab_bytes = splitk ? (unsigned)((size_t)p.M * p.ws_ld * 4u) : 0u;
   __amdgpu_buffer_rsrc_t rws = rw;
   if (splitk)
@@ -649,7 +624,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     }
     return;
   }
-#ifndef IGEMM_FAST_ONLY
   // one pass = GC column blocks [JG, JG+GC) of accumulator row-block I (all compile-time so acc stays in registers)
   auto pass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
     constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
@@ -790,7 +764,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
       if (n0 + c < p.Cout) dst[(size_t)which * p.cs_ld + n0 + c] = v;
     }
   }
-#endif
 }
 
 }  // namespace crdr

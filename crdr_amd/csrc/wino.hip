@@ -85,9 +85,6 @@ struct WinoIO {
 template <bool PAIRS>
 __device__ __forceinline__ void wino_issue(const IgemmArgs& p, float* smem, const WinoIO& io, int k8, int sub, int kc, int lane, int wave) {
   constexpr int kStageFloats = WinoLds<PAIRS>::kStageFloats, kNIn = WinoLds<PAIRS>::kNIn;
-#ifdef WINO_EXP_NODMA
-  if (k8 > 0) return;
-#endif
   float* st = smem + (k8 & 1) * kStageFloats;
   // k8 = sub * kchunks + kc (the caller keeps both counters: no division in the loop).  Sub-filter (sa, sb) of a 5x5 kernel
   // (2 x 2 of them) reads the patch 3 sa rows / 3 sb columns further down / right
@@ -163,11 +160,7 @@ __device__ __forceinline__ void wino_loop(const IgemmArgs& p, float* smem, const
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-#ifdef WINO_EXP_NORAW
-        d[a][j] = f32x4{(float)buf, 1.f, 2.f, (float)(a + j)};
-#else
         d[a][j] = *reinterpret_cast<const f32x4*>(st + ro[a][j]);
-#endif
       }
 #pragma unroll
     for (int q = 0; q < 4; ++q) bfa[q] = *reinterpret_cast<const f32x4*>(st + bo + q * 512);

@@ -119,17 +119,39 @@ def _stream_ids():
     return [n + 1 + v for v in range(ns)] + ([n + 1 + ns + v for v in range(lib.crdr_conv2d_num_wino_configs())] if WINOGRAD else [])
 
 
-def _autotune(key, ncfg: int, max_log2_split: int, run, extra=(), penalty=None) -> int:
+# A candidate may only win if its result agrees with the baseline plan's (algo 0, the built-in plan the parity tests run) on the
+# very operands it is timed on: max |candidate - baseline| <= TUNE_AGREE[kind] x max |baseline|.  Two correct plans differ by fp32
+# summation order only (measured over every entry of the shipped database: profiles/r4_plan_replay.json); a mis-tiled edge, a
+# wrong split reduce or a stale workspace is orders of magnitude above that and must not ship because it is fast.
+TUNE_AGREE = {"conv": 2e-5, "wgrad": 2e-4}
+TUNE_REJECTED = []   # (key, algo, measured disagreement) of every candidate refused
+
+
+def _autotune(key, ncfg: int, max_log2_split: int, run, extra=(), penalty=None, result=None, reset=None, agree: float = 2e-5) -> int:
     """run(algo) -> bool (False if the library rejects the combination). Returns the fastest algo id.  penalty() -> ms added to
     the candidate just timed: cost the launch causes elsewhere (the batched reduce reads every partial slab a weight-gradient
-    launch writes, so a deeper pixel split that is 1 % faster in isolation can cost more than it gains)."""
+    launch writes, so a deeper pixel split that is 1 % faster in isolation can cost more than it gains).
+    result() -> the tensor the launch just wrote (for weight-gradient slab launches: after their reduce); reset() restores the
+    operands a launch reads AND writes (accumulating epilogues) before a run whose result is compared."""
+    def fresh(a):
+        if reset is not None:
+            reset()
+        return run(a)
+    fresh(0)
+    ref = result().detach().clone() if result is not None else None
+    ref_scale = float(ref.abs().max()) if ref is not None else 0.0
     best, best_t = 0, _time_call(lambda: run(0)) + (penalty() if penalty else 0.0)
     base_t = best_t
     cands = [(c + 1) | (ls << 8) for c in range(ncfg) for ls in range(max_log2_split + 1)] + list(extra)
     for algo in cands:
         try:
-            if not run(algo):
+            if not fresh(algo):
                 continue
+            if ref is not None:
+                dis = float((result() - ref).abs().max())
+                if not dis <= agree * ref_scale:   # (NaN fails too)
+                    TUNE_REJECTED.append((key, algo, dis / (ref_scale + 1e-30)))
+                    continue
             t = _time_call(lambda: run(algo)) + (penalty() if penalty else 0.0)
         except L.CrdrHipError:
             continue
@@ -138,6 +160,14 @@ def _autotune(key, ncfg: int, max_log2_split: int, run, extra=(), penalty=None) 
     _algo_cache[key] = best
     TUNE_LOG.append((key, best, base_t, best_t))
     return best
+
+
+def _tune_scratch(nfloats: int, device):
+    """-> (scratch output tensor for tuner trials, reset() that restores its fixed pseudo-random content: accumulating epilogues
+    read what they write, and a result is only comparable between plans if both started from the same content)"""
+    scratch = torch.empty(nfloats, dtype=torch.float32, device=device)
+    pattern = torch.rand(nfloats, dtype=torch.float32, device=device) - 0.5
+    return scratch, (lambda: scratch.copy_(pattern))
 
 
 DEFAULT_TUNE_DB = __import__("os").path.join(__import__("os").path.dirname(__file__), "tune_gfx950.json")
@@ -377,7 +407,8 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
                 nb = lib.crdr_conv2d_workspace(C.byref(d))
                 w_, wn_ = workspace(nb, x.device, conv=True) if nb else (None, 0)
                 return lib.crdr_conv2d(C.byref(d), C.byref(io), w_, wn_, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids())
+            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids(), result=lambda: out_t,
+                             agree=TUNE_AGREE["conv"])
         d.reserved = algo
     nbytes = lib.crdr_conv2d_workspace(C.byref(d))
     ws, ws_n = workspace(nbytes, x.device, conv=True) if nbytes else (None, 0)
@@ -418,7 +449,7 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
         key = ("w", n, ph, pw, pc4, ldp, qh, qw, qc4, ldq, k, stride, pad, g.shape[0], g.shape[1]) + ((1,) if MATRIX_BF16X3 else ())
         algo = _algo_cache.get(key)
         if algo is None:
-            tmp = torch.empty_like(g)
+            tmp = torch.zeros_like(g)
 
             def run(a):
                 d.algo, d.accumulate = _wa(a), 0
@@ -427,7 +458,7 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
                     return False
                 w_, wn_ = workspace(nb, p.device)
                 return lib.crdr_conv2d_wgrad(C.byref(d), p.data_ptr(), q.data_ptr(), tmp.data_ptr(), w_, wn_, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run)
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, result=lambda: tmp, agree=TUNE_AGREE["wgrad"])
             d.accumulate = int(accumulate)
         d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
@@ -506,8 +537,7 @@ class DeferredWgrad:
             host = b"".join(bytes(j) for j in js)
             pre = np.zeros(len(js) + 1, dtype=np.int64)
             for k, j in enumerate(js):
-                # tiles of crdr_wgrad_reduce_batched: one output row x 64 input channels x all taps (RGB / many-tap jobs: 256 outputs)
-                pre[k + 1] = pre[k] + ((j.gI * j.gJ * j.T + 255) // 256 if (j.smallj or j.T > 32) else j.gI * ((j.gJ + 63) // 64))
+                pre[k + 1] = pre[k] + _wgrad_job_tiles(j)
             for tk in ([twin] if twin is not None and not torch.cuda.is_current_stream_capturing() else []):
                 self._table((tk, ri), host, pre, len(js))
             tb = self._table((key, ri), host, pre, len(js))
@@ -547,6 +577,27 @@ class DeferredWgrad:
             tb["meta"].copy_(torch.tensor([njobs, int(pre[-1])], dtype=torch.int64))
             tb["host"] = host
         return tb
+
+
+def _wgrad_job_tiles(j) -> int:
+    """tiles of crdr_wgrad_reduce_batched for one job: one output row x 64 input channels x all taps (RGB / many-tap jobs: 256 outputs)"""
+    return (j.gI * j.gJ * j.T + 255) // 256 if (j.smallj or j.T > 32) else j.gI * ((j.gJ + 63) // 64)
+
+
+def reduce_jobs_now(jobs, device) -> None:
+    """One crdr_wgrad_reduce_batched launch over `jobs` (a ctypes array / list of WgradJob) with a throw-away device table: the
+    tuner finishes a trial's partial slabs with it so that the candidate's weight gradient can be compared with the baseline's."""
+    import numpy as np
+    js = list(jobs)
+    host = b"".join(bytes(j) for j in js)
+    pre = np.zeros(len(js) + 1, dtype=np.int64)
+    for k, j in enumerate(js):
+        pre[k + 1] = pre[k] + _wgrad_job_tiles(j)
+    tj = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+    tp = torch.from_numpy(pre).to(device)
+    tm = torch.tensor([len(js), int(pre[-1])], dtype=torch.int64).to(device)
+    L.check(L.load().crdr_wgrad_reduce_batched(tj.data_ptr(), tp.data_ptr(), tm.data_ptr(), _stream()), "wgrad_reduce_batched")
+    torch.cuda.current_stream().synchronize()   # (the table dies with this frame)
 
 
 WGRAD_DEFER: Optional[DeferredWgrad] = None  # set by a trainer; every backward must then be followed by flush_wgrads()
@@ -673,28 +724,27 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
         key = ("g", GP, n, h, w, d.C, oc, k, pad, int(transposed), d.ldx, d.ldy, flags, d.ldpre, d.ldmask, wrows, wcols)
         algo = _algo_cache.get(key)
         if algo is None:
-            if (flags & (L.EPI_ACCUM | L.EPI_PREADD)) or self_res:
-                # timing runs would accumulate into live data: tune on scratch outputs with the same strides
-                span = (n * h * w - 1) * y0.ld + oc
-                scratch = torch.empty(G * span + 64, dtype=torch.float32, device=device)
-                tio = (L.ConvIO * G)()
-                for g in range(G):
-                    for f_, _ in L.ConvIO._fields_:
-                        setattr(tio[g], f_, getattr(ios[g], f_))
-                    tio[g].y = scratch.data_ptr() + 4 * g * span
-                    if pres is not None and pres[g].ptr == ys[g].ptr:
-                        tio[g].pre = tio[g].y
-                    if self_res:
-                        tio[g].res = tio[g].y
-            else:
-                tio = ios
+            # trials run on scratch outputs with the same strides (timing runs would accumulate into live data; and the tuner
+            # compares every candidate's result with the baseline plan's on a tensor it owns)
+            span = (n * h * w - 1) * y0.ld + oc
+            scratch, reset = _tune_scratch(G * span + 64, device)
+            tio = (L.ConvIO * G)()
+            for g in range(G):
+                for f_, _ in L.ConvIO._fields_:
+                    setattr(tio[g], f_, getattr(ios[g], f_))
+                tio[g].y = scratch.data_ptr() + 4 * g * span
+                if pres is not None and pres[g].ptr == ys[g].ptr:
+                    tio[g].pre = tio[g].y
+                if self_res:
+                    tio[g].res = tio[g].y
 
             def run(a):
                 d.reserved = a
                 nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
                 w_, wn_ = workspace(nb, device, conv=True) if nb else (None, 0)
                 return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids())
+            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids(), result=lambda: scratch, reset=reset,
+                             agree=TUNE_AGREE["conv"])
         d.reserved = algo
     elif GP != G:
         d.reserved = lib.crdr_conv2d_choose_algo(C.byref(d), GP)
@@ -724,7 +774,7 @@ def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[i
         key = ("wg", G, n, h, w, p0.c, p0.ld, q0.c, q0.ld, k, pad, gi, gj) + ((1,) if MATRIX_BF16X3 else ())
         algo = _algo_cache.get(key)
         if algo is None:
-            tmp = torch.empty(G * gi * gj * k[0] * k[1] + 64, dtype=torch.float32, device=device)
+            tmp = torch.zeros(G * gi * gj * k[0] * k[1] + 64, dtype=torch.float32, device=device)
             ta = (C.c_void_p * G)(*[tmp.data_ptr() + 4 * g * gi * gj * k[0] * k[1] for g in range(G)])
             jobs_t = (L.WgradJob * G)()
 
@@ -739,7 +789,11 @@ def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[i
                 w_, wn_ = workspace(nb, device)
                 return lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ta, G, w_, wn_, jobs_t, _stream()) == 0
             # + the batched reduce's read of these slabs at its measured 3.8 TB/s (profiles/r2_h_hbm_families.json)
-            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, penalty=lambda: slab[0] / 3.8e9)
+            def finished():   # the trial's slabs reduced into tmp (the jobs accumulate: tmp is zeroed by reset())
+                reduce_jobs_now(jobs_t, device)
+                return tmp
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, penalty=lambda: slab[0] / 3.8e9, result=finished,
+                             reset=tmp.zero_, agree=TUNE_AGREE["wgrad"])
         d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
     jobs = (L.WgradJob * G)()
@@ -766,7 +820,7 @@ def wgrad_split(n: int, h: int, w: int, p: V, q: V, parts, k: Tuple[int, int], p
         key = ("ws", n, h, w, p.c, p.ld, q.c, q.ld, k, pad) + ((1,) if MATRIX_BF16X3 else ())
         algo = _algo_cache.get(key)
         if algo is None:
-            tmp = torch.empty(p.c * q.c * k[0] * k[1], dtype=torch.float32, device=device)
+            tmp = torch.zeros(p.c * q.c * k[0] * k[1], dtype=torch.float32, device=device)
 
             def run(a):
                 d.algo, d.accumulate = _wa(a), 0
@@ -775,7 +829,7 @@ def wgrad_split(n: int, h: int, w: int, p: V, q: V, parts, k: Tuple[int, int], p
                     return False
                 w_, wn_ = workspace(nb, device)
                 return lib.crdr_conv2d_wgrad(C.byref(d), p.ptr, q.ptr, tmp.data_ptr(), w_, wn_, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run)
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, result=lambda: tmp, agree=TUNE_AGREE["wgrad"])
             d.accumulate = 1
         d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
@@ -968,12 +1022,15 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
         if algo is None:
             tio = (L.ConvIO * G)()
             C.memmove(tio, ios, C.sizeof(ios))
-            if flags & (L.EPI_ACCUM | L.EPI_PREADD):  # timing runs must not accumulate into live data
-                scratch = torch.empty(G * span + 64, dtype=torch.float32, device=device)
-                for g in range(G):
-                    tio[g].y = scratch.data_ptr() + 4 * g * span
-                    if pres is not None and pres[g].ptr == ys[g].ptr:
-                        tio[g].pre = tio[g].y
+            # trials run on scratch outputs (timing runs must not accumulate into live data; the tuner compares every candidate's
+            # result with the baseline plan's on a tensor it owns)
+            scratch, reset = _tune_scratch(G * span + 64, device)
+            for g in range(G):
+                tio[g].y = scratch.data_ptr() + 4 * g * span
+                if pres is not None and pres[g].ptr == ys[g].ptr:
+                    tio[g].pre = tio[g].y
+                if ress is not None and ress[g].ptr == ys[g].ptr:
+                    tio[g].res = tio[g].y
             keep = []
 
             def run(a):
@@ -989,7 +1046,8 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
                 nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
                 w_, wn_ = workspace(nb, device, conv=True) if nb else (None, 0)
                 return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids())
+            algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids(), result=lambda: scratch, reset=reset,
+                             agree=TUNE_AGREE["conv"])
         d.reserved = algo
     out = None
     if colsum:
@@ -1023,7 +1081,7 @@ def wgrad_multi(n: int, ph: int, pw: int, qh: int, qw: int, ps, qs, gs, gi: int,
         key = ("wm", G, n, ph, pw, pc, p0.ld, qh, qw, qc, q0.ld, k, stride, pad, gi, gj) + ((1,) if MATRIX_BF16X3 else ())
         algo = _algo_cache.get(key)
         if algo is None:
-            tmp = torch.empty(G * gi * gj * k[0] * k[1] + 64, dtype=torch.float32, device=device)
+            tmp = torch.zeros(G * gi * gj * k[0] * k[1] + 64, dtype=torch.float32, device=device)
             ta = (C.c_void_p * G)(*[tmp.data_ptr() + 4 * g * gi * gj * k[0] * k[1] for g in range(G)])
             jobs_t = (L.WgradJob * G)()
 
@@ -1038,7 +1096,11 @@ def wgrad_multi(n: int, ph: int, pw: int, qh: int, qw: int, ps, qs, gs, gi: int,
                 w_, wn_ = workspace(nb, device)
                 return lib.crdr_conv2d_wgrad_partial_grouped(C.byref(d), pa, qa, ta, G, w_, wn_, jobs_t, _stream()) == 0
             # + the batched reduce's read of these slabs at its measured 3.8 TB/s (profiles/r2_h_hbm_families.json)
-            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, penalty=lambda: slab[0] / 3.8e9)
+            def finished():   # the trial's slabs reduced into tmp (the jobs accumulate: tmp is zeroed by reset())
+                reduce_jobs_now(jobs_t, device)
+                return tmp
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, penalty=lambda: slab[0] / 3.8e9, result=finished,
+                             reset=tmp.zero_, agree=TUNE_AGREE["wgrad"])
         d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
     jobs = (L.WgradJob * G)()

@@ -108,14 +108,43 @@ def all_reduce_mean_(buffers: List[torch.Tensor]) -> None:
             _mean_reduce_(b, ws)
 
 
+# Overlap trace (bench.py --gpus N, tests): a list switches it on; every AsyncGradSync then appends
+# {"label", "bytes", "ready", "start", "done", "waitpoint"} -- timing events for: the bucket's gradients complete on the compute
+# stream / the collective starts on the communication stream / it completes / the compute stream reaches the point where it
+# needs the result.  max(0, done - waitpoint) is the part of the all-reduce that was NOT hidden behind compute.
+TRACE: Optional[list] = None
+
+
+def trace_summary(trace: list) -> dict:
+    """Per-bucket averages over the traced steps (ms)."""
+    by = {}
+    for r in trace:
+        b = by.setdefault(r["label"], {"MB": r["bytes"] / 1e6, "n": 0, "queue_ms": 0.0, "allreduce_ms": 0.0, "exposed_ms": 0.0, "slack_ms": 0.0})
+        b["n"] += 1
+        b["queue_ms"] += r["ready"].elapsed_time(r["start"])        # waiting for the communication stream (earlier buckets)
+        b["allreduce_ms"] += r["start"].elapsed_time(r["done"])
+        gap = r["waitpoint"].elapsed_time(r["done"]) if r.get("waitpoint") is not None else 0.0
+        b["exposed_ms"] += max(0.0, gap)                           # compute stream idle until the collective finished
+        b["slack_ms"] += max(0.0, -gap)                            # collective finished this long before it was needed
+    out = []
+    for label, b in by.items():
+        n = max(b.pop("n"), 1)
+        out.append({"bucket": label, "MB": round(b["MB"], 1), **{k: round(v / n, 3) for k, v in b.items() if k != "MB"},
+                    "busbw_GBps": round(b["MB"] / 1e3 / max(b["allreduce_ms"] / n * 1e-3, 1e-9), 1)})
+    return {"buckets": out, "exposed_ms_per_step": round(sum(r["exposed_ms"] for r in out), 3),
+            "note": "HIP events on the compute and communication streams around every gradient all-reduce; exposed = the compute "
+                    "stream reached the point where it needs the bucket before the collective had finished"}
+
+
 class AsyncGradSync:
     """Mean all-reduce of flat gradient buffers (+ MAX all-reduce of flags) issued on the communication stream WITHOUT
     making the caller's stream wait: independent work (the discriminator's forward/backward while the generator's
     510 MB of gradients travel over xGMI) overlaps the collective; wait() orders the caller's stream behind it."""
 
-    def __init__(self, mean_buffers: List[torch.Tensor], max_flags: Optional[List[torch.Tensor]] = None):
+    def __init__(self, mean_buffers: List[torch.Tensor], max_flags: Optional[List[torch.Tensor]] = None, label: str = ""):
         ts = list(mean_buffers) + list(max_flags or [])
         self._comm = None
+        self._rec = None
         if not is_dist() or not ts:
             return
         ws = dist.get_world_size()
@@ -132,18 +161,32 @@ class AsyncGradSync:
             comm = _comm_streams.get(ts[0].device)
             if comm is None:
                 comm = _comm_streams[ts[0].device] = torch.cuda.Stream(ts[0].device)
+            tr = TRACE is not None
+            if tr:
+                self._rec = {"label": label, "bytes": sum(b.numel() * b.element_size() for b in mean_buffers),
+                             "ready": torch.cuda.Event(enable_timing=True), "start": torch.cuda.Event(enable_timing=True), "waitpoint": None}
+                self._rec["ready"].record(cur)
             comm.wait_stream(cur)
             with torch.cuda.stream(comm):
+                if tr:
+                    self._rec["start"].record(comm)
                 issue()
-                self._done = torch.cuda.Event()
+                self._done = torch.cuda.Event(enable_timing=tr)
                 self._done.record(comm)  # later collectives queued on the same stream are not waited for
+            if tr:
+                self._rec["done"] = self._done
+                TRACE.append(self._rec)
             self._comm = comm
         else:
             issue()
 
     def wait(self) -> None:
         if self._comm is not None:
-            torch.cuda.current_stream(self._comm.device).wait_event(self._done)
+            cur = torch.cuda.current_stream(self._comm.device)
+            if self._rec is not None:
+                self._rec["waitpoint"] = torch.cuda.Event(enable_timing=True)
+                self._rec["waitpoint"].record(cur)
+            cur.wait_event(self._done)
             self._comm = None
 
 

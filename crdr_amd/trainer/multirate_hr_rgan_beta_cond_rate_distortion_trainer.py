@@ -138,9 +138,9 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
             ctx, g_syncs = self._run_generator_staged(run, real, cond, noise, current_iter)
         else:
             ctx = run("g", lambda: self._seg_generator(real, cond, noise, current_iter))
-            g_syncs = [D.AsyncGradSync(self.g_optimizer.flat_grads(), [ctx["bad"]])]       # overlaps the D forward/backward
+            g_syncs = [D.AsyncGradSync(self.g_optimizer.flat_grads(), [ctx["bad"]], label="g.all")]       # overlaps the D forward/backward
         ctx_d = run("dfb", lambda: self._seg_dfwdbwd(ctx))
-        d_sync = D.AsyncGradSync(self.d_optimizer.flat_grads(partitions=self._d_parts(ctx["q"])))  # overlaps the G update
+        d_sync = D.AsyncGradSync(self.d_optimizer.flat_grads(partitions=self._d_parts(ctx["q"])), label="d")  # overlaps the G update
         for sy in g_syncs:
             sy.wait()
         ctx2 = run("u", lambda: self._seg_update(ctx))

@@ -172,7 +172,7 @@ class RateDistortionTrainer(BaseTrainer):
         for k in range(len(self.PIECES)):
             out = run(f"gb{k}", lambda k=k: self._seg_gbwd(f, k, current_iter))
             ctx = out if k == 0 else ctx
-            syncs.append(D.AsyncGradSync(bufs[k], [ctx["bad"]] if k == len(self.PIECES) - 1 else None))
+            syncs.append(D.AsyncGradSync(bufs[k], [ctx["bad"]] if k == len(self.PIECES) - 1 else None, label=f"g.{self.PIECES[k] or 'rest'}"))
         return ctx, syncs
 
     def _seg_update(self, ctx: Dict) -> Dict:

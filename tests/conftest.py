@@ -21,6 +21,25 @@ def hip_lib():
     return lib.load()
 
 
+@pytest.fixture(autouse=True, scope="session")
+def _record_forced_decisions():
+    """every O.check_forced / O.check_forced_indexes of the session also reports its counts to tests/parity_margins.py"""
+    from oracle import crdr_oracle as O
+    from tests import parity_margins as PM
+    cf, cfi = O.check_forced, O.check_forced_indexes
+
+    def check_forced(report, numel):
+        PM.record_forced(report)
+        return cf(report, numel)
+
+    def check_forced_indexes(report):
+        PM.record_forced(report)
+        return cfi(report)
+    O.check_forced, O.check_forced_indexes = check_forced, check_forced_indexes
+    yield
+    O.check_forced, O.check_forced_indexes = cf, cfi
+
+
 def pytest_sessionfinish(session, exitstatus):
     path = os.environ.get("CRDR_PARITY_DUMP")
     if path:

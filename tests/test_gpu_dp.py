@@ -163,3 +163,114 @@ def _dp_identity_body(build_trainer):
         assert max(bad0, bad1) == badf == 0.0
         for k in lf:
             assert abs((l0[k] + l1[k]) / 2 - lf[k]) <= 2e-5 * max(1.0, abs(lf[k])), (k, l0[k], l1[k], lf[k])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE config #4 on real ranks: W processes under torch.distributed.run, one GPU each, RCCL.  W = 1 runs everywhere (the
+# launcher, per-rank device selection, sharding and dump plumbing on a 1-rank RCCL group); W = 2 runs the moment two GPUs are
+# visible and is the first N > 1 execution of the staged data-parallel step.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _launch_ranks(out, world, extra, port):
+    """fresh child processes (never an exec from this GPU-initialised one): torchrun -> tests.dp_step_worker on cuda:LOCAL_RANK"""
+    env = dict(os.environ, CRDR_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "tests.dp_step_worker", str(out), "--graphs", "--shard"] + list(extra)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return [torch.load(f"{out}.rank{k}", map_location="cpu", weights_only=False) for k in range(world)]
+
+
+def _by_module(layout, got, ref):
+    off, acc = 0, {}
+    for name, n in layout:
+        top = name.split(".")
+        top = ".".join(top[:2]) if top[0] == "context_model" else top[0]
+        a = acc.setdefault(top, [0.0, 0.0])
+        a[0] += float((got[off:off + n] - ref[off:off + n]).double().square().sum())
+        a[1] += float(ref[off:off + n].double().square().sum())
+        off += n
+    assert off == ref.numel() == got.numel()
+    return {k: (d2 / max(n2, 1e-300)) ** 0.5 for k, (d2, n2) in acc.items()}
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_two_rank_rccl_staged_step(tmp_path, world):
+    """Stage 3, HIP graphs on, staged generator step (forward graph | all-reduce of the mean qbpp | three backward graphs with one
+    asynchronous RCCL bucket each), a global batch of 4 seeded images with explicit noise split over `world` ranks:
+
+    * the lambda_A / lambda_B switch is STRADDLED: the target rate sits between the two half-batch means of the quantised bpp, so a
+      rank deciding on its local mean would take the other branch than the global mean does (rate_loss.py:172-175 at global batch);
+    * all ranks hold bit-identical generator and discriminator parameters after 5 iterations;
+    * the all-reduced gradients of iteration 1 equal the one-GPU run of the whole batch within the data-parallel identity's
+      tolerances (test_dp_identity_on_the_real_trainer: 2e-5 behind the quantiser, encoder 5e-3, mean / scale transforms 5e-4) --
+      a rank on the wrong lambda branch would be off by the ratio lambda_A / lambda_B in the rate gradient."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs (have {torch.cuda.device_count()})")
+    q, gbs = 2, 4
+    common = ("--stage", "3", "--fixed-q", str(q), "--global-bs", str(gbs), "--forced-algo", "1")
+    # per-image quantised bpp of the global batch (one GPU, no training) -> a target between the half-batch means
+    probe = tmp_path / "probe.pt"
+    env = dict(os.environ, CRDR_FORCE_DIST="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "tests.dp_step_worker", str(probe), "--shard", "--report-qbpp", *common], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    qb = torch.load(probe, weights_only=False)["qbpp"].double()
+    lo, hi = sorted([float(qb[: gbs // 2].mean()), float(qb[gbs // 2:].mean())])
+    assert hi - lo > 1e-4 * hi, ("the two halves of the seeded batch have the same mean qbpp", lo, hi)
+    glob = float(qb.mean())
+    target = lo + 0.25 * (hi - lo)          # lo < target < global mean < hi: global decision lambda_A, the low half alone would say lambda_B
+    assert lo < target < glob < hi
+    extra = common + ("--target-rate", repr(target))
+    # the whole batch on one GPU, plain (no process group): the reference the ranks must reproduce
+    single = tmp_path / "single.pt"
+    r = subprocess.run([sys.executable, "-m", "tests.dp_step_worker", str(single), "--graphs", "--shard", *extra], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ref = torch.load(single, map_location="cpu", weights_only=False)
+    assert ref["dist"] is False
+    ranks = _launch_ranks(tmp_path / "dp.pt", world, extra, 29650 + world)
+    assert all(s["dist"] and s["world"] == world and s["staged"] for s in ranks)
+    assert all(s["graphs"] >= 7 for s in ranks), [s["graphs"] for s in ranks]
+    assert all(lg is not None for s in ranks for lg in s["logs"]), "an iteration was skipped"
+    if world == 2:   # the straddle is real on the ranks' own logs (iteration 1: the probe's parameters)
+        l0, l1 = sorted(float(s["logs"][0]["qbpp"]) for s in ranks)
+        assert l0 < target < l1, (l0, target, l1)
+    for s in ranks[1:]:
+        for part in ("G", "D"):
+            for k in ranks[0][part]:
+                assert torch.equal(ranks[0][part][k], s[part][k]), (part, k)
+        assert torch.equal(ranks[0]["grads"]["G"], s["grads"]["G"]) and torch.equal(ranks[0]["grads"]["D"], s["grads"]["D"])
+    errs = _by_module(ranks[0]["g_layout"], ranks[0]["grads"]["G"], ref["grads"]["G"])
+    if world == 1:     # same batch, same plans: the 1-rank RCCL path changes nothing
+        assert max(errs.values()) == 0.0, errs
+        assert torch.equal(ranks[0]["grads"]["D"], ref["grads"]["D"])
+        for part in ("G", "D"):
+            for k in ref[part]:
+                assert torch.equal(ranks[0][part][k], ref[part][k]), (part, k)
+        return
+    tol = {"encoder": 5e-3, "context_model.mean_slice_transforms": 5e-4, "context_model.scale_slice_transforms": 5e-4}
+    for k, e in errs.items():
+        assert e < tol.get(k, 2e-5), (k, e, errs)
+    assert rel(ranks[0]["grads"]["D"], ref["grads"]["D"]) < 2e-5
+
+
+def test_bench_two_gpus_reports_two_rccl_ranks():
+    """`python bench.py --gpus 2 --steps 5` (the driver's scaling command, self-launched) on two GPUs: the line says n_gpus 2, the
+    process group really had two RCCL ranks (all-reduce of ones = 2) and the per-bucket overlap report is there."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "3", "--no-cpu-baseline", "--no-secondary"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["rccl_ranks"]["world_size"] == 2 and line["rccl_ranks"]["allreduce_of_ones"] == 2
+    assert line["comm_overlap"]["buckets"], line["comm_overlap"]

@@ -131,17 +131,61 @@ def test_stage3_step_winograd():
         ops.PREFER_WINOGRAD = False
 
 
-def _stage3_step():
+class _ShippedPlans:
+    """what bench.py and scripts/train.py run: ops.AUTOTUNE on with the shipped perf database (crdr_amd/hip/tune_gfx950.json)"""
+
+    def __enter__(self):
+        from crdr_amd.hip import ops
+        self.ops, self.keep = ops, (ops.AUTOTUNE, dict(ops._algo_cache))
+        ops._algo_cache.clear()
+        assert ops.load_tune_cache(ops.DEFAULT_TUNE_DB) > 0, "the shipped perf database is not of this library build"
+        ops.AUTOTUNE = True
+        self.log0 = len(ops.TUNE_LOG)
+        return self
+
+    def tuned_here(self):
+        """shapes the database did not hold (tuned on the spot, with the agreement check of ops._autotune)"""
+        return [k for k, *_ in self.ops.TUNE_LOG[self.log0:]]
+
+    def __exit__(self, *exc):
+        self.ops.AUTOTUNE = self.keep[0]
+        self.ops._algo_cache.clear()
+        self.ops._algo_cache.update(self.keep[1])
+
+
+def test_stage3_step_256_tuned_vs_oracle():
+    """BASELINE config #3 as benchmarked: bs 16, 256x256 crops, the shipped per-shape plans (tile / split / streaming 1x1 /
+    Winograd ids) -- every loss term and every G / D / aux gradient tensor against the oracle's step
+    (multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:13-114), same forced-decision windows as the 64x64 test."""
+    from tests import parity_margins as PM
+    with _ShippedPlans() as sp:
+        _stage3_step(bs=16, size=256)
+        new = sp.tuned_here()
+    PM.record("plans", "shapes tuned on the spot (not in the shipped database)", float(len(new)))
+    assert len(new) <= 8, new
+
+
+def test_stage1_step_256_tuned_vs_oracle():
+    """BASELINE config #2 (bs 8, 256x256) under the shipped plans against the oracle's stage-1 step (rate_distortion_trainer.py:57-101)"""
+    from tests import parity_margins as PM
+    with _ShippedPlans() as sp:
+        _stage1_step(bs=8, size=256)
+        new = sp.tuned_here()
+    PM.record("plans", "shapes tuned on the spot (not in the shipped database)", float(len(new)))
+    assert len(new) <= 8, new
+
+
+def _stage3_step(bs: int = 2, size: int = 64):
     from oracle import crdr_oracle as O
     from crdr_amd.trainer import build_trainer
-    tr = build_trainer(_opt(3))
+    tr = build_trainer(_opt(3, bs, size))
     # the optimisers flattened the parameters on the device: seed in place (views are preserved)
     sd_g = _seed_params(tr.comp_model, "")
     sd_d = _seed_params(tr.discriminator, "")
     sd_l = _seed_params(tr.perceptual_loss.lpips, "lpips.")
-    x = seeded_input("image", (2, 3, 64, 64))
-    ny = seeded_input("noise.y", (2, 320, 4, 4), 0.5)
-    nz = seeded_input("noise.z", (2, 192, 1, 1), 0.5)
+    x = seeded_input("image", (bs, 3, size, size))
+    ny = seeded_input("noise.y", (bs, 320, size // 16, size // 16), 0.5)
+    nz = seeded_input("noise.z", (bs, 192, size // 64, size // 64), 0.5)
     q, beta = 2, 2.56
 
     captured = {}
@@ -228,14 +272,18 @@ def _stage3_step():
 
 
 def test_stage1_step():
+    _stage1_step()
+
+
+def _stage1_step(bs: int = 2, size: int = 64):
     from oracle import crdr_oracle as O
     from crdr_amd.trainer import build_trainer
-    tr = build_trainer(_opt(1))
+    tr = build_trainer(_opt(1, bs, size))
     sd_g = _seed_params(tr.comp_model, "")
     sd_l = _seed_params(tr.perceptual_loss.lpips, "lpips.")
-    x = seeded_input("image", (2, 3, 64, 64))
-    ny = seeded_input("noise.y", (2, 320, 4, 4), 0.5)
-    nz = seeded_input("noise.z", (2, 192, 1, 1), 0.5)
+    x = seeded_input("image", (bs, 3, size, size))
+    ny = seeded_input("noise.y", (bs, 320, size // 16, size // 16), 0.5)
+    nz = seeded_input("noise.z", (bs, 192, size // 64, size // 64), 0.5)
     captured = {}
     g_step = tr.g_optimizer.step
     tr.loss_huge_threshold = float("inf")

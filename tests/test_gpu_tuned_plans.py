@@ -1,0 +1,494 @@
+"""Parity of the plan set the headline bench and scripts/train.py actually run.
+
+bench.py and scripts/train.py switch `ops.AUTOTUNE` on and load the shipped perf database `crdr_amd/hip/tune_gfx950.json`
+(per-shape tile configuration / split depth / streaming-1x1 / Winograd choices at bs 16 and bs 8, 256x256 crops -- the analogue of
+the reference's `cudnn.benchmark = True`, base_trainer.py:20).  Every other oracle comparison of the suite runs the library's
+built-in plans at 64x64, so this file replays EVERY entry of the database at its own shape through the product's launch
+wrappers (`ops.conv2d_raw / conv_group / conv_multi`, `ops.conv2d_wgrad_raw / wgrad_group / wgrad_multi / wgrad_split`, with
+the deferred weight-gradient reduce and the column-sum partial rows the training step uses) and compares
+
+ (i)  with the built-in plan's result on the same operands: max |tuned - builtin| <= 1e-5 of the output scale (two correct fp32
+      summation orders), and
+ (ii) with float64 torch on the CPU on a strided sample of >= 4 096 output pixels that includes all four borders and the
+      first / last image (weight gradients: a 32 x 32 sample of (out, in) channel pairs, all taps, full reduction).
+
+The autotuner is not allowed to run here: an entry whose reconstructed key misses the database fails the test.
+"""
+import ast
+import ctypes as C
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DB = os.path.join(ROOT, "crdr_amd", "hip", "tune_gfx950.json")
+BF16 = 16384
+# measured over all 759 entries of the v371 database (profiles/r4_plan_replay.json): tuned vs built-in <= 5.5e-6 (column sums 5.6e-6),
+# vs float64 <= 3.7e-6 (exact fp32) / 5.4e-6 (bf16x3 entries); the gates sit at ~3x those
+TOL_PLAN = 1e-5      # tuned plan against the built-in plan (fp32 summation order only)
+TOL_F64 = 2e-5       # against float64, exact-fp32 entries
+TOL_F64_BF16X3 = 2e-5  # opt-in bf16x3 entries (split-bf16 triples: per-product error 3 * 2^-16, random in sign)
+RESULTS = {}
+
+
+def _entries(kind):
+    db = json.load(open(DB))
+    out = []
+    for k, v in db["algos"].items():
+        key = ast.literal_eval(k)
+        if key[0] == kind:
+            out.append((key, int(v)))
+    return out
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test needs a HIP device"
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.rand(shape, generator=g, device="cuda") * 2 - 1) * scale
+
+
+class _Replay:
+    """AUTOTUNE on with the shipped database and the tuner disarmed / AUTOTUNE off (built-in plan)."""
+
+    def __enter__(self):
+        from crdr_amd.hip import ops
+        self.ops = ops
+        self.keep = (ops.AUTOTUNE, dict(ops._algo_cache), ops._autotune, ops.MATRIX_BF16X3, ops.WGRAD_DEFER)
+        ops._algo_cache.clear()
+        assert ops.load_tune_cache(DB) > 0, "the shipped perf database is not of this library build (signature mismatch)"
+
+        def refuse(key, *a, **k):
+            raise AssertionError(f"replay reconstructed a key the shipped database does not hold: {key}")
+        ops._autotune = refuse
+        ops.WGRAD_DEFER = ops.DeferredWgrad(_dev(), arena_bytes=1 << 30)
+        return self
+
+    def __exit__(self, *exc):
+        ops = self.ops
+        ops.AUTOTUNE, cache, ops._autotune, ops.MATRIX_BF16X3, ops.WGRAD_DEFER = self.keep
+        ops._algo_cache.clear()
+        ops._algo_cache.update(cache)
+
+    def mode(self, tuned: bool, bf16x3: bool):
+        self.ops.AUTOTUNE = tuned
+        self.ops.MATRIX_BF16X3 = bf16x3
+
+
+def _sel(n, cap):
+    """<= cap indices of range(n): both ends, their neighbours, and an even spread in between"""
+    if n <= cap:
+        return list(range(n))
+    s = {0, 1, n - 2, n - 1}
+    m = cap - len(s)
+    s |= {2 + int((i + 0.5) * (n - 4) / m) for i in range(m)}
+    return sorted(s)
+
+
+def _sample_pixels(n, oh, ow):
+    ys, xs = _sel(oh, 32), _sel(ow, 32)
+    need = -(-4096 // (len(ys) * len(xs)))
+    ns = _sel(n, max(2, min(n, need)))
+    idx = torch.cartesian_prod(torch.tensor(ns), torch.tensor(ys), torch.tensor(xs))
+    return idx[:, 0], idx[:, 1], idx[:, 2]
+
+
+def _conv_ref64(xb, wp, geo, pix):
+    """float64 accumulator of the convolution at the sampled output pixels.  xb: CPU [N,H,W,ld] float32; wp: CPU pack
+    [T][wrows][wcols] (wlayout 0) or [1][wrows][4T..] (wlayout 1); -> [P][OC] float64"""
+    n, h, w, c, oh, ow, oc, kh, kw, stride, pad, transposed, wlayout = geo
+    pn, py, px = pix
+    acc = torch.zeros((pn.numel(), oc), dtype=torch.float64)
+    xb = xb[..., :c]
+    for r in range(kh):
+        for s in range(kw):
+            if transposed:   # out[i*stride - pad + r] += in[i] * w[r]
+                ny, nx = py + pad - r, px + pad - s
+                ok = (ny % stride == 0) & (nx % stride == 0)
+                iy, ix = torch.div(ny, stride, rounding_mode="floor"), torch.div(nx, stride, rounding_mode="floor")
+            else:            # out[o] = sum_r in[o*stride - pad + r] * w[r]
+                iy, ix = py * stride - pad + r, px * stride - pad + s
+                ok = torch.ones_like(iy, dtype=torch.bool)
+            ok = ok & (iy >= 0) & (iy < h) & (ix >= 0) & (ix < w)
+            if not ok.any():
+                continue
+            t = r * kw + s
+            patch = xb[pn[ok], iy[ok], ix[ok]].double()                    # [P'][c]
+            if wlayout == 1:
+                wt = wp[0, :oc, 4 * t:4 * t + c].double()                  # [oc][c]
+            else:
+                wt = wp[t, :oc, :c].double()
+            acc[ok] += patch @ wt.t()
+    return acc
+
+
+def _epilogue64(v, flags, o, pix, oc):
+    """the fused epilogue (include/crdr_hip.h CRDR_EPI_*, in the kernel's order) in float64 on the sampled pixels.
+    o: dict of CPU operands; -> (value written, sigmoid or None)"""
+    from crdr_amd.hip import lib as L
+    pn, py, px = pix
+
+    def at(name):
+        return o[name][pn, py, px, :oc].double()
+
+    def vec(name):
+        return o[name][:oc].double().view(1, -1)
+    sig = None
+    if flags & L.EPI_PREADD:
+        v = v + at("pre")
+    if flags & L.EPI_BIAS:
+        v = v + vec("bias")
+    if flags & L.EPI_RELU:
+        v = v.clamp_min(0)
+    if flags & L.EPI_LRELU:
+        v = torch.where(v > 0, v, 0.2 * v)
+    if flags & L.EPI_VEC2:
+        v = v + vec("vec2")
+    if flags & L.EPI_RES:
+        v = v + at("res")
+    if flags & L.EPI_GATE:
+        sig = torch.sigmoid(v)
+        v = at("gx") + at("gt") * sig
+    if flags & L.EPI_AFFINE:
+        v = v * vec("scale") + vec("shift")
+    if flags & (L.EPI_RELUMASK | L.EPI_LRELUMASK):
+        mv = at("mask") - (vec("vec2") if flags & L.EPI_MASKOFF else 0.0)
+        v = torch.where(mv > 0, v, 0.2 * v if flags & L.EPI_LRELUMASK else torch.zeros_like(v))
+    if flags & L.EPI_ACCUM:
+        v = v + at("y0")
+    return v, sig
+
+
+def _nchw(buf, c):
+    """[N,H,W,ld] buffer -> logical NCHW tensor of its first c channels (memory stays NHWC)"""
+    return buf.permute(0, 3, 1, 2)[:, :c]
+
+
+def _replay_conv(rp, key, algo, seed):
+    """-> dict of measured errors for one database entry of kind c / g / m"""
+    from crdr_amd.hip import lib as L, ops
+    dev = _dev()
+    kind = key[0]
+    if kind == "c":
+        _, n, h, w, c, oh, ow, oc, k, stride, pad, tr, ldx, ldy, flags, ldres, ldg, wlayout = key
+        G, ldpre, ldmask = 1, 0, 0
+        wrows = ops.round32(oc)
+        wcols = ops.round32(4 * k[0] * k[1]) if wlayout else ops.round32(c)
+    elif kind == "g":
+        _, G, n, h, w, c, oc, k, pad, tr, ldx, ldy, flags, ldpre, ldmask, wrows, wcols = key
+        oh, ow, stride, wlayout, ldres, ldg = h, w, 1, 0, 0, 0
+    else:
+        _, G, n, h, w, oh, ow, c, oc, k, stride, pad, tr, ldx, ldy, flags, ldres, ldpre, ldmask, wrows, wcols, wlayout = key
+        ldg = 0
+    bf = bool(flags & BF16)
+    f = flags & ~BF16
+    self_res = kind == "g" and (f & L.EPI_RES)      # conv_group: pure accumulation = residual epilogue with the output as its operand
+    T = k[0] * k[1]
+    fan = c * T / (stride * stride if tr else 1)
+    xs = [_rand((n, h, w, ldx), seed + 10 * g + 1) for g in range(G)]
+    wps = []
+    for g in range(G):
+        wp = _rand((1 if wlayout else T, wrows, wcols), seed + 10 * g + 2, fan ** -0.5)
+        wp[:, oc:] = 0
+        wp[:, :, (4 * T if wlayout else c):] = 0
+        wps.append(wp)
+    y0 = [_rand((n, oh, ow, ldy), seed + 10 * g + 3) for g in range(G)]
+    opn = {}
+    if f & L.EPI_BIAS:
+        opn["bias"] = [_rand((oc,), seed + 10 * g + 4) for g in range(G)]
+    if f & (L.EPI_VEC2 | L.EPI_MASKOFF):
+        opn["vec2"] = [_rand((oc,), seed + 5, 0.3)]
+    if f & L.EPI_AFFINE:
+        opn["scale"], opn["shift"] = [_rand((oc,), seed + 6) + 1.5], [_rand((oc,), seed + 7)]
+    alias_pre = bool(f & L.EPI_PREADD) and ldpre == ldy
+    if (f & L.EPI_PREADD) and not alias_pre:
+        opn["pre"] = [_rand((n, oh, ow, ldpre), seed + 10 * g + 8) for g in range(G)]
+    if (f & L.EPI_RES) and not self_res:
+        opn["res"] = [_rand((n, oh, ow, ldres), seed + 10 * g + 9) for g in range(G)]
+    if f & (L.EPI_RELUMASK | L.EPI_LRELUMASK):
+        opn["mask"] = [_rand((n, oh, ow, ldmask), seed + 10 * g + 11) for g in range(G)]
+    if f & L.EPI_GATE:
+        opn["gx"], opn["gt"] = [_rand((n, oh, ow, ldg), seed + 12)], [_rand((n, oh, ow, ldg), seed + 13)]
+
+    def launch(tuned):
+        rp.mode(tuned, bf)
+        ys = [t.clone() for t in y0]
+        sig, cs = None, None
+        if kind == "c":
+            kw = {}
+            if "res" in opn:
+                kw["res"] = _nchw(opn["res"][0], oc)
+            if "scale" in opn:
+                kw["scale"], kw["shift"] = opn["scale"][0], opn["shift"][0]
+            if f & L.EPI_GATE:
+                sig = torch.zeros((n, oh, ow, ldg), device=dev)
+                kw.update(gate_x=_nchw(opn["gx"][0], oc), gate_t=_nchw(opn["gt"][0], oc), sig_out=sig)
+            ops.conv2d_raw(_nchw(xs[0], c), wps[0], oc, k, stride, pad, bool(tr), (oh, ow), bias=opn["bias"][0] if "bias" in opn else None,
+                           vec2=opn["vec2"][0] if "vec2" in opn else None, flags=f, out=_nchw(ys[0], oc), wlayout=wlayout, **kw)
+        else:
+            xv = [ops.view(t, 0, c) for t in xs]
+            yv = [ops.view(t, 0, oc) for t in ys]
+            biases = [t.data_ptr() for t in opn["bias"]] if "bias" in opn else None
+            pres = None
+            if f & L.EPI_PREADD:
+                pres = yv if alias_pre else [ops.view(t, 0, oc) for t in opn["pre"]]
+            masks = [ops.view(t, 0, oc) for t in opn["mask"]] if "mask" in opn else None
+            wa = [t.data_ptr() for t in wps]
+            if kind == "g":
+                ops.conv_group(n, h, w, xv, wa, yv, oc, k, pad, bool(tr), wrows=wrows, wcols=wcols, biases=biases, pres=pres,
+                               masks=masks, flags=(L.EPI_ACCUM if self_res else f & (L.EPI_RELU | L.EPI_ACCUM)), device=dev)
+            else:
+                q = ops.colsum_queue(dev)
+                r = ops.conv_multi(n, h, w, oh, ow, xv, wa, yv, oc, k, stride, pad, bool(tr), wrows=wrows, wcols=wcols, biases=biases,
+                                   pres=pres, masks=masks, ress=[ops.view(t, 0, oc) for t in opn["res"]] if "res" in opn else None,
+                                   vec2=opn["vec2"][0].data_ptr() if "vec2" in opn else None,
+                                   scale=opn["scale"][0].data_ptr() if "scale" in opn else None,
+                                   shift=opn["shift"][0].data_ptr() if "shift" in opn else None,
+                                   flags=f & ~(L.EPI_BIAS | L.EPI_PREADD | L.EPI_RES | L.EPI_AFFINE | L.EPI_COLSUM),
+                                   colsum=bool(f & L.EPI_COLSUM), wlayout=wlayout, device=dev)
+                if r is not None:   # partial column-sum rows live in the queue's arena: add them up (what colsum_finish does)
+                    cs = []
+                    for ptr, rows, ld in r:
+                        off = ptr - q.arena.data_ptr()
+                        part = q.arena[off:off + rows * 2 * ld * 4].view(torch.float32).view(rows, 2, ld)
+                        cs.append(part.double().sum(0)[:, :oc].clone())
+                    q.off, q.jobs, q.scratch_off = 0, [], 0
+        torch.cuda.synchronize()
+        return ys, sig, cs
+
+    yb, sigb, csb = launch(False)
+    yt, sigt, cst = launch(True)
+    out = {}
+    scale = max(float(t[..., :oc].abs().max()) for t in yb) + 1e-20
+    out["vs_builtin"] = max(float((a[..., :oc] - b[..., :oc]).abs().max()) for a, b in zip(yt, yb)) / scale
+    oc4 = (oc + 3) // 4 * 4
+    for a, b, z in zip(yt, yb, y0):   # nothing beyond the output channels (and their 16-byte lane padding) may be touched by either plan
+        assert torch.equal(a[..., oc4:], z[..., oc4:]) and torch.equal(b[..., oc4:], z[..., oc4:]), f"{key}: write outside the output channels"
+    if sigb is not None:
+        out["sig_vs_builtin"] = float((sigt - sigb).abs().max())
+    if csb is not None:
+        cscale = max(float(t.abs().max()) for t in csb) + 1e-20
+        out["colsum_vs_builtin"] = max(float((a - b).abs().max()) for a, b in zip(cst, csb)) / cscale
+    # float64 on the CPU: first and last problem of the group, sampled pixels
+    pix = _sample_pixels(n, oh, ow)
+    gpix = [t.to(dev) for t in pix]
+    geo = (n, h, w, c, oh, ow, oc, k[0], k[1], stride, pad, tr, wlayout)
+    e64 = e64b = 0.0
+    for g in sorted({0, G - 1}):
+        acc = _conv_ref64(xs[g].cpu(), wps[g].cpu(), geo, pix)
+        o = {"y0": y0[g].cpu()}
+        for name, lst in opn.items():
+            o[name] = lst[g if len(lst) > 1 else 0].cpu()
+        if alias_pre:
+            o["pre"] = o["y0"]
+        if self_res:
+            o["res"] = o["y0"]
+        ref, sref = _epilogue64(acc, f, o, pix, oc)
+        rs = float(ref.abs().max()) + 1e-20
+        got = yt[g][gpix[0], gpix[1], gpix[2], :oc].cpu().double()
+        gotb = yb[g][gpix[0], gpix[1], gpix[2], :oc].cpu().double()
+        e64 = max(e64, float((got - ref).abs().max()) / rs)
+        e64b = max(e64b, float((gotb - ref).abs().max()) / rs)
+        if sref is not None:
+            out["sig_vs_f64"] = float((sigt[gpix[0], gpix[1], gpix[2], :oc].cpu().double() - sref).abs().max())
+    out["vs_f64"], out["builtin_vs_f64"], out["pixels"] = e64, e64b, int(pix[0].numel())
+    out["bf16x3"] = bf
+    return out
+
+
+def _wgrad_ref64(pb, qb, geo, isel, jsel):
+    """g[i][j][t] = sum P[n,a,b,i] Q[n, a*stride - pad + r, b*stride - pad + s, j] in float64 for i in isel, j in jsel"""
+    n, ph, pw, qh, qw, kh, kw, stride, pad = geo
+    P = pb[..., isel].double().reshape(-1, len(isel))                                # [M][I']
+    Q = qb[..., jsel].double()
+    out = torch.zeros((len(isel), len(jsel), kh * kw), dtype=torch.float64)
+    a = torch.arange(ph) * stride - pad
+    b = torch.arange(pw) * stride - pad
+    for r in range(kh):
+        for s in range(kw):
+            iy, ix = a + r, b + s
+            oky, okx = (iy >= 0) & (iy < qh), (ix >= 0) & (ix < qw)
+            g = torch.zeros((n, ph, pw, len(jsel)), dtype=torch.float64)
+            sub = Q[:, iy[oky]][:, :, ix[okx]]
+            g[:, oky.nonzero().view(-1, 1), okx.nonzero().view(1, -1)] = sub
+            out[:, :, r * kw + s] = P.t() @ g.reshape(-1, len(jsel))
+    return out
+
+
+def _replay_wgrad(rp, key, algo, seed):
+    from crdr_amd.hip import ops
+    dev = _dev()
+    kind = key[0]
+    bf = len(key) > {"w": 15, "wg": 13, "wm": 16, "ws": 10}[kind]
+    if kind == "w":
+        _, n, ph, pw, pc, ldp, qh, qw, qc, ldq, k, stride, pad, gi, gj = key[:15]
+        G = 1
+    elif kind == "wg":
+        _, G, n, ph, pw, pc, ldp, qc, ldq, k, pad, gi, gj = key[:13]
+        qh, qw, stride = ph, pw, 1
+    elif kind == "wm":
+        _, G, n, ph, pw, pc, ldp, qh, qw, qc, ldq, k, stride, pad, gi, gj = key[:16]
+    else:
+        _, n, ph, pw, pc, ldp, qc, ldq, k, pad = key[:10]
+        G, qh, qw, stride, gi, gj = 1, ph, pw, 1, pc, qc
+    T = k[0] * k[1]
+    ps = [_rand((n, ph, pw, ldp), seed + 10 * g + 1) for g in range(G)]
+    qs = [_rand((n, qh, qw, ldq), seed + 10 * g + 2) for g in range(G)]
+    for t in ps:   # lanes between the operand's channels and the next multiple of 4 are layout padding the product keeps at zero
+        t[..., gi:pc] = 0   # (RGB: the 4th lane); channels past pc / qc belong to a wider tensor and stay random: they must not be read
+    for t in qs:
+        t[..., gj:qc] = 0
+
+    def launch(tuned):
+        rp.mode(tuned, bf)
+        gs = [torch.zeros((gi, gj, k[0], k[1]), device=dev) for _ in range(G)]
+        if kind == "w":
+            ops.conv2d_wgrad_raw(_nchw(ps[0], gi), _nchw(qs[0], gj), gs[0], k, stride, pad, accumulate=False)
+        elif kind == "wg":
+            ops.wgrad_group(n, ph, pw, [ops.view(t, 0, pc) for t in ps], [ops.view(t, 0, qc) for t in qs], [(g.data_ptr(), gj) for g in gs],
+                            gi, gj, k, pad, device=dev)
+        elif kind == "wm":
+            ops.wgrad_multi(n, ph, pw, qh, qw, [ops.view(t, 0, pc) for t in ps], [ops.view(t, 0, qc) for t in qs], [g.data_ptr() for g in gs],
+                            gi, gj, k, stride, pad, device=dev)
+        else:
+            ops.wgrad_split(n, ph, pw, ops.view(ps[0], 0, pc), ops.view(qs[0], 0, qc), [(0, pc, gs[0].data_ptr(), qc)], k, pad, device=dev)
+        ops.flush_wgrads(("replay", kind, tuned))
+        torch.cuda.synchronize()
+        return gs
+
+    gb = launch(False)
+    gt = launch(True)
+    scale = max(float(t.abs().max()) for t in gb) + 1e-20
+    out = {"vs_builtin": max(float((a - b).abs().max()) for a, b in zip(gt, gb)) / scale, "bf16x3": bf}
+    isel, jsel = _sel(gi, 32), _sel(gj, 32)
+    e = eb = 0.0
+    for g in sorted({0, G - 1}):
+        ref = _wgrad_ref64(ps[g].cpu(), qs[g].cpu(), (n, ph, pw, qh, qw, k[0], k[1], stride, pad), isel, jsel)
+        rs = float(ref.abs().max()) + 1e-20
+        pick = lambda t: t.cpu().double().reshape(gi, gj, T)[isel][:, jsel]
+        e = max(e, float((pick(gt[g]) - ref).abs().max()) / rs)
+        eb = max(eb, float((pick(gb[g]) - ref).abs().max()) / rs)
+    out["vs_f64"], out["builtin_vs_f64"] = e, eb
+    return out
+
+
+def _depth(key):
+    """length of the fp32 accumulation chain behind one output element of the entry"""
+    kind = key[0]
+    if kind == "c":
+        return key[4] * key[8][0] * key[8][1]
+    if kind == "g":
+        return key[5] * key[7][0] * key[7][1]
+    if kind == "m":
+        return key[7] * key[9][0] * key[9][1]
+    return key[1 if kind in ("w", "ws") else 2] * key[2 if kind in ("w", "ws") else 3] * key[3 if kind in ("w", "ws") else 4]   # N * PH * PW pixels
+
+
+def _tolerances(key, r):
+    """(tuned vs built-in, vs float64).  Two correct fp32 plans differ by summation order only: the bound grows with the square root
+    of the accumulation depth (MFMA chains are sequential in K); measured margins: profiles/r4_plan_replay.json."""
+    depth = _depth(key)
+    wg = key[0].startswith("w")
+    plan = max(TOL_PLAN, (1.5e-7 if not wg else 2.5e-7) * depth ** 0.5)
+    f64 = TOL_F64_BF16X3 if r["bf16x3"] else TOL_F64
+    if os.environ.get("CRDR_PLAN_REPLAY_MEASURE") == "1":   # first measurement of a new database: gross errors only
+        plan, f64 = 1e-3, 3e-3
+    return plan, f64
+
+
+def _run_kind(kind, replay):
+    from crdr_amd.hip import lib as L
+    entries = _entries(kind)
+    assert entries, f"no '{kind}' entries in the shipped perf database"
+    bad, rows = [], []
+    nwino = nstream = nsplit = 0
+    lib = L.load()
+    ncfg, nstr = lib.crdr_conv2d_num_configs(), lib.crdr_conv2d_num_stream_configs()
+    with _Replay() as rp:
+        for i, (key, algo) in enumerate(entries):
+            try:
+                r = replay(rp, key, algo, 1000 * (i + 1))
+            except (AssertionError, L.CrdrHipError) as e:
+                bad.append((key, algo, f"{type(e).__name__}: {e}"))
+                continue
+            if kind in ("c", "g", "m"):
+                nstream += ncfg < (algo & 0xFF) <= ncfg + nstr and algo < 256
+                nwino += (algo & 0xFF) > ncfg + nstr and algo < 256
+                nsplit += algo >= 256
+            tol_plan, tol64 = _tolerances(key, r)
+            rows.append({"key": repr(key), "algo": algo, "depth": _depth(key), **{k: v for k, v in r.items()}})
+            fails = [n for n, v, t in (("vs_builtin", r["vs_builtin"], tol_plan), ("vs_f64", r["vs_f64"], tol64),
+                                       ("builtin_vs_f64", r["builtin_vs_f64"], tol64),
+                                       ("colsum_vs_builtin", r.get("colsum_vs_builtin", 0.0), 5 * tol_plan),
+                                       ("sig_vs_builtin", r.get("sig_vs_builtin", 0.0), 1e-5),
+                                       ("sig_vs_f64", r.get("sig_vs_f64", 0.0), 1e-4)) if not v <= t]
+            if fails:
+                bad.append((key, algo, {n: r.get(n) for n in fails}))
+            if i % 16 == 15:
+                torch.cuda.empty_cache()
+
+    def worst(name, pred=lambda r: True):
+        return max([r[name] for r in rows if name in r and pred(r)] + [0.0])
+    RESULTS[kind] = {"entries": len(entries), "failed": len(bad), "streaming_1x1_ids": int(nstream), "winograd_ids": int(nwino),
+                     "split_ids": int(nsplit),
+                     "worst": {"vs_builtin": worst("vs_builtin"), "vs_f64": worst("vs_f64", lambda r: not r["bf16x3"]),
+                               "vs_f64_bf16x3": worst("vs_f64", lambda r: r["bf16x3"]),
+                               "builtin_vs_f64": worst("builtin_vs_f64", lambda r: not r["bf16x3"]),
+                               "colsum_vs_builtin": worst("colsum_vs_builtin"),
+                               "vs_builtin_over_sqrt_depth": max([r["vs_builtin"] / r["depth"] ** 0.5 for r in rows] + [0.0])}}
+    path = os.environ.get("CRDR_PLAN_REPLAY_DUMP")
+    if path:
+        prev = json.load(open(path)) if os.path.exists(path) else {"kinds": {}, "rows": {}}
+        prev["what"] = ("replay of every entry of crdr_amd/hip/tune_gfx950.json at its own shape: max-abs error over the output scale of the "
+                        "tuned plan against the built-in plan and against float64 (tests/test_gpu_tuned_plans.py)")
+        prev["database"] = json.load(open(DB))["signature"]
+        prev["kinds"][kind] = RESULTS[kind]
+        if os.environ.get("CRDR_PLAN_REPLAY_ROWS") == "1":
+            prev["rows"][kind] = rows
+        with open(path, "w") as fjs:
+            json.dump(prev, fjs, indent=1, sort_keys=True)
+    assert not bad, f"{len(bad)} of {len(entries)} '{kind}' entries disagree: {bad[:6]}"
+
+
+@pytest.mark.parametrize("kind", ["c", "g", "m"])
+def test_every_tuned_conv_plan_matches_builtin_and_float64(kind):
+    _run_kind(kind, _replay_conv)
+
+
+@pytest.mark.parametrize("kind", ["w", "wg", "wm", "ws"])
+def test_every_tuned_wgrad_plan_matches_builtin_and_float64(kind):
+    _run_kind(kind, _replay_wgrad)
+
+
+def test_autotuner_rejects_a_candidate_that_disagrees():
+    """ops._autotune compares every candidate's output with the baseline plan's before it may win (a mis-tiled edge must not ship
+    because it is fast): a `run` whose candidate 2 writes a wrong value is never chosen, whatever its time."""
+    from crdr_amd.hip import ops
+    dev = _dev()
+    out = torch.zeros(4096, device=dev)
+    slow = torch.zeros(1 << 24, device=dev)
+
+    def run(a):
+        if a == 0:
+            slow.add_(1.0)          # the baseline is the slowest
+        out.fill_(1.0)
+        if a == 2:
+            out[17] = 1.001         # fastest, but wrong
+        if a == 3:
+            slow[:1 << 20].add_(1.0)
+        return a in (0, 2, 3)
+    keep = dict(ops._algo_cache)
+    try:
+        best = ops._autotune(("test-reject",), 3, 0, run, result=lambda: out)
+    finally:
+        ops._algo_cache.clear()
+        ops._algo_cache.update(keep)
+    assert best == 3, best
+    assert any(k == ("test-reject",) and a == 2 for k, a, _ in ops.TUNE_REJECTED)
