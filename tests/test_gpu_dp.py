@@ -274,3 +274,24 @@ def test_bench_two_gpus_reports_two_rccl_ranks():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     assert line["rccl_ranks"]["world_size"] == 2 and line["rccl_ranks"]["allreduce_of_ones"] == 2
     assert line["comm_overlap"]["buckets"], line["comm_overlap"]
+
+
+def test_bench_reports_comm_overlap_on_a_one_rank_group():
+    """bench.py's data-parallel reporting on ONE GPU (1-rank RCCL group, CRDR_FORCE_DIST=1): the line carries `rccl_ranks` and the
+    per-bucket overlap trace of the staged generator step -- three generator buckets in backward order + the active sub-discriminator's
+    -- with every all-reduce hidden behind compute (the events that a SCALE run will show at N = 2, 4, 8)."""
+    import json
+    env = dict(os.environ, CRDR_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29688")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
+                        "--profile-steps", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rccl_ranks"]["backend"] == "nccl" and line["rccl_ranks"]["allreduce_of_ones"] == 1
+    assert line["ms_per_step_median"] and line["value_at_median"]
+    names = [b["bucket"] for b in line["comm_overlap"]["buckets"]]
+    assert names == ["g.decoder", "g.context_model", "g.rest", "d"], names
+    mb = {b["bucket"]: b["MB"] for b in line["comm_overlap"]["buckets"]}
+    assert abs(mb["g.decoder"] + mb["g.context_model"] + mb["g.rest"] - 510.8) < 1.0 and abs(mb["d"] - 18.8) < 0.2, mb
+    assert all(b["allreduce_ms"] > 0 and b["exposed_ms"] >= 0 for b in line["comm_overlap"]["buckets"])

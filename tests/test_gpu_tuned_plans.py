@@ -101,12 +101,13 @@ def _sample_pixels(n, oh, ow):
 
 
 def _conv_ref64(xb, wp, geo, pix):
-    """float64 accumulator of the convolution at the sampled output pixels.  xb: CPU [N,H,W,ld] float32; wp: CPU pack
-    [T][wrows][wcols] (wlayout 0) or [1][wrows][4T..] (wlayout 1); -> [P][OC] float64"""
+    """float64 accumulator of the convolution at the sampled output pixels.  xb: [N,H,W,ld] float32; wp: pack [T][wrows][wcols]
+    (wlayout 0) or [1][wrows][4T..] (wlayout 1), on any device: the sampled input rows are GATHERED where the tensors live (a copy,
+    no arithmetic) and every product and sum runs in float64 on the CPU; -> [P][OC] float64"""
     n, h, w, c, oh, ow, oc, kh, kw, stride, pad, transposed, wlayout = geo
     pn, py, px = pix
     acc = torch.zeros((pn.numel(), oc), dtype=torch.float64)
-    xb = xb[..., :c]
+    x2d = xb.reshape(n * h * w, xb.shape[-1])
     for r in range(kh):
         for s in range(kw):
             if transposed:   # out[i*stride - pad + r] += in[i] * w[r]
@@ -120,11 +121,12 @@ def _conv_ref64(xb, wp, geo, pix):
             if not ok.any():
                 continue
             t = r * kw + s
-            patch = xb[pn[ok], iy[ok], ix[ok]].double()                    # [P'][c]
+            rows = ((pn[ok] * h + iy[ok]) * w + ix[ok]).to(x2d.device)
+            patch = x2d.index_select(0, rows)[:, :c].cpu().double()            # [P'][c]
             if wlayout == 1:
-                wt = wp[0, :oc, 4 * t:4 * t + c].double()                  # [oc][c]
+                wt = wp[0, :oc, 4 * t:4 * t + c].cpu().double()                # [oc][c]
             else:
-                wt = wp[t, :oc, :c].double()
+                wt = wp[t, :oc, :c].cpu().double()
             acc[ok] += patch @ wt.t()
     return acc
 
@@ -135,11 +137,13 @@ def _epilogue64(v, flags, o, pix, oc):
     from crdr_amd.hip import lib as L
     pn, py, px = pix
 
-    def at(name):
-        return o[name][pn, py, px, :oc].double()
+    def at(name):   # (gathered on the operand's device, then float64 on the CPU)
+        t = o[name]
+        rows = ((pn * t.shape[1] + py) * t.shape[2] + px).to(t.device)
+        return t.reshape(-1, t.shape[-1]).index_select(0, rows)[:, :oc].cpu().double()
 
     def vec(name):
-        return o[name][:oc].double().view(1, -1)
+        return o[name][:oc].cpu().double().view(1, -1)
     sig = None
     if flags & L.EPI_PREADD:
         v = v + at("pre")
@@ -282,10 +286,10 @@ def _replay_conv(rp, key, algo, seed):
     geo = (n, h, w, c, oh, ow, oc, k[0], k[1], stride, pad, tr, wlayout)
     e64 = e64b = 0.0
     for g in sorted({0, G - 1}):
-        acc = _conv_ref64(xs[g].cpu(), wps[g].cpu(), geo, pix)
-        o = {"y0": y0[g].cpu()}
+        acc = _conv_ref64(xs[g], wps[g], geo, pix)
+        o = {"y0": y0[g]}
         for name, lst in opn.items():
-            o[name] = lst[g if len(lst) > 1 else 0].cpu()
+            o[name] = lst[g if len(lst) > 1 else 0]
         if alias_pre:
             o["pre"] = o["y0"]
         if self_res:
@@ -306,18 +310,15 @@ def _replay_conv(rp, key, algo, seed):
 def _wgrad_ref64(pb, qb, geo, isel, jsel):
     """g[i][j][t] = sum P[n,a,b,i] Q[n, a*stride - pad + r, b*stride - pad + s, j] in float64 for i in isel, j in jsel"""
     n, ph, pw, qh, qw, kh, kw, stride, pad = geo
-    P = pb[..., isel].double().reshape(-1, len(isel))                                # [M][I']
-    Q = qb[..., jsel].double()
+    P = pb.index_select(-1, torch.tensor(isel, device=pb.device)).cpu().double().reshape(-1, len(isel))   # [M][I'] (channel gather on the operand's device)
+    Q = qb.index_select(-1, torch.tensor(jsel, device=qb.device)).cpu().double()
     out = torch.zeros((len(isel), len(jsel), kh * kw), dtype=torch.float64)
-    a = torch.arange(ph) * stride - pad
-    b = torch.arange(pw) * stride - pad
+    ext = pad + kh + kw + stride   # zero border wide enough for every tap of every dense pixel
+    Qp = torch.nn.functional.pad(Q, (0, 0, ext, ext, ext, ext))
     for r in range(kh):
         for s in range(kw):
-            iy, ix = a + r, b + s
-            oky, okx = (iy >= 0) & (iy < qh), (ix >= 0) & (ix < qw)
-            g = torch.zeros((n, ph, pw, len(jsel)), dtype=torch.float64)
-            sub = Q[:, iy[oky]][:, :, ix[okx]]
-            g[:, oky.nonzero().view(-1, 1), okx.nonzero().view(1, -1)] = sub
+            y0, x0 = ext - pad + r, ext - pad + s
+            g = Qp[:, y0:y0 + stride * (ph - 1) + 1:stride, x0:x0 + stride * (pw - 1) + 1:stride]   # Q[n, a*stride - pad + r, b*stride - pad + s]
             out[:, :, r * kw + s] = P.t() @ g.reshape(-1, len(jsel))
     return out
 
@@ -370,7 +371,7 @@ def _replay_wgrad(rp, key, algo, seed):
     isel, jsel = _sel(gi, 32), _sel(gj, 32)
     e = eb = 0.0
     for g in sorted({0, G - 1}):
-        ref = _wgrad_ref64(ps[g].cpu(), qs[g].cpu(), (n, ph, pw, qh, qw, k[0], k[1], stride, pad), isel, jsel)
+        ref = _wgrad_ref64(ps[g], qs[g], (n, ph, pw, qh, qw, k[0], k[1], stride, pad), isel, jsel)
         rs = float(ref.abs().max()) + 1e-20
         pick = lambda t: t.cpu().double().reshape(gi, gj, T)[isel][:, jsel]
         e = max(e, float((pick(gt[g]) - ref).abs().max()) / rs)
