@@ -235,6 +235,20 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
   pl->stream = -1;
   pl->wino = 0;
   const int wino_variant = d->reserved != 0 ? (d->reserved & 0xff) - 1 - kNumCfgs - stream_num_variants() : -1;
+  if (wino_variant == 2) {   // forced: the Winograd F(4x4, 3x3) kernel (wino4.hip)
+    CRDR_REQUIRE(!fallback && wino4_eligible(d, G, true), "conv2d: forced F(4x4, 3x3) Winograd kernel: not a 3x3 stride-1 convolution it takes");
+    CRDR_REQUIRE(((d->reserved >> 8) & 0xf) == 0, "conv2d: the Winograd kernel has no split-K");
+    pl->wino = 3;
+    pl->cfg = -1;
+    a.nsplit = 1;
+    a.ws_ld = 0;
+    pl->grid = dim3(1, 1, 1);
+    pl->lds = 0;
+    a.cs_ld = round_up(d->OC, 32);
+    a.cs_rows = want_cs ? wino4_colsum_rows(d) : 0;
+    pl->ws_bytes = (size_t)CRDR_CONV_TICKETS * sizeof(int) + wino4_workspace(d, G);
+    return 0;
+  }
   if (wino_variant >= 0 && wino_variant < 2) {  // forced: the Winograd F(2x2, 3x3) kernel (wino.hip); variant 1 = pair tiles for a channel tail <= 32
     CRDR_REQUIRE(!fallback && wino_eligible(d, G), "conv2d: forced Winograd kernel: not a 3x3 / 5x5 stride-1 convolution it takes");
     CRDR_REQUIRE(wino_variant == 0 || wino_pairs_ok(d), "conv2d: Winograd pair-tile variant: needs a channel tail of 1..32 and more than one patch");
@@ -356,7 +370,7 @@ using namespace crdr;
 
 extern "C" int crdr_conv2d_num_configs(void) { return kNumCfgs; }
 extern "C" int crdr_conv2d_num_stream_configs(void) { return stream_num_variants(); }
-extern "C" int crdr_conv2d_num_wino_configs(void) { return 2; }
+extern "C" int crdr_conv2d_num_wino_configs(void) { return 3; }
 
 extern "C" size_t crdr_conv2d_workspace(const crdr_conv_desc* d) {
   Plan pl;
@@ -450,8 +464,11 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   a.fast_epi = (v && a.Cout % 4 == 0 && span < (1ll << 31) && !(a.flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_EPI_ACCUM))) ? 1 : 0;
   if (pl.wino) {
     void* prof = profile_begin(as_stream(s));
-    if (int rc = wino_launch(d, pl.wino - 1, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
-    profile_end(3, G * crdr_conv2d_flops(d), prof, as_stream(s));   // kind 3: filter transform + Winograd kernel, direct-convolution flop count
+    if (pl.wino == 3) {
+      if (int rc = wino4_launch(d, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
+    } else if (int rc = wino_launch(d, pl.wino - 1, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
+    // kind 3 / 5: filter transform + Winograd F(2x2, 3x3) / F(4x4, 3x3) kernel, direct-convolution flop count
+    profile_end(pl.wino == 3 ? 5 : 3, G * crdr_conv2d_flops(d), prof, as_stream(s));
     return 0;
   }
   if (pl.stream >= 0 && !a.vec_epi && d->reserved == 0) {

@@ -90,8 +90,9 @@ def _time_call(fn, reps: int = 2) -> float:
 WINOGRAD = __import__("os").environ.get("CRDR_WINOGRAD", "1") != "0"   # 0: the tuner never offers the Winograd kernel
 
 
-# Tests: every convolution the Winograd kernel accepts takes it (without the tuner, whose choice is per shape and speed): the
-# model-level parity tests run once more through it.
+# Tests: every convolution a Winograd kernel accepts takes it (without the tuner, whose choice is per shape and speed): the
+# model-level parity tests run once more through it.  True: the F(2x2, 3x3) kernel (variants 0 / 1); 4: the F(4x4, 3x3) kernel
+# (variant 2) where it applies, F(2x2, 3x3) elsewhere.
 PREFER_WINOGRAD = False
 
 
@@ -102,7 +103,8 @@ def _prefer_wino(d, G: int = 1) -> int:
     lib = L.load()
     keep, algo = d.reserved, 0
     base = lib.crdr_conv2d_num_configs() + 1 + lib.crdr_conv2d_num_stream_configs()
-    for v in reversed(range(lib.crdr_conv2d_num_wino_configs())):   # (the pair-tile variant where it applies)
+    nv = lib.crdr_conv2d_num_wino_configs() if PREFER_WINOGRAD == 4 else min(2, lib.crdr_conv2d_num_wino_configs())
+    for v in reversed(range(nv)):   # (F(4x4) / the pair-tile variant where they apply)
         d.reserved = base + v
         if lib.crdr_conv2d_choose_algo(C.byref(d), G) == d.reserved:
             algo = d.reserved

@@ -104,6 +104,119 @@ def test_winograd_epilogues_and_slices():
     _close(out, F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1), 0.2), "lrelu")
 
 
+W4_CASES = [
+    # name, N, Cin, H, W, Cout, pad   (F(4x4, 3x3): output tiles of 8 x 64 pixels x 32 channels, >= 48 output columns)
+    ("w4_96_96_64", 2, 96, 64, 64, 96, 1),
+    ("w4_128_128_ragged", 1, 128, 21, 70, 128, 1),      # partial tiles on both edges, 21 = 2 * 8 + 5 rows, 70 = 64 + 6 columns
+    ("w4_36_40_c4", 1, 36, 9, 50, 40, 1),               # channel tail of 4 (half a chunk), output channels not a multiple of 32
+    ("w4_64_160_valid", 1, 64, 18, 66, 160, 0),         # pad 0: 16 x 64 outputs
+    ("w4_256_64_128", 1, 256, 16, 128, 64, 1),          # two tile columns
+    ("w4_8_8_wide", 3, 8, 5, 48, 8, 1),
+]
+
+
+@pytest.mark.parametrize("case", W4_CASES, ids=[c[0] for c in W4_CASES])
+def test_winograd_f4x4_fwd_dgrad(case):
+    """Winograd F(4x4, 3x3) kernel (csrc/wino4.hip, Winograd variant 2) against fp64 torch: forward and input gradient.  Its transforms
+    carry the constants 4, 5, 8, 1/24: the deviation from fp64 is ~8x the direct kernel's (numpy model: 5e-6 .. 1e-5 of the output
+    scale at 96 .. 256 channels) and is gated at 5e-5; the measured errors of the three kernels are printed."""
+    from crdr_amd.hip import ops
+    name, n, ci, h, w, co, p = case
+    dev = _dev()
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(co, ci, 3, 3, seed=2, scale=(ci * 9) ** -0.5)
+    b = _rand(co, seed=3)
+    xr = x.double().requires_grad_(True)
+    ref = F.conv2d(xr, wt.double(), b.double(), padding=p)
+    oh, ow = ref.shape[2:]
+    dy = _rand(*ref.shape, seed=4)
+    ref.backward(dy.double())
+    xd, wd, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
+    wp = ops.pack_weight(wd, transpose=False)
+    a4 = _wino_id() + 2
+    direct = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=1)
+    w2 = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=_wino_id())
+    out = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=a4)
+    torch.cuda.synchronize()
+    sc = ref.abs().max().item()
+    e4 = (out.cpu().double() - ref.detach()).abs().max().item() / sc
+    e2 = (w2.cpu().double() - ref.detach()).abs().max().item() / sc
+    ed = (direct.cpu().double() - ref.detach()).abs().max().item() / sc
+    print(f"{name}: fwd max err / scale: F(4x4) {e4:.2e}  F(2x2) {e2:.2e}  direct {ed:.2e}")
+    _close(out, ref, name + " fwd", rtol=5e-5)
+    wq = ops.pack_weight(wd, transpose=True)
+    dx = ops.conv2d_raw(dyd, wq, ci, (3, 3), 1, p, True, (h, w), algo=a4) if w >= 48 else None
+    if dx is not None:
+        _close(dx, xr.grad, name + " dgrad", rtol=5e-5)
+    out2 = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=a4)
+    assert torch.equal(out, out2), "not deterministic"
+
+
+def test_winograd_f4x4_epilogues_slices_groups_colsum():
+    """every epilogue the F(4x4) kernel takes: bias + ReLU + vec2 + residual + affine, LeakyReLU, accumulate, ReLU-mask with column sums (the
+    input-gradient launches of a conv chain), channel slices in and out, a grouped launch"""
+    from crdr_amd.hip import lib as L
+    from crdr_amd.hip import ops
+    dev = _dev()
+    a4 = _wino_id() + 2
+    n, ci, h, w, co = 2, 64, 20, 72, 96
+    wide = _rand(n, ci + 32, h, w, seed=5).to(dev).contiguous(memory_format=torch.channels_last)
+    x = wide[:, 16:16 + ci]
+    wt = _rand(co, ci, 3, 3, seed=6, scale=(ci * 9) ** -0.5).to(dev)
+    b, v2, sc, sh = (_rand(co, seed=s).to(dev) for s in (7, 8, 9, 10))
+    res = _rand(n, co, h, w, seed=11).to(dev).contiguous(memory_format=torch.channels_last)
+    wp = ops.pack_weight(wt, transpose=False)
+    z = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    view = lambda t: t.double().view(1, -1, 1, 1)
+    flags = L.EPI_BIAS | L.EPI_RELU | L.EPI_VEC2 | L.EPI_RES | L.EPI_AFFINE
+    ref = (z.relu() + view(v2) + res.double()) * view(sc) + view(sh)
+    owide = torch.zeros(n, co + 40, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+    out = ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (h, w), bias=b, flags=flags, vec2=v2, res=res, scale=sc, shift=sh,
+                         out=owide[:, 8:8 + co], algo=a4)
+    torch.cuda.synchronize()
+    _close(out, ref, "epilogues", rtol=5e-5)
+    assert float(owide[:, :8].abs().max()) == 0.0 and float(owide[:, 8 + co:].abs().max()) == 0.0
+    out = ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (h, w), bias=b, flags=L.EPI_BIAS | L.EPI_LRELU, algo=a4)
+    _close(out, F.leaky_relu(z, 0.2), "lrelu", rtol=5e-5)
+    # accumulate into an existing tensor
+    acc0 = _rand(n, co, h, w, seed=12).to(dev).contiguous(memory_format=torch.channels_last)
+    acc = acc0.clone()
+    ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (h, w), bias=b, flags=L.EPI_BIAS | L.EPI_ACCUM, out=acc, algo=a4)
+    _close(acc, z + acc0.double(), "accumulate", rtol=5e-5)
+    # grouped launch with ReLU mask + column sums (conv_multi: what a chain's input-gradient launches look like), against the built-in plan
+    G = 2
+    xs = [_rand(n, h, w, ci, seed=20 + g).to(dev) for g in range(G)]
+    ws_ = [ops.pack_weight(_rand(co, ci, 3, 3, seed=30 + g, scale=(ci * 9) ** -0.5).to(dev), transpose=False) for g in range(G)]
+    masks = [_rand(n, h, w, co, seed=40 + g).to(dev) for g in range(G)]
+
+    def run(algo):
+        keep = ops.FORCED_CONV_ALGO
+        ops.FORCED_CONV_ALGO = algo
+        try:
+            ys = [torch.zeros(n, h, w, co, device=dev) for _ in range(G)]
+            q = ops.colsum_queue(dev)
+            r = ops.conv_multi(n, h, w, h, w, [ops.view(t, 0, ci) for t in xs], [t.data_ptr() for t in ws_], [ops.view(t, 0, co) for t in ys], co,
+                               (3, 3), 1, 1, False, wrows=ws_[0].shape[1], wcols=ws_[0].shape[2], masks=[ops.view(t, 0, co) for t in masks],
+                               flags=L.EPI_RELUMASK, colsum=True, device=dev)
+            cs = []
+            for ptr, rows, ld in r:
+                off = ptr - q.arena.data_ptr()
+                cs.append(q.arena[off:off + rows * 2 * ld * 4].view(torch.float32).view(rows, 2, ld).double().sum(0)[:, :co].clone())
+            q.off, q.jobs, q.scratch_off = 0, [], 0
+            torch.cuda.synchronize()
+            return ys, cs
+        finally:
+            ops.FORCED_CONV_ALGO = keep
+    yb, cb = run(1)
+    y4, c4 = run(a4)
+    for g in range(G):
+        _close(y4[g], yb[g], f"grouped masked output {g}", rtol=5e-5)
+        _close(c4[g], cb[g], f"grouped column sums {g}", rtol=5e-5)
+        refg = F.conv2d(xs[g].permute(0, 3, 1, 2).double().cpu(), ws_[g][:, :co, :ci].permute(1, 2, 0).reshape(co, ci, 3, 3).double().cpu(), padding=1)
+        refg = torch.where(masks[g].permute(0, 3, 1, 2).cpu() > 0, refg, torch.zeros_like(refg))
+        _close(y4[g].permute(0, 3, 1, 2), refg, f"grouped masked output {g} vs fp64", rtol=5e-5)
+
+
 def test_winograd_rejects_other_shapes():
     from crdr_amd.hip import lib as L
     from crdr_amd.hip import ops
@@ -115,6 +228,11 @@ def test_winograd_rejects_other_shapes():
     w3 = ops.pack_weight(_rand(32, 32, 3, 3, seed=2).to(dev), transpose=False)
     with pytest.raises(L.CrdrHipError):
         ops.conv2d_raw(x, w3, 32, (3, 3), 2, 1, False, (4, 4), algo=_wino_id())
+    with pytest.raises(L.CrdrHipError):   # F(4x4, 3x3): fewer than 48 output columns
+        ops.conv2d_raw(x, w3, 32, (3, 3), 1, 1, False, (8, 8), algo=_wino_id() + 2)
+    with pytest.raises(L.CrdrHipError):   # no 5x5 sub-filter form
+        w5 = ops.pack_weight(_rand(32, 32, 5, 5, seed=2).to(dev), transpose=False)
+        ops.conv2d_raw(_rand(1, 32, 8, 64, seed=1).to(dev), w5, 32, (5, 5), 1, 2, False, (8, 64), algo=_wino_id() + 2)
 
 
 WG_CASES = [

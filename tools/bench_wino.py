@@ -67,8 +67,15 @@ def main():
             best = min(best, (t, cfg))
         tw = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (kk, kk), 1, kk // 2, False, (hw, hw), bias=b, flags=3, algo=wid), reps=3)
         fl = 2.0 * a.bs * hw * hw * ci * co * kk * kk
+        t4 = None
+        if kk == 3 and lib.crdr_conv2d_num_wino_configs() > 2:
+            try:   # F(4x4, 3x3) (wino4.hip): wide images only
+                t4 = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (kk, kk), 1, kk // 2, False, (hw, hw), bias=b, flags=3, algo=wid + 2), reps=3)
+            except L.CrdrHipError:
+                pass
+        f4 = f"   F(4x4) {t4 * 1e3:8.1f} us ({fl / t4 / 1e9:6.1f} TF-eq) x{best[0] / t4:.2f}" if t4 else ""
         print(f"{ci:4d}->{co:4d} @{hw:3d}: direct {best[0] * 1e3:8.1f} us ({fl / best[0] / 1e9:6.1f} TF, cfg {best[1]})   winograd {tw * 1e3:8.1f} us "
-              f"({fl / tw / 1e9:6.1f} TF-eq)   x{best[0] / tw:.2f}", flush=True)
+              f"({fl / tw / 1e9:6.1f} TF-eq)   x{best[0] / tw:.2f}{f4}", flush=True)
 
 
 if __name__ == "__main__":
