@@ -1,5 +1,5 @@
-// Winograd F(4x4, 3x3) convolution on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32) for the 3x3 stride-1 layers at >= 64 pixels
-// of width (elic_layers.py:23-36, cheng_nlam.py:31-46, clic21_gvae_discriminator.py:27-40) and their input gradients:
+// Winograd F(4x4, 3x3) convolution on the exact-fp32 matrix cores for the 3x3 stride-1 layers at >= 48 output columns
+// (elic_layers.py:23-36, cheng_nlam.py:31-46, clic21_gvae_discriminator.py:27-40) and their input gradients:
 //   Y = A^T [ (G g G^T) . (B^T d B) ] A   with 6x6 transforms (Lavin & Gray 2016, interpolation points 0, +-1, +-2, inf):
 // 36 element-wise products per 4x4 outputs and channel pair instead of 144 -- 4x fewer MFMAs than the implicit GEMM, 1.78x fewer
 // than the F(2x2, 3x3) kernel of wino.hip.  Arithmetic is fp32 throughout (the filter transform is evaluated in double and rounded
@@ -7,20 +7,20 @@
 // of the output scale at 96 .. 256 input channels (the direct kernels: ~1e-6): a tuner candidate for TRAINING launches only (the
 // codec never runs tuned plans), behind the forced-algorithm id of Winograd variant 2, tests/test_gpu_wino.py.
 //
-// One output tile = 8 rows x 64 columns of output pixels (2 x 16 Winograd tiles of 4 x 4 = the 32 MFMA columns) of one image x 32
-// output channels, on FOUR waves (one per SIMD: 512 registers each, no co-resident wave to share the matrix pipe with):
-//   wave (ph, pw): transform rows xi in {3 ph .. 3 ph + 2}, columns nu in {3 pw .. 3 pw + 2}: 9 of the 36 positions, i.e. 9
-//   accumulator blocks of 32 channels x 32 tiles.  MFMA operand A = filter fragment (row = channel), B = transformed data (column =
-//   tile): a lane ends up with 16 channels (4 groups of 4 consecutive ones) of ONE tile, so the epilogue works with 16-byte accesses.
-// K loop: sub-steps of 8 input channels, one barrier each, operands double buffered in LDS and filled by LDS-DMA:
+// One output tile = 8 rows x 64 columns of output pixels (2 x 16 Winograd tiles of 4 x 4) of one image x 32 output channels, on FOUR
+// waves (one per SIMD: 512 registers each), all running the SAME code: wave (th, oh) owns the 16 tiles of tile row th x the 16
+// channels of half oh x ALL 36 transform positions = 36 accumulator blocks of v_mfma_f32_16x16x4_f32 (A = filter fragment: row =
+// channel; B = transformed data: column = tile).  A lane ends up with 4 consecutive channels of ONE tile at all 36 positions: the
+// output transform is pure register arithmetic (no hand-over between waves) and the epilogue works with 16-byte accesses.
+// (A first version split the positions over the waves -- 9 per wave, MFMA 32x32x2 -- and lost to its epilogue: four role-specialised
+// copies of the output transform + a four-pass LDS hand-over did not fit the instruction cache, 400-470 us where this form takes less.)
+// K loop: sub-steps of 8 input channels, one barrier each; LDS holds three raw-patch buffers and two filter buffers filled by LDS-DMA:
 //   * the raw 10 x 66 x 8 input patch, stored by pixel class (row & 3, column & 3): [half h = channels 4h..4h+3][class 16][3 rows][17
-//     slots]; the 16 tiles of a tile row read patch pixel (i, j) from 16 consecutive 16-byte slots (conflict free);
-//   * the transformed filters of the sub-step: [position 36][h][channel 32][4] = 36 KiB, contiguous in memory and in LDS.
-//   Every wave reads the 5 x 5 patch pixels its 3 x 3 positions depend on (rows ph .. ph + 4, columns pw .. pw + 4), applies the
-//   two 1-D transforms in registers (6 fma-class operations per 5 inputs and 3 outputs) and issues 36 MFMAs.
-// Epilogue: every wave forms its part of A^T M A for all 16 output pixels of a tile (partial sums over its own xi, nu); wave w
-// finishes output row w of every tile: three rounds of hand-over through LDS in fixed order, then the element-wise epilogue of
-// the implicit-GEMM kernel (same order of operations) with 16-byte buffer loads / stores.
+//     slots of 16 B]; lane (tile tx, channel pair kg) reads 8 bytes of patch pixel (i, j): the 16 tiles of a row x 2 pairs of a half
+//     cover 256 consecutive bytes (conflict free);
+//   * the transformed filters of the sub-step: [position 36][channel pair 4][channel 32][2] = 36 KiB, contiguous in memory and in LDS.
+//   Every lane transforms the 6 x 6 patch of its tile for its 2 channels in registers (12 fma-class operations per 1-D transform)
+//   and the wave issues 72 MFMAs; the work is laid out by hand in 72 slots of one MFMA + its share of loads / transform / DMA.
 #include <algorithm>
 #include <atomic>
 
@@ -34,14 +34,13 @@ namespace {
 
 constexpr int kNT4 = 256;
 constexpr int kTY = 2, kTX = 16;                       // Winograd tiles per output tile (rows, columns)
-constexpr int kInUsed4 = 2 * 16 * 3 * 17;              // 16-byte slots of the input patch image per stage
+constexpr int kInUsed4 = 2 * 16 * 3 * 17;              // 16-byte slots of the input patch image per buffer
 constexpr int kInPieces = 28;                          // DMA instructions (1 KiB each) for it: 26 needed, 28 = 7 per wave (uniform vmcnt counts)
 constexpr int kInSlots4 = kInPieces * 64;
 constexpr int kUSlots4 = 36 * 2 * 32;                  // slots of one filter block (8 channels x 32 output channels): 36 pieces
 constexpr int kRawBufs = 3, kFiltBufs = 2;            // raw patches are requested two sub-steps ahead (they come from HBM), filters one (L2)
-constexpr int kRingFloats4 = (kRawBufs * kInSlots4 + kFiltBufs * kUSlots4) * 4;
-constexpr int kXFloats4 = 4 * 4 * 4 * 64 * 4;          // hand-over area of the epilogue: [destination 4][source 4][4][64 lanes][4] floats (64 KiB), in the filter buffers
-constexpr int kLdsFloats4 = (kRingFloats4 > kXFloats4 ? kRingFloats4 : kXFloats4);
+constexpr int kRF = kInSlots4 * 4, kFF = kUSlots4 * 4;   // floats of a raw buffer / a filter buffer
+constexpr int kLdsFloats4 = kRawBufs * kRF + kFiltBufs * kFF;
 
 __device__ __forceinline__ void lds_barrier4() {
   __builtin_amdgcn_sched_barrier(0);
@@ -50,22 +49,29 @@ __device__ __forceinline__ void lds_barrier4() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// 1-D data transform, three of the six outputs of B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],
-// [0,4,0,-5,0,1]] from the five inputs they depend on.  HALF 0: outputs 0, 1, 2 from inputs d0..d4; HALF 1: outputs 3, 4, 5 from
-// inputs d1..d5 (passed as e0..e4).
-template <int HALF>
-__device__ __forceinline__ void bt6(const f32x4 e0, const f32x4 e1, const f32x4 e2, const f32x4 e3, const f32x4 e4, f32x4 (&o)[3]) {
-  if constexpr (HALF == 0) {
-    const f32x4 a = e4 - 4.0f * e2, b = e3 - 4.0f * e1;
-    o[0] = 4.0f * e0 + (e4 - 5.0f * e2);
-    o[1] = a + b;
-    o[2] = a - b;
-  } else {   // e0..e4 = d1..d5
-    const f32x4 c = e3 - e1, e = e2 - e0;
-    o[0] = c + 2.0f * e;
-    o[1] = c - 2.0f * e;
-    o[2] = 4.0f * e0 + (e4 - 5.0f * e2);
-  }
+// 1-D data transform B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]] on scalars: packed
+// f32 instructions issued beside MFMAs cost several times their scalar pair on this part (MI355X_MICROARCH.md, 'price of one filler
+// beside MFMAs'), so the K loop works on scalars (the file is compiled with -fno-slp-vectorize).  12 operations.
+__device__ __forceinline__ void bt6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
+                                    float& o0, float& o1, float& o2, float& o3, float& o4, float& o5) {
+  const float a = __builtin_fmaf(-4.0f, d2, d4), b = __builtin_fmaf(-4.0f, d1, d3);
+  const float c = d4 - d2, e = d3 - d1;
+  o0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
+  o1 = a + b;
+  o2 = a - b;
+  o3 = __builtin_fmaf(2.0f, e, c);
+  o4 = __builtin_fmaf(-2.0f, e, c);
+  o5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
+}
+
+// 1-D output transform A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]: 10 operations
+__device__ __forceinline__ void at6(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
+                                    float& o0, float& o1, float& o2, float& o3) {
+  const float p = m1 + m2, q = m1 - m2, u = m3 + m4, w = m3 - m4;
+  o0 = m0 + p + u;
+  o1 = __builtin_fmaf(2.0f, w, q);
+  o2 = __builtin_fmaf(4.0f, u, p);
+  o3 = __builtin_fmaf(8.0f, w, q) + m5;
 }
 
 struct Wino4Tile { int gidx, n, oh0, ow0, n0, patch; };
@@ -102,23 +108,6 @@ __device__ __forceinline__ unsigned wino4_in_off(const IgemmArgs& p, const Wino4
   return ok ? (unsigned)((((t.n * p.H + ih) * p.W + iw) * p.ldx + 4 * h) * 4) : kOobOffset;
 }
 
-// scalar forms of the 1-D data transform (bt6 above on one component): packed f32 instructions issued beside MFMAs cost several
-// times their scalar pair on this part (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'), so the K loop works on scalars
-template <int HALF>
-__device__ __forceinline__ void bt6s(const float e0, const float e1, const float e2, const float e3, const float e4, float& o0, float& o1, float& o2) {
-  if constexpr (HALF == 0) {
-    const float a = __builtin_fmaf(-4.0f, e2, e4), b = __builtin_fmaf(-4.0f, e1, e3);
-    o0 = __builtin_fmaf(4.0f, e0, __builtin_fmaf(-5.0f, e2, e4));
-    o1 = a + b;
-    o2 = a - b;
-  } else {   // e0..e4 = d1..d5
-    const float c = e3 - e1, e = e2 - e0;
-    o0 = __builtin_fmaf(2.0f, e, c);
-    o1 = __builtin_fmaf(-2.0f, e, c);
-    o2 = __builtin_fmaf(4.0f, e0, __builtin_fmaf(-5.0f, e2, e4));
-  }
-}
-
 // where the DMA of one output tile reads: descriptors of its image tensor and filter blocks, this lane's seven raw-piece offsets
 struct Wino4Src {
   __amdgpu_buffer_rsrc_t rx, ru;
@@ -131,129 +120,120 @@ __device__ __forceinline__ void wino4_dma_raw(float* smem, const Wino4Src& sr, i
   const int piece = wave + 4 * j;
   unsigned off = live ? sr.a_off[j] : kOobOffset;
   if (kr * 8 + 8 > Cin && (piece * 64 + lane) >= 16 * 51) off = kOobOffset;   // the chunk's upper half lies past Cin
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.rx, (lds_ptr_t)(smem + rbuf * (kInSlots4 * 4) + piece * 256), 16, (int)off, (int)(kr * 32), 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.rx, (lds_ptr_t)(smem + rbuf * kRF + piece * 256), 16, (int)off, (int)(kr * 32), 0, 0);
 }
 // filter piece 9 wave + j (j = 0..8) of block kf -> F[kf & 1]
 __device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, int j, int kf, bool live, int lane, int wave) {
   const int piece = wave * 9 + j;
   const unsigned off = live ? (unsigned)((piece * 64 + lane) * 16) : kOobOffset;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.ru, (lds_ptr_t)(smem + kRawBufs * (kInSlots4 * 4) + (kf & 1) * (kUSlots4 * 4) + piece * 256), 16, (int)off,
-                                           (int)(sr.u_off0 + (unsigned)kf * (kUSlots4 * 16u)), 0, 0);
+  // (u_off0 is wave-uniform; said so explicitly, or the compiler wraps every request in a waterfall loop over the scalar offset)
+  const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)sr.u_off0) + (unsigned)kf * (kUSlots4 * 16u);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.ru, (lds_ptr_t)(smem + kRawBufs * kRF + (kf & 1) * kFF + piece * 256), 16, (int)off, (int)so, 0, 0);
 }
-
-// the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and / or filter block 0 (-> F0)
-__device__ __forceinline__ void wino4_prologue_dma(float* smem, const Wino4Src& sr, int Cin, int K8, int lane, int wave, bool raw, bool filt) {
-  if (raw) {
+// the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and filter block 0 (-> F0)
+__device__ __forceinline__ void wino4_prologue_dma(float* smem, const Wino4Src& sr, int Cin, int K8, int lane, int wave) {
 #pragma unroll
-    for (int kr = 0; kr < 3; ++kr)
+  for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
-      for (int j = 0; j < 7; ++j) wino4_dma_raw(smem, sr, Cin, j, kr, kr, kr < K8, lane, wave);
-  }
-  if (filt) {
+    for (int j = 0; j < 7; ++j) wino4_dma_raw(smem, sr, Cin, j, kr, kr, kr < K8, lane, wave);
 #pragma unroll
-    for (int j = 0; j < 9; ++j) wino4_dma_filt(smem, sr, j, 0, true, lane, wave);
-  }
+  for (int j = 0; j < 9; ++j) wino4_dma_filt(smem, sr, j, 0, true, lane, wave);
 }
 
 // K loop of one wave (the only wave of its SIMD: nothing else hides its latencies, so the loop is software pipelined by hand).
-// LDS: three raw-patch buffers R0..R2 and two filter buffers F0, F1.  Sub-step k multiplies V_k (registers) with the filters of F[k & 1];
-// in the shadow of those 36 MFMAs the wave reads raw patch k + 1 from R[(k + 1) % 3] and transforms it into V_{k+1}, and issues the DMA of
-// filters k + 1 (-> F[(k + 1) & 1], last read in sub-step k - 1; they come out of L2) and of raw patch k + 3 (-> R[k % 3], last read in
-// sub-step k - 1; raw patches come from HBM / the Infinity Cache: with one sub-step of lead the loop stood waiting for them).  The
-// sub-step ends with vmcnt(7) + barrier: the seven raw pieces just requested stay in flight, everything older has landed.
-// The body is laid out as 36 slots of one MFMA + its share of the other work, pinned by sched_barrier:
-//   slot s: MFMA of position j = s / 4 (row x = j / 3), channel pair s % 4; filter fragment j + 2 requested at slot 4 j + 3;
-//   raw column b (5 pixels) requested in slots 4 b .. 4 b + 2, its vertical transform in slots 4 b + 4 .. 4 b + 7 (one component each);
-//   horizontal transform of row 0 / row 1 of V_{k+1} in slots 24..27 / 28..31 (straight into the registers of V_k's rows, whose MFMAs
-//   are done by then); row 2 follows at the top of the next sub-step (its MFMAs run last); DMA instructions in slots 0..15.
-template <int PH, int PW>
-__device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, const Wino4Src& sr, bool prefetched, int lane, int wave, f32x16 (&acc)[3][3]) {
+// LDS: raw-patch buffers R0..R2, filter buffers F0, F1.  Sub-step k multiplies V_k (registers) with the filters of F[k & 1]; in the
+// shadow of those 72 MFMAs the wave reads raw patch k + 1 from R[(k + 1) % 3] and transforms it into V_{k+1}, and issues the DMA of
+// filter block k + 1 (-> F[(k + 1) & 1], last read in sub-step k - 1; filters come out of L2) and of raw patch k + 3 (-> R[k % 3], last
+// read in sub-step k - 1; raw patches come from HBM / the Infinity Cache).  The sub-step ends with vmcnt(7) + barrier: the seven raw
+// pieces just requested stay in flight, everything older has landed.  72 slots, pinned by sched_barrier:
+//   slot s: MFMA of position j = s / 2 (transform row x = j / 6), channel s % 2 of the lane's pair; filter fragment j + 2 requested at
+//   slot 2 j + 1; raw column b (6 pixels) requested in slots 6 b .. 6 b + 5, its vertical transform (two channels) in slots
+//   6 b + 6 .. 6 b + 11; horizontal transform of row x < 5 of V_{k+1} in slots 42 + 6 x .. 47 + 6 x -- straight into the registers of
+//   V_k's row x, whose MFMAs (slots 12 x .. 12 x + 11) are done by then; row 5 follows at the top of the next sub-step; DMA
+//   instruction q at slot 4 q + 1.
+__device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, const Wino4Src& sr, bool prefetched, int lane, int wave, f32x4 (&acc)[36]) {
   const int K8 = p.kchunks;
-  const int m = lane & 31, fh = lane >> 5;
-  const int ty = m >> 4, tx = m & 15;
-  constexpr int kRF = kInSlots4 * 4, kFF = kUSlots4 * 4;   // floats of a raw buffer / a filter buffer
-  // this lane's raw reads: patch pixel (PH + a, PW + b), a, b < 5, of tile (ty, tx) sits at float offset rbase + ro(a, b) of a raw buffer
-  const int rbase = ((fh * 48 + ty) * 17 + tx) * 4;
-  auto ro = [](int a, int b) constexpr { return ((((PH + a) & 3) * 4 + ((PW + b) & 3)) * 51 + ((PH + a) >> 2) * 17 + ((PW + b) >> 2)) * 4; };
-  const int fbase = kRawBufs * kRF + (fh * 32 + m) * 4;   // filter fragment of position pos: + (k & 1) * kFF + pos * 256
-  constexpr int pos0 = (3 * PH) * 6 + 3 * PW;      // position (x, y) of this wave: pos0 + 6 x + y
+  const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
+  // this lane's raw reads: patch pixel (i, j) of tile (th, tx), channels 2 kg, 2 kg + 1: float offset rbase + ro(i, j) of a raw buffer
+  const int rbase = (((kg >> 1) * 48 + th) * 17 + tx) * 4 + (kg & 1) * 2;
+  auto ro = [](int i, int j) constexpr { return (((i & 3) * 4 + (j & 3)) * 51 + (i >> 2) * 17 + (j >> 2)) * 4; };
+  // filter fragment of position pos (channel 16 oh + tx, channels 2 kg, 2 kg + 1 of the sub-step): + (k & 1) * kFF + pos * 256
+  const int fbase = kRawBufs * kRF + ((kg * 32) + 16 * oh + tx) * 2;
 
-  // DMA instruction q (0..15) of this wave in sub-step k: q < 9: filter piece q of block k + 1; else raw piece q - 9 of patch k + 3
-  // (filters first: the sub-step's closing vmcnt(7) then covers them and leaves the raw pieces in flight)
-  auto dma = [&](int q, int k, int rbuf, bool live_f, bool live_r) __attribute__((always_inline)) {
-    if (q < 9) wino4_dma_filt(smem, sr, q, k + 1, live_f, lane, wave);
-    else wino4_dma_raw(smem, sr, p.Cin, q - 9, k + 3, rbuf, live_r, lane, wave);
-  };
-
-  float t[3][5][4];   // vertical pass of the patch being transformed
-  float v[3][3][4];   // V of the current sub-step (rows 0, 1: replaced in place by the next one's during the sub-step)
-  f32x4 dcol[2][5];   // raw pixels of one patch column, double buffered by column parity
-  auto vread = [&](const float* rp, int b, int a) __attribute__((always_inline)) { dcol[b & 1][a] = *reinterpret_cast<const f32x4*>(rp + ro(a, b)); };
+  float t[6][6][2];   // vertical pass of the patch being transformed: [xi][column][channel]
+  float v[6][6][2];   // V of the current sub-step (rows 0..4: replaced in place by the next one's during the sub-step)
+  f32x2 dcol[2][6];   // raw pixels of one patch column (two channels), double buffered by column parity
+  auto vread = [&](const float* rp, int b, int i) __attribute__((always_inline)) { dcol[b & 1][i] = *reinterpret_cast<const f32x2*>(rp + ro(i, b)); };
   auto vpass = [&](int b, int c) __attribute__((always_inline)) {
-    bt6s<PH>(dcol[b & 1][0][c], dcol[b & 1][1][c], dcol[b & 1][2][c], dcol[b & 1][3][c], dcol[b & 1][4][c], t[0][b][c], t[1][b][c], t[2][b][c]);
+    bt6(dcol[b & 1][0][c], dcol[b & 1][1][c], dcol[b & 1][2][c], dcol[b & 1][3][c], dcol[b & 1][4][c], dcol[b & 1][5][c],
+        t[0][b][c], t[1][b][c], t[2][b][c], t[3][b][c], t[4][b][c], t[5][b][c]);
   };
   auto hpass = [&](int x, int c) __attribute__((always_inline)) {
-    bt6s<PW>(t[x][0][c], t[x][1][c], t[x][2][c], t[x][3][c], t[x][4][c], v[x][0][c], v[x][1][c], v[x][2][c]);
+    bt6(t[x][0][c], t[x][1][c], t[x][2][c], t[x][3][c], t[x][4][c], t[x][5][c], v[x][0][c], v[x][1][c], v[x][2][c], v[x][3][c], v[x][4][c], v[x][5][c]);
   };
 
-  // ---- prologue: filters 0 and patches 0, 1, 2 (requested by the previous tile's epilogue where there was one: then at least 16
-  // younger vector-memory operations -- that tile's stores -- are in flight and need not be waited for); V_0 rows 0, 1 and the vertical
-  // pass of row 2
+  // ---- prologue: filter block 0 and patches 0, 1, 2 (requested by the previous tile's epilogue where there was one: then at least 16
+  // younger vector-memory operations -- that tile's stores -- are in flight and need not be waited for); V_0 rows 0..4 and the
+  // vertical pass of row 5
   if (!prefetched) {
-    wino4_prologue_dma(smem, sr, p.Cin, K8, lane, wave, true, true);
-    __builtin_amdgcn_s_waitcnt(0xC07F & ~0xC00F);   // vmcnt(0)
+    wino4_prologue_dma(smem, sr, p.Cin, K8, lane, wave);
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
   } else {
-    __builtin_amdgcn_s_waitcnt((0xC07F & ~0xC00F) | 0x4000);   // vmcnt(16)
+    __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16)
   }
   lds_barrier4();
   {
     const float* rp = smem + rbase;
 #pragma unroll
-    for (int b = 0; b < 5; ++b) {
+    for (int b = 0; b < 6; ++b) {
 #pragma unroll
-      for (int a = 0; a < 5; ++a) vread(rp, b, a);
+      for (int i = 0; i < 6; ++i) vread(rp, b, i);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) vpass(b, c);
+      for (int c = 0; c < 2; ++c) vpass(b, c);
     }
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < 5; ++x)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) hpass(x, c);
+      for (int c = 0; c < 2; ++c) hpass(x, c);
   }
 
   int r1 = 1, r0 = 0;   // raw buffer of patch k + 1 / of patch k (= the one patch k + 3 goes to)
   for (int k = 0; k < K8; ++k) {
-    const float* rp = smem + rbase + r1 * kRF;                      // raw patch k + 1
-    const float* fp = smem + fbase + (k & 1) * kFF + pos0 * 256;    // filters k
+    const float* rp = smem + rbase + r1 * kRF;            // raw patch k + 1
+    const float* fp = smem + fbase + (k & 1) * kFF;       // filter block k
     const bool live1 = k + 1 < K8, live3 = k + 3 < K8;
-    f32x4 uf[3];
-    uf[0] = *reinterpret_cast<const f32x4*>(fp);
-    uf[1] = *reinterpret_cast<const f32x4*>(fp + 1 * 256);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) hpass(2, c);   // row 2 of V_k (its vertical pass was done during the previous sub-step)
+    f32x2 uf[4];
+    uf[0] = *reinterpret_cast<const f32x2*>(fp);
+    uf[1] = *reinterpret_cast<const f32x2*>(fp + 1 * 256);
+    hpass(5, 0);   // row 5 of V_k (its vertical pass was done during the previous sub-step; its MFMAs are the last ones)
+    hpass(5, 1);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 36; ++s) {
-      const int j = s >> 2, c = s & 3, x = j / 3, y = j - 3 * x;
-      acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[j % 3][c], v[x][y][c], acc[x][y], 0, 0, 0);
-      if (c == 3 && j + 2 < 9) uf[(j + 2) % 3] = *reinterpret_cast<const f32x4*>(fp + ((j + 2) / 3 * 6 + (j + 2) % 3) * 256);
-      // raw column b: pixels 0, 1 requested at slot 4 b, 2, 3 at 4 b + 1, 4 at 4 b + 2 (into the buffer the vertical pass of column b - 2
-      // finished with at slot 4 b - 1); vertical pass of column b at slots 4 b + 4 + c
-      if (s < 20) {
-        const int b = s >> 2;
-        if ((s & 3) == 0) { vread(rp, b, 0); vread(rp, b, 1); }
-        if ((s & 3) == 1) { vread(rp, b, 2); vread(rp, b, 3); }
-        if ((s & 3) == 2) vread(rp, b, 4);
+#pragma clang loop unroll(full)
+    for (int s = 0; s < 72; ++s) {
+      const int j = s >> 1, c = s & 1, x = j / 6, y = j - 6 * x;
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[j & 3][c], v[x][y][c], acc[j], 0, 0, 0);
+      if (c == 1 && j + 2 < 36) uf[(j + 2) & 3] = *reinterpret_cast<const f32x2*>(fp + (j + 2) * 256);
+      if (s < 36) vread(rp, s / 6, s % 6);                                          // raw column b = s / 6, pixel s % 6
+      if (s >= 6 && s < 42) {                                                       // vertical pass of column (s - 6) / 6: 24 operations over 6 slots
+        const int b = (s - 6) / 6, part = (s - 6) % 6;
+        if (part == 0) vpass(b, 0);
+        if (part == 3) vpass(b, 1);
       }
-      if (s >= 4 && s < 24) vpass((s - 4) >> 2, (s - 4) & 3);
-      if (s >= 24 && s < 32) hpass((s - 24) >> 2, (s - 24) & 3);
-      if (s < 16) dma(s, k, r0, live1, live3);
+      if (s >= 42) {                                                                // horizontal pass of row (s - 42) / 6
+        const int xr = (s - 42) / 6, part = (s - 42) % 6;
+        if (part == 0) hpass(xr, 0);
+        if (part == 3) hpass(xr, 1);
+      }
+      if ((s & 3) == 1 && (s >> 2) < 16) {
+        const int q = s >> 2;
+        if (q < 9) wino4_dma_filt(smem, sr, q, k + 1, live1, lane, wave);
+        else wino4_dma_raw(smem, sr, p.Cin, q - 9, k + 3, r0, live3, lane, wave);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     r0 = r1;
     r1 = r1 == 2 ? 0 : r1 + 1;
-    // filters k + 1 (and everything older: patch k + 2) have landed; the seven raw pieces of patch k + 3 stay in flight
-    __builtin_amdgcn_sched_barrier(0);
+    // filter block k + 1 (and everything older: patch k + 2) has landed; the seven raw pieces of patch k + 3 stay in flight
     __builtin_amdgcn_s_waitcnt(0x0077);   // vmcnt(7) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -270,170 +250,161 @@ __device__ __forceinline__ float acc_read(float v) {
   return o;
 }
 
-// Output transform rows of A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]] restricted to a wave's three transform
-// indices: HALF 0: indices 0, 1, 2; HALF 1: indices 3, 4, 5.  o[a] = sum_x AT[a][3 HALF + x] m[x].
-template <int HALF>
-__device__ __forceinline__ void at6(const float m0, const float m1, const float m2, float (&o)[4]) {
-  if constexpr (HALF == 0) {
-    const float s = m1 + m2, d = m1 - m2;
-    o[0] = m0 + s; o[1] = d; o[2] = s; o[3] = d;
-  } else {
-    const float s = m0 + m1, d = m0 - m1;
-    o[0] = s; o[1] = 2.0f * d; o[2] = 4.0f * s; o[3] = 8.0f * d + m2;
-  }
-}
-
-template <int PH, int PW, typename AfterHandover>
-__device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile& tl, float* smem, const float* sV, int lane, f32x16 (&acc)[3][3],
-                                             AfterHandover after_handover) {
-  // This wave's partial sums of all 16 output pixels (a, b) of its tiles: row a = wave stays in registers (own[b][r]), the other three
-  // rows go to the waves that finish them, through LDS, in four passes of 4 accumulator registers each (16-byte accesses):
-  // sX[destination wave 4][source wave 4][b 4][64 lanes][4 registers] = 64 KiB, placed in the filter buffers (the raw buffers already
-  // receive the next tile's first patches); the source = destination blocks are not used.
-  constexpr int kMe = 2 * PH + PW;   // = wave
-  float own[4][16];
-  float* sX = smem + kRawBufs * kInSlots4 * 4;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 part[4][4];   // [a][b]: registers 4 q .. 4 q + 3
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const int r = 4 * q + r4;
-      float sv[3][4];   // sv[y][a]: vertical output transform of position column y
-#pragma unroll
-      for (int y = 0; y < 3; ++y) at6<PH>(acc_read(acc[0][y][r]), acc_read(acc[1][y][r]), acc_read(acc[2][y][r]), sv[y]);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        float yb[4];
-        at6<PW>(sv[0][a], sv[1][a], sv[2][a], yb);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) part[a][b][r4] = yb[b];
-      }
-      __builtin_amdgcn_sched_barrier(0);   // (one accumulator register at a time: the accumulators live in the other register file)
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (a == kMe) {
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) own[b][4 * q + r4] = part[a][b][r4];
-        } else {
-          *reinterpret_cast<f32x4*>(sX + ((((a * 4 + kMe) * 4 + b) * 64 + lane) * 4)) = part[a][b];
-        }
-      }
-    lds_barrier4();
-#pragma unroll
-    for (int src = 0; src < 4; ++src) {   // fixed order of the sum: own part, then the other waves in ascending order
-      if (src == kMe) continue;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(sX + ((((kMe * 4 + src) * 4 + b) * 64 + lane) * 4));
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) own[b][4 * q + r4] += o[r4];
-      }
-    }
-    lds_barrier4();   // (the next pass overwrites the area)
-  }
-  after_handover();   // (the filter buffers are free again: the next tile's first filter block is requested here)
-
-  // ---- element-wise epilogue + stores (order of operations: epilogue_store of igemm_kernel.hpp).  This lane: tile (ty, tx), output
-  // row `wave` of it, pixels b = 0..3, channels n0 + 8 g + 4 fh + e (register r = 4 g + e).  One channel group g at a time (keeps the
-  // live registers of this part small: the accumulators still sit in the other half of the register file), the residual / mask /
-  // accumulate operands of group g + 1 requested before group g is computed.
+// Output transform + element-wise epilogue + stores of one wave: lane (tile tx of row th, channel group kg) holds M[36] for channels
+// n0 + 16 oh + 4 kg + r, r < 4.  Order of the element-wise operations: epilogue_store of igemm_kernel.hpp.
+__device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile& tl, float* smem, const float* sV, int lane, int wave, f32x4 (&acc)[36]) {
   const int f = p.flags;
   const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
   const bool do_cs = (f & CRDR_EPI_COLSUM) != 0, accum = (f & CRDR_EPI_ACCUM) != 0;
-  const int m = lane & 31, fh = lane >> 5, ty = m >> 4, tx = m & 15;
-  const int oy = tl.oh0 + 4 * ty + kMe, ox0 = tl.ow0 + 4 * tx;
-  const bool row_ok = oy < p.OH;
-  const unsigned pix0 = (unsigned)(((size_t)tl.n * p.OH + oy) * p.OW + ox0);
+  const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
+  const int c0 = tl.n0 + 16 * oh + 4 * kg;                      // this lane's first channel
+  const int oy0 = tl.oh0 + 4 * th, ox0 = tl.ow0 + 4 * tx;       // first output pixel of its tile
   auto tdesc = [&](const float* base, int ld) __attribute__((always_inline)) {
     const unsigned long long bytes = (((unsigned long long)p.N * p.OH * p.OW - 1) * ld + p.Cout) * 4ull;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (unsigned)bytes, 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t ry = tdesc(p.y, p.ldy), rr = tdesc(has_res ? p.res : p.y, p.ldres), rm = tdesc(has_mask ? p.mask : p.y, p.ldmask);
-  unsigned okb = 0;   // bit b: pixel b of this lane's row lies inside the image
+  const unsigned pix00 = (unsigned)(((size_t)tl.n * p.OH + oy0) * p.OW + ox0);
+  const bool c_ok = c0 < p.Cout;   // (Cout % 4 == 0: a group of four channels is in or out as a whole)
+  // validity of this lane's 16 output pixels (bit 4 a + b) and the per-lane part of their byte offsets per operand stride: the (a, b)
+  // displacement is wave-uniform and travels as the buffer instruction's scalar offset (the range check only sees the lane part)
+  unsigned okm = 0;
 #pragma unroll
-  for (int b2 = 0; b2 < 4; ++b2) okb |= (row_ok && ox0 + b2 < p.OW) ? (1u << b2) : 0u;
-  auto off = [&](int ld, int b2, int g) __attribute__((always_inline)) {
-    const int c = tl.n0 + 8 * g + 4 * fh;
-    return (((okb >> b2) & 1u) && c < p.Cout) ? (unsigned)(((pix0 + b2) * ld + c) * 4) : kOobOffset;
-  };
-  f32x4 resv[2][4], mskv[2][4], oldv[2][4];
-  auto request = [&](int g) __attribute__((always_inline)) {
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b2 = 0; b2 < 4; ++b2) {
-      if (has_res) resv[g & 1][b2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off(p.ldres, b2, g), 0, 0));
-      if (has_mask) mskv[g & 1][b2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, off(p.ldmask, b2, g), 0, 0));
-      if (accum) oldv[g & 1][b2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, off(p.ldy, b2, g), 0, 0));
+    for (int b = 0; b < 4; ++b) okm |= (c_ok && oy0 + a < p.OH && ox0 + b < p.OW) ? (1u << (4 * a + b)) : 0u;
+  const unsigned base_y = (pix00 * (unsigned)p.ldy + (unsigned)c0) * 4u, base_r = (pix00 * (unsigned)p.ldres + (unsigned)c0) * 4u,
+                 base_m = (pix00 * (unsigned)p.ldmask + (unsigned)c0) * 4u;
+  auto voff = [&](unsigned base, int a, int b) __attribute__((always_inline)) { return ((okm >> (4 * a + b)) & 1u) ? base : kOobOffset; };
+  auto soff = [&](int ld, int a, int b) __attribute__((always_inline)) { return (a * p.OW + b) * ld * 4; };
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(sV + 0 * 32 + 16 * oh + 4 * kg);
+  const f32x4 vec2 = *reinterpret_cast<const f32x4*>(sV + 1 * 32 + 16 * oh + 4 * kg);
+  const f32x4 scale = *reinterpret_cast<const f32x4*>(sV + 2 * 32 + 16 * oh + 4 * kg);
+  const f32x4 shift = *reinterpret_cast<const f32x4*>(sV + 3 * 32 + 16 * oh + 4 * kg);
+  f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
+
+  // output transform per channel register r: s[a][nu] = sum_xi AT[a][xi] M[xi][nu], then Y[a][b] = sum_nu AT[b][nu] s[a][nu]
+  float yv[4][4][4];   // [a][b][r]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float sv[4][6];
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu)
+      at6(acc_read(acc[0 * 6 + nu][r]), acc_read(acc[1 * 6 + nu][r]), acc_read(acc[2 * 6 + nu][r]), acc_read(acc[3 * 6 + nu][r]), acc_read(acc[4 * 6 + nu][r]),
+          acc_read(acc[5 * 6 + nu][r]), sv[0][nu], sv[1][nu], sv[2][nu], sv[3][nu]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) at6(sv[a][0], sv[a][1], sv[a][2], sv[a][3], sv[a][4], sv[a][5], yv[a][0][r], yv[a][1][r], yv[a][2][r], yv[a][3][r]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // element-wise part: ONE PASS PER EPILOGUE FLAG over the lane's outputs (a flag is tested once per half tile, not once per element:
+  // every instruction here is matrix time lost), two halves of 8 pixels (output rows 0, 1 and 2, 3) so that the residual / mask /
+  // accumulate operands of a half fit the registers; the operands of the second half are requested before the first is computed.
+  f32x4 resv[2][8], mskv[2][8], oldv[2][8];
+  auto request = [&](int hf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int a = 2 * hf + (q >> 2), b = q & 3;
+      if (has_res) resv[hf][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, voff(base_r, a, b), soff(p.ldres, a, b), 0));
+      if (has_mask) mskv[hf][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, voff(base_m, a, b), soff(p.ldmask, a, b), 0));
+      if (accum) oldv[hf][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, voff(base_y, a, b), soff(p.ldy, a, b), 0));
     }
   };
-  float* sC = smem + kRawBufs * kInSlots4 * 4 + kUSlots4 * 4;   // column sums: [wave 4][which 2][16 r][64 lanes] = 32 KiB in filter buffer F1 (F0 receives the next tile's block 0)
-  request(0);
+  if (has_res || has_mask || accum) {
+    request(0);
+    request(1);
+  }
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if (g + 1 < 4) request(g + 1);
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(sV + 0 * 32 + 8 * g + 4 * fh);
-    const f32x4 vec2 = *reinterpret_cast<const f32x4*>(sV + 1 * 32 + 8 * g + 4 * fh);
-    const f32x4 scale = *reinterpret_cast<const f32x4*>(sV + 2 * 32 + 8 * g + 4 * fh);
-    const f32x4 shift = *reinterpret_cast<const f32x4*>(sV + 3 * 32 + 8 * g + 4 * fh);
-    f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
-    const bool c_ok[4] = {tl.n0 + 8 * g + 4 * fh + 0 < p.Cout, tl.n0 + 8 * g + 4 * fh + 1 < p.Cout, tl.n0 + 8 * g + 4 * fh + 2 < p.Cout,
-                          tl.n0 + 8 * g + 4 * fh + 3 < p.Cout};
+  for (int hf = 0; hf < 2; ++hf) {
+    f32x4 o[8];
+    bool pix_ok[8];
 #pragma unroll
-    for (int b2 = 0; b2 < 4; ++b2) {
-      f32x4 v = {own[b2][4 * g], own[b2][4 * g + 1], own[b2][4 * g + 2], own[b2][4 * g + 3]};
-      const bool pix_ok = ((okb >> b2) & 1u) != 0;
-      if (f & CRDR_EPI_BIAS) v += bias;
-      if (f & CRDR_EPI_RELU) {
+    for (int q = 0; q < 8; ++q) {
+      const int a = 2 * hf + (q >> 2), b = q & 3;
+      o[q] = f32x4{yv[a][b][0], yv[a][b][1], yv[a][b][2], yv[a][b][3]};
+      pix_ok[q] = ((okm >> (4 * a + b)) & 1u) != 0;
+    }
+    if (f & CRDR_EPI_BIAS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-      }
-      if (f & CRDR_EPI_LRELU) {
+      for (int q = 0; q < 8; ++q) o[q] += bias;
+    }
+    if (f & CRDR_EPI_RELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.2f * v[e];
-      }
-      if (f & CRDR_EPI_VEC2) v += vec2;
-      if (has_res) v += resv[g & 1][b2];
-      if (f & CRDR_EPI_AFFINE) v = v * scale + shift;
-      if (do_cs) {
+      for (int q = 0; q < 8; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cpre[e] += (pix_ok && c_ok[e]) ? v[e] : 0.f;
-      }
-      if (has_mask) {
+        for (int e = 0; e < 4; ++e) o[q][e] = fmaxf(o[q][e], 0.0f);
+    }
+    if (f & CRDR_EPI_LRELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float mv = mskv[g & 1][b2][e] - ((f & CRDR_EPI_MASKOFF) ? vec2[e] : 0.f);
-          v[e] = mv > 0.0f ? v[e] : ((f & CRDR_EPI_LRELUMASK) ? 0.2f * v[e] : 0.0f);
-        }
-      }
-      if (do_cs) {
+      for (int q = 0; q < 8; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cpost[e] += (pix_ok && c_ok[e]) ? v[e] : 0.f;
-      }
-      if (accum) v += oldv[g & 1][b2];
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, off(p.ldy, b2, g), 0, 0);
+        for (int e = 0; e < 4; ++e) o[q][e] = o[q][e] > 0.0f ? o[q][e] : 0.2f * o[q][e];
+    }
+    if (f & CRDR_EPI_VEC2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] += vec2;
+    }
+    if (has_res) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] += resv[hf][q];
+    }
+    if (f & CRDR_EPI_AFFINE) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = o[q] * scale + shift;
     }
     if (do_cs) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        sC[((kMe * 2 + 0) * 16 + 4 * g + e) * 64 + lane] = cpre[e];
-        sC[((kMe * 2 + 1) * 16 + 4 * g + e) * 64 + lane] = cpost[e];
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cpre[e] += pix_ok[q] ? o[q][e] : 0.f;
+    }
+    if (has_mask) {
+      const f32x4 moff = (f & CRDR_EPI_MASKOFF) ? vec2 : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (f & CRDR_EPI_LRELUMASK) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[q][e] = (mskv[hf][q][e] - moff[e]) > 0.0f ? o[q][e] : 0.2f * o[q][e];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[q][e] = (mskv[hf][q][e] - moff[e]) > 0.0f ? o[q][e] : 0.0f;
       }
+    }
+    if (do_cs) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cpost[e] += pix_ok[q] ? o[q][e] : 0.f;
+    }
+    if (accum) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] += oldv[hf][q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int a = 2 * hf + (q >> 2), b = q & 3;
+#ifndef W4_NOSTORE
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[q]), ry, voff(base_y, a, b), soff(p.ldy, a, b), 0);
+#else
+      if (o[q][0] == 1.2345f && o[q][3] == 0.77f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[q]), ry, voff(base_y, a, b), soff(p.ldy, a, b), 0);
+#endif
     }
   }
   if (do_cs) {
-    // column sums of the tile: lane (tile m, half fh) held 16 channels; fixed-order sum over the 32 tiles of a half and the 4 waves
+    // column sums of the tile, fixed order: channel c = 16 oh + 4 kg + r <- waves (th = 0, 1; oh), lanes kg * 16 + tx, tx = 0..15.
+    // sC[wave 4][which 2][64 lanes][4 r] = 8 KiB in filter buffer F1 (F0 already receives the next tile's block 0)
+    float* sC = smem + kRawBufs * kRF + kFF;
+    *reinterpret_cast<f32x4*>(sC + ((wave * 2 + 0) * 64 + lane) * 4) = cpre;
+    *reinterpret_cast<f32x4*>(sC + ((wave * 2 + 1) * 64 + lane) * 4) = cpost;
     lds_barrier4();
-    const int tid = kMe * 64 + lane;
+    const int tid = wave * 64 + lane;
     if (tid < 64) {
-      const int which = tid >> 5, c = tid & 31;          // channel c = 8 g + 4 fh + e
-      const int g = c >> 3, h2 = (c >> 2) & 1, e = c & 3, r = 4 * g + e;
-      float v = 0.f;
-      for (int w2 = 0; w2 < 4; ++w2)
-        for (int t2 = 0; t2 < 32; ++t2) v += sC[((w2 * 2 + which) * 16 + r) * 64 + h2 * 32 + t2];
-      if (tl.n0 + c < p.Cout) p.cs[((size_t)tl.patch * 2 + which) * p.cs_ld + tl.n0 + c] = v;
+      const int which = tid >> 5, c = tid & 31, oh2 = c >> 4, kg2 = (c >> 2) & 3, r = c & 3;
+      float sum = 0.f;
+      for (int th2 = 0; th2 < 2; ++th2)
+        for (int t2 = 0; t2 < 16; ++t2) sum += sC[(((th2 * 2 + oh2) * 2 + which) * 64 + kg2 * 16 + t2) * 4 + r];
+      if (tl.n0 + c < p.Cout) p.cs[((size_t)tl.patch * 2 + which) * p.cs_ld + tl.n0 + c] = sum;
     }
   }
 }
@@ -466,8 +437,8 @@ __device__ __forceinline__ void wino4_vectors(const IgemmArgs& p, const IgemmGro
 }
 
 // Persistent: at most one workgroup per CU, each walks the tiles vb = blockIdx.x, + gridDim.x, ...  Between the K loop and the
-// epilogue of a tile the waves request the next tile's first raw patches (into the raw buffers, free by then) and its epilogue vectors,
-// after the hand-over its first filter block: the DMA latency of a fresh tile and the memory latency of the stores hide behind each other.
+// epilogue of a tile the waves request the next tile's first raw patches and filter block (the buffers are free by then) and its
+// epilogue vectors: the DMA latency of a fresh tile and the memory latency of the stores hide behind each other.
 __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gyn, int gz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -493,42 +464,26 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
       sr = wino4_src(p_, grp, tl, gyn, lane, wave);
       wino4_vectors(p_, grp, tl, sV, tid);   // (published by the K loop's first barrier)
     }
-
-    f32x16 acc[3][3];
+    f32x4 acc[36];
 #pragma unroll
-    for (int x = 0; x < 3; ++x)
-#pragma unroll
-      for (int y = 0; y < 3; ++y)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-    const int role = wave;
+    for (int j = 0; j < 36; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef W4_SKIP_LOOP
-    if (role == 0) wino4_loop<0, 0>(p, smem, sr, prefetched, lane, wave, acc);
-    else if (role == 1) wino4_loop<0, 1>(p, smem, sr, prefetched, lane, wave, acc);
-    else if (role == 2) wino4_loop<1, 0>(p, smem, sr, prefetched, lane, wave, acc);
-    else wino4_loop<1, 1>(p, smem, sr, prefetched, lane, wave, acc);
+    wino4_loop(p, smem, sr, prefetched, lane, wave, acc);
 #endif
     // (the loop ends with a barrier: every wave is past its last LDS read, raw and filter buffers are free)
     const bool more = vb + (int)gridDim.x < total;
-    if (more) {   // the next tile: raw patches 0, 1, 2 and the epilogue vectors now, filter block 0 after the hand-over
+    if (more) {   // the next tile: raw patches 0, 1, 2, filter block 0 and the epilogue vectors
       const Wino4Tile tn = wino4_tile(p_, vb + (int)gridDim.x, gx, gyn, gz);
       sr = wino4_src(p_, grp, tn, gyn, lane, wave);
-      wino4_prologue_dma(smem, sr, p_.Cin, p_.kchunks, lane, wave, true, false);
+#ifndef W4_NOPROLOGUE
+      wino4_prologue_dma(smem, sr, p_.Cin, p_.kchunks, lane, wave);
+#endif
       wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * 128, tid);
     }
-    auto after = [&]() __attribute__((always_inline)) {
-      if (more) wino4_prologue_dma(smem, sr, p_.Cin, p_.kchunks, lane, wave, false, true);
-    };
-#ifdef W4_SAMEROLE
-    wino4_finish<0, 0>(p, tl, smem, sV, lane, acc, after);
-#elif !defined(W4_SKIP_FINISH)
-    if (role == 0) wino4_finish<0, 0>(p, tl, smem, sV, lane, acc, after);
-    else if (role == 1) wino4_finish<0, 1>(p, tl, smem, sV, lane, acc, after);
-    else if (role == 2) wino4_finish<1, 0>(p, tl, smem, sV, lane, acc, after);
-    else wino4_finish<1, 1>(p, tl, smem, sV, lane, acc, after);
+#ifndef W4_SKIP_FINISH
+    wino4_finish(p, tl, smem, sV, lane, wave, acc);
 #else
-    after();
-    if (acc[0][0][0] == 1.2345f && acc[1][1][3] == 2.5f && acc[2][2][7] == 0.3f) p.y[lane] = acc[0][1][1];
+    if (acc[0][0] == 1.2345f && acc[17][3] == 2.5f && acc[35][1] == 0.3f) p.y[lane] = acc[5][1];
 #endif
     prefetched = more;
     cur ^= 1;
@@ -537,22 +492,21 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
 }
 
 // Filter transform U = G g G^T, G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]], evaluated in double
-// and rounded once, from the implicit-GEMM weight pack (tap-major [tap][wrows][wcols]) into the stage-block layout of wino4_kernel:
-// [N tile of 32][chunk of 8 channels][position 36][h 2][oc 32][4].  One thread per (N tile, chunk, h, oc).
+// and rounded once, from the implicit-GEMM weight pack (tap-major [tap][wrows][wcols]) into the block layout of wino4_kernel:
+// [N tile of 32][chunk of 8 channels][position 36][channel pair 4][oc 32][2].
 struct Wino4Taps { int widx[9]; };
 __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const float* w0, float* u, int Cin, int Cout, int wrows, int wcols, int kchunks,
                                     int ntile, Wino4Taps tp) {
-  // one thread per (N tile, chunk, h, oc, channel e of the half): consecutive threads read consecutive input channels of one weight-pack
-  // row and write consecutive floats of a 16-byte slot
+  // one thread per (N tile, chunk, oc, channel c of the chunk): consecutive threads read consecutive input channels of one weight-pack row
   const long long total = (long long)ntile * kchunks * 256;
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= total) return;
   const int g = blockIdx.y;
   const float* w = ngroup > 1 ? grp.w[g] : w0;
-  const int e = (int)(id & 3), oc32 = (int)((id >> 2) & 31), h = (int)((id >> 7) & 1);
+  const int c8 = (int)(id & 7), oc32 = (int)((id >> 3) & 31);
   const long long blk = id >> 8;   // (N tile, chunk)
   const int kc = (int)(blk % kchunks), ct = (int)(blk / kchunks);
-  const int oc = ct * 32 + oc32, c = kc * 8 + h * 4 + e;
+  const int oc = ct * 32 + oc32, c = kc * 8 + c8;
   const bool live = oc < Cout && c < Cin;
   double g9[3][3];
 #pragma unroll
@@ -561,7 +515,7 @@ __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const floa
     for (int b = 0; b < 3; ++b) g9[a][b] = live ? (double)w[((size_t)tp.widx[a * 3 + b] * wrows + oc) * wcols + c] : 0.0;
   const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-  float* dst = u + ((size_t)g * ntile * kchunks + (size_t)blk) * (kUSlots4 * 4) + ((size_t)h * 32 + oc32) * 4 + e;
+  float* dst = u + ((size_t)g * ntile * kchunks + (size_t)blk) * (kUSlots4 * 4) + ((size_t)(c8 >> 1) * 32 + oc32) * 2 + (c8 & 1);
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
     double t[3];
