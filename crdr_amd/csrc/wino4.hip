@@ -7,20 +7,23 @@
 // of the output scale at 96 .. 256 input channels (the direct kernels: ~1e-6): a tuner candidate for TRAINING launches only (the
 // codec never runs tuned plans), behind the forced-algorithm id of Winograd variant 2, tests/test_gpu_wino.py.
 //
-// One output tile = 8 rows x 64 columns of output pixels (2 x 16 Winograd tiles of 4 x 4) of one image x 32 output channels, on FOUR
-// waves (one per SIMD: 512 registers each), all running the SAME code: wave (th, oh) owns the 16 tiles of tile row th x the 16
-// channels of half oh x ALL 36 transform positions = 36 accumulator blocks of v_mfma_f32_16x16x4_f32 (A = filter fragment: row =
-// channel; B = transformed data: column = tile).  A lane ends up with 4 consecutive channels of ONE tile at all 36 positions: the
-// output transform is pure register arithmetic (no hand-over between waves) and the epilogue works with 16-byte accesses.
-// (A first version split the positions over the waves -- 9 per wave, MFMA 32x32x2 -- and lost to its epilogue: four role-specialised
-// copies of the output transform + a four-pass LDS hand-over did not fit the instruction cache, 400-470 us where this form takes less.)
-// K loop: sub-steps of 8 input channels, one barrier each; LDS holds three raw-patch buffers and two filter buffers filled by LDS-DMA:
-//   * the raw 10 x 66 x 8 input patch, stored by pixel class (row & 3, column & 3): [half h = channels 4h..4h+3][class 16][3 rows][17
-//     slots of 16 B]; lane (tile tx, channel pair kg) reads 8 bytes of patch pixel (i, j): the 16 tiles of a row x 2 pairs of a half
-//     cover 256 consecutive bytes (conflict free);
-//   * the transformed filters of the sub-step: [position 36][channel pair 4][channel 32][2] = 36 KiB, contiguous in memory and in LDS.
-//   Every lane transforms the 6 x 6 patch of its tile for its 2 channels in registers (12 fma-class operations per 1-D transform)
-//   and the wave issues 72 MFMAs; the work is laid out by hand in 72 slots of one MFMA + its share of loads / transform / DMA.
+// One output tile = 8 rows x 64 columns of output pixels (2 x 16 Winograd tiles of 4 x 4) of one image x 64 output channels, on FOUR
+// waves (one per SIMD: 512 registers each), all running the SAME code: wave (th, oh) owns the 16 tiles of tile row th x the 32
+// channels of half oh x ALL 36 transform positions = 72 accumulator blocks of v_mfma_f32_16x16x4_f32 (A = filter fragment: row =
+// channel; B = transformed data: column = tile; k = the 4 input channels of a sub-step, one per 16-lane group).  A lane ends up with
+// 2 x 4 consecutive channels of ONE tile at all 36 positions: the output transform is pure register arithmetic (no hand-over between
+// waves) and the epilogue works with 16-byte accesses.
+// History of the form (measured, 128 -> 128 channels at 128 x 128, bs 16; the F(2x2) kernel: 396 us): positions split over the waves
+// (9 per wave, MFMA 32x32x2, four role-specialised epilogues + LDS hand-over: instruction-cache bound) 470 us; this symmetric form
+// with 16 channels per wave and 8-channel sub-steps 349 us -- one wave per SIMD issues EVERYTHING itself, and 288 transform
+// operations + 71 LDS reads + 16 DMA per 72 MFMAs made the loop issue-bound at 1.8x the MFMA time; 32 channels per wave and
+// 4-channel sub-steps halve the non-MFMA instructions per MFMA.
+// K loop: sub-steps of 4 input channels, one barrier each; LDS holds three raw-patch buffers and two filter buffers filled by LDS-DMA:
+//   * the raw 10 x 66 x 4 input patch, stored by pixel class (row & 3, column & 3): [class 16][3 rows][17 slots of 16 B]; lane (tile tx,
+//     channel kg) reads 4 bytes of patch pixel (i, j): the 16 tiles of a row x 4 channels cover 256 consecutive bytes (conflict free);
+//   * the transformed filters of the sub-step: [position 36][channel 4][output channel 64] = 36 KiB, contiguous in memory and in LDS.
+//   Every lane transforms the 6 x 6 patch of its tile for its channel in registers (12 fma-class operations per 1-D transform) and
+//   the wave issues 72 MFMAs; the work is laid out by hand in 72 slots of one MFMA + its share of loads / transform / DMA.
 #include <algorithm>
 #include <atomic>
 
@@ -34,11 +37,12 @@ namespace {
 
 constexpr int kNT4 = 256;
 constexpr int kTY = 2, kTX = 16;                       // Winograd tiles per output tile (rows, columns)
-constexpr int kInUsed4 = 2 * 16 * 3 * 17;              // 16-byte slots of the input patch image per buffer
-constexpr int kInPieces = 28;                          // DMA instructions (1 KiB each) for it: 26 needed, 28 = 7 per wave (uniform vmcnt counts)
+constexpr int kBN4 = 64;                               // output channels per tile
+constexpr int kInUsed4 = 16 * 3 * 17;                  // 16-byte slots (4 channels of one pixel) of the input patch image per buffer
+constexpr int kInPieces = 16;                          // DMA instructions (1 KiB each) for it: 13 needed, 16 = 4 per wave (uniform vmcnt counts)
 constexpr int kInSlots4 = kInPieces * 64;
-constexpr int kUSlots4 = 36 * 2 * 32;                  // slots of one filter block (8 channels x 32 output channels): 36 pieces
-constexpr int kRawBufs = 3, kFiltBufs = 2;            // raw patches are requested two sub-steps ahead (they come from HBM), filters one (L2)
+constexpr int kUSlots4 = 36 * 4 * kBN4 / 4;            // slots of one filter block (4 channels x 64 output channels): 36 pieces
+constexpr int kRawBufs = 3, kFiltBufs = 3;            // raw patches are requested three sub-steps ahead, filter blocks two: nothing requested during a sub-step is waited for at its end
 constexpr int kRF = kInSlots4 * 4, kFF = kUSlots4 * 4;   // floats of a raw buffer / a filter buffer
 constexpr int kLdsFloats4 = kRawBufs * kRF + kFiltBufs * kFF;
 
@@ -49,19 +53,24 @@ __device__ __forceinline__ void lds_barrier4() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// 1-D data transform B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]] on scalars: packed
-// f32 instructions issued beside MFMAs cost several times their scalar pair on this part (MI355X_MICROARCH.md, 'price of one filler
-// beside MFMAs'), so the K loop works on scalars (the file is compiled with -fno-slp-vectorize).  12 operations.
-__device__ __forceinline__ void bt6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
-                                    float& o0, float& o1, float& o2, float& o3, float& o4, float& o5) {
-  const float a = __builtin_fmaf(-4.0f, d2, d4), b = __builtin_fmaf(-4.0f, d1, d3);
-  const float c = d4 - d2, e = d3 - d1;
-  o0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
-  o1 = a + b;
-  o2 = a - b;
-  o3 = __builtin_fmaf(2.0f, e, c);
-  o4 = __builtin_fmaf(-2.0f, e, c);
-  o5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
+// 1-D data transform B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]] on scalars, in two
+// independent halves of 6 operations (outputs 0..2 / 3..5).  Scalars on purpose: packed f32 instructions issued beside MFMAs cost
+// several times their scalar pair on this part (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'); the file is compiled with
+// -fno-slp-vectorize.
+template <int HALF>
+__device__ __forceinline__ void bt6h(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
+                                     float& o0, float& o1, float& o2) {
+  if constexpr (HALF == 0) {
+    const float a = __builtin_fmaf(-4.0f, d2, d4), b = __builtin_fmaf(-4.0f, d1, d3);
+    o0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
+    o1 = a + b;
+    o2 = a - b;
+  } else {
+    const float c = d4 - d2, e = d3 - d1;
+    o0 = __builtin_fmaf(2.0f, e, c);
+    o1 = __builtin_fmaf(-2.0f, e, c);
+    o2 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
+  }
 }
 
 // 1-D output transform A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]: 10 operations
@@ -91,95 +100,97 @@ __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int 
   const int prem = t.patch - t.n * ppi, by = prem / p.GW, bx = prem - by * p.GW;
   t.oh0 = by * (4 * kTY);
   t.ow0 = bx * (4 * kTX);
-  t.n0 = tn * 32;
+  t.n0 = tn * kBN4;
   return t;
 }
 
 // byte offset (into the input tensor's descriptor) of the pixel a DMA lane stages for input piece `piece`: slot S = piece * 64 + lane ->
-// (h, class (ci, cj), R, Cc) -> patch pixel (4 R + ci, 4 Cc + cj), channels 4h .. 4h + 3; out of range where the slot is unused or the
-// pixel lies outside the image (the range check of the buffer load then delivers zeros: padding)
+// (class (ci, cj), R, Cc) -> patch pixel (4 R + ci, 4 Cc + cj), channels 0..3 of the sub-step; out of range where the slot is unused or
+// the pixel lies outside the image (the range check of the buffer load then delivers zeros: padding)
 __device__ __forceinline__ unsigned wino4_in_off(const IgemmArgs& p, const Wino4Tile& t, int piece, int lane) {
   const int S = piece * 64 + lane;
-  const int h = S / (16 * 51), rem = S - h * (16 * 51), cls = rem / 51, r2 = rem - cls * 51, R = r2 / 17, Cc = r2 - R * 17;
+  const int cls = S / 51, r2 = S - cls * 51, R = r2 / 17, Cc = r2 - R * 17;
   const int ci = cls >> 2, cj = cls & 3;
   const int pi = 4 * R + ci, pj = 4 * Cc + cj;
   const int ih = t.oh0 - p.si + pi, iw = t.ow0 - p.si + pj;
   const bool ok = S < kInUsed4 && pi < 4 * kTY + 2 && pj < 4 * kTX + 2 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-  return ok ? (unsigned)((((t.n * p.H + ih) * p.W + iw) * p.ldx + 4 * h) * 4) : kOobOffset;
+  return ok ? (unsigned)((((t.n * p.H + ih) * p.W + iw) * p.ldx) * 4) : kOobOffset;
 }
 
-// where the DMA of one output tile reads: descriptors of its image tensor and filter blocks, this lane's seven raw-piece offsets
+// where the DMA of one output tile reads: descriptors of its image tensor and filter blocks, this lane's four raw-piece offsets
 struct Wino4Src {
   __amdgpu_buffer_rsrc_t rx, ru;
   unsigned u_off0;     // byte offset of the N tile's first filter block
-  unsigned a_off[7];   // raw piece wave + 4 j: byte offset of this lane's pixel (chunk 0), or out of range
+  unsigned a_off[4];   // raw piece wave + 4 j: byte offset of this lane's pixel (chunk 0), or out of range
 };
 
-// raw piece j (0..6) of this wave, patch kr -> raw buffer rbuf; live false: the sub-step does not exist (zeros land in a buffer nobody reads)
-__device__ __forceinline__ void wino4_dma_raw(float* smem, const Wino4Src& sr, int Cin, int j, int kr, int rbuf, bool live, int lane, int wave) {
+// raw piece j (0..3) of this wave, patch kr -> raw buffer rbuf; live false: the sub-step does not exist (zeros land in a buffer nobody reads)
+__device__ __forceinline__ void wino4_dma_raw(float* smem, const Wino4Src& sr, int j, int kr, int rbuf, bool live, int lane, int wave) {
   const int piece = wave + 4 * j;
-  unsigned off = live ? sr.a_off[j] : kOobOffset;
-  if (kr * 8 + 8 > Cin && (piece * 64 + lane) >= 16 * 51) off = kOobOffset;   // the chunk's upper half lies past Cin
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.rx, (lds_ptr_t)(smem + rbuf * kRF + piece * 256), 16, (int)off, (int)(kr * 32), 0, 0);
+  const unsigned off = live ? sr.a_off[j] : kOobOffset;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.rx, (lds_ptr_t)(smem + rbuf * kRF + piece * 256), 16, (int)off, (int)(kr * 16), 0, 0);
 }
-// filter piece 9 wave + j (j = 0..8) of block kf -> F[kf & 1]
-__device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, int j, int kf, bool live, int lane, int wave) {
+// filter piece 9 wave + j (j = 0..8) of block kf -> filter buffer fbuf
+__device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, int j, int kf, int fbuf, bool live, int lane, int wave) {
   const int piece = wave * 9 + j;
   const unsigned off = live ? (unsigned)((piece * 64 + lane) * 16) : kOobOffset;
   // (u_off0 is wave-uniform; said so explicitly, or the compiler wraps every request in a waterfall loop over the scalar offset)
   const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)sr.u_off0) + (unsigned)kf * (kUSlots4 * 16u);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.ru, (lds_ptr_t)(smem + kRawBufs * kRF + (kf & 1) * kFF + piece * 256), 16, (int)off, (int)so, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.ru, (lds_ptr_t)(smem + kRawBufs * kRF + fbuf * kFF + piece * 256), 16, (int)off, (int)so, 0, 0);
 }
-// the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and filter block 0 (-> F0)
-__device__ __forceinline__ void wino4_prologue_dma(float* smem, const Wino4Src& sr, int Cin, int K8, int lane, int wave) {
+// the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and filter blocks 0, 1 (-> F0, F1)
+__device__ __forceinline__ void wino4_prologue_dma(float* smem, const Wino4Src& sr, int K4, int lane, int wave) {
 #pragma unroll
   for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
-    for (int j = 0; j < 7; ++j) wino4_dma_raw(smem, sr, Cin, j, kr, kr, kr < K8, lane, wave);
+    for (int j = 0; j < 4; ++j) wino4_dma_raw(smem, sr, j, kr, kr, kr < K4, lane, wave);
 #pragma unroll
-  for (int j = 0; j < 9; ++j) wino4_dma_filt(smem, sr, j, 0, true, lane, wave);
+  for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) wino4_dma_filt(smem, sr, j, kf, kf, kf < K4, lane, wave);
 }
 
 // K loop of one wave (the only wave of its SIMD: nothing else hides its latencies, so the loop is software pipelined by hand).
 // LDS: raw-patch buffers R0..R2, filter buffers F0, F1.  Sub-step k multiplies V_k (registers) with the filters of F[k & 1]; in the
 // shadow of those 72 MFMAs the wave reads raw patch k + 1 from R[(k + 1) % 3] and transforms it into V_{k+1}, and issues the DMA of
 // filter block k + 1 (-> F[(k + 1) & 1], last read in sub-step k - 1; filters come out of L2) and of raw patch k + 3 (-> R[k % 3], last
-// read in sub-step k - 1; raw patches come from HBM / the Infinity Cache).  The sub-step ends with vmcnt(7) + barrier: the seven raw
-// pieces just requested stay in flight, everything older has landed.  72 slots, pinned by sched_barrier:
-//   slot s: MFMA of position j = s / 2 (transform row x = j / 6), channel s % 2 of the lane's pair; filter fragment j + 2 requested at
-//   slot 2 j + 1; raw column b (6 pixels) requested in slots 6 b .. 6 b + 5, its vertical transform (two channels) in slots
-//   6 b + 6 .. 6 b + 11; horizontal transform of row x < 5 of V_{k+1} in slots 42 + 6 x .. 47 + 6 x -- straight into the registers of
-//   V_k's row x, whose MFMAs (slots 12 x .. 12 x + 11) are done by then; row 5 follows at the top of the next sub-step; DMA
-//   instruction q at slot 4 q + 1.
-__device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, const Wino4Src& sr, bool prefetched, int lane, int wave, f32x4 (&acc)[36]) {
-  const int K8 = p.kchunks;
+// read in sub-step k - 1).  The sub-step ends with vmcnt(13) + barrier: what it requested itself stays in flight, everything older has landed.  72 slots, pinned by sched_barrier:
+//   slot s: MFMA of position j = s / 2 (transform row x = j / 6), channel block s % 2; the two filter fragments of position j + 4
+//   requested at slot 2 j + 1; raw column b (6 pixels) requested in slots 6 b .. 6 b + 5, its vertical transform in slots 6 b + 8 and
+//   6 b + 11 (half each); horizontal transform of row x < 5 of V_{k+1} in slots 44 + 5 x and 46 + 5 x -- straight into the registers of
+//   V_k's row x, whose MFMAs (slots 12 x .. 12 x + 11) are done by then; row 5 follows at the top of the next sub-step; DMA instruction
+//   q (9 filter pieces, then 4 raw pieces) at slot 5 q + 2.
+__device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, const Wino4Src& sr, bool prefetched, int lane, int wave, f32x4 (&acc)[64],
+                                           f32x4 (&accv)[8]) {
+  const int K4 = p.kchunks;
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
-  // this lane's raw reads: patch pixel (i, j) of tile (th, tx), channels 2 kg, 2 kg + 1: float offset rbase + ro(i, j) of a raw buffer
-  const int rbase = (((kg >> 1) * 48 + th) * 17 + tx) * 4 + (kg & 1) * 2;
+  // this lane's raw reads: patch pixel (i, j) of tile (th, tx), channel kg: float offset rbase + ro(i, j) of a raw buffer
+  const int rbase = (th * 17 + tx) * 4 + kg;
   auto ro = [](int i, int j) constexpr { return (((i & 3) * 4 + (j & 3)) * 51 + (i >> 2) * 17 + (j >> 2)) * 4; };
-  // filter fragment of position pos (channel 16 oh + tx, channels 2 kg, 2 kg + 1 of the sub-step): + (k & 1) * kFF + pos * 256
-  const int fbase = kRawBufs * kRF + ((kg * 32) + 16 * oh + tx) * 2;
+  // filter fragments of position pos (channel kg of the sub-step, output channels 32 oh + 16 ob + tx): + (k & 1) * kFF + pos * 256 + 16 ob
+  const int fbase = kRawBufs * kRF + kg * kBN4 + 32 * oh + tx;
 
-  float t[6][6][2];   // vertical pass of the patch being transformed: [xi][column][channel]
-  float v[6][6][2];   // V of the current sub-step (rows 0..4: replaced in place by the next one's during the sub-step)
-  f32x2 dcol[2][6];   // raw pixels of one patch column (two channels), double buffered by column parity
-  auto vread = [&](const float* rp, int b, int i) __attribute__((always_inline)) { dcol[b & 1][i] = *reinterpret_cast<const f32x2*>(rp + ro(i, b)); };
-  auto vpass = [&](int b, int c) __attribute__((always_inline)) {
-    bt6(dcol[b & 1][0][c], dcol[b & 1][1][c], dcol[b & 1][2][c], dcol[b & 1][3][c], dcol[b & 1][4][c], dcol[b & 1][5][c],
-        t[0][b][c], t[1][b][c], t[2][b][c], t[3][b][c], t[4][b][c], t[5][b][c]);
+  float t[6][6];   // vertical pass of the patch being transformed: [xi][column]
+  float v[6][6];   // V of the current sub-step (rows 0..4: replaced in place by the next one's during the sub-step)
+  float dcol[2][6];   // raw pixels of one patch column, double buffered by column parity
+  auto vread = [&](const float* rp, int b, int i) __attribute__((always_inline)) { dcol[b & 1][i] = rp[ro(i, b)]; };
+  auto vpass0 = [&](int b) __attribute__((always_inline)) {
+    bt6h<0>(dcol[b & 1][0], dcol[b & 1][1], dcol[b & 1][2], dcol[b & 1][3], dcol[b & 1][4], dcol[b & 1][5], t[0][b], t[1][b], t[2][b]);
   };
-  auto hpass = [&](int x, int c) __attribute__((always_inline)) {
-    bt6(t[x][0][c], t[x][1][c], t[x][2][c], t[x][3][c], t[x][4][c], t[x][5][c], v[x][0][c], v[x][1][c], v[x][2][c], v[x][3][c], v[x][4][c], v[x][5][c]);
+  auto vpass1 = [&](int b) __attribute__((always_inline)) {
+    bt6h<1>(dcol[b & 1][0], dcol[b & 1][1], dcol[b & 1][2], dcol[b & 1][3], dcol[b & 1][4], dcol[b & 1][5], t[3][b], t[4][b], t[5][b]);
   };
+  auto hpass0 = [&](int x) __attribute__((always_inline)) { bt6h<0>(t[x][0], t[x][1], t[x][2], t[x][3], t[x][4], t[x][5], v[x][0], v[x][1], v[x][2]); };
+  auto hpass1 = [&](int x) __attribute__((always_inline)) { bt6h<1>(t[x][0], t[x][1], t[x][2], t[x][3], t[x][4], t[x][5], v[x][3], v[x][4], v[x][5]); };
 
-  // ---- prologue: filter block 0 and patches 0, 1, 2 (requested by the previous tile's epilogue where there was one: then at least 16
+  // ---- prologue: filter block 0 and patches 0, 1, 2 (requested by the previous tile's epilogue where there was one: then at least 32
   // younger vector-memory operations -- that tile's stores -- are in flight and need not be waited for); V_0 rows 0..4 and the
   // vertical pass of row 5
   if (!prefetched) {
-    wino4_prologue_dma(smem, sr, p.Cin, K8, lane, wave);
+    wino4_prologue_dma(smem, sr, K4, lane, wave);
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
   } else {
-    __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16)
+    __builtin_amdgcn_s_waitcnt(0x8070);   // vmcnt(32)
   }
   lds_barrier4();
   {
@@ -188,53 +199,66 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
     for (int b = 0; b < 6; ++b) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) vread(rp, b, i);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) vpass(b, c);
+      vpass0(b);
+      vpass1(b);
     }
 #pragma unroll
-    for (int x = 0; x < 5; ++x)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) hpass(x, c);
+    for (int x = 0; x < 5; ++x) {
+      hpass0(x);
+      hpass1(x);
+    }
   }
 
   int r1 = 1, r0 = 0;   // raw buffer of patch k + 1 / of patch k (= the one patch k + 3 goes to)
-  for (int k = 0; k < K8; ++k) {
+  for (int k = 0; k < K4; ++k) {
     const float* rp = smem + rbase + r1 * kRF;            // raw patch k + 1
-    const float* fp = smem + fbase + (k & 1) * kFF;       // filter block k
-    const bool live1 = k + 1 < K8, live3 = k + 3 < K8;
-    f32x2 uf[4];
-    uf[0] = *reinterpret_cast<const f32x2*>(fp);
-    uf[1] = *reinterpret_cast<const f32x2*>(fp + 1 * 256);
-    hpass(5, 0);   // row 5 of V_k (its vertical pass was done during the previous sub-step; its MFMAs are the last ones)
-    hpass(5, 1);
+    const float* fp = smem + fbase + r0 * kFF;            // filter block k (the filter ring turns with the raw ring: block k in buffer k % 3)
+    const bool live2 = k + 2 < K4, live3 = k + 3 < K4;
+    const int f2 = r1 == 2 ? 0 : r1 + 1;                  // buffer of filter block k + 2
+    float uf[8][2];   // filter fragments of positions j .. j + 3 in flight (ring of 8, indexed j & 7)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uf[j][0] = fp[j * 256];
+      uf[j][1] = fp[j * 256 + 16];
+    }
+    hpass0(5);   // row 5 of V_k (its vertical pass was done during the previous sub-step; its MFMAs are the last ones)
+    hpass1(5);
     __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(full)
     for (int s = 0; s < 72; ++s) {
-      const int j = s >> 1, c = s & 1, x = j / 6, y = j - 6 * x;
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[j & 3][c], v[x][y][c], acc[j], 0, 0, 0);
-      if (c == 1 && j + 2 < 36) uf[(j + 2) & 3] = *reinterpret_cast<const f32x2*>(fp + (j + 2) * 256);
+      const int j = s >> 1, ob = s & 1, x = j / 6, y = j - 6 * x;
+      // 72 blocks x 4 = 288 accumulator registers: 64 blocks in the accumulation half of the register file, the last 8 (positions 32..35)
+      // pinned to ordinary vector registers (left to the compiler they bounce between the two files: 72 moves per sub-step)
+      if (s < 64) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[j & 7][ob], v[x][y], acc[s], 0, 0, 0);
+      else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[s - 64]) : "v"(uf[j & 7][ob]), "v"(v[x][y]));
+      if (ob == 1 && j + 4 < 36) {   // four positions (8 slots) ahead of their use
+        uf[(j + 4) & 7][0] = fp[(j + 4) * 256];
+        uf[(j + 4) & 7][1] = fp[(j + 4) * 256 + 16];
+      }
       if (s < 36) vread(rp, s / 6, s % 6);                                          // raw column b = s / 6, pixel s % 6
-      if (s >= 6 && s < 42) {                                                       // vertical pass of column (s - 6) / 6: 24 operations over 6 slots
-        const int b = (s - 6) / 6, part = (s - 6) % 6;
-        if (part == 0) vpass(b, 0);
-        if (part == 3) vpass(b, 1);
+      // vertical pass of column b: outputs 0..2 (inputs 0..4, the last one requested at slot 6 b + 4) at slot 6 b + 8, outputs 3..5
+      // (inputs 1..5) at slot 6 b + 11; the column buffer is overwritten from slot 6 b + 12 (input 0) / 6 b + 13 (input 1) on
+      if (s >= 8 && s < 44) {
+        if ((s - 8) % 6 == 0) vpass0((s - 8) / 6);
+        if ((s - 8) % 6 == 3) vpass1((s - 8) / 6);
       }
-      if (s >= 42) {                                                                // horizontal pass of row (s - 42) / 6
-        const int xr = (s - 42) / 6, part = (s - 42) % 6;
-        if (part == 0) hpass(xr, 0);
-        if (part == 3) hpass(xr, 1);
+      // horizontal pass of row x < 5 at slots 44 + 5 x and 46 + 5 x (the row's MFMAs ended at slot 12 x + 11)
+      if (s >= 44 && s < 69) {
+        if ((s - 44) % 5 == 0) hpass0((s - 44) / 5);
+        if ((s - 44) % 5 == 2) hpass1((s - 44) / 5);
       }
-      if ((s & 3) == 1 && (s >> 2) < 16) {
-        const int q = s >> 2;
-        if (q < 9) wino4_dma_filt(smem, sr, q, k + 1, live1, lane, wave);
-        else wino4_dma_raw(smem, sr, p.Cin, q - 9, k + 3, r0, live3, lane, wave);
+      if (s % 5 == 2 && s / 5 < 13) {
+        const int q = s / 5;
+        if (q < 9) wino4_dma_filt(smem, sr, q, k + 2, f2, live2, lane, wave);
+        else wino4_dma_raw(smem, sr, q - 9, k + 3, r0, live3, lane, wave);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     r0 = r1;
     r1 = r1 == 2 ? 0 : r1 + 1;
-    // filter block k + 1 (and everything older: patch k + 2) has landed; the seven raw pieces of patch k + 3 stay in flight
-    __builtin_amdgcn_s_waitcnt(0x0077);   // vmcnt(7) lgkmcnt(0)
+    // the 13 requests of this sub-step (filter block k + 2, patch k + 3) stay in flight; everything older (filter block k + 1, patch
+    // k + 2) has landed
+    __builtin_amdgcn_s_waitcnt(0x007D);   // vmcnt(13) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -243,7 +267,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
 }
 
 // The accumulators live in the accumulation half of the register file; the output transform takes them out one register at a time
-// (left to itself the compiler copies all 144 into vector registers at the loop exit and spills them to scratch)
+// (left to itself the compiler copies them all into vector registers at the loop exit and spills to scratch)
 __device__ __forceinline__ float acc_read(float v) {
   float o;
   asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(o) : "a"(v));
@@ -251,159 +275,176 @@ __device__ __forceinline__ float acc_read(float v) {
 }
 
 // Output transform + element-wise epilogue + stores of one wave: lane (tile tx of row th, channel group kg) holds M[36] for channels
-// n0 + 16 oh + 4 kg + r, r < 4.  Order of the element-wise operations: epilogue_store of igemm_kernel.hpp.
-__device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile& tl, float* smem, const float* sV, int lane, int wave, f32x4 (&acc)[36]) {
+// n0 + 32 oh + 16 ob + 4 kg + r, ob < 2, r < 4.  Order of the element-wise operations: epilogue_store of igemm_kernel.hpp.
+__device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile& tl, float* smem, const float* sV, int lane, int wave, f32x4 (&acc)[64],
+                                             f32x4 (&accv)[8]) {
   const int f = p.flags;
   const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
   const bool do_cs = (f & CRDR_EPI_COLSUM) != 0, accum = (f & CRDR_EPI_ACCUM) != 0;
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
-  const int c0 = tl.n0 + 16 * oh + 4 * kg;                      // this lane's first channel
-  const int oy0 = tl.oh0 + 4 * th, ox0 = tl.ow0 + 4 * tx;       // first output pixel of its tile
+  const int oy0 = tl.oh0 + 4 * th, ox0 = tl.ow0 + 4 * tx;       // first output pixel of this lane's tile
   auto tdesc = [&](const float* base, int ld) __attribute__((always_inline)) {
     const unsigned long long bytes = (((unsigned long long)p.N * p.OH * p.OW - 1) * ld + p.Cout) * 4ull;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (unsigned)bytes, 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t ry = tdesc(p.y, p.ldy), rr = tdesc(has_res ? p.res : p.y, p.ldres), rm = tdesc(has_mask ? p.mask : p.y, p.ldmask);
   const unsigned pix00 = (unsigned)(((size_t)tl.n * p.OH + oy0) * p.OW + ox0);
-  const bool c_ok = c0 < p.Cout;   // (Cout % 4 == 0: a group of four channels is in or out as a whole)
-  // validity of this lane's 16 output pixels (bit 4 a + b) and the per-lane part of their byte offsets per operand stride: the (a, b)
-  // displacement is wave-uniform and travels as the buffer instruction's scalar offset (the range check only sees the lane part)
-  unsigned okm = 0;
+  // validity of this lane's 16 output pixels (bit 4 a + b); the (a, b) displacement of an access is wave-uniform and travels as the
+  // buffer instruction's scalar offset (the range check only sees the lane part)
+  unsigned pixm = 0;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) okm |= (c_ok && oy0 + a < p.OH && ox0 + b < p.OW) ? (1u << (4 * a + b)) : 0u;
-  const unsigned base_y = (pix00 * (unsigned)p.ldy + (unsigned)c0) * 4u, base_r = (pix00 * (unsigned)p.ldres + (unsigned)c0) * 4u,
-                 base_m = (pix00 * (unsigned)p.ldmask + (unsigned)c0) * 4u;
-  auto voff = [&](unsigned base, int a, int b) __attribute__((always_inline)) { return ((okm >> (4 * a + b)) & 1u) ? base : kOobOffset; };
+    for (int b = 0; b < 4; ++b) pixm |= (oy0 + a < p.OH && ox0 + b < p.OW) ? (1u << (4 * a + b)) : 0u;
   auto soff = [&](int ld, int a, int b) __attribute__((always_inline)) { return (a * p.OW + b) * ld * 4; };
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(sV + 0 * 32 + 16 * oh + 4 * kg);
-  const f32x4 vec2 = *reinterpret_cast<const f32x4*>(sV + 1 * 32 + 16 * oh + 4 * kg);
-  const f32x4 scale = *reinterpret_cast<const f32x4*>(sV + 2 * 32 + 16 * oh + 4 * kg);
-  const f32x4 shift = *reinterpret_cast<const f32x4*>(sV + 3 * 32 + 16 * oh + 4 * kg);
-  f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
+  float* sC = smem + kRawBufs * kRF + 2 * kFF;   // column sums: [wave 4][which 2][ob 2][64 lanes][4 r] = 16 KiB in filter buffer F2 (F0, F1 receive the next tile's blocks 0, 1)
 
-  // output transform per channel register r: s[a][nu] = sum_xi AT[a][xi] M[xi][nu], then Y[a][b] = sum_nu AT[b][nu] s[a][nu]
-  float yv[4][4][4];   // [a][b][r]
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float sv[4][6];
+  for (int ob = 0; ob < 2; ++ob) {
+    const int cl = 32 * oh + 16 * ob + 4 * kg;                  // first of this lane's four channels inside the tile
+    const int c0 = tl.n0 + cl;
+    const bool c_ok = c0 < p.Cout;   // (Cout % 4 == 0: a group of four channels is in or out as a whole)
+    const unsigned okm = c_ok ? pixm : 0u;
+    const unsigned base_y = (pix00 * (unsigned)p.ldy + (unsigned)c0) * 4u, base_r = (pix00 * (unsigned)p.ldres + (unsigned)c0) * 4u,
+                   base_m = (pix00 * (unsigned)p.ldmask + (unsigned)c0) * 4u;
+    auto voff = [&](unsigned base, int a, int b) __attribute__((always_inline)) { return ((okm >> (4 * a + b)) & 1u) ? base : kOobOffset; };
+    // residual / mask / accumulate operands, 8 pixels (two output rows) at a time.  Launches carry at most one of them as a rule (the
+    // ReLU mask of an input-gradient conv, the residual of a forward one): that one is requested for both halves up front and its
+    // latency hides behind the output transform; with several present they are fetched where they are used.
+    const int nopnd = (has_res ? 1 : 0) + (has_mask ? 1 : 0) + (accum ? 1 : 0);
+    f32x4 opnd[2][8];
+    auto fetch = [&](f32x4 (&dst)[8], __amdgpu_buffer_rsrc_t rs, unsigned base, int ld, int hf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int nu = 0; nu < 6; ++nu)
-      at6(acc_read(acc[0 * 6 + nu][r]), acc_read(acc[1 * 6 + nu][r]), acc_read(acc[2 * 6 + nu][r]), acc_read(acc[3 * 6 + nu][r]), acc_read(acc[4 * 6 + nu][r]),
-          acc_read(acc[5 * 6 + nu][r]), sv[0][nu], sv[1][nu], sv[2][nu], sv[3][nu]);
+      for (int q = 0; q < 8; ++q) {
+        const int a = 2 * hf + (q >> 2), b = q & 3;
+        dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff(base, a, b), soff(ld, a, b), 0));
+      }
+    };
+    if (nopnd == 1) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) at6(sv[a][0], sv[a][1], sv[a][2], sv[a][3], sv[a][4], sv[a][5], yv[a][0][r], yv[a][1][r], yv[a][2][r], yv[a][3][r]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // element-wise part: ONE PASS PER EPILOGUE FLAG over the lane's outputs (a flag is tested once per half tile, not once per element:
-  // every instruction here is matrix time lost), two halves of 8 pixels (output rows 0, 1 and 2, 3) so that the residual / mask /
-  // accumulate operands of a half fit the registers; the operands of the second half are requested before the first is computed.
-  f32x4 resv[2][8], mskv[2][8], oldv[2][8];
-  auto request = [&](int hf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int a = 2 * hf + (q >> 2), b = q & 3;
-      if (has_res) resv[hf][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, voff(base_r, a, b), soff(p.ldres, a, b), 0));
-      if (has_mask) mskv[hf][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, voff(base_m, a, b), soff(p.ldmask, a, b), 0));
-      if (accum) oldv[hf][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, voff(base_y, a, b), soff(p.ldy, a, b), 0));
+      for (int hf = 0; hf < 2; ++hf) {
+        if (has_res) fetch(opnd[hf], rr, base_r, p.ldres, hf);
+        else if (has_mask) fetch(opnd[hf], rm, base_m, p.ldmask, hf);
+        else fetch(opnd[hf], ry, base_y, p.ldy, hf);
+      }
     }
-  };
-  if (has_res || has_mask || accum) {
-    request(0);
-    request(1);
-  }
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(sV + 0 * kBN4 + cl);
+    const f32x4 vec2 = *reinterpret_cast<const f32x4*>(sV + 1 * kBN4 + cl);
+    const f32x4 scale = *reinterpret_cast<const f32x4*>(sV + 2 * kBN4 + cl);
+    const f32x4 shift = *reinterpret_cast<const f32x4*>(sV + 3 * kBN4 + cl);
+    f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
+    // output transform per channel register r: s[a][nu] = sum_xi AT[a][xi] M[xi][nu], then Y[a][b] = sum_nu AT[b][nu] s[a][nu]
+    float yv[4][4][4];   // [a][b][r]
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
-    f32x4 o[8];
-    bool pix_ok[8];
+    for (int r = 0; r < 4; ++r) {
+      float sv[4][6];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int a = 2 * hf + (q >> 2), b = q & 3;
-      o[q] = f32x4{yv[a][b][0], yv[a][b][1], yv[a][b][2], yv[a][b][3]};
-      pix_ok[q] = ((okm >> (4 * a + b)) & 1u) != 0;
+      for (int nu = 0; nu < 6; ++nu) {
+        float mcol[6];
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi) {
+          const int blk = 2 * (xi * 6 + nu) + ob;
+          mcol[xi] = blk < 64 ? acc_read(acc[blk < 64 ? blk : 0][r]) : accv[blk >= 64 ? blk - 64 : 0][r];
+        }
+        at6(mcol[0], mcol[1], mcol[2], mcol[3], mcol[4], mcol[5], sv[0][nu], sv[1][nu], sv[2][nu], sv[3][nu]);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) at6(sv[a][0], sv[a][1], sv[a][2], sv[a][3], sv[a][4], sv[a][5], yv[a][0][r], yv[a][1][r], yv[a][2][r], yv[a][3][r]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (f & CRDR_EPI_BIAS) {
+    // element-wise part: ONE PASS PER EPILOGUE FLAG over 8 outputs pixels at a time (a flag is tested once per half tile, not once per
+    // element: every instruction here is matrix time lost)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) o[q] += bias;
-    }
-    if (f & CRDR_EPI_RELU) {
+    for (int hf = 0; hf < 2; ++hf) {
+      f32x4 o[8];
+      bool pix_ok[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
+      for (int q = 0; q < 8; ++q) {
+        const int a = 2 * hf + (q >> 2), b = q & 3;
+        o[q] = f32x4{yv[a][b][0], yv[a][b][1], yv[a][b][2], yv[a][b][3]};
+        pix_ok[q] = ((okm >> (4 * a + b)) & 1u) != 0;
+      }
+      if (f & CRDR_EPI_BIAS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[q][e] = fmaxf(o[q][e], 0.0f);
-    }
-    if (f & CRDR_EPI_LRELU) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[q][e] = o[q][e] > 0.0f ? o[q][e] : 0.2f * o[q][e];
-    }
-    if (f & CRDR_EPI_VEC2) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) o[q] += vec2;
-    }
-    if (has_res) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) o[q] += resv[hf][q];
-    }
-    if (f & CRDR_EPI_AFFINE) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) o[q] = o[q] * scale + shift;
-    }
-    if (do_cs) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cpre[e] += pix_ok[q] ? o[q][e] : 0.f;
-    }
-    if (has_mask) {
-      const f32x4 moff = (f & CRDR_EPI_MASKOFF) ? vec2 : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (f & CRDR_EPI_LRELUMASK) {
+        for (int q = 0; q < 8; ++q) o[q] += bias;
+      }
+      if (f & CRDR_EPI_RELU) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[q][e] = (mskv[hf][q][e] - moff[e]) > 0.0f ? o[q][e] : 0.2f * o[q][e];
-      } else {
+          for (int e = 0; e < 4; ++e) o[q][e] = fmaxf(o[q][e], 0.0f);
+      }
+      if (f & CRDR_EPI_LRELU) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[q][e] = (mskv[hf][q][e] - moff[e]) > 0.0f ? o[q][e] : 0.0f;
+          for (int e = 0; e < 4; ++e) o[q][e] = o[q][e] > 0.0f ? o[q][e] : 0.2f * o[q][e];
+      }
+      if (f & CRDR_EPI_VEC2) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += vec2;
+      }
+      if (has_res) {
+        if (nopnd > 1) fetch(opnd[hf], rr, base_r, p.ldres, hf);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += opnd[hf][q];
+      }
+      if (f & CRDR_EPI_AFFINE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = o[q] * scale + shift;
+      }
+      if (do_cs) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cpre[e] += pix_ok[q] ? o[q][e] : 0.f;
+      }
+      if (has_mask) {
+        if (nopnd > 1) fetch(opnd[hf], rm, base_m, p.ldmask, hf);
+        const f32x4 moff = (f & CRDR_EPI_MASKOFF) ? vec2 : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (f & CRDR_EPI_LRELUMASK) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[q][e] = (opnd[hf][q][e] - moff[e]) > 0.0f ? o[q][e] : 0.2f * o[q][e];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[q][e] = (opnd[hf][q][e] - moff[e]) > 0.0f ? o[q][e] : 0.0f;
+        }
+      }
+      if (do_cs) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cpost[e] += pix_ok[q] ? o[q][e] : 0.f;
+      }
+      if (accum) {
+        if (nopnd > 1) fetch(opnd[hf], ry, base_y, p.ldy, hf);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += opnd[hf][q];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int a = 2 * hf + (q >> 2), b = q & 3;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[q]), ry, voff(base_y, a, b), soff(p.ldy, a, b), 0);
       }
     }
     if (do_cs) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cpost[e] += pix_ok[q] ? o[q][e] : 0.f;
-    }
-    if (accum) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) o[q] += oldv[hf][q];
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int a = 2 * hf + (q >> 2), b = q & 3;
-#ifndef W4_NOSTORE
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[q]), ry, voff(base_y, a, b), soff(p.ldy, a, b), 0);
-#else
-      if (o[q][0] == 1.2345f && o[q][3] == 0.77f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[q]), ry, voff(base_y, a, b), soff(p.ldy, a, b), 0);
-#endif
+      *reinterpret_cast<f32x4*>(sC + (((wave * 2 + 0) * 2 + ob) * 64 + lane) * 4) = cpre;
+      *reinterpret_cast<f32x4*>(sC + (((wave * 2 + 1) * 2 + ob) * 64 + lane) * 4) = cpost;
     }
   }
   if (do_cs) {
-    // column sums of the tile, fixed order: channel c = 16 oh + 4 kg + r <- waves (th = 0, 1; oh), lanes kg * 16 + tx, tx = 0..15.
-    // sC[wave 4][which 2][64 lanes][4 r] = 8 KiB in filter buffer F1 (F0 already receives the next tile's block 0)
-    float* sC = smem + kRawBufs * kRF + kFF;
-    *reinterpret_cast<f32x4*>(sC + ((wave * 2 + 0) * 64 + lane) * 4) = cpre;
-    *reinterpret_cast<f32x4*>(sC + ((wave * 2 + 1) * 64 + lane) * 4) = cpost;
+    // column sums of the tile, fixed order: channel c = 32 oh + 16 ob + 4 kg + r <- waves (th = 0, 1; oh), lanes kg * 16 + tx, tx = 0..15
     lds_barrier4();
     const int tid = wave * 64 + lane;
-    if (tid < 64) {
-      const int which = tid >> 5, c = tid & 31, oh2 = c >> 4, kg2 = (c >> 2) & 3, r = c & 3;
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63, oh2 = c >> 5, ob2 = (c >> 4) & 1, kg2 = (c >> 2) & 3, r = c & 3;
       float sum = 0.f;
       for (int th2 = 0; th2 < 2; ++th2)
-        for (int t2 = 0; t2 < 16; ++t2) sum += sC[(((th2 * 2 + oh2) * 2 + which) * 64 + kg2 * 16 + t2) * 4 + r];
+        for (int t2 = 0; t2 < 16; ++t2) sum += sC[((((th2 * 2 + oh2) * 2 + which) * 2 + ob2) * 64 + kg2 * 16 + t2) * 4 + r];
       if (tl.n0 + c < p.Cout) p.cs[((size_t)tl.patch * 2 + which) * p.cs_ld + tl.n0 + c] = sum;
     }
   }
@@ -417,22 +458,22 @@ __device__ __forceinline__ Wino4Src wino4_src(const IgemmArgs& p, const IgemmGro
   // transformed filters of group gidx: [N tile][chunk][2304 slots of 16 B]
   const size_t ublock = (size_t)gyn * p.kchunks * kUSlots4 * 4;   // floats per group
   sr.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (size_t)tl.gidx * ublock, 0, (unsigned)(ublock * 4), 0x00020000);
-  sr.u_off0 = (unsigned)(tl.n0 / 32) * (unsigned)p.kchunks * (kUSlots4 * 16u);
+  sr.u_off0 = (unsigned)(tl.n0 / kBN4) * (unsigned)p.kchunks * (kUSlots4 * 16u);
 #pragma unroll
-  for (int j = 0; j < 7; ++j) sr.a_off[j] = wino4_in_off(p, tl, wave + 4 * j, lane);
+  for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off(p, tl, wave + 4 * j, lane);
   return sr;
 }
 
-// per-column epilogue vectors of tile tl -> sV[4][32] (bias, vec2, scale, shift)
+// per-column epilogue vectors of tile tl -> sV[4][64] (bias, vec2, scale, shift)
 __device__ __forceinline__ void wino4_vectors(const IgemmArgs& p, const IgemmGroup& grp, const Wino4Tile& tl, float* sV, int tid) {
-  if (tid < 32) {
+  if (tid < kBN4) {
     const int f0 = p.flags;
     const bool live = tl.n0 + tid < p.Cout;
     const float* bias = p.ngroup > 1 ? grp.bias[tl.gidx] : p.bias;
-    sV[0 * 32 + tid] = (live && (f0 & CRDR_EPI_BIAS)) ? bias[tl.n0 + tid] : 0.f;
-    sV[1 * 32 + tid] = (live && (f0 & (CRDR_EPI_VEC2 | CRDR_EPI_MASKOFF))) ? p.vec2[tl.n0 + tid] : 0.f;
-    sV[2 * 32 + tid] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.scale[tl.n0 + tid] : 1.f;
-    sV[3 * 32 + tid] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[tl.n0 + tid] : 0.f;
+    sV[0 * kBN4 + tid] = (live && (f0 & CRDR_EPI_BIAS)) ? bias[tl.n0 + tid] : 0.f;
+    sV[1 * kBN4 + tid] = (live && (f0 & (CRDR_EPI_VEC2 | CRDR_EPI_MASKOFF))) ? p.vec2[tl.n0 + tid] : 0.f;
+    sV[2 * kBN4 + tid] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.scale[tl.n0 + tid] : 1.f;
+    sV[3 * kBN4 + tid] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[tl.n0 + tid] : 0.f;
   }
 }
 
@@ -443,7 +484,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int total = gx * gyn * gz;
-  float* sVb = smem + kLdsFloats4;   // [2][4][32]: bias, vec2, scale, shift of the current / the next tile
+  float* sVb = smem + kLdsFloats4;   // [2][4][64]: bias, vec2, scale, shift of the current / the next tile
   int cur = 0;
   bool prefetched = false;
   Wino4Src sr;
@@ -459,41 +500,35 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
       const int g = tl.gidx;
       p.x = grp.x[g]; p.y = grp.y[g]; p.bias = grp.bias[g]; p.mask = grp.mask[g]; p.res = grp.res[g]; p.cs = grp.cs[g];
     }
-    float* sV = sVb + cur * 128;
+    float* sV = sVb + cur * (4 * kBN4);
     if (!prefetched) {
       sr = wino4_src(p_, grp, tl, gyn, lane, wave);
       wino4_vectors(p_, grp, tl, sV, tid);   // (published by the K loop's first barrier)
     }
-    f32x4 acc[36];
+    f32x4 acc[64], accv[8];
 #pragma unroll
-    for (int j = 0; j < 36; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifndef W4_SKIP_LOOP
-    wino4_loop(p, smem, sr, prefetched, lane, wave, acc);
-#endif
+    for (int j = 0; j < 64; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wino4_loop(p, smem, sr, prefetched, lane, wave, acc, accv);
     // (the loop ends with a barrier: every wave is past its last LDS read, raw and filter buffers are free)
     const bool more = vb + (int)gridDim.x < total;
     if (more) {   // the next tile: raw patches 0, 1, 2, filter block 0 and the epilogue vectors
       const Wino4Tile tn = wino4_tile(p_, vb + (int)gridDim.x, gx, gyn, gz);
       sr = wino4_src(p_, grp, tn, gyn, lane, wave);
-#ifndef W4_NOPROLOGUE
-      wino4_prologue_dma(smem, sr, p_.Cin, p_.kchunks, lane, wave);
-#endif
-      wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * 128, tid);
+      wino4_prologue_dma(smem, sr, p_.kchunks, lane, wave);
+      wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * (4 * kBN4), tid);
     }
-#ifndef W4_SKIP_FINISH
-    wino4_finish(p, tl, smem, sV, lane, wave, acc);
-#else
-    if (acc[0][0] == 1.2345f && acc[17][3] == 2.5f && acc[35][1] == 0.3f) p.y[lane] = acc[5][1];
-#endif
+    wino4_finish(p, tl, smem, sV, lane, wave, acc, accv);
     prefetched = more;
     cur ^= 1;
-    lds_barrier4();   // column-sum area, sV of this tile: free (the stores stay in flight: the next tile's first wait is vmcnt(16))
+    lds_barrier4();   // column-sum area, sV of this tile: free (the stores stay in flight: the next tile's first wait is vmcnt(32))
   }
 }
 
 // Filter transform U = G g G^T, G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]], evaluated in double
 // and rounded once, from the implicit-GEMM weight pack (tap-major [tap][wrows][wcols]) into the block layout of wino4_kernel:
-// [N tile of 32][chunk of 8 channels][position 36][channel pair 4][oc 32][2].
+// [N tile of 64][chunk of 4 channels][position 36][channel 4][oc 64].
 struct Wino4Taps { int widx[9]; };
 __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const float* w0, float* u, int Cin, int Cout, int wrows, int wcols, int kchunks,
                                     int ntile, Wino4Taps tp) {
@@ -503,10 +538,10 @@ __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const floa
   if (id >= total) return;
   const int g = blockIdx.y;
   const float* w = ngroup > 1 ? grp.w[g] : w0;
-  const int c8 = (int)(id & 7), oc32 = (int)((id >> 3) & 31);
+  const int c4 = (int)(id & 3), oc64 = (int)((id >> 2) & 63);
   const long long blk = id >> 8;   // (N tile, chunk)
   const int kc = (int)(blk % kchunks), ct = (int)(blk / kchunks);
-  const int oc = ct * 32 + oc32, c = kc * 8 + c8;
+  const int oc = ct * kBN4 + oc64, c = kc * 4 + c4;
   const bool live = oc < Cout && c < Cin;
   double g9[3][3];
 #pragma unroll
@@ -515,7 +550,7 @@ __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const floa
     for (int b = 0; b < 3; ++b) g9[a][b] = live ? (double)w[((size_t)tp.widx[a * 3 + b] * wrows + oc) * wcols + c] : 0.0;
   const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-  float* dst = u + ((size_t)g * ntile * kchunks + (size_t)blk) * (kUSlots4 * 4) + ((size_t)(c8 >> 1) * 32 + oc32) * 2 + (c8 & 1);
+  float* dst = u + ((size_t)g * ntile * kchunks + (size_t)blk) * (kUSlots4 * 4) + (size_t)c4 * kBN4 + oc64;
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
     double t[3];
@@ -547,7 +582,7 @@ bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok) {
   return true;
 }
 
-size_t wino4_workspace(const crdr_conv_desc* d, int G) { return (size_t)G * cdiv(d->OC, 32) * cdiv(d->C, 8) * kUSlots4 * 16; }
+size_t wino4_workspace(const crdr_conv_desc* d, int G) { return (size_t)G * cdiv(d->OC, kBN4) * cdiv(d->C, 4) * kUSlots4 * 16; }
 
 int wino4_colsum_rows(const crdr_conv_desc* d) { return d->N * cdiv(d->OH, 4 * kTY) * cdiv(d->OW, 4 * kTX); }
 
@@ -565,7 +600,7 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
     wt.widx[dh * 3 + dw] = v >> 16;
   }
   for (int t = 0; t < 9; ++t) CRDR_REQUIRE(wt.widx[t] >= 0, "conv2d: Winograd F(4x4): incomplete 3x3 window");
-  const int ntile = cdiv(d->OC, 32), kchunks = cdiv(d->C, 8);
+  const int ntile = cdiv(d->OC, kBN4), kchunks = cdiv(d->C, 4);
   {
     const long long total = (long long)ntile * kchunks * 256;
     hipLaunchKernelGGL(wino4_filter_kernel, dim3((unsigned)cdiv64(total, 256), G), dim3(256), 0, s, grp, G, a.w, u, d->C, d->OC, d->wrows, d->wcols, kchunks,
@@ -591,7 +626,7 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.store(true, std::memory_order_release);
   }
-  const size_t lds = (size_t)(kLdsFloats4 + 2 * 4 * 32) * sizeof(float);
+  const size_t lds = (size_t)(kLdsFloats4 + 2 * 4 * kBN4) * sizeof(float);
   hipLaunchKernelGGL(wino4_kernel, dim3(std::min(total, ncu)), dim3(kNT4), lds, s, a, grp, gx, ntile, G);
   CRDR_CHECK_LAUNCH("wino4_kernel");
   return 0;
