@@ -19,9 +19,10 @@
 // operations + 71 LDS reads + 16 DMA per 72 MFMAs made the loop issue-bound at 1.8x the MFMA time; 32 channels per wave and
 // 4-channel sub-steps halve the non-MFMA instructions per MFMA.
 // K loop: sub-steps of 4 input channels, one barrier each; LDS holds three raw-patch buffers and two filter buffers filled by LDS-DMA:
-//   * the raw 10 x 66 x 4 input patch, stored by pixel class (row & 3, column & 3): [class 16][3 rows][17 slots of 16 B]; lane (tile tx,
+//   * the raw 10 x 66 x 4 input patch, stored by pixel class (row & 3, column & 3): [class 16][64 slots of 16 B: 3 rows x 17 used]; lane (tile tx,
 //     channel kg) reads 4 bytes of patch pixel (i, j): the 16 tiles of a row x 4 channels cover 256 consecutive bytes (conflict free);
-//   * the transformed filters of the sub-step: [position 36][channel 4][output channel 64] = 36 KiB, contiguous in memory and in LDS.
+//   * the transformed filters of the sub-step: [position 36][channel 4][oh 2][tx 16][ob 2] (output channel 32 oh + 16 ob + tx) = 36 KiB,
+//     contiguous in memory and in LDS.
 //   Every lane transforms the 6 x 6 patch of its tile for its channel in registers (12 fma-class operations per 1-D transform) and
 //   the wave issues 72 MFMAs; the work is laid out by hand in 72 slots of one MFMA + its share of loads / transform / DMA.
 #include <algorithm>
@@ -38,8 +39,10 @@ namespace {
 constexpr int kNT4 = 256;
 constexpr int kTY = 2, kTX = 16;                       // Winograd tiles per output tile (rows, columns)
 constexpr int kBN4 = 64;                               // output channels per tile
-constexpr int kInUsed4 = 16 * 3 * 17;                  // 16-byte slots (4 channels of one pixel) of the input patch image per buffer
-constexpr int kInPieces = 16;                          // DMA instructions (1 KiB each) for it: 13 needed, 16 = 4 per wave (uniform vmcnt counts)
+constexpr int kClsSlots = 64;                          // slots per pixel class: 3 rows x 17 = 51 used; 64 = 1 KiB apart, so that two pixels of a patch column
+                                                       // (different classes) are one ds_read2st64_b32
+constexpr int kInUsed4 = 16 * kClsSlots;               // 16-byte slots (4 channels of one pixel) of the input patch image per buffer
+constexpr int kInPieces = 16;                          // DMA instructions (1 KiB each) for it, 4 per wave
 constexpr int kInSlots4 = kInPieces * 64;
 constexpr int kUSlots4 = 36 * 4 * kBN4 / 4;            // slots of one filter block (4 channels x 64 output channels): 36 pieces
 constexpr int kRawBufs = 3, kFiltBufs = 3;            // raw patches are requested three sub-steps ahead, filter blocks two: nothing requested during a sub-step is waited for at its end
@@ -109,11 +112,11 @@ __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int 
 // the pixel lies outside the image (the range check of the buffer load then delivers zeros: padding)
 __device__ __forceinline__ unsigned wino4_in_off(const IgemmArgs& p, const Wino4Tile& t, int piece, int lane) {
   const int S = piece * 64 + lane;
-  const int cls = S / 51, r2 = S - cls * 51, R = r2 / 17, Cc = r2 - R * 17;
+  const int cls = S / kClsSlots, r2 = S - cls * kClsSlots, R = r2 / 17, Cc = r2 - R * 17;
   const int ci = cls >> 2, cj = cls & 3;
   const int pi = 4 * R + ci, pj = 4 * Cc + cj;
   const int ih = t.oh0 - p.si + pi, iw = t.ow0 - p.si + pj;
-  const bool ok = S < kInUsed4 && pi < 4 * kTY + 2 && pj < 4 * kTX + 2 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+  const bool ok = S < kInUsed4 && r2 < 51 && pi < 4 * kTY + 2 && pj < 4 * kTX + 2 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
   return ok ? (unsigned)((((t.n * p.H + ih) * p.W + iw) * p.ldx) * 4) : kOobOffset;
 }
 
@@ -124,30 +127,33 @@ struct Wino4Src {
   unsigned a_off[4];   // raw piece wave + 4 j: byte offset of this lane's pixel (chunk 0), or out of range
 };
 
-// raw piece j (0..3) of this wave, patch kr -> raw buffer rbuf; live false: the sub-step does not exist (zeros land in a buffer nobody reads)
-__device__ __forceinline__ void wino4_dma_raw(float* smem, const Wino4Src& sr, int j, int kr, int rbuf, bool live, int lane, int wave) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wino4_empty_rsrc() { return __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000); }
+
+// raw piece j (0..3) of this wave, patch kr -> raw buffer rbuf through descriptor rx: the tile's own (sr.rx), or an EMPTY one where the
+// sub-step does not exist (every lane out of range: zeros land in a buffer nobody reads) -- liveness is wave-uniform, so it travels in the
+// scalar descriptor instead of a per-lane select (every vector instruction of the K loop costs matrix time)
+__device__ __forceinline__ void wino4_dma_raw(float* smem, const Wino4Src& sr, __amdgpu_buffer_rsrc_t rx, int j, int kr, int rbuf, int lane, int wave) {
   const int piece = wave + 4 * j;
-  const unsigned off = live ? sr.a_off[j] : kOobOffset;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.rx, (lds_ptr_t)(smem + rbuf * kRF + piece * 256), 16, (int)off, (int)(kr * 16), 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + rbuf * kRF + piece * 256), 16, (int)sr.a_off[j], (int)(kr * 16), 0, 0);
 }
 // filter piece 9 wave + j (j = 0..8) of block kf -> filter buffer fbuf
-__device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, int j, int kf, int fbuf, bool live, int lane, int wave) {
+__device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, __amdgpu_buffer_rsrc_t ru, int j, int kf, int fbuf, int lane, int wave) {
   const int piece = wave * 9 + j;
-  const unsigned off = live ? (unsigned)((piece * 64 + lane) * 16) : kOobOffset;
+  const unsigned off = (unsigned)((piece * 64 + lane) * 16);
   // (u_off0 is wave-uniform; said so explicitly, or the compiler wraps every request in a waterfall loop over the scalar offset)
   const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)sr.u_off0) + (unsigned)kf * (kUSlots4 * 16u);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.ru, (lds_ptr_t)(smem + kRawBufs * kRF + fbuf * kFF + piece * 256), 16, (int)off, (int)so, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(smem + kRawBufs * kRF + fbuf * kFF + piece * 256), 16, (int)off, (int)so, 0, 0);
 }
 // the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and filter blocks 0, 1 (-> F0, F1)
 __device__ __forceinline__ void wino4_prologue_dma(float* smem, const Wino4Src& sr, int K4, int lane, int wave) {
 #pragma unroll
   for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wino4_dma_raw(smem, sr, j, kr, kr, kr < K4, lane, wave);
+    for (int j = 0; j < 4; ++j) wino4_dma_raw(smem, sr, kr < K4 ? sr.rx : wino4_empty_rsrc(), j, kr, kr, lane, wave);
 #pragma unroll
   for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
-    for (int j = 0; j < 9; ++j) wino4_dma_filt(smem, sr, j, kf, kf, kf < K4, lane, wave);
+    for (int j = 0; j < 9; ++j) wino4_dma_filt(smem, sr, kf < K4 ? sr.ru : wino4_empty_rsrc(), j, kf, kf, lane, wave);
 }
 
 // K loop of one wave (the only wave of its SIMD: nothing else hides its latencies, so the loop is software pipelined by hand).
@@ -156,7 +162,7 @@ __device__ __forceinline__ void wino4_prologue_dma(float* smem, const Wino4Src& 
 // filter block k + 1 (-> F[(k + 1) & 1], last read in sub-step k - 1; filters come out of L2) and of raw patch k + 3 (-> R[k % 3], last
 // read in sub-step k - 1).  The sub-step ends with vmcnt(13) + barrier: what it requested itself stays in flight, everything older has landed.  72 slots, pinned by sched_barrier:
 //   slot s: MFMA of position j = s / 2 (transform row x = j / 6), channel block s % 2; the two filter fragments of position j + 4
-//   requested at slot 2 j + 1; raw column b (6 pixels) requested in slots 6 b .. 6 b + 5, its vertical transform in slots 6 b + 8 and
+//   requested at slot 2 j + 1; raw column b (6 pixels) requested in slots 6 b, 6 b + 2, 6 b + 4 (two each), its vertical transform in slots 6 b + 8 and
 //   6 b + 11 (half each); horizontal transform of row x < 5 of V_{k+1} in slots 44 + 5 x and 46 + 5 x -- straight into the registers of
 //   V_k's row x, whose MFMAs (slots 12 x .. 12 x + 11) are done by then; row 5 follows at the top of the next sub-step; DMA instruction
 //   q (9 filter pieces, then 4 raw pieces) at slot 5 q + 2.
@@ -166,9 +172,10 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
   // this lane's raw reads: patch pixel (i, j) of tile (th, tx), channel kg: float offset rbase + ro(i, j) of a raw buffer
   const int rbase = (th * 17 + tx) * 4 + kg;
-  auto ro = [](int i, int j) constexpr { return (((i & 3) * 4 + (j & 3)) * 51 + (i >> 2) * 17 + (j >> 2)) * 4; };
-  // filter fragments of position pos (channel kg of the sub-step, output channels 32 oh + 16 ob + tx): + (k & 1) * kFF + pos * 256 + 16 ob
-  const int fbase = kRawBufs * kRF + kg * kBN4 + 32 * oh + tx;
+  auto ro = [](int i, int j) constexpr { return (((i & 3) * 4 + (j & 3)) * kClsSlots + (i >> 2) * 17 + (j >> 2)) * 4; };
+  // filter fragments of position pos (channel kg of the sub-step, output channels 32 oh + 16 ob + tx, ob = 0, 1: adjacent, one 8-byte read):
+  // + buffer * kFF + pos * 256
+  const int fbase = kRawBufs * kRF + kg * kBN4 + 32 * oh + 2 * tx;
 
   float t[6][6];   // vertical pass of the patch being transformed: [xi][column]
   float v[6][6];   // V of the current sub-step (rows 0..4: replaced in place by the next one's during the sub-step)
@@ -211,15 +218,21 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
 
   int r1 = 1, r0 = 0;   // raw buffer of patch k + 1 / of patch k (= the one patch k + 3 goes to)
   for (int k = 0; k < K4; ++k) {
-    const float* rp = smem + rbase + r1 * kRF;            // raw patch k + 1
-    const float* fp = smem + fbase + r0 * kFF;            // filter block k (the filter ring turns with the raw ring: block k in buffer k % 3)
-    const bool live2 = k + 2 < K4, live3 = k + 3 < K4;
+    // (the two base offsets are made opaque: every LDS read of the sub-step is then `base register + 16-bit immediate`; left visible,
+    // the compiler folds the buffer constants into the offsets, overflows the immediate and spends an add per read)
+    int rpo = rbase + r1 * kRF, fpo = fbase + r0 * kFF;
+    asm volatile("" : "+v"(rpo));
+    asm volatile("" : "+v"(fpo));
+    const float* rp = smem + rpo;                         // raw patch k + 1
+    const float* fp = smem + fpo;                         // filter block k (the filter ring turns with the raw ring: block k in buffer k % 3)
+    const __amdgpu_buffer_rsrc_t ru2 = k + 2 < K4 ? sr.ru : wino4_empty_rsrc(), rx3 = k + 3 < K4 ? sr.rx : wino4_empty_rsrc();
     const int f2 = r1 == 2 ? 0 : r1 + 1;                  // buffer of filter block k + 2
     float uf[8][2];   // filter fragments of positions j .. j + 3 in flight (ring of 8, indexed j & 7)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      uf[j][0] = fp[j * 256];
-      uf[j][1] = fp[j * 256 + 16];
+      const f32x2 u2 = *reinterpret_cast<const f32x2*>(fp + j * 256);
+      uf[j][0] = u2[0];
+      uf[j][1] = u2[1];
     }
     hpass0(5);   // row 5 of V_k (its vertical pass was done during the previous sub-step; its MFMAs are the last ones)
     hpass1(5);
@@ -232,10 +245,14 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
       if (s < 64) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[j & 7][ob], v[x][y], acc[s], 0, 0, 0);
       else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[s - 64]) : "v"(uf[j & 7][ob]), "v"(v[x][y]));
       if (ob == 1 && j + 4 < 36) {   // four positions (8 slots) ahead of their use
-        uf[(j + 4) & 7][0] = fp[(j + 4) * 256];
-        uf[(j + 4) & 7][1] = fp[(j + 4) * 256 + 16];
+        const f32x2 u2 = *reinterpret_cast<const f32x2*>(fp + (j + 4) * 256);
+        uf[(j + 4) & 7][0] = u2[0];
+        uf[(j + 4) & 7][1] = u2[1];
       }
-      if (s < 36) vread(rp, s / 6, s % 6);                                          // raw column b = s / 6, pixel s % 6
+      if (s < 36 && (s & 1) == 0) {   // raw column b = s / 6, pixels s % 6 and s % 6 + 1: same slot row, classes 4 KiB apart = one ds_read2st64_b32
+        vread(rp, s / 6, s % 6);
+        vread(rp, s / 6, s % 6 + 1);
+      }
       // vertical pass of column b: outputs 0..2 (inputs 0..4, the last one requested at slot 6 b + 4) at slot 6 b + 8, outputs 3..5
       // (inputs 1..5) at slot 6 b + 11; the column buffer is overwritten from slot 6 b + 12 (input 0) / 6 b + 13 (input 1) on
       if (s >= 8 && s < 44) {
@@ -249,8 +266,8 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
       }
       if (s % 5 == 2 && s / 5 < 13) {
         const int q = s / 5;
-        if (q < 9) wino4_dma_filt(smem, sr, q, k + 2, f2, live2, lane, wave);
-        else wino4_dma_raw(smem, sr, q - 9, k + 3, r0, live3, lane, wave);
+        if (q < 9) wino4_dma_filt(smem, sr, ru2, q, k + 2, f2, lane, wave);
+        else wino4_dma_raw(smem, sr, rx3, q - 9, k + 3, r0, lane, wave);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -528,7 +545,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
 
 // Filter transform U = G g G^T, G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]], evaluated in double
 // and rounded once, from the implicit-GEMM weight pack (tap-major [tap][wrows][wcols]) into the block layout of wino4_kernel:
-// [N tile of 64][chunk of 4 channels][position 36][channel 4][oc 64].
+// [N tile of 64][chunk of 4 channels][position 36][channel 4][oh 2][tx 16][ob 2], output channel = 32 oh + 16 ob + tx.
 struct Wino4Taps { int widx[9]; };
 __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const float* w0, float* u, int Cin, int Cout, int wrows, int wcols, int kchunks,
                                     int ntile, Wino4Taps tp) {
@@ -550,7 +567,7 @@ __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const floa
     for (int b = 0; b < 3; ++b) g9[a][b] = live ? (double)w[((size_t)tp.widx[a * 3 + b] * wrows + oc) * wcols + c] : 0.0;
   const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-  float* dst = u + ((size_t)g * ntile * kchunks + (size_t)blk) * (kUSlots4 * 4) + (size_t)c4 * kBN4 + oc64;
+  float* dst = u + ((size_t)g * ntile * kchunks + (size_t)blk) * (kUSlots4 * 4) + (size_t)c4 * kBN4 + (oc64 >> 5) * 32 + (oc64 & 15) * 2 + ((oc64 >> 4) & 1);
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
     double t[3];
