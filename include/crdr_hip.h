@@ -139,14 +139,19 @@ int crdr_conv2d_choose_algo(const crdr_conv_desc* d, int G);
  * 16-byte aligned rows, no GATE / PREADD / ACCUM epilogue and a weight tile that fits LDS.  Results are bit-identical to
  * the unsplit tile configurations; CRDR_EPI_COLSUM rows are per 128- or 256-row tile (crdr_conv2d_colsum_layout) */
 int crdr_conv2d_num_stream_configs(void);
-/* number of Winograd variants (2; v = 1 covers a channel tail of <= 32 with PAIR tiles -- the tail's channels of two 16x16 patches per
- * workgroup -- so that e.g. 96 channels cost 1.5 tiles per patch, not 2): forced algorithm id crdr_conv2d_num_configs() + 1 + crdr_conv2d_num_stream_configs() + v, no
- * split bits.  F(2x2, 3x3) minimal filtering on the exact-fp32 matrix cores for 3x3 stride-1 convolutions and their input
- * gradients (2.25x fewer multiply-accumulates than the implicit GEMM; what cuDNN's WINOGRAD algorithms do for the reference,
- * base_trainer.py:20 cudnn.benchmark).  fp32 arithmetic throughout (data transform +-1, filter transform halves); the sums are
- * associated differently from the direct form.  Rejected unless kh = kw = 3, stride 1, C % 4 == 0 and the epilogue has no GATE /
- * PREADD (grouped: nor VEC2 / AFFINE / MASKOFF).  The transformed filters are rebuilt from the weight pack into the workspace by
- * every launch (crdr_conv2d_workspace with the same `reserved`); CRDR_EPI_COLSUM rows are per 16x16-pixel output patch. */
+/* number of Winograd variants (3): forced algorithm id crdr_conv2d_num_configs() + 1 + crdr_conv2d_num_stream_configs() + v, no split bits.
+ * v = 0, 1: F(2x2, 3x3) minimal filtering on the exact-fp32 matrix cores for 3x3 stride-1 convolutions and their input gradients (2.25x
+ * fewer multiply-accumulates than the implicit GEMM; what cuDNN's WINOGRAD algorithms do for the reference, base_trainer.py:20
+ * cudnn.benchmark); v = 1 covers a channel tail of <= 32 with PAIR tiles -- the tail's channels of two 16x16 patches per workgroup -- so
+ * that e.g. 96 channels cost 1.5 tiles per patch, not 2.  fp32 arithmetic throughout (data transform +-1, filter transform halves); the
+ * sums are associated differently from the direct form.  Rejected unless kh = kw = 3 (or 5, as 2 x 2 sub-filters), stride 1, C % 4 == 0
+ * and the epilogue has no GATE / PREADD (grouped: nor VEC2 / AFFINE / MASKOFF).
+ * v = 2: F(4x4, 3x3) (wino4.hip): 4x fewer multiply-accumulates than the implicit GEMM, output tiles of 8 x 64 pixels x 64 channels;
+ * additionally needs >= 48 output columns, OC % 4 == 0 and 16-byte aligned operand rows.  Its transforms carry the constants 4, 5, 8 and
+ * 1/4 .. 1/24: results deviate from float64 by ~5e-6 .. 1e-5 of the output scale (the other kernels: ~1e-6) -- a candidate of the
+ * training-side tuner only, never of the built-in plan (the codec runs built-in plans).
+ * The transformed filters are rebuilt from the weight pack into the workspace by every launch (crdr_conv2d_workspace with the same
+ * `reserved`); CRDR_EPI_COLSUM rows are per output tile (16x16 pixels for v = 0, 1; 8x64 for v = 2), crdr_conv2d_colsum_layout. */
 int crdr_conv2d_num_wino_configs(void);
 /* bytes of workspace crdr_conv2d needs for this problem (split-K partial slabs; may be 0) */
 size_t crdr_conv2d_workspace(const crdr_conv_desc* d);
