@@ -356,7 +356,7 @@ def test_winograd_ids_are_planned_only_for_the_shapes_they_take(lib):
     import ctypes as C
     from crdr_amd.hip import lib as L
     base = lib.crdr_conv2d_num_configs() + 1 + lib.crdr_conv2d_num_stream_configs()
-    assert lib.crdr_conv2d_num_wino_configs() == 2
+    assert lib.crdr_conv2d_num_wino_configs() == 3
 
     def desc(c, oc, h, k, stride=1, pad=None, transposed=0, n=2):
         pad = k // 2 if pad is None else pad
@@ -386,6 +386,17 @@ def test_winograd_ids_are_planned_only_for_the_shapes_they_take(lib):
     d5 = desc(32, 64, 16, 5)
     d5.reserved = base
     assert lib.crdr_conv2d_workspace(C.byref(d5)) == tickets + 1 * 4 * 4 * 16 * 2 * 64 * 16
+    # variant 2 = F(4x4, 3x3) (wino4.hip): 3x3 stride 1 with >= 48 output columns, C and OC multiples of 4; no 5x5 form; workspace =
+    # tickets + N tiles of 64 x chunks of 4 channels x 36 positions x 4 x 64 floats
+    assert plan(desc(96, 96, 64, 3), base + 2) == base + 2
+    assert plan(desc(96, 96, 64, 3, transposed=1), base + 2) == base + 2
+    assert plan(desc(96, 96, 32, 3), base + 2) == 0                   # 32 output columns
+    assert plan(desc(96, 96, 64, 3, stride=2), base + 2) == 0
+    assert plan(desc(320, 224, 64, 5), base + 2) == 0
+    assert plan(desc(96, 98, 64, 3), base + 2) == 0                   # OC % 4 != 0
+    d4 = desc(100, 96, 64, 3)
+    d4.reserved = base + 2
+    assert lib.crdr_conv2d_workspace(C.byref(d4)) == tickets + 2 * 25 * 36 * 4 * 64 * 4
     nw = lib.crdr_conv2d_wgrad_num_configs()
 
     def wdesc(k, stride):

@@ -131,6 +131,18 @@ def test_stage3_step_winograd():
         ops.PREFER_WINOGRAD = False
 
 
+def test_stage3_step_128_winograd_f4x4():
+    """the stage-3 step at 128x128 with every convolution the F(4x4, 3x3) Winograd kernel accepts (3x3 stride 1 at >= 48 output columns:
+    the 64x64 bottleneck / NLAM stages of both transforms, the discriminator's 128x128 and 64x64 layers and their input gradients) on that
+    kernel, the F(2x2, 3x3) kernel on the other 3x3 layers: same oracle, same gates (ops.PREFER_WINOGRAD = 4)"""
+    from crdr_amd.hip import ops
+    ops.PREFER_WINOGRAD = 4
+    try:
+        _stage3_step(bs=2, size=128)
+    finally:
+        ops.PREFER_WINOGRAD = False
+
+
 class _ShippedPlans:
     """what bench.py and scripts/train.py run: ops.AUTOTUNE on with the shipped perf database (crdr_amd/hip/tune_gfx950.json)"""
 

@@ -26,7 +26,7 @@ elif algo:
     ops.AUTOTUNE = True
     key_hook = {}
     orig = ops._autotune
-    ops._autotune = lambda key, ncfg, mls, run: (ops._algo_cache.__setitem__(key, algo) or algo)
+    ops._autotune = lambda key, *a, **k: (ops._algo_cache.__setitem__(key, algo) or algo)
 for _ in range(10):
     ops.conv2d_raw(x, wf, co, (k, k), s, p, bool(tr), (oh, oh), out=y)
 torch.cuda.synchronize()

@@ -31,7 +31,7 @@ def main():
     torch.cuda.synchronize()
     lib.crdr_profile_enable(0)
     out = {}
-    for kind, name in ((0, "igemm"), (1, "wgrad"), (3, "winograd"), (4, "winograd_wgrad")):
+    for kind, name in ((0, "igemm"), (1, "wgrad"), (3, "winograd"), (4, "winograd_wgrad"), (5, "winograd_f4x4")):
         fl, ms, n = C.c_double(), C.c_double(), C.c_longlong()
         lib.crdr_profile_read(kind, C.byref(fl), C.byref(ms), C.byref(n))
         out[name] = {"launches": n.value, "gflop": fl.value / 1e9, "ms": ms.value}

@@ -3,13 +3,13 @@ import csv, glob, sys
 tag = sys.argv[1]; gflop = float(sys.argv[2]); mb = float(sys.argv[3])
 def last(d, counter):
     f = max(glob.glob(f"gpurun_out/pmc_{tag}_{d}/**/*counter_collection.csv", recursive=True), key=__import__("os").path.getmtime)
-    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("igemm_kernel", "gemm1x1_kernel", "wino_kernel"))]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("igemm_kernel", "gemm1x1_kernel", "wino_kernel", "wino4_kernel"))]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     rows = rows[-10:]
     return sum(float(r["Counter_Value"]) for r in rows) / len(rows), rows[-1]
 def dur(d):
     f = max(glob.glob(f"gpurun_out/pmc_{tag}_{d}/**/*kernel_trace.csv", recursive=True), key=__import__("os").path.getmtime)
-    rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "gemm1x1_kernel", "wino_kernel"))]
+    rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "gemm1x1_kernel", "wino_kernel", "wino4_kernel"))]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     rows = rows[-10:]
     return sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows) / len(rows) / 1e3, rows[-1]
