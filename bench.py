@@ -265,11 +265,13 @@ def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: in
         agg = {}
         for kind, rec in prof.items():
             for fl, e0, e1, label, nb in rec:
-                t = agg.setdefault((kind, label), [0, 0.0, 0.0])
-                t[0] += 1; t[1] += e0.elapsed_time(e1); t[2] += fl
+                t = agg.setdefault((kind, label), [0, 0.0, 0.0, 1e30, 0.0])
+                dt_ = e0.elapsed_time(e1)
+                t[0] += 1; t[1] += dt_; t[2] += fl; t[3] = min(t[3], dt_); t[4] = max(t[4], dt_)
         with open(shape_table, "w") as f:
-            for (kind, label), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                f.write(f"{ms / max(profile_steps, 1):8.3f} ms/step  {cnt / max(profile_steps, 1):6.1f} calls/step  {fl / (ms * 1e-3) / 1e12:6.1f} TF  {kind:5s} {label}\n")
+            for (kind, label), (cnt, ms, fl, lo, hi) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{ms / max(profile_steps, 1):8.3f} ms/step  {cnt / max(profile_steps, 1):6.1f} calls/step  {fl / (ms * 1e-3) / 1e12:6.1f} TF  "
+                        f"[{lo * 1e3:7.1f} .. {hi * 1e3:7.1f} us]  {kind:5s} {label}\n")
     out = {"value": ws * bs * steps / dt, "ms_per_step": dt / steps * 1e3, "median_ms": median_ms, "comm": comm, "igemm": ig, "wgrad": wg,
            "alg_bytes_per_igemm_launch": alg_bytes, "graphs": bool(graphs_on), "trainer": tr}
     return out

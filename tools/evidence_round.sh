@@ -12,5 +12,6 @@ timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-second
 bash tools/pmc_round.sh
 cp gpurun_out/hbm_families.json gpurun_out/pmc_shapes.txt $O/
 timeout 600 python3 tools/fullres_codec.py > $O/fullres_codec.json 2> $O/fullres_codec.err
+timeout 900 python3 tools/fullres_sweep.py > $O/fullres_sweep.json 2> $O/fullres_sweep.err
 timeout 600 python3 bench.py --no-cpu-baseline --steps 100 --warmup 20 --no-secondary > $O/bench_100steps.json 2> /dev/null
 ls -la $O
