@@ -86,18 +86,22 @@ __device__ __forceinline__ void at6(const float m0, const float m1, const float 
   o3 = __builtin_fmaf(8.0f, w, q) + m5;
 }
 
-struct Wino4Tile { int gidx, n, oh0, ow0, n0, patch; };
+struct Wino4Tile { int gidx, n, oh0, ow0, n0, patch, tn, phase; };   // phase: output phase of a stride-2 transposed conv (0 otherwise)
 
 __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int gx, int gyn, int gz) {
   // XCD-aware order (see igemm_kernel.hpp): the hardware deals workgroups round-robin over the 8 XCDs; every XCD walks a contiguous
   // range of (patch, N tile) pairs, the N tiles of a patch back to back (they re-read the patch out of that XCD's L2)
   Wino4Tile t;
-  const int T = gx * gyn, nwg = T * gz, cpx = nwg >> 3;
+  const int nph = p.so * p.so;   // output phases (4 for a stride-2 transposed conv: each is a stride-1 conv of its own with the same input)
+  const int T = gx * gyn * nph, nwg = T * gz, cpx = nwg >> 3;
   const int q = vb < cpx * 8 ? (vb & 7) * cpx + (vb >> 3) : vb;
   t.gidx = q / T;
   const int r = q - t.gidx * T;
-  const int tn = r % gyn;
-  t.patch = r / gyn;
+  t.phase = r % nph;
+  const int r1 = r / nph;
+  const int tn = r1 % gyn;
+  t.patch = r1 / gyn;
+  t.tn = tn;
   const int ppi = p.GH * p.GW;
   t.n = t.patch / ppi;
   const int prem = t.patch - t.n * ppi, by = prem / p.GW, bx = prem - by * p.GW;
@@ -115,7 +119,10 @@ __device__ __forceinline__ unsigned wino4_in_off(const IgemmArgs& p, const Wino4
   const int cls = S / kClsSlots, r2 = S - cls * kClsSlots, R = r2 / 17, Cc = r2 - R * 17;
   const int ci = cls >> 2, cj = cls & 3;
   const int pi = 4 * R + ci, pj = 4 * Cc + cj;
-  const int ih = t.oh0 - p.si + pi, iw = t.ow0 - p.si + pj;
+  // (5x5 stride-2 conv as four parity sub-filters: plane pixel m of parity (ph, pw) is image pixel 2 m + parity; the parity displacement
+  // is wave-uniform and travels in the request's scalar offset; H and W are even there, so validity does not depend on the parity)
+  const int ist = p.nphase == 4 ? 2 : 1;
+  const int ih = ist * (t.oh0 - p.si + pi), iw = ist * (t.ow0 - p.si + pj);
   const bool ok = S < kInUsed4 && r2 < 51 && pi < 4 * kTY + 2 && pj < 4 * kTX + 2 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
   return ok ? (unsigned)((((t.n * p.H + ih) * p.W + iw) * p.ldx) * 4) : kOobOffset;
 }
@@ -132,9 +139,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wino4_empty_rsrc() { return __
 // raw piece j (0..3) of this wave, patch kr -> raw buffer rbuf through descriptor rx: the tile's own (sr.rx), or an EMPTY one where the
 // sub-step does not exist (every lane out of range: zeros land in a buffer nobody reads) -- liveness is wave-uniform, so it travels in the
 // scalar descriptor instead of a per-lane select (every vector instruction of the K loop costs matrix time)
-__device__ __forceinline__ void wino4_dma_raw(float* smem, const Wino4Src& sr, __amdgpu_buffer_rsrc_t rx, int j, int kr, int rbuf, int lane, int wave) {
+__device__ __forceinline__ void wino4_dma_raw(float* smem, const Wino4Src& sr, __amdgpu_buffer_rsrc_t rx, int j, int soff, int rbuf, int lane, int wave) {
   const int piece = wave + 4 * j;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + rbuf * kRF + piece * 256), 16, (int)sr.a_off[j], (int)(kr * 16), 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + rbuf * kRF + piece * 256), 16, (int)sr.a_off[j], soff, 0, 0);
+}
+// scalar byte offset of sub-step kr's raw patch: channel chunk kr % Kc, parity sub-filter kr / Kc (stride-2 conv: + (ph W + pw) pixels)
+__device__ __forceinline__ int wino4_raw_soff(const IgemmArgs& p, int kr) {
+  if (p.nphase == 1) return kr * 16;
+  const int Kc = p.kchunks / p.nphase, sub = kr / Kc, ch = kr - sub * Kc;
+  return ch * 16 + ((sub >> 1) * p.W + (sub & 1)) * p.ldx * 4;
 }
 // filter piece 9 wave + j (j = 0..8) of block kf -> filter buffer fbuf
 __device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, __amdgpu_buffer_rsrc_t ru, int j, int kf, int fbuf, int lane, int wave) {
@@ -145,11 +158,11 @@ __device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(smem + kRawBufs * kRF + fbuf * kFF + piece * 256), 16, (int)off, (int)so, 0, 0);
 }
 // the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and filter blocks 0, 1 (-> F0, F1)
-__device__ __forceinline__ void wino4_prologue_dma(float* smem, const Wino4Src& sr, int K4, int lane, int wave) {
+__device__ __forceinline__ void wino4_prologue_dma(const IgemmArgs& p, float* smem, const Wino4Src& sr, int K4, int lane, int wave) {
 #pragma unroll
   for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wino4_dma_raw(smem, sr, kr < K4 ? sr.rx : wino4_empty_rsrc(), j, kr, kr, lane, wave);
+    for (int j = 0; j < 4; ++j) wino4_dma_raw(smem, sr, kr < K4 ? sr.rx : wino4_empty_rsrc(), j, wino4_raw_soff(p, kr), kr, lane, wave);
 #pragma unroll
   for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
@@ -194,7 +207,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
   // younger vector-memory operations -- that tile's stores -- are in flight and need not be waited for); V_0 rows 0..4 and the
   // vertical pass of row 5
   if (!prefetched) {
-    wino4_prologue_dma(smem, sr, K4, lane, wave);
+    wino4_prologue_dma(p, smem, sr, K4, lane, wave);
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
   } else {
     __builtin_amdgcn_s_waitcnt(0x8070);   // vmcnt(32)
@@ -217,6 +230,8 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
   }
 
   int r1 = 1, r0 = 0;   // raw buffer of patch k + 1 / of patch k (= the one patch k + 3 goes to)
+  const int Kc = K4 / p.nphase;   // channel chunks per parity sub-filter (stride-2 conv: 4 sub-filters; else 1)
+  int ch3 = 3 % Kc, sub3 = 3 / Kc;   // chunk / sub-filter of sub-step k + 3 (counters: no division in the loop)
   for (int k = 0; k < K4; ++k) {
     // (the two base offsets are made opaque: every LDS read of the sub-step is then `base register + 16-bit immediate`; left visible,
     // the compiler folds the buffer constants into the offsets, overflows the immediate and spends an add per read)
@@ -226,6 +241,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
     const float* rp = smem + rpo;                         // raw patch k + 1
     const float* fp = smem + fpo;                         // filter block k (the filter ring turns with the raw ring: block k in buffer k % 3)
     const __amdgpu_buffer_rsrc_t ru2 = k + 2 < K4 ? sr.ru : wino4_empty_rsrc(), rx3 = k + 3 < K4 ? sr.rx : wino4_empty_rsrc();
+    const int soff3 = ch3 * 16 + ((sub3 >> 1) * p.W + (sub3 & 1)) * p.ldx * 4;   // (sub3 = 0 unless the conv is the stride-2 form)
     const int f2 = r1 == 2 ? 0 : r1 + 1;                  // buffer of filter block k + 2
     float uf[8][2];   // filter fragments of positions j .. j + 3 in flight (ring of 8, indexed j & 7)
 #pragma unroll
@@ -267,12 +283,13 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
       if (s % 5 == 2 && s / 5 < 13) {
         const int q = s / 5;
         if (q < 9) wino4_dma_filt(smem, sr, ru2, q, k + 2, f2, lane, wave);
-        else wino4_dma_raw(smem, sr, rx3, q - 9, k + 3, r0, lane, wave);
+        else wino4_dma_raw(smem, sr, rx3, q - 9, soff3, r0, lane, wave);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     r0 = r1;
     r1 = r1 == 2 ? 0 : r1 + 1;
+    if (++ch3 == Kc) { ch3 = 0; ++sub3; }
     // the 13 requests of this sub-step (filter block k + 2, patch k + 3) stay in flight; everything older (filter block k + 1, patch
     // k + 2) has landed
     __builtin_amdgcn_s_waitcnt(0x007D);   // vmcnt(13) lgkmcnt(0)
@@ -305,15 +322,18 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (unsigned)bytes, 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t ry = tdesc(p.y, p.ldy), rr = tdesc(has_res ? p.res : p.y, p.ldres), rm = tdesc(has_mask ? p.mask : p.y, p.ldmask);
-  const unsigned pix00 = (unsigned)(((size_t)tl.n * p.OH + oy0) * p.OW + ox0);
+  // output pixel (a, b) of the lane's tile: (so (oy0 + a) + py, so (ox0 + b) + px) -- so = 2 and (py, px) = the tile's phase for a
+  // stride-2 transposed conv, so = 1 otherwise
+  const int so = p.so, py = tl.phase >> 1, px = tl.phase & 1;
+  const unsigned pix00 = (unsigned)(((size_t)tl.n * p.OH + so * oy0 + py) * p.OW + so * ox0 + px);
   // validity of this lane's 16 output pixels (bit 4 a + b); the (a, b) displacement of an access is wave-uniform and travels as the
   // buffer instruction's scalar offset (the range check only sees the lane part)
   unsigned pixm = 0;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) pixm |= (oy0 + a < p.OH && ox0 + b < p.OW) ? (1u << (4 * a + b)) : 0u;
-  auto soff = [&](int ld, int a, int b) __attribute__((always_inline)) { return (a * p.OW + b) * ld * 4; };
+    for (int b = 0; b < 4; ++b) pixm |= (so * (oy0 + a) + py < p.OH && so * (ox0 + b) + px < p.OW) ? (1u << (4 * a + b)) : 0u;
+  auto soff = [&](int ld, int a, int b) __attribute__((always_inline)) { return so * (a * p.OW + b) * ld * 4; };
   float* sC = smem + kRawBufs * kRF + 2 * kFF;   // column sums: [wave 4][which 2][ob 2][64 lanes][4 r] = 16 KiB in filter buffer F2 (F0, F1 receive the next tile's blocks 0, 1)
 
 #pragma unroll
@@ -462,7 +482,7 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
       float sum = 0.f;
       for (int th2 = 0; th2 < 2; ++th2)
         for (int t2 = 0; t2 < 16; ++t2) sum += sC[((((th2 * 2 + oh2) * 2 + which) * 2 + ob2) * 64 + kg2 * 16 + t2) * 4 + r];
-      if (tl.n0 + c < p.Cout) p.cs[((size_t)tl.patch * 2 + which) * p.cs_ld + tl.n0 + c] = sum;
+      if (tl.n0 + c < p.Cout) p.cs[(((size_t)tl.patch * (p.so * p.so) + tl.phase) * 2 + which) * p.cs_ld + tl.n0 + c] = sum;
     }
   }
 }
@@ -473,9 +493,10 @@ __device__ __forceinline__ Wino4Src wino4_src(const IgemmArgs& p, const IgemmGro
   const float* x = p.ngroup > 1 ? grp.x[tl.gidx] : p.x;
   sr.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)((((unsigned long long)p.N * p.H * p.W - 1) * p.ldx + p.Cin) * 4ull), 0x00020000);
   // transformed filters of group gidx: [N tile][chunk][2304 slots of 16 B]
-  const size_t ublock = (size_t)gyn * p.kchunks * kUSlots4 * 4;   // floats per group
+  const int nph = p.so * p.so;
+  const size_t ublock = (size_t)gyn * nph * p.kchunks * kUSlots4 * 4;   // floats per group: [N tile][output phase][sub-step][2304 slots]
   sr.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (size_t)tl.gidx * ublock, 0, (unsigned)(ublock * 4), 0x00020000);
-  sr.u_off0 = (unsigned)(tl.n0 / kBN4) * (unsigned)p.kchunks * (kUSlots4 * 16u);
+  sr.u_off0 = (unsigned)(tl.tn * nph + tl.phase) * (unsigned)p.kchunks * (kUSlots4 * 16u);
 #pragma unroll
   for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off(p, tl, wave + 4 * j, lane);
   return sr;
@@ -500,7 +521,7 @@ __device__ __forceinline__ void wino4_vectors(const IgemmArgs& p, const IgemmGro
 __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gyn, int gz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int total = gx * gyn * gz;
+  const int total = gx * gyn * gz * p_.so * p_.so;
   float* sVb = smem + kLdsFloats4;   // [2][4][64]: bias, vec2, scale, shift of the current / the next tile
   int cur = 0;
   bool prefetched = false;
@@ -533,7 +554,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     if (more) {   // the next tile: raw patches 0, 1, 2, filter block 0 and the epilogue vectors
       const Wino4Tile tn = wino4_tile(p_, vb + (int)gridDim.x, gx, gyn, gz);
       sr = wino4_src(p_, grp, tn, gyn, lane, wave);
-      wino4_prologue_dma(smem, sr, p_.kchunks, lane, wave);
+      wino4_prologue_dma(p_, smem, sr, p_.kchunks, lane, wave);
       wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * (4 * kBN4), tid);
     }
     wino4_finish(p, tl, smem, sV, lane, wave, acc, accv);
@@ -546,28 +567,34 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
 // Filter transform U = G g G^T, G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]], evaluated in double
 // and rounded once, from the implicit-GEMM weight pack (tap-major [tap][wrows][wcols]) into the block layout of wino4_kernel:
 // [N tile of 64][chunk of 4 channels][position 36][channel 4][oh 2][tx 16][ob 2], output channel = 32 oh + 16 ob + tx.
-struct Wino4Taps { int widx[9]; };
+struct Wino4Taps { int widx[4][9]; };   // [variant][3 a + b]: weight-pack tap of sub-filter element (a, b), -1 = zero
 __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const float* w0, float* u, int Cin, int Cout, int wrows, int wcols, int kchunks,
-                                    int ntile, Wino4Taps tp) {
-  // one thread per (N tile, chunk, oc, channel c of the chunk): consecutive threads read consecutive input channels of one weight-pack row
-  const long long total = (long long)ntile * kchunks * 256;
+                                    int ntile, int nvar, int var_inner, Wino4Taps tp) {
+  // one thread per (N tile, variant, chunk, oc, channel c of the chunk); variant = parity sub-filter of a stride-2 conv (blocks of one
+  // tile: [sub][chunk], var_inner = 0 ... the K loop walks them) or output phase of a stride-2 transposed conv ([phase][chunk] as well,
+  // each phase being a tile of its own); consecutive threads read consecutive input channels of one weight-pack row
+  const long long total = (long long)ntile * nvar * kchunks * 256;
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= total) return;
+  (void)var_inner;
   const int g = blockIdx.y;
   const float* w = ngroup > 1 ? grp.w[g] : w0;
   const int c4 = (int)(id & 3), oc64 = (int)((id >> 2) & 63);
-  const long long blk = id >> 8;   // (N tile, chunk)
-  const int kc = (int)(blk % kchunks), ct = (int)(blk / kchunks);
+  const long long blk = id >> 8;   // (N tile, variant, chunk)
+  const int kc = (int)(blk % kchunks), var = (int)((blk / kchunks) % nvar), ct = (int)(blk / ((long long)kchunks * nvar));
   const int oc = ct * kBN4 + oc64, c = kc * 4 + c4;
   const bool live = oc < Cout && c < Cin;
   double g9[3][3];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) g9[a][b] = live ? (double)w[((size_t)tp.widx[a * 3 + b] * wrows + oc) * wcols + c] : 0.0;
+    for (int b = 0; b < 3; ++b) {
+      const int wi = tp.widx[var][a * 3 + b];
+      g9[a][b] = (live && wi >= 0) ? (double)w[((size_t)wi * wrows + oc) * wcols + c] : 0.0;
+    }
   const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-  float* dst = u + ((size_t)g * ntile * kchunks + (size_t)blk) * (kUSlots4 * 4) + (size_t)c4 * kBN4 + (oc64 >> 5) * 32 + (oc64 & 15) * 2 + ((oc64 >> 4) & 1);
+  float* dst = u + ((size_t)g * ntile * nvar * kchunks + (size_t)blk) * (kUSlots4 * 4) + (size_t)c4 * kBN4 + (oc64 >> 5) * 32 + (oc64 & 15) * 2 + ((oc64 >> 4) & 1);
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
     double t[3];
@@ -580,13 +607,27 @@ __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const floa
 
 }  // namespace
 
+// the three forms the kernel takes: 0 = none, 1 = 3x3 stride 1 (conv or its transposed twin), 2 = 5x5 stride-2 conv (pad 2, even H / W: four
+// parity sub-filters of 3x3 accumulated), 3 = 5x5 stride-2 transposed conv (pad 2, output = 2 x input: four output phases, each a 3x3
+// stride-1 conv of the input -- elic_layers.py:14-21 up_conv, elic_autoencoder.py:42-52 and their input gradients)
+static int wino4_mode(const crdr_conv_desc* d) {
+  if (d->wlayout != 0) return 0;
+  if (d->kh == 3 && d->kw == 3 && d->stride == 1) {
+    const int grow = d->transposed ? 2 - 2 * d->pad : 2 * d->pad - 2;   // (a stride-1 transposed conv = a conv with pad k - 1 - pad)
+    return (d->OH == d->H + grow && d->OW == d->W + grow && d->pad >= 0 && d->pad <= 2) ? 1 : 0;
+  }
+  if (d->kh == 5 && d->kw == 5 && d->stride == 2 && d->pad == 2) {
+    if (!d->transposed) return (d->H % 2 == 0 && d->W % 2 == 0 && d->OH == d->H / 2 && d->OW == d->W / 2) ? 2 : 0;
+    return (d->OH == 2 * d->H && d->OW == 2 * d->W) ? 3 : 0;
+  }
+  return 0;
+}
+
 bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok) {
-  if (!(d->kh == 3 && d->kw == 3) || d->stride != 1 || d->wlayout != 0) return false;
-  const int grow = d->transposed ? 2 - 2 * d->pad : 2 * d->pad - 2;   // (a stride-1 transposed conv = a conv with pad k - 1 - pad)
-  if (d->OH != d->H + grow || d->OW != d->W + grow) return false;
-  if (d->pad < 0 || d->pad > 2) return false;
+  const int mode = wino4_mode(d);
+  if (!mode) return false;
   if (d->C % 4 != 0 || d->ldx % 4 != 0 || d->OC % 4 != 0 || d->ldy % 4 != 0) return false;
-  if (d->OW < 48) return false;   // the 8 x 64 output tile wants wide images (the F(2x2) kernel serves the rest)
+  if ((mode == 3 ? d->W : d->OW) < 48) return false;   // the 8 x 64 tile (of the output, or of one output phase) wants wide images
   if ((d->flags & CRDR_EPI_RES) && d->ldres % 4 != 0) return false;
   if ((d->flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) && d->ldmask % 4 != 0) return false;
   if (d->flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_CONV_BF16X3)) return false;
@@ -599,37 +640,70 @@ bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok) {
   return true;
 }
 
-size_t wino4_workspace(const crdr_conv_desc* d, int G) { return (size_t)G * cdiv(d->OC, kBN4) * cdiv(d->C, 4) * kUSlots4 * 16; }
+size_t wino4_workspace(const crdr_conv_desc* d, int G) {
+  const int nvar = wino4_mode(d) >= 2 ? 4 : 1;   // parity sub-filters / output phases
+  return (size_t)G * cdiv(d->OC, kBN4) * nvar * cdiv(d->C, 4) * kUSlots4 * 16;
+}
 
-int wino4_colsum_rows(const crdr_conv_desc* d) { return d->N * cdiv(d->OH, 4 * kTY) * cdiv(d->OW, 4 * kTX); }
+int wino4_colsum_rows(const crdr_conv_desc* d) {
+  const int mode = wino4_mode(d);
+  if (mode == 3) return d->N * cdiv(d->H, 4 * kTY) * cdiv(d->W, 4 * kTX) * 4;
+  return d->N * cdiv(d->OH, 4 * kTY) * cdiv(d->OW, 4 * kTX);
+}
 
 int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s) {
-  CRDR_REQUIRE(wino4_eligible(d, G, a.vec_epi != 0), "conv2d: the F(4x4, 3x3) Winograd kernel takes 3x3 stride-1 convolutions of >= 48 output columns with "
-               "C, OC %% 4 == 0, 16-byte aligned operand rows and no gate / pre-add epilogue");
+  CRDR_REQUIRE(wino4_eligible(d, G, a.vec_epi != 0), "conv2d: the F(4x4, 3x3) Winograd kernel takes 3x3 stride-1 and 5x5 stride-2 (pad 2) convolutions of >= 48 "
+               "output (phase) columns with C, OC %% 4 == 0, 16-byte aligned operand rows and no gate / pre-add epilogue");
+  const int mode = wino4_mode(d);
   Wino4Taps wt;
-  int dmin = 127;
-  for (int t = 0; t < 9; ++t) dmin = std::min(dmin, (int)(signed char)(taps.packed[t] & 0xff));
-  for (int t = 0; t < 9; ++t) wt.widx[t] = -1;
-  for (int t = 0; t < 9; ++t) {
-    const int v = taps.packed[t];
-    const int dh = (int)(signed char)(v & 0xff) - dmin, dw = (int)(signed char)((v >> 8) & 0xff) - dmin;
-    CRDR_REQUIRE(dh >= 0 && dh < 3 && dw >= 0 && dw < 3, "conv2d: Winograd F(4x4): tap offsets are not a 3x3 window");
-    wt.widx[dh * 3 + dw] = v >> 16;
+  for (int v = 0; v < 4; ++v)
+    for (int t = 0; t < 9; ++t) wt.widx[v][t] = -1;
+  int si = 1;
+  if (mode == 1) {
+    int dmin = 127;
+    for (int t = 0; t < 9; ++t) dmin = std::min(dmin, (int)(signed char)(taps.packed[t] & 0xff));
+    for (int t = 0; t < 9; ++t) {
+      const int v = taps.packed[t];
+      const int dh = (int)(signed char)(v & 0xff) - dmin, dw = (int)(signed char)((v >> 8) & 0xff) - dmin;
+      CRDR_REQUIRE(dh >= 0 && dh < 3 && dw >= 0 && dw < 3, "conv2d: Winograd F(4x4): tap offsets are not a 3x3 window");
+      wt.widx[0][dh * 3 + dw] = v >> 16;
+    }
+    for (int t = 0; t < 9; ++t) CRDR_REQUIRE(wt.widx[0][t] >= 0, "conv2d: Winograd F(4x4): incomplete 3x3 window");
+    si = -dmin;   // the patch starts `si` pixels above / left of its first output pixel
+  } else if (mode == 2) {
+    // out[o] = sum_t w[t] x[2 o - 2 + t], t = 2 a + p: sub-filter (ph, pw) element (a, b) = w[2 a + ph][2 b + pw] over the parity plane
+    // x[2 m + ph], a 3-tap 'pad 1' correlation; the pack's tap index of kernel element (r, s) is 5 r + s
+    for (int sub = 0; sub < 4; ++sub)
+      for (int a2 = 0; a2 < 3; ++a2)
+        for (int b2 = 0; b2 < 3; ++b2) {
+          const int r = 2 * a2 + (sub >> 1), c = 2 * b2 + (sub & 1);
+          if (r < 5 && c < 5) wt.widx[sub][a2 * 3 + b2] = r * 5 + c;
+        }
+  } else {
+    // out[2 u + py] = sum_{a'} w[2 (2 - a') + py] in[u - 1 + a']: phase (py, px) element (a', b') = w[2 (2 - a') + py][2 (2 - b') + px]
+    for (int ph = 0; ph < 4; ++ph)
+      for (int a2 = 0; a2 < 3; ++a2)
+        for (int b2 = 0; b2 < 3; ++b2) {
+          const int r = 2 * (2 - a2) + (ph >> 1), c = 2 * (2 - b2) + (ph & 1);
+          if (r < 5 && c < 5) wt.widx[ph][a2 * 3 + b2] = r * 5 + c;
+        }
   }
-  for (int t = 0; t < 9; ++t) CRDR_REQUIRE(wt.widx[t] >= 0, "conv2d: Winograd F(4x4): incomplete 3x3 window");
+  const int nvar = mode >= 2 ? 4 : 1;
   const int ntile = cdiv(d->OC, kBN4), kchunks = cdiv(d->C, 4);
   {
-    const long long total = (long long)ntile * kchunks * 256;
+    const long long total = (long long)ntile * nvar * kchunks * 256;
     hipLaunchKernelGGL(wino4_filter_kernel, dim3((unsigned)cdiv64(total, 256), G), dim3(256), 0, s, grp, G, a.w, u, d->C, d->OC, d->wrows, d->wcols, kchunks,
-                       ntile, wt);
+                       ntile, nvar, 0, wt);
     CRDR_CHECK_LAUNCH("wino4_filter_kernel");
   }
   a.w = u;
-  a.kchunks = kchunks;
-  a.nphase = 1;
-  a.GH = cdiv(d->OH, 4 * kTY);
-  a.GW = cdiv(d->OW, 4 * kTX);
-  a.si = -dmin;   // the patch starts `si` pixels above / left of its first output pixel
+  a.nphase = mode == 2 ? 4 : 1;               // parity sub-filters the K loop accumulates
+  a.kchunks = kchunks * a.nphase;             // sub-steps of a tile
+  a.so = mode == 3 ? 2 : 1;                   // output stride (4 output phases = 4 tiles per patch and N tile)
+  const int gh = mode == 3 ? d->H : d->OH, gw = mode == 3 ? d->W : d->OW;   // the grid the 8 x 64 tiles cover
+  a.GH = cdiv(gh, 4 * kTY);
+  a.GW = cdiv(gw, 4 * kTX);
+  a.si = si;
   a.cs_rows = wino4_colsum_rows(d);
   static const int ncu = [] {
     int dev = 0, n = 0;
@@ -637,7 +711,7 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
     return n / 8 * 8;
   }();
   const int gx = d->N * a.GH * a.GW;
-  const int total = gx * ntile * G;
+  const int total = gx * ntile * G * a.so * a.so;
   static std::atomic<bool> attr_done;
   if (!attr_done.load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

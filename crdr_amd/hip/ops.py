@@ -98,7 +98,7 @@ PREFER_WINOGRAD = False
 
 def _prefer_wino(d, G: int = 1) -> int:
     """-> the Winograd algorithm id if PREFER_WINOGRAD is set and the library accepts it for this launch, else 0."""
-    if not PREFER_WINOGRAD or (d.kh, d.kw, d.stride) not in ((3, 3, 1), (5, 5, 1)):
+    if not PREFER_WINOGRAD or (d.kh, d.kw, d.stride) not in (((3, 3, 1), (5, 5, 1), (5, 5, 2)) if PREFER_WINOGRAD == 4 else ((3, 3, 1), (5, 5, 1))):
         return 0
     lib = L.load()
     keep, algo = d.reserved, 0

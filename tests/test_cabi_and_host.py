@@ -392,7 +392,15 @@ def test_winograd_ids_are_planned_only_for_the_shapes_they_take(lib):
     assert plan(desc(96, 96, 64, 3, transposed=1), base + 2) == base + 2
     assert plan(desc(96, 96, 32, 3), base + 2) == 0                   # 32 output columns
     assert plan(desc(96, 96, 64, 3, stride=2), base + 2) == 0
-    assert plan(desc(320, 224, 64, 5), base + 2) == 0
+    assert plan(desc(320, 224, 64, 5), base + 2) == 0                 # 5x5 stride 1: no F(4x4) form
+    # 5x5 stride 2 pad 2: conv as four parity sub-filters (even input, >= 48 output columns), transposed conv as four output phases
+    assert plan(desc(192, 192, 128, 5, stride=2), base + 2) == base + 2
+    assert plan(desc(192, 192, 64, 5, stride=2), base + 2) == 0       # 32 output columns
+    dt = desc(256, 256, 64, 5, stride=2, transposed=1)
+    dt.OH = dt.OW = 128                                               # output_padding 1
+    assert plan(dt, base + 2) == base + 2
+    dt.reserved = base + 2
+    assert lib.crdr_conv2d_workspace(C.byref(dt)) == 16384 * 4 + 4 * 4 * 64 * 36 * 4 * 64 * 4   # 4 N tiles x 4 phases x 64 chunks x 36 KiB
     assert plan(desc(96, 98, 64, 3), base + 2) == 0                   # OC % 4 != 0
     d4 = desc(100, 96, 64, 3)
     d4.reserved = base + 2

@@ -152,6 +152,65 @@ def test_winograd_f4x4_fwd_dgrad(case):
     assert torch.equal(out, out2), "not deterministic"
 
 
+W4S2_CASES = [
+    # name, N, Cin, H, W, Cout   (5x5 stride 2 pad 2; conv: input H x W -> H/2 x W/2; transposed: input H x W -> 2H x 2W)
+    ("w4s2_192_192_128", 1, 192, 32, 128, 192),
+    ("w4s2_64_96_ragged", 2, 64, 20, 104, 96),        # 10 x 52 outputs: partial tiles both ways
+    ("w4s2_36_40_c4", 1, 36, 16, 96, 40),
+    ("w4s2_256_256_wide", 1, 256, 16, 256, 256),
+]
+
+
+@pytest.mark.parametrize("case", W4S2_CASES, ids=[c[0] for c in W4S2_CASES])
+def test_winograd_f4x4_5x5_stride2(case):
+    """the 5x5 stride-2 layers through the F(4x4, 3x3) kernel: Conv2d 5x5 s2 p2 as four parity sub-filters accumulated over the parity
+    planes of the input (elic_autoencoder.py:42-52), ConvTranspose2d 5x5 s2 p2 op1 as four output phases (elic_layers.py:14-21), and the
+    input gradient of each (= the other form), against fp64 torch"""
+    from crdr_amd.hip import ops
+    name, n, ci, h, w, co = case
+    dev = _dev()
+    a4 = _wino_id() + 2
+    # Conv2d 5x5 s2: forward + input gradient
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(co, ci, 5, 5, seed=2, scale=(ci * 25 / 4) ** -0.5)
+    b = _rand(co, seed=3)
+    xr = x.double().requires_grad_(True)
+    ref = F.conv2d(xr, wt.double(), b.double(), stride=2, padding=2)
+    oh, ow = ref.shape[2:]
+    dy = _rand(*ref.shape, seed=4)
+    ref.backward(dy.double())
+    xd, wd, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
+    wp = ops.pack_weight(wd, transpose=False)
+    if ow >= 48:
+        direct = ops.conv2d_raw(xd, wp, co, (5, 5), 2, 2, False, (oh, ow), bias=bd, flags=1, algo=1)
+        out = ops.conv2d_raw(xd, wp, co, (5, 5), 2, 2, False, (oh, ow), bias=bd, flags=1, algo=a4)
+        torch.cuda.synchronize()
+        sc = ref.abs().max().item()
+        print(f"{name}: conv s2 fwd max err / scale: F(4x4) {(out.cpu().double() - ref.detach()).abs().max().item() / sc:.2e}  "
+              f"direct {(direct.cpu().double() - ref.detach()).abs().max().item() / sc:.2e}")
+        _close(out, ref, name + " conv fwd", rtol=5e-5)
+        assert torch.equal(out, ops.conv2d_raw(xd, wp, co, (5, 5), 2, 2, False, (oh, ow), bias=bd, flags=1, algo=a4))
+        # its input gradient: a transposed stride-2 launch (output = the conv's input grid, phases of oh x ow)
+        wq = ops.pack_weight(wd, transpose=True)
+        dx = ops.conv2d_raw(dyd, wq, ci, (5, 5), 2, 2, True, (h, w), algo=a4)
+        _close(dx, xr.grad, name + " conv dgrad", rtol=5e-5)
+    # ConvTranspose2d 5x5 s2 p2 op1: forward + input gradient
+    if w >= 48:
+        wt2 = _rand(ci, co, 5, 5, seed=5, scale=(ci * 25 / 4) ** -0.5)
+        xr2 = x.double().requires_grad_(True)
+        ref2 = F.conv_transpose2d(xr2, wt2.double(), b.double(), stride=2, padding=2, output_padding=1)
+        oh2, ow2 = ref2.shape[2:]
+        dy2 = _rand(*ref2.shape, seed=6)
+        ref2.backward(dy2.double())
+        w2d = wt2.to(dev)
+        wp2 = ops.pack_weight(w2d, transpose=True)     # rows = Cout, cols = Cin
+        out2 = ops.conv2d_raw(xd, wp2, co, (5, 5), 2, 2, True, (oh2, ow2), bias=bd, flags=1, algo=a4)
+        _close(out2, ref2, name + " convT fwd", rtol=5e-5)
+        wq2 = ops.pack_weight(w2d, transpose=False)    # rows = Cin, cols = Cout
+        dx2 = ops.conv2d_raw(dy2.to(dev), wq2, ci, (5, 5), 2, 2, False, (h, w), algo=a4)
+        _close(dx2, xr2.grad, name + " convT dgrad", rtol=5e-5)
+
+
 def test_winograd_f4x4_epilogues_slices_groups_colsum():
     """every epilogue the F(4x4) kernel takes: bias + ReLU + vec2 + residual + affine, LeakyReLU, accumulate, ReLU-mask with column sums (the
     input-gradient launches of a conv chain), channel slices in and out, a grouped launch"""

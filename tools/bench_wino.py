@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--wino-only", action="store_true")
     ap.add_argument("--shapes", default=None, help="ci,co,hw;ci,co,hw;... instead of the built-in list")
     ap.add_argument("--k5", action="store_true", help="the 5x5 stride-1 shapes of the Charm at 16x16 instead")
+    ap.add_argument("--k5s2", action="store_true", help="the 5x5 stride-2 conv / transposed conv shapes: tuned direct kernel vs F(4x4, 3x3) over parity sub-filters / output phases")
     ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient kernels instead (direct slab kernel vs Winograd F(3x3, 2x2))")
     a = ap.parse_args()
     ops.TUNE_COLD = a.cold
@@ -48,6 +49,28 @@ def main():
             d, w = res["direct"], res["winograd"]
             print(f"wgrad {co:4d}x{ci:4d} @{hw:3d}: direct {d[0] * 1e3:8.1f} us ({fl / d[0] / 1e9:6.1f} TF, cfg {d[1]} split {1 << d[2]})   winograd {w[0] * 1e3:8.1f} us "
                   f"({fl / w[0] / 1e9:6.1f} TF-eq, split {1 << w[2]})   x{d[0] / w[0]:.2f}", flush=True)
+        return
+    if a.k5s2:
+        for tr, ci, co, hw in [(1, 256, 256, 64), (0, 192, 192, 128), (0, 256, 256, 128), (1, 192, 192, 64)]:
+            x = torch.randn(a.bs, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+            wt = (torch.randn(ci, co, 5, 5, device=dev) if tr else torch.randn(co, ci, 5, 5, device=dev)) * (ci * 25) ** -0.5
+            b = torch.randn(co, device=dev)
+            wp = ops.pack_weight(wt, transpose=bool(tr))
+            out = (2 * hw, 2 * hw) if tr else (hw // 2, hw // 2)
+            best = (1e9, 0)
+            for cfg in range(lib.crdr_conv2d_num_configs()):
+                try:
+                    t = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (5, 5), 2, 2, bool(tr), out, bias=b, flags=1, algo=cfg + 1), reps=3)
+                except L.CrdrHipError:
+                    continue
+                best = min(best, (t, cfg))
+            y0 = ops.conv2d_raw(x, wp, co, (5, 5), 2, 2, bool(tr), out, bias=b, flags=1, algo=best[1] + 1)
+            y4 = ops.conv2d_raw(x, wp, co, (5, 5), 2, 2, bool(tr), out, bias=b, flags=1, algo=wid + 2)
+            err = float((y4 - y0).abs().max() / y0.abs().max())
+            t4 = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (5, 5), 2, 2, bool(tr), out, bias=b, flags=1, algo=wid + 2), reps=3)
+            fl = 2.0 * a.bs * (hw * hw if tr else out[0] * out[1]) * ci * co * 25
+            print(f"{'T' if tr else 'C'} {ci:4d}->{co:4d} k5s2 in{hw:3d}: direct {best[0] * 1e3:8.1f} us ({fl / best[0] / 1e9:6.1f} TF, cfg {best[1]})   F(4x4) {t4 * 1e3:8.1f} us "
+                  f"({fl / t4 / 1e9:6.1f} TF-eq) x{best[0] / t4:.2f}   max rel diff {err:.2e}", flush=True)
         return
     if a.shapes:
         SHAPES[:] = [tuple(int(v) for v in t.split(",")) for t in a.shapes.split(";")]
