@@ -238,15 +238,15 @@ def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: in
         return {"launches_per_step": round(n / ps, 1), "avg_launch_us": round(ms * 1e3 / n, 2),
                 "avg_gflop_per_launch": round(fl / n / 1e9, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                 "ms_per_step": round(ms / ps, 2)}
-    r0, r3, r5 = raw(0), raw(3), raw(5)   # implicit-GEMM / streaming launches, Winograd F(2x2) / F(4x4) launches (all counted with the direct convolution's flops)
+    r0, r3, r5, r6 = raw(0), raw(3), raw(5), raw(6)   # implicit-GEMM / streaming launches, Winograd F(2x2) / F(4x4) / F(4x4)-on-5x5-stride-2 launches (all counted with the direct convolution's flops)
     r1, r4 = raw(1), raw(4)   # weight-gradient slab launches: direct, Winograd F(3x3, 2x2)
-    ig, wg, sk = (fam(r0[0] + r3[0] + r5[0], r0[1] + r3[1] + r5[1], r0[2] + r3[2] + r5[2]), fam(r1[0] + r4[0], r1[1] + r4[1], r1[2] + r4[2]),
+    ig, wg, sk = (fam(r0[0] + r3[0] + r5[0] + r6[0], r0[1] + r3[1] + r5[1] + r6[1], r0[2] + r3[2] + r5[2] + r6[2]), fam(r1[0] + r4[0], r1[1] + r4[1], r1[2] + r4[2]),
                   fam(*raw(2)))
     if wg is not None and r4[2]:
         wg["winograd"] = dict(fam(*r4), executed_tflops=round(r4[0] / 2.25 / (r4[1] * 1e-3) / 1e12, 2))
         wg["direct"] = fam(*r1)
         wg["executed_mfma_tflops"] = round((r1[0] + r4[0] / 2.25) / ((r1[1] + r4[1]) * 1e-3) / 1e12, 2)
-    if ig is not None and (r3[2] or r5[2]):
+    if ig is not None and (r3[2] or r5[2] or r6[2]):
         # what the matrix cores execute: a Winograd F(2x2, 3x3) launch does 16 multiply-accumulates per 2x2 outputs and channel pair
         # instead of 36, an F(4x4, 3x3) launch 36 per 4x4 outputs instead of 144 -- effective rates may exceed the MFMA peak, executed
         # rates may not
@@ -254,8 +254,10 @@ def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: in
             ig["winograd"] = dict(fam(*r3), executed_tflops=round(r3[0] / 2.25 / (r3[1] * 1e-3) / 1e12, 2))
         if r5[2]:
             ig["winograd_f4x4"] = dict(fam(*r5), executed_tflops=round(r5[0] / 4.0 / (r5[1] * 1e-3) / 1e12, 2))
+        if r6[2]:   # a 5x5 stride-2 layer as four 3x3 sub-filters / output phases: 4 x 36 products per 16 outputs instead of 25 x 16
+            ig["winograd_f4x4_k5s2"] = dict(fam(*r6), executed_tflops=round(r6[0] * 9.0 / 25.0 / (r6[1] * 1e-3) / 1e12, 2))
         ig["direct"] = fam(*r0)
-        ig["executed_mfma_tflops"] = round((r0[0] + r3[0] / 2.25 + r5[0] / 4.0) / ((r0[1] + r3[1] + r5[1]) * 1e-3) / 1e12, 2)
+        ig["executed_mfma_tflops"] = round((r0[0] + r3[0] / 2.25 + r5[0] / 4.0 + r6[0] * 9.0 / 25.0) / ((r0[1] + r3[1] + r5[1] + r6[1]) * 1e-3) / 1e12, 2)
     if ig is not None and sk is not None:
         ig["splitk_epilogue"] = {"launches_per_step": sk["launches_per_step"], "avg_launch_us": sk["avg_launch_us"], "ms_per_step": sk["ms_per_step"]}
     alg_bytes = None
@@ -449,7 +451,7 @@ def main():
                       "ones: tiled implicit GEMM, the streaming 1x1 kernel and, where the tuner found them faster, the Winograd F(2x2,3x3) / "
                       "F(4x4,3x3) kernels with their filter transforms; v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32)",
             "effective_rate_note": "`achieved` / `frac` price the ALGORITHMIC (direct-convolution) flops of every launch against the fp32 MFMA "
-                                   "peak, as SURVEY 8(d) defines the unit; a Winograd launch executes 2.25x (F(2x2)) or 4x (F(4x4)) fewer multiply-accumulates than it is "
+                                   "peak, as SURVEY 8(d) defines the unit; a Winograd launch executes 2.25x (F(2x2)), 4x (F(4x4)) or 25/9 x (F(4x4) on a 5x5 stride-2 layer) fewer multiply-accumulates than it is "
                                    "credited with, so this is an effective rate (a single Winograd launch may exceed 1.0). What the matrix cores "
                                    "actually execute is detail.executed_mfma_tflops (frac_executed below); detail.direct / detail.winograd split "
                                    "the family.",

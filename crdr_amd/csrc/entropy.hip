@@ -13,8 +13,58 @@
 
 namespace crdr {
 
-__device__ __forceinline__ float std_cdf(float x) { return 0.5f * erfcf(-0.70710678118654752440f * x); }
-__device__ __forceinline__ float std_pdf(float x) { return 0.39894228040143267794f * expf(-0.5f * x * x); }
+// ---- the interval likelihood of the training kernels ------------------------------------------------------------------------------
+// Phi(zu) - Phi(zl), zu = (1/2 - a) / sigma, zl = (-1/2 - a) / sigma, a = |v| (compressai's sign trick keeps both arguments on the
+// side where the tail is relatively accurate; GaussianConditional._likelihood as the reference subclasses it,
+// src/models/subnet/entropy_model/ste_gaussian_conditional.py:20-27) = 1/2 [erfc(xl) - erfc(xh)], xl = (a - 1/2) rs, xh = (a + 1/2) rs,
+// rs = 1 / (sqrt 2 sigma).  Two library erfcf calls per likelihood are ~4 divergent branches each on this target; here
+//   erfc(x) = exp(-x^2) erfcx(x), x >= 0,   erfc(x) = 2 - exp(-x^2) erfcx(-x), x < 0,
+// branch-free: erfcx by one polynomial over the whole half line, (1 + 2 x) erfcx(x) = 1 + p(q), q = (x - 2) / (x + 2) in [-1, 1)
+// (degree 11, Chebyshev interpolant converted to monomials: 1.7e-8 of erfcx in exact arithmetic; the variable change is the one of
+// Shepherd & Laframboise's (1 + 2x) exp(x^2) erfc x expansion), and exp(-x^2) with the rounding error of x^2 and of the change of base
+// carried into the exponent (expf(-x * x) alone loses x^2 2^-24: 2e-6 at the likelihood floor).  The two exponentials are the Gaussian
+// densities the backward needs.  Against float64 (tests/test_gpu_model.py::test_gauss_cond_likelihood_against_float64): the same
+// accuracy class as the erfcf form -- relative in the tail, 2e-7 absolute where the two erfc values are O(1).
+__device__ __forceinline__ float exp_neg_sq(float x) {   // exp(-x^2), |x| <= 1e4
+  const float kL2Ehi = 1.44269502162933349609375f, kL2Elo = 1.92596299112661746e-8f;   // log2(e) = hi + lo
+  const float s = x * x, slo = __builtin_fmaf(x, x, -s);
+  const float ti = __builtin_rintf(s * kL2Ehi);
+  float tf = __builtin_fmaf(s, kL2Ehi, -ti);
+  tf = __builtin_fmaf(s, kL2Elo, tf);
+  tf = __builtin_fmaf(slo, kL2Ehi, tf);
+  return __builtin_ldexpf(__builtin_amdgcn_exp2f(-tf), -(int)ti);   // (|tf| <= 1/2 + ...: no denormal path needed in v_exp_f32)
+}
+__device__ __forceinline__ float erfcx_pos(float a) {   // exp(a^2) erfc(a), 0 <= a <= 1e4
+  const float q = (a - 2.f) * __builtin_amdgcn_rcpf(a + 2.f);
+  float p = 6.807514774e-05f;
+  p = __builtin_fmaf(p, q, 1.608403462e-04f);
+  p = __builtin_fmaf(p, q, -3.709284118e-04f);
+  p = __builtin_fmaf(p, q, -1.395805088e-03f);
+  p = __builtin_fmaf(p, q, 1.230503218e-03f);
+  p = __builtin_fmaf(p, q, 8.689252695e-03f);
+  p = __builtin_fmaf(p, q, -8.024739103e-03f);
+  p = __builtin_fmaf(p, q, -5.421199524e-02f);
+  p = __builtin_fmaf(p, q, 1.640504971e-01f);
+  p = __builtin_fmaf(p, q, -1.660310904e-01f);
+  p = __builtin_fmaf(p, q, -9.276381574e-02f);
+  p = __builtin_fmaf(p, q, 2.769783912e-01f);
+  const float r = __builtin_amdgcn_rcpf(__builtin_fmaf(2.f, a, 1.f));
+  return __builtin_fmaf(p, r, r);
+}
+// 1 / (sqrt 2 sigma): hardware reciprocal + one Newton step (the argument error is amplified by 2 x^2 in the tail)
+__device__ __forceinline__ float gc_rs(float sg) {
+  const float r0 = __builtin_amdgcn_rcpf(sg);
+  return __builtin_fmaf(__builtin_fmaf(-sg, r0, 1.f), r0, r0) * 0.70710678118654752440f;
+}
+// -> the raw likelihood; e_lo = exp(-xl^2) = exp(-zu^2 / 2), e_hi = exp(-xh^2) = exp(-zl^2 / 2)
+__device__ __forceinline__ float gc_lik(float a, float rs, float& e_lo, float& e_hi) {
+  const float xh = fminf((a + 0.5f) * rs, 1e4f), xl = fminf(fmaxf((a - 0.5f) * rs, -1e4f), 1e4f);
+  e_hi = exp_neg_sq(xh);
+  e_lo = exp_neg_sq(xl);
+  const float th = e_hi * erfcx_pos(xh), tl = e_lo * erfcx_pos(fabsf(xl));
+  const float l = 0.5f * ((xl < 0.f ? 2.f - tl : tl) - th);
+  return a != a ? a : l;   // (the clamps above would swallow a NaN latent)
+}
 
 __device__ __forceinline__ float block_sum(float v, float* red) {  // any block size multiple of 64, <= 1024
 #pragma unroll
@@ -64,23 +114,22 @@ __device__ __forceinline__ float gc_noise(const GcArgs& p, size_t pix, int c) {
 // One element of the forward: quantise, both likelihoods, bit terms.
 __device__ __forceinline__ void gc_elem(const GcArgs& p, float yv, float m, float sraw, float u, bool noisy, bool want_q, float& q_plus_m,
                                         float& lq, float& ln, float& sn, float& sq) {
-  const float inv_ln2 = 1.4426950408889634f;
   const float sg = fmaxf(sraw, p.d.scale_bound);
+  const float rs = gc_rs(sg);
   const float q = rintf(yv - m);  // torch.round: half to even
   q_plus_m = q + m;
+  float e0, e1;
   if (want_q) {
-    const float a = fabsf(q);  // |round(y - mu) + mu - mu|
-    float l = std_cdf((0.5f - a) / sg) - std_cdf((-0.5f - a) / sg);
+    float l = gc_lik(fabsf(q), rs, e0, e1);  // |round(y - mu) + mu - mu|
     l = fmaxf(l, p.d.likelihood_bound);
     lq = l;
-    sq -= logf(l) * inv_ln2;
+    sq -= __builtin_amdgcn_logf(l);   // v_log_f32 = log2 (l >= the bound: never denormal)
   }
   if (noisy) {
-    const float a = fabsf(yv + u - m);
-    float l = std_cdf((0.5f - a) / sg) - std_cdf((-0.5f - a) / sg);
+    float l = gc_lik(fabsf(yv + u - m), rs, e0, e1);
     l = fmaxf(l, p.d.likelihood_bound);
     ln = l;
-    sn -= logf(l) * inv_ln2;
+    sn -= __builtin_amdgcn_logf(l);
   }
 }
 
@@ -153,16 +202,18 @@ __global__ __launch_bounds__(256) void gauss_cond_fwd_kernel(const GcArgs p, flo
   }
 }
 
-// one wave per image: lane l adds the partials of blocks l, l + 64, ... in that order, then the fixed shuffle tree
-__global__ __launch_bounds__(64) void gauss_cond_finish_kernel(const float* part, int B, float* bits_noisy, float* bits_quant) {
+// one block per image: thread t adds the partials of blocks t, t + 256, ... in that order (every load in flight at once: a single
+// wave walking 2 048 partials one after the other took 8.7 us at the codec's sizes), then the fixed shuffle + LDS tree of block_sum
+__global__ __launch_bounds__(256) void gauss_cond_finish_kernel(const float* part, int B, float* bits_noisy, float* bits_quant) {
+  __shared__ float red[16];
   const int n = blockIdx.x;
   float sn = 0.f, sq = 0.f;
-  for (int b = threadIdx.x; b < B; b += 64) {
+  for (int b = threadIdx.x; b < B; b += 256) {
     const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)n * B + b) * 2);
     sn += v.x; sq += v.y;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { sn += __shfl_down(sn, o, 64); sq += __shfl_down(sq, o, 64); }
+  sn = block_sum(sn, red);
+  sq = block_sum(sq, red);
   if (threadIdx.x == 0) {
     if (bits_noisy) bits_noisy[n] += sn;
     if (bits_quant) bits_quant[n] += sq;
@@ -175,14 +226,16 @@ __device__ __forceinline__ void gc_elem_bwd(const GcArgs& p, float yv, float m, 
   const float sg = fmaxf(sraw, p.d.scale_bound);
   const float dlt = yv + u - m;
   const float a = fabsf(dlt), sgn = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
-  const float zu = (0.5f - a) / sg, zl = (-0.5f - a) / sg;
-  const float lraw = std_cdf(zu) - std_cdf(zl);
+  const float rs = gc_rs(sg), inv_sg = rs * 1.41421356237309504880f;
+  const float zu = (0.5f - a) * inv_sg, zl = (-0.5f - a) * inv_sg;
+  float e_lo, e_hi;
+  const float lraw = gc_lik(a, rs, e_lo, e_hi);
   const float l = fmaxf(lraw, p.d.likelihood_bound);
   const float glik = gb * (-inv_ln2 / l);                                         // d(-log2 l)/dl scaled
   const float graw = (lraw >= p.d.likelihood_bound || glik < 0.f) ? glik : 0.f;  // LowerBound backward
-  const float pu = std_pdf(zu), pl = std_pdf(zl);
-  const float dl_da = (pl - pu) / sg;
-  const float dl_dsg = (zl * pl - zu * pu) / sg;
+  const float pu = 0.39894228040143267794f * e_lo, pl = 0.39894228040143267794f * e_hi;   // the densities at zu, zl
+  const float dl_da = (pl - pu) * inv_sg;
+  const float dl_dsg = (zl * pl - zu * pu) * inv_sg;
   const float gy = graw * dl_da * sgn;
   const float gsg = graw * dl_dsg;
   gsig = (sraw >= p.d.scale_bound || gsg < 0.f) ? gsg : 0.f;
@@ -511,7 +564,7 @@ extern "C" int crdr_gauss_cond_fwd2(const crdr_gc_desc2* d, const crdr_gc_io* io
   CRDR_CHECK_LAUNCH("gauss_cond_fwd");
   if (part) {
     const bool noisy = io->noise || io->philox;
-    hipLaunchKernelGGL(gauss_cond_finish_kernel, dim3(d->N), dim3(64), 0, as_stream(s), part, B, noisy ? io->bits_noisy : nullptr,
+    hipLaunchKernelGGL(gauss_cond_finish_kernel, dim3(d->N), dim3(256), 0, as_stream(s), part, B, noisy ? io->bits_noisy : nullptr,
                        io->bits_quant);
     CRDR_CHECK_LAUNCH("gauss_cond_finish");
   }

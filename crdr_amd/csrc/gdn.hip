@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256) void gdn_fused_fwd_kernel(const GdnFusedArgs p
         float* q = img + lds_off(row, frow >> 2) + (frow & 3);
         const float n = acc[j][r] + bta;
         const float xv = *q;
-        *q = p.mode ? n : (p.inverse ? xv * sqrtf(n) : xv / sqrtf(n));
+        // (v_rsq_f32 / v_sqrt_f32: 1 ulp, one instruction each; the library sqrtf + division pair is ~25 and the epilogue of a wave that
+        // owns its SIMD is not hidden behind anything.  n >= beta_min > 0: no denormal path)
+        *q = p.mode ? n : (p.inverse ? xv * __builtin_amdgcn_sqrtf(n) : xv * __builtin_amdgcn_rsqf(n));
       }
     }
     // (the rows are private to the wave: program order is enough) 16-byte stores, 8 rows x 128 B per wave instruction

@@ -467,8 +467,9 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
     if (pl.wino == 3) {
       if (int rc = wino4_launch(d, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
     } else if (int rc = wino_launch(d, pl.wino - 1, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
-    // kind 3 / 5: filter transform + Winograd F(2x2, 3x3) / F(4x4, 3x3) kernel, direct-convolution flop count
-    profile_end(pl.wino == 3 ? 5 : 3, G * crdr_conv2d_flops(d), prof, as_stream(s));
+    // kind 3 / 5 / 6: filter transform + Winograd F(2x2, 3x3) / F(4x4, 3x3) kernel (6: a 5x5 stride-2 layer through it), direct-convolution
+    // flop count
+    profile_end(pl.wino == 3 ? (d->kh == 5 ? 6 : 5) : 3, G * crdr_conv2d_flops(d), prof, as_stream(s));
     return 0;
   }
   if (pl.stream >= 0 && !a.vec_epi && d->reserved == 0) {

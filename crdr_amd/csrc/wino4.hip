@@ -37,7 +37,14 @@ namespace crdr {
 namespace {
 
 constexpr int kNT4 = 256;
-constexpr int kTY = 2, kTX = 16;                       // Winograd tiles per output tile (rows, columns)
+// How the 32 Winograd tiles (4 x 4 outputs each) of an output tile lie over the image -- geometry 0: 2 rows x 16 columns (8 x 64 pixels:
+// images of >= 33 columns), geometry 1: 4 rows x 8 columns (16 x 32 pixels: the 32-column images, where geometry 0 would compute a
+// half-empty tile).  A wave owns 16 of them: tile row th (geometry 0) or tile rows 2 th, 2 th + 1 (geometry 1); lane (tx, kg) -> tile
+// (ty, txx).  The raw patch keeps its layout [class 16][64 slots], a class row being TX + 1 slots (17 x 3 = 51 / 9 x 5 = 45 used); with
+// geometry 1 the two tile rows of a wave read 2 x 128 bytes 144 bytes apart: four banks are touched twice (one extra cycle per read).
+template <int GEO> struct W4Geo { static constexpr int TY = GEO == 0 ? 2 : 4, TX = GEO == 0 ? 16 : 8, PR = TX + 1, USED = (TY + 1) * (TX + 1); };
+template <int GEO> __device__ __forceinline__ int w4_ty(int th, int tx) { return GEO == 0 ? th : 2 * th + (tx >> 3); }
+template <int GEO> __device__ __forceinline__ int w4_tx(int tx) { return GEO == 0 ? tx : tx & 7; }
 constexpr int kBN4 = 64;                               // output channels per tile
 constexpr int kClsSlots = 64;                          // slots per pixel class: 3 rows x 17 = 51 used; 64 = 1 KiB apart, so that two pixels of a patch column
                                                        // (different classes) are one ds_read2st64_b32
@@ -88,6 +95,7 @@ __device__ __forceinline__ void at6(const float m0, const float m1, const float 
 
 struct Wino4Tile { int gidx, n, oh0, ow0, n0, patch, tn, phase; };   // phase: output phase of a stride-2 transposed conv (0 otherwise)
 
+template <int GEO>
 __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int gx, int gyn, int gz) {
   // XCD-aware order (see igemm_kernel.hpp): the hardware deals workgroups round-robin over the 8 XCDs; every XCD walks a contiguous
   // range of (patch, N tile) pairs, the N tiles of a patch back to back (they re-read the patch out of that XCD's L2)
@@ -105,8 +113,8 @@ __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int 
   const int ppi = p.GH * p.GW;
   t.n = t.patch / ppi;
   const int prem = t.patch - t.n * ppi, by = prem / p.GW, bx = prem - by * p.GW;
-  t.oh0 = by * (4 * kTY);
-  t.ow0 = bx * (4 * kTX);
+  t.oh0 = by * (4 * W4Geo<GEO>::TY);
+  t.ow0 = bx * (4 * W4Geo<GEO>::TX);
   t.n0 = tn * kBN4;
   return t;
 }
@@ -114,16 +122,18 @@ __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int 
 // byte offset (into the input tensor's descriptor) of the pixel a DMA lane stages for input piece `piece`: slot S = piece * 64 + lane ->
 // (class (ci, cj), R, Cc) -> patch pixel (4 R + ci, 4 Cc + cj), channels 0..3 of the sub-step; out of range where the slot is unused or
 // the pixel lies outside the image (the range check of the buffer load then delivers zeros: padding)
+template <int GEO>
 __device__ __forceinline__ unsigned wino4_in_off(const IgemmArgs& p, const Wino4Tile& t, int piece, int lane) {
+  using G = W4Geo<GEO>;
   const int S = piece * 64 + lane;
-  const int cls = S / kClsSlots, r2 = S - cls * kClsSlots, R = r2 / 17, Cc = r2 - R * 17;
+  const int cls = S / kClsSlots, r2 = S - cls * kClsSlots, R = r2 / G::PR, Cc = r2 - R * G::PR;
   const int ci = cls >> 2, cj = cls & 3;
   const int pi = 4 * R + ci, pj = 4 * Cc + cj;
   // (5x5 stride-2 conv as four parity sub-filters: plane pixel m of parity (ph, pw) is image pixel 2 m + parity; the parity displacement
   // is wave-uniform and travels in the request's scalar offset; H and W are even there, so validity does not depend on the parity)
   const int ist = p.nphase == 4 ? 2 : 1;
   const int ih = ist * (t.oh0 - p.si + pi), iw = ist * (t.ow0 - p.si + pj);
-  const bool ok = S < kInUsed4 && r2 < 51 && pi < 4 * kTY + 2 && pj < 4 * kTX + 2 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+  const bool ok = S < kInUsed4 && r2 < G::USED && pi < 4 * G::TY + 2 && pj < 4 * G::TX + 2 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
   return ok ? (unsigned)((((t.n * p.H + ih) * p.W + iw) * p.ldx) * 4) : kOobOffset;
 }
 
@@ -179,13 +189,14 @@ __device__ __forceinline__ void wino4_prologue_dma(const IgemmArgs& p, float* sm
 //   6 b + 11 (half each); horizontal transform of row x < 5 of V_{k+1} in slots 44 + 5 x and 46 + 5 x -- straight into the registers of
 //   V_k's row x, whose MFMAs (slots 12 x .. 12 x + 11) are done by then; row 5 follows at the top of the next sub-step; DMA instruction
 //   q (9 filter pieces, then 4 raw pieces) at slot 5 q + 2.
+template <int GEO>
 __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, const Wino4Src& sr, bool prefetched, int lane, int wave, f32x4 (&acc)[64],
                                            f32x4 (&accv)[8]) {
   const int K4 = p.kchunks;
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
   // this lane's raw reads: patch pixel (i, j) of tile (th, tx), channel kg: float offset rbase + ro(i, j) of a raw buffer
-  const int rbase = (th * 17 + tx) * 4 + kg;
-  auto ro = [](int i, int j) constexpr { return (((i & 3) * 4 + (j & 3)) * kClsSlots + (i >> 2) * 17 + (j >> 2)) * 4; };
+  const int rbase = (w4_ty<GEO>(th, tx) * W4Geo<GEO>::PR + w4_tx<GEO>(tx)) * 4 + kg;
+  auto ro = [](int i, int j) constexpr { return (((i & 3) * 4 + (j & 3)) * kClsSlots + (i >> 2) * W4Geo<GEO>::PR + (j >> 2)) * 4; };
   // filter fragments of position pos (channel kg of the sub-step, output channels 32 oh + 16 ob + tx, ob = 0, 1: adjacent, one 8-byte read):
   // + buffer * kFF + pos * 256
   const int fbase = kRawBufs * kRF + kg * kBN4 + 32 * oh + 2 * tx;
@@ -310,13 +321,14 @@ __device__ __forceinline__ float acc_read(float v) {
 
 // Output transform + element-wise epilogue + stores of one wave: lane (tile tx of row th, channel group kg) holds M[36] for channels
 // n0 + 32 oh + 16 ob + 4 kg + r, ob < 2, r < 4.  Order of the element-wise operations: epilogue_store of igemm_kernel.hpp.
+template <int GEO>
 __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile& tl, float* smem, const float* sV, int lane, int wave, f32x4 (&acc)[64],
                                              f32x4 (&accv)[8]) {
   const int f = p.flags;
   const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
   const bool do_cs = (f & CRDR_EPI_COLSUM) != 0, accum = (f & CRDR_EPI_ACCUM) != 0;
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
-  const int oy0 = tl.oh0 + 4 * th, ox0 = tl.ow0 + 4 * tx;       // first output pixel of this lane's tile
+  const int oy0 = tl.oh0 + 4 * w4_ty<GEO>(th, tx), ox0 = tl.ow0 + 4 * w4_tx<GEO>(tx);       // first output pixel of this lane's tile
   auto tdesc = [&](const float* base, int ld) __attribute__((always_inline)) {
     const unsigned long long bytes = (((unsigned long long)p.N * p.OH * p.OW - 1) * ld + p.Cout) * 4ull;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (unsigned)bytes, 0x00020000);
@@ -488,6 +500,7 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
 }
 
 // DMA sources of tile tl (group pointers resolved)
+template <int GEO>
 __device__ __forceinline__ Wino4Src wino4_src(const IgemmArgs& p, const IgemmGroup& grp, const Wino4Tile& tl, int gyn, int lane, int wave) {
   Wino4Src sr;
   const float* x = p.ngroup > 1 ? grp.x[tl.gidx] : p.x;
@@ -498,7 +511,7 @@ __device__ __forceinline__ Wino4Src wino4_src(const IgemmArgs& p, const IgemmGro
   sr.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (size_t)tl.gidx * ublock, 0, (unsigned)(ublock * 4), 0x00020000);
   sr.u_off0 = (unsigned)(tl.tn * nph + tl.phase) * (unsigned)p.kchunks * (kUSlots4 * 16u);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off(p, tl, wave + 4 * j, lane);
+  for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO>(p, tl, wave + 4 * j, lane);
   return sr;
 }
 
@@ -518,6 +531,7 @@ __device__ __forceinline__ void wino4_vectors(const IgemmArgs& p, const IgemmGro
 // Persistent: at most one workgroup per CU, each walks the tiles vb = blockIdx.x, + gridDim.x, ...  Between the K loop and the
 // epilogue of a tile the waves request the next tile's first raw patches and filter block (the buffers are free by then) and its
 // epilogue vectors: the DMA latency of a fresh tile and the memory latency of the stores hide behind each other.
+template <int GEO>
 __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gyn, int gz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -532,7 +546,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     asm volatile("" : "+v"(lane));
     asm volatile("" : "+s"(wave));
     const int tid = wave * 64 + lane;
-    const Wino4Tile tl = wino4_tile(p_, vb, gx, gyn, gz);
+    const Wino4Tile tl = wino4_tile<GEO>(p_, vb, gx, gyn, gz);
     IgemmArgs p = p_;
     if (p.ngroup > 1) {
       const int g = tl.gidx;
@@ -540,7 +554,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     }
     float* sV = sVb + cur * (4 * kBN4);
     if (!prefetched) {
-      sr = wino4_src(p_, grp, tl, gyn, lane, wave);
+      sr = wino4_src<GEO>(p_, grp, tl, gyn, lane, wave);
       wino4_vectors(p_, grp, tl, sV, tid);   // (published by the K loop's first barrier)
     }
     f32x4 acc[64], accv[8];
@@ -548,16 +562,16 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     for (int j = 0; j < 64; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) accv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wino4_loop(p, smem, sr, prefetched, lane, wave, acc, accv);
+    wino4_loop<GEO>(p, smem, sr, prefetched, lane, wave, acc, accv);
     // (the loop ends with a barrier: every wave is past its last LDS read, raw and filter buffers are free)
     const bool more = vb + (int)gridDim.x < total;
     if (more) {   // the next tile: raw patches 0, 1, 2, filter block 0 and the epilogue vectors
-      const Wino4Tile tn = wino4_tile(p_, vb + (int)gridDim.x, gx, gyn, gz);
-      sr = wino4_src(p_, grp, tn, gyn, lane, wave);
+      const Wino4Tile tn = wino4_tile<GEO>(p_, vb + (int)gridDim.x, gx, gyn, gz);
+      sr = wino4_src<GEO>(p_, grp, tn, gyn, lane, wave);
       wino4_prologue_dma(p_, smem, sr, p_.kchunks, lane, wave);
       wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * (4 * kBN4), tid);
     }
-    wino4_finish(p, tl, smem, sV, lane, wave, acc, accv);
+    wino4_finish<GEO>(p, tl, smem, sV, lane, wave, acc, accv);
     prefetched = more;
     cur ^= 1;
     lds_barrier4();   // column-sum area, sV of this tile: free (the stores stay in flight: the next tile's first wait is vmcnt(32))
@@ -623,11 +637,16 @@ static int wino4_mode(const crdr_conv_desc* d) {
   return 0;
 }
 
+// tile geometry of a launch (W4Geo): by the width of the grid the tiles cover -- the output, or one output phase
+static int wino4_geo(const crdr_conv_desc* d, int mode) { return (mode == 3 ? d->W : d->OW) <= 32 ? 1 : 0; }
+static int wino4_tile_rows(int geo) { return geo == 0 ? 8 : 16; }
+static int wino4_tile_cols(int geo) { return geo == 0 ? 64 : 32; }
+
 bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok) {
   const int mode = wino4_mode(d);
   if (!mode) return false;
   if (d->C % 4 != 0 || d->ldx % 4 != 0 || d->OC % 4 != 0 || d->ldy % 4 != 0) return false;
-  if ((mode == 3 ? d->W : d->OW) < 48) return false;   // the 8 x 64 tile (of the output, or of one output phase) wants wide images
+  if ((mode == 3 ? d->W : d->OW) < 24) return false;   // the 8 x 64 / 16 x 32 tile (of the output, or of one output phase) wants wide images
   if ((d->flags & CRDR_EPI_RES) && d->ldres % 4 != 0) return false;
   if ((d->flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) && d->ldmask % 4 != 0) return false;
   if (d->flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_CONV_BF16X3)) return false;
@@ -647,12 +666,13 @@ size_t wino4_workspace(const crdr_conv_desc* d, int G) {
 
 int wino4_colsum_rows(const crdr_conv_desc* d) {
   const int mode = wino4_mode(d);
-  if (mode == 3) return d->N * cdiv(d->H, 4 * kTY) * cdiv(d->W, 4 * kTX) * 4;
-  return d->N * cdiv(d->OH, 4 * kTY) * cdiv(d->OW, 4 * kTX);
+  const int geo = wino4_geo(d, mode), tr = wino4_tile_rows(geo), tc = wino4_tile_cols(geo);
+  if (mode == 3) return d->N * cdiv(d->H, tr) * cdiv(d->W, tc) * 4;
+  return d->N * cdiv(d->OH, tr) * cdiv(d->OW, tc);
 }
 
 int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s) {
-  CRDR_REQUIRE(wino4_eligible(d, G, a.vec_epi != 0), "conv2d: the F(4x4, 3x3) Winograd kernel takes 3x3 stride-1 and 5x5 stride-2 (pad 2) convolutions of >= 48 "
+  CRDR_REQUIRE(wino4_eligible(d, G, a.vec_epi != 0), "conv2d: the F(4x4, 3x3) Winograd kernel takes 3x3 stride-1 and 5x5 stride-2 (pad 2) convolutions of >= 24 "
                "output (phase) columns with C, OC %% 4 == 0, 16-byte aligned operand rows and no gate / pre-add epilogue");
   const int mode = wino4_mode(d);
   Wino4Taps wt;
@@ -701,8 +721,9 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
   a.kchunks = kchunks * a.nphase;             // sub-steps of a tile
   a.so = mode == 3 ? 2 : 1;                   // output stride (4 output phases = 4 tiles per patch and N tile)
   const int gh = mode == 3 ? d->H : d->OH, gw = mode == 3 ? d->W : d->OW;   // the grid the 8 x 64 tiles cover
-  a.GH = cdiv(gh, 4 * kTY);
-  a.GW = cdiv(gw, 4 * kTX);
+  const int geo = wino4_geo(d, mode);
+  a.GH = cdiv(gh, wino4_tile_rows(geo));
+  a.GW = cdiv(gw, wino4_tile_cols(geo));
   a.si = si;
   a.cs_rows = wino4_colsum_rows(d);
   static const int ncu = [] {
@@ -714,11 +735,13 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
   const int total = gx * ntile * G * a.so * a.so;
   static std::atomic<bool> attr_done;
   if (!attr_done.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.store(true, std::memory_order_release);
   }
   const size_t lds = (size_t)(kLdsFloats4 + 2 * 4 * kBN4) * sizeof(float);
-  hipLaunchKernelGGL(wino4_kernel, dim3(std::min(total, ncu)), dim3(kNT4), lds, s, a, grp, gx, ntile, G);
+  if (geo == 0) hipLaunchKernelGGL(wino4_kernel<0>, dim3(std::min(total, ncu)), dim3(kNT4), lds, s, a, grp, gx, ntile, G);
+  else hipLaunchKernelGGL(wino4_kernel<1>, dim3(std::min(total, ncu)), dim3(kNT4), lds, s, a, grp, gx, ntile, G);
   CRDR_CHECK_LAUNCH("wino4_kernel");
   return 0;
 }

@@ -32,7 +32,8 @@ const char* crdr_arch(void); /* "gfx950" */
 /* measurement aid: bracket conv launches with HIP events on their stream; read = sum over launches of `kind`
  * (0: igemm kernel of a conv forward / input gradient, 1: weight-gradient slab kernel (+ its reduce when not deferred),
  * 2: split-K epilogue kernels, 3: Winograd launches of a conv forward / input gradient -- filter transform + kernel, counted with the
- * direct convolution's FLOPs, 2.25x what the matrix cores execute, 4: Winograd weight-gradient slab launches, likewise) of
+ * direct convolution's FLOPs, 2.25x what the matrix cores execute, 4: Winograd weight-gradient slab launches, likewise, 5: F(4x4, 3x3)
+ * Winograd launches of a 3x3 layer (4x what is executed), 6: of a 5x5 stride-2 layer as four 3x3 sub-filters / phases (25/9 x)) of
  * algorithmic FLOPs and elapsed ms, then clear */
 void crdr_profile_enable(int on);
 int crdr_profile_read(int kind, double* flops, double* ms, long long* launches);

@@ -153,6 +153,61 @@ def test_gauss_cond_fwd_bwd():
     assert torch.equal(la, lb)
 
 
+def test_gauss_cond_likelihood_against_float64():
+    """The kernels' interval likelihood (erfc = exp(-x^2) erfcx(x), csrc/entropy.hip gc_lik) on the grid the oracle is pinned on
+    (tests/test_entropy_parity.py::test_gaussian_likelihood_against_float64_scipy: both sides of the sigma bound, the rounding
+    boundary, the tail down to the likelihood floor, |v| up to 1e4) plus a dense random sample: against float64 scipy within the
+    oracle's own bounds (3e-6 relative + 3e-7 absolute above 1e-5, 3e-7 absolute below -- the erfcf form holds 2e-7 there), bit
+    terms within 1e-5, the floor exact; and against the oracle's fp32 result.  Noisy (given-noise) and quantised paths: the same
+    function of |v|."""
+    import numpy as np
+    from scipy.stats import norm
+    from oracle import crdr_oracle as O
+    from crdr_amd.hip import functional as HF
+    sig = np.concatenate([[-1.0, 0.0, 0.01, 0.05, 0.1099, 0.11, 0.1101], np.geomspace(0.12, 256.0, 40)])
+    v = np.concatenate([[0.0, 1e-4, 0.25, 0.4999, 0.5, 0.5001, 1.0, 1.5], np.linspace(2.0, 60.0, 59), [200.0, 1e4]])
+    S, V = np.meshgrid(sig, v, indexing="ij")
+    rng = np.random.default_rng(5)
+    s_r = np.exp(rng.uniform(np.log(0.05), np.log(256.0), 200000))
+    v_r = np.abs(rng.standard_normal(200000)) * np.maximum(s_r, 0.11) * 2.5 * rng.uniform(0, 1, 200000)
+    S = torch.tensor(np.concatenate([S.ravel(), s_r]), dtype=torch.float32)
+    V = torch.tensor(np.concatenate([V.ravel(), v_r]), dtype=torch.float32)
+    pad = (-S.numel()) % 4
+    S, V = torch.cat([S, S[:pad]]), torch.cat([V, V[:pad]])
+    mu = torch.full_like(S, 0.375)
+    y = mu + V                                       # the noisy path sees |y + 0 - mu| (zero noise given)
+    shp = (1, 4, S.numel() // 4, 1)
+    d = [t.reshape(shp).to(dev()).contiguous(memory_format=torch.channels_last) for t in (y, mu, S)]
+    _, bn, _, ln, _ = HF.gauss_cond(d[0], d[1], d[2], torch.zeros(shp, device=dev()), 0.11, 1e-9, True)
+    lik = ln.reshape(-1).double().cpu().numpy()      # (logical NCHW order = the order of the flat operands)
+    yv, muv, sv = y, mu, S
+    a = np.abs(yv.double().numpy() - muv.double().numpy())
+    s64 = np.maximum(sv.double().numpy(), 0.11)
+    ref = np.maximum(norm.sf((a - 0.5) / s64) - norm.sf((a + 0.5) / s64), 1e-9)   # (survival form: exact in the tail)
+    big = ref > 1e-5
+    err = np.abs(lik - ref)
+    assert np.all(err[big] <= 3e-6 * ref[big] + 3e-7), float(np.max(err[big] / ref[big]))
+    assert np.all(err[~big] <= 3e-7), float(err[~big].max())
+    floor = float(np.float32(1e-9))
+    assert np.all(lik >= floor) and np.any(lik == floor)
+    bits, bits_ref = -np.log2(lik), -np.log2(ref)
+    # (bit terms: the likelihood bound above through d(-log2 l) = dl / (l ln 2), plus v_log_f32's own 1e-5)
+    assert np.all(np.abs(bits[big] - bits_ref[big]) <= 1.5 * (3e-6 + 3e-7 / ref[big]) + 1e-5 * np.maximum(1.0, bits_ref[big]) + 1e-5)
+    # the tail (a >= 1/2, both erfc arguments positive) is relative: 4e-6, + 1e-6 x the cancellation erfc(xl) / (erfc(xl) - erfc(xh)) (wide
+    # sigma: the two values are close), + 5e-7 xl^2 (an fp32 argument: d ln erfc(x) = -2 x dx, three roundings in x -- the erfcf form
+    # of the reference has the same two terms)
+    tail = (a >= 0.5) & (ref > 1e-9)
+    cancel = norm.sf((a[tail] - 0.5) / s64[tail]) / ref[tail]
+    xl2 = ((a[tail] - 0.5) / s64[tail]) ** 2 / 2.0
+    tail_bound = ref[tail] * (4e-6 + 1e-6 * cancel + 5e-7 * xl2)
+    assert np.all(err[tail] <= tail_bound), float(np.max(err[tail] / tail_bound))
+    # the oracle's fp32 (torch erfc) result on the same operands
+    ol = O.gaussian_likelihood(yv, muv, sv).double().numpy()
+    assert np.all(np.abs(lik - ol) <= 5e-6 * ol + 4e-7), float(np.max(np.abs(lik - ol)))
+    tot = float(bn.sum())
+    assert abs(tot - float(np.sum(bits_ref))) <= 2e-6 * float(np.sum(bits_ref))
+
+
 def test_entropy_bottleneck_fwd_bwd_aux():
     from oracle import crdr_oracle as O
     from crdr_amd.models.subnet.entropy_model.entropy_bottleneck import SteEntropyBottleneck

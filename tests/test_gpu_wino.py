@@ -105,13 +105,17 @@ def test_winograd_epilogues_and_slices():
 
 
 W4_CASES = [
-    # name, N, Cin, H, W, Cout, pad   (F(4x4, 3x3): output tiles of 8 x 64 pixels x 32 channels, >= 48 output columns)
+    # name, N, Cin, H, W, Cout, pad   (F(4x4, 3x3): output tiles of 8 x 64 pixels x 64 channels beyond 32 output columns, of 16 x 32 pixels at 24..32)
     ("w4_96_96_64", 2, 96, 64, 64, 96, 1),
     ("w4_128_128_ragged", 1, 128, 21, 70, 128, 1),      # partial tiles on both edges, 21 = 2 * 8 + 5 rows, 70 = 64 + 6 columns
     ("w4_36_40_c4", 1, 36, 9, 50, 40, 1),               # channel tail of 4 (half a chunk), output channels not a multiple of 32
     ("w4_64_160_valid", 1, 64, 18, 66, 160, 0),         # pad 0: 16 x 64 outputs
     ("w4_256_64_128", 1, 256, 16, 128, 64, 1),          # two tile columns
     ("w4_8_8_wide", 3, 8, 5, 48, 8, 1),
+    ("w4_128_128_32", 2, 128, 32, 32, 128, 1),          # the 16 x 32 tile geometry: two tiles per image
+    ("w4_96_72_narrow_ragged", 3, 96, 21, 27, 72, 1),   # partial tiles both ways (21 = 16 + 5 rows, 27 of 32 columns)
+    ("w4_64_64_valid_30", 1, 64, 34, 32, 64, 0),        # pad 0: 32 x 30 outputs
+    ("w4_40_36_pad2_28", 1, 40, 12, 28, 36, 2),         # pad 2 (the transposed twin of pad 0): 14 x 30 outputs
 ]
 
 
@@ -145,7 +149,7 @@ def test_winograd_f4x4_fwd_dgrad(case):
     print(f"{name}: fwd max err / scale: F(4x4) {e4:.2e}  F(2x2) {e2:.2e}  direct {ed:.2e}")
     _close(out, ref, name + " fwd", rtol=5e-5)
     wq = ops.pack_weight(wd, transpose=True)
-    dx = ops.conv2d_raw(dyd, wq, ci, (3, 3), 1, p, True, (h, w), algo=a4) if w >= 48 else None
+    dx = ops.conv2d_raw(dyd, wq, ci, (3, 3), 1, p, True, (h, w), algo=a4) if w >= 24 else None
     if dx is not None:
         _close(dx, xr.grad, name + " dgrad", rtol=5e-5)
     out2 = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=a4)
@@ -158,6 +162,9 @@ W4S2_CASES = [
     ("w4s2_64_96_ragged", 2, 64, 20, 104, 96),        # 10 x 52 outputs: partial tiles both ways
     ("w4s2_36_40_c4", 1, 36, 16, 96, 40),
     ("w4s2_256_256_wide", 1, 256, 16, 256, 256),
+    ("w4s2_192_192_64", 2, 192, 64, 64, 192),         # 32 x 32 outputs / phases of 64 x 64: the 16 x 32 tile geometry for the conv
+    ("w4s2_96_64_narrow", 1, 96, 36, 28, 64),         # transposed: phases of 36 x 28 (ragged 16 x 32 tiles); conv: 14 output columns, not taken
+    ("w4s2_64_128_c56", 3, 64, 24, 56, 128),          # conv: 12 x 28 outputs
 ]
 
 
@@ -181,7 +188,7 @@ def test_winograd_f4x4_5x5_stride2(case):
     ref.backward(dy.double())
     xd, wd, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
     wp = ops.pack_weight(wd, transpose=False)
-    if ow >= 48:
+    if ow >= 24:
         direct = ops.conv2d_raw(xd, wp, co, (5, 5), 2, 2, False, (oh, ow), bias=bd, flags=1, algo=1)
         out = ops.conv2d_raw(xd, wp, co, (5, 5), 2, 2, False, (oh, ow), bias=bd, flags=1, algo=a4)
         torch.cuda.synchronize()
@@ -195,7 +202,7 @@ def test_winograd_f4x4_5x5_stride2(case):
         dx = ops.conv2d_raw(dyd, wq, ci, (5, 5), 2, 2, True, (h, w), algo=a4)
         _close(dx, xr.grad, name + " conv dgrad", rtol=5e-5)
     # ConvTranspose2d 5x5 s2 p2 op1: forward + input gradient
-    if w >= 48:
+    if w >= 24:
         wt2 = _rand(ci, co, 5, 5, seed=5, scale=(ci * 25 / 4) ** -0.5)
         xr2 = x.double().requires_grad_(True)
         ref2 = F.conv_transpose2d(xr2, wt2.double(), b.double(), stride=2, padding=2, output_padding=1)
@@ -287,7 +294,7 @@ def test_winograd_rejects_other_shapes():
     w3 = ops.pack_weight(_rand(32, 32, 3, 3, seed=2).to(dev), transpose=False)
     with pytest.raises(L.CrdrHipError):
         ops.conv2d_raw(x, w3, 32, (3, 3), 2, 1, False, (4, 4), algo=_wino_id())
-    with pytest.raises(L.CrdrHipError):   # F(4x4, 3x3): fewer than 48 output columns
+    with pytest.raises(L.CrdrHipError):   # F(4x4, 3x3): fewer than 24 output columns
         ops.conv2d_raw(x, w3, 32, (3, 3), 1, 1, False, (8, 8), algo=_wino_id() + 2)
     with pytest.raises(L.CrdrHipError):   # no 5x5 sub-filter form
         w5 = ops.pack_weight(_rand(32, 32, 5, 5, seed=2).to(dev), transpose=False)

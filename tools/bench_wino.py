@@ -51,7 +51,7 @@ def main():
                   f"({fl / w[0] / 1e9:6.1f} TF-eq, split {1 << w[2]})   x{d[0] / w[0]:.2f}", flush=True)
         return
     if a.k5s2:
-        for tr, ci, co, hw in [(1, 256, 256, 64), (0, 192, 192, 128), (0, 256, 256, 128), (1, 192, 192, 64)]:
+        for tr, ci, co, hw in [(1, 256, 256, 64), (0, 192, 192, 128), (0, 256, 256, 128), (1, 192, 192, 64), (1, 256, 256, 32), (0, 192, 192, 64), (0, 256, 256, 64), (1, 192, 192, 32)]:
             x = torch.randn(a.bs, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
             wt = (torch.randn(ci, co, 5, 5, device=dev) if tr else torch.randn(co, ci, 5, 5, device=dev)) * (ci * 25) ** -0.5
             b = torch.randn(co, device=dev)
