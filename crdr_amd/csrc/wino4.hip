@@ -42,9 +42,14 @@ constexpr int kNT4 = 256;
 // half-empty tile).  A wave owns 16 of them: tile row th (geometry 0) or tile rows 2 th, 2 th + 1 (geometry 1); lane (tx, kg) -> tile
 // (ty, txx).  The raw patch keeps its layout [class 16][64 slots], a class row being TX + 1 slots (17 x 3 = 51 / 9 x 5 = 45 used); with
 // geometry 1 the two tile rows of a wave read 2 x 128 bytes 144 bytes apart: four banks are touched twice (one extra cycle per read).
-template <int GEO> struct W4Geo { static constexpr int TY = GEO == 0 ? 2 : 4, TX = GEO == 0 ? 16 : 8, PR = TX + 1, USED = (TY + 1) * (TX + 1); };
-template <int GEO> __device__ __forceinline__ int w4_ty(int th, int tx) { return GEO == 0 ? th : 2 * th + (tx >> 3); }
-template <int GEO> __device__ __forceinline__ int w4_tx(int tx) { return GEO == 0 ? tx : tx & 7; }
+// Geometry 2: TWO images of at most 16 x 16 pixels (4 x 4 tiles each), wave th = image th of the pair: the 16 x 16 stage of the context
+// model; a class holds 2 x 32 slots, image th's 5 x 5 used ones at 32 th.
+template <int GEO> struct W4Geo {
+  static constexpr int TY = GEO == 0 ? 2 : 4, TX = GEO == 0 ? 16 : (GEO == 1 ? 8 : 4), PR = TX + 1, USED = GEO == 2 ? 57 : (TY + 1) * (TX + 1);
+};
+template <int GEO> __device__ __forceinline__ int w4_ty(int th, int tx) { return GEO == 0 ? th : (GEO == 1 ? 2 * th + (tx >> 3) : tx >> 2); }
+template <int GEO> __device__ __forceinline__ int w4_tx(int tx) { return GEO == 0 ? tx : (GEO == 1 ? tx & 7 : tx & 3); }
+template <int GEO> __device__ __forceinline__ int w4_slot0(int th) { return GEO == 2 ? 32 * th : 0; }   // first slot of the wave's image inside a class
 constexpr int kBN4 = 64;                               // output channels per tile
 constexpr int kClsSlots = 64;                          // slots per pixel class: 3 rows x 17 = 51 used; 64 = 1 KiB apart, so that two pixels of a patch column
                                                        // (different classes) are one ds_read2st64_b32
@@ -110,11 +115,17 @@ __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int 
   const int tn = r1 % gyn;
   t.patch = r1 / gyn;
   t.tn = tn;
-  const int ppi = p.GH * p.GW;
-  t.n = t.patch / ppi;
-  const int prem = t.patch - t.n * ppi, by = prem / p.GW, bx = prem - by * p.GW;
-  t.oh0 = by * (4 * W4Geo<GEO>::TY);
-  t.ow0 = bx * (4 * W4Geo<GEO>::TX);
+  if constexpr (GEO == 2) {
+    t.n = 2 * t.patch;   // (first image of the pair; wave th works on image n + th)
+    t.oh0 = 0;
+    t.ow0 = 0;
+  } else {
+    const int ppi = p.GH * p.GW;
+    t.n = t.patch / ppi;
+    const int prem = t.patch - t.n * ppi, by = prem / p.GW, bx = prem - by * p.GW;
+    t.oh0 = by * (4 * W4Geo<GEO>::TY);
+    t.ow0 = bx * (4 * W4Geo<GEO>::TX);
+  }
   t.n0 = tn * kBN4;
   return t;
 }
@@ -122,19 +133,27 @@ __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int 
 // byte offset (into the input tensor's descriptor) of the pixel a DMA lane stages for input piece `piece`: slot S = piece * 64 + lane ->
 // (class (ci, cj), R, Cc) -> patch pixel (4 R + ci, 4 Cc + cj), channels 0..3 of the sub-step; out of range where the slot is unused or
 // the pixel lies outside the image (the range check of the buffer load then delivers zeros: padding)
-template <int GEO>
-__device__ __forceinline__ unsigned wino4_in_off(const IgemmArgs& p, const Wino4Tile& t, int piece, int lane) {
+// FORM 1 (a 5x5 stride-1 layer as four 3x3 sub-filters, taps 3 bi + a, 3 bj + b): sub-filter `sub` = (bi, bj) reads the patch displaced by
+// (3 bi, 3 bj) pixels; whether a pixel is padding then depends on the sub-filter, so the lane offsets are re-derived when the K loop
+// moves to the next one (four times per tile).
+template <int GEO, int FORM>
+__device__ __forceinline__ unsigned wino4_in_off(const IgemmArgs& p, const Wino4Tile& t, int piece, int lane, int sub) {
   using G = W4Geo<GEO>;
   const int S = piece * 64 + lane;
-  const int cls = S / kClsSlots, r2 = S - cls * kClsSlots, R = r2 / G::PR, Cc = r2 - R * G::PR;
+  const int cls = S / kClsSlots, r2f = S - cls * kClsSlots;
+  const int img = GEO == 2 ? r2f >> 5 : 0, r2 = GEO == 2 ? r2f & 31 : r2f;
+  const int R = r2 / G::PR, Cc = r2 - R * G::PR;
   const int ci = cls >> 2, cj = cls & 3;
-  const int pi = 4 * R + ci, pj = 4 * Cc + cj;
+  const int pi = 4 * R + ci + (FORM == 1 ? 3 * (sub >> 1) : 0), pj = 4 * Cc + cj + (FORM == 1 ? 3 * (sub & 1) : 0);
+  const int pmax_i = 4 * G::TY + 2 + (FORM == 1 ? 3 * (sub >> 1) : 0), pmax_j = 4 * G::TX + 2 + (FORM == 1 ? 3 * (sub & 1) : 0);
+  const int n = t.n + img;
   // (5x5 stride-2 conv as four parity sub-filters: plane pixel m of parity (ph, pw) is image pixel 2 m + parity; the parity displacement
   // is wave-uniform and travels in the request's scalar offset; H and W are even there, so validity does not depend on the parity)
-  const int ist = p.nphase == 4 ? 2 : 1;
+  const int ist = (FORM == 0 && p.nphase == 4) ? 2 : 1;
   const int ih = ist * (t.oh0 - p.si + pi), iw = ist * (t.ow0 - p.si + pj);
-  const bool ok = S < kInUsed4 && r2 < G::USED && pi < 4 * G::TY + 2 && pj < 4 * G::TX + 2 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-  return ok ? (unsigned)((((t.n * p.H + ih) * p.W + iw) * p.ldx) * 4) : kOobOffset;
+  const bool ok = S < kInUsed4 && r2 < (GEO == 2 ? 25 : G::USED) && pi < pmax_i && pj < pmax_j && n < p.N && (unsigned)ih < (unsigned)p.H &&
+                  (unsigned)iw < (unsigned)p.W;
+  return ok ? (unsigned)((((n * p.H + ih) * p.W + iw) * p.ldx) * 4) : kOobOffset;
 }
 
 // where the DMA of one output tile reads: descriptors of its image tensor and filter blocks, this lane's four raw-piece offsets
@@ -154,9 +173,11 @@ __device__ __forceinline__ void wino4_dma_raw(float* smem, const Wino4Src& sr, _
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + rbuf * kRF + piece * 256), 16, (int)sr.a_off[j], soff, 0, 0);
 }
 // scalar byte offset of sub-step kr's raw patch: channel chunk kr % Kc, parity sub-filter kr / Kc (stride-2 conv: + (ph W + pw) pixels)
+template <int FORM>
 __device__ __forceinline__ int wino4_raw_soff(const IgemmArgs& p, int kr) {
   if (p.nphase == 1) return kr * 16;
   const int Kc = p.kchunks / p.nphase, sub = kr / Kc, ch = kr - sub * Kc;
+  if (FORM == 1) return ch * 16;   // (the displacement of a shifted sub-filter sits in the lane offsets: wino4_in_off)
   return ch * 16 + ((sub >> 1) * p.W + (sub & 1)) * p.ldx * 4;
 }
 // filter piece 9 wave + j (j = 0..8) of block kf -> filter buffer fbuf
@@ -168,11 +189,12 @@ __device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(smem + kRawBufs * kRF + fbuf * kFF + piece * 256), 16, (int)off, (int)so, 0, 0);
 }
 // the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and filter blocks 0, 1 (-> F0, F1)
+template <int FORM>
 __device__ __forceinline__ void wino4_prologue_dma(const IgemmArgs& p, float* smem, const Wino4Src& sr, int K4, int lane, int wave) {
 #pragma unroll
   for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wino4_dma_raw(smem, sr, kr < K4 ? sr.rx : wino4_empty_rsrc(), j, wino4_raw_soff(p, kr), kr, lane, wave);
+    for (int j = 0; j < 4; ++j) wino4_dma_raw(smem, sr, kr < K4 ? sr.rx : wino4_empty_rsrc(), j, wino4_raw_soff<FORM>(p, kr), kr, lane, wave);
 #pragma unroll
   for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
@@ -189,13 +211,13 @@ __device__ __forceinline__ void wino4_prologue_dma(const IgemmArgs& p, float* sm
 //   6 b + 11 (half each); horizontal transform of row x < 5 of V_{k+1} in slots 44 + 5 x and 46 + 5 x -- straight into the registers of
 //   V_k's row x, whose MFMAs (slots 12 x .. 12 x + 11) are done by then; row 5 follows at the top of the next sub-step; DMA instruction
 //   q (9 filter pieces, then 4 raw pieces) at slot 5 q + 2.
-template <int GEO>
-__device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, const Wino4Src& sr, bool prefetched, int lane, int wave, f32x4 (&acc)[64],
-                                           f32x4 (&accv)[8]) {
+template <int GEO, int FORM>
+__device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& tl, float* smem, Wino4Src& sr, bool prefetched, int lane, int wave,
+                                           f32x4 (&acc)[64], f32x4 (&accv)[8]) {
   const int K4 = p.kchunks;
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
   // this lane's raw reads: patch pixel (i, j) of tile (th, tx), channel kg: float offset rbase + ro(i, j) of a raw buffer
-  const int rbase = (w4_ty<GEO>(th, tx) * W4Geo<GEO>::PR + w4_tx<GEO>(tx)) * 4 + kg;
+  const int rbase = (w4_slot0<GEO>(th) + w4_ty<GEO>(th, tx) * W4Geo<GEO>::PR + w4_tx<GEO>(tx)) * 4 + kg;
   auto ro = [](int i, int j) constexpr { return (((i & 3) * 4 + (j & 3)) * kClsSlots + (i >> 2) * W4Geo<GEO>::PR + (j >> 2)) * 4; };
   // filter fragments of position pos (channel kg of the sub-step, output channels 32 oh + 16 ob + tx, ob = 0, 1: adjacent, one 8-byte read):
   // + buffer * kFF + pos * 256
@@ -218,7 +240,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
   // younger vector-memory operations -- that tile's stores -- are in flight and need not be waited for); V_0 rows 0..4 and the
   // vertical pass of row 5
   if (!prefetched) {
-    wino4_prologue_dma(p, smem, sr, K4, lane, wave);
+    wino4_prologue_dma<FORM>(p, smem, sr, K4, lane, wave);
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
   } else {
     __builtin_amdgcn_s_waitcnt(0x8070);   // vmcnt(32)
@@ -252,7 +274,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
     const float* rp = smem + rpo;                         // raw patch k + 1
     const float* fp = smem + fpo;                         // filter block k (the filter ring turns with the raw ring: block k in buffer k % 3)
     const __amdgpu_buffer_rsrc_t ru2 = k + 2 < K4 ? sr.ru : wino4_empty_rsrc(), rx3 = k + 3 < K4 ? sr.rx : wino4_empty_rsrc();
-    const int soff3 = ch3 * 16 + ((sub3 >> 1) * p.W + (sub3 & 1)) * p.ldx * 4;   // (sub3 = 0 unless the conv is the stride-2 form)
+    const int soff3 = FORM == 1 ? ch3 * 16 : ch3 * 16 + ((sub3 >> 1) * p.W + (sub3 & 1)) * p.ldx * 4;   // (sub3 = 0 unless the conv is the stride-2 form)
     const int f2 = r1 == 2 ? 0 : r1 + 1;                  // buffer of filter block k + 2
     float uf[8][2];   // filter fragments of positions j .. j + 3 in flight (ring of 8, indexed j & 7)
 #pragma unroll
@@ -300,7 +322,16 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, float* smem, cons
     }
     r0 = r1;
     r1 = r1 == 2 ? 0 : r1 + 1;
-    if (++ch3 == Kc) { ch3 = 0; ++sub3; }
+    if (++ch3 == Kc) {
+      ch3 = 0;
+      ++sub3;
+      if constexpr (FORM == 1) {   // the patches requested from here on belong to the next shifted sub-filter: its padding pattern
+        if (sub3 < 4) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub3);
+        }
+      }
+    }
     // the 13 requests of this sub-step (filter block k + 2, patch k + 3) stay in flight; everything older (filter block k + 1, patch
     // k + 2) has landed
     __builtin_amdgcn_s_waitcnt(0x007D);   // vmcnt(13) lgkmcnt(0)
@@ -337,14 +368,15 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
   // output pixel (a, b) of the lane's tile: (so (oy0 + a) + py, so (ox0 + b) + px) -- so = 2 and (py, px) = the tile's phase for a
   // stride-2 transposed conv, so = 1 otherwise
   const int so = p.so, py = tl.phase >> 1, px = tl.phase & 1;
-  const unsigned pix00 = (unsigned)(((size_t)tl.n * p.OH + so * oy0 + py) * p.OW + so * ox0 + px);
+  const int img = tl.n + (GEO == 2 ? th : 0);   // (geometry 2: the wave's image of the pair)
+  const unsigned pix00 = (unsigned)(((size_t)img * p.OH + so * oy0 + py) * p.OW + so * ox0 + px);
   // validity of this lane's 16 output pixels (bit 4 a + b); the (a, b) displacement of an access is wave-uniform and travels as the
   // buffer instruction's scalar offset (the range check only sees the lane part)
   unsigned pixm = 0;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) pixm |= (so * (oy0 + a) + py < p.OH && so * (ox0 + b) + px < p.OW) ? (1u << (4 * a + b)) : 0u;
+    for (int b = 0; b < 4; ++b) pixm |= (img < p.N && so * (oy0 + a) + py < p.OH && so * (ox0 + b) + px < p.OW) ? (1u << (4 * a + b)) : 0u;
   auto soff = [&](int ld, int a, int b) __attribute__((always_inline)) { return so * (a * p.OW + b) * ld * 4; };
   float* sC = smem + kRawBufs * kRF + 2 * kFF;   // column sums: [wave 4][which 2][ob 2][64 lanes][4 r] = 16 KiB in filter buffer F2 (F0, F1 receive the next tile's blocks 0, 1)
 
@@ -500,7 +532,7 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
 }
 
 // DMA sources of tile tl (group pointers resolved)
-template <int GEO>
+template <int GEO, int FORM>
 __device__ __forceinline__ Wino4Src wino4_src(const IgemmArgs& p, const IgemmGroup& grp, const Wino4Tile& tl, int gyn, int lane, int wave) {
   Wino4Src sr;
   const float* x = p.ngroup > 1 ? grp.x[tl.gidx] : p.x;
@@ -511,7 +543,7 @@ __device__ __forceinline__ Wino4Src wino4_src(const IgemmArgs& p, const IgemmGro
   sr.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (size_t)tl.gidx * ublock, 0, (unsigned)(ublock * 4), 0x00020000);
   sr.u_off0 = (unsigned)(tl.tn * nph + tl.phase) * (unsigned)p.kchunks * (kUSlots4 * 16u);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO>(p, tl, wave + 4 * j, lane);
+  for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, 0);
   return sr;
 }
 
@@ -531,7 +563,7 @@ __device__ __forceinline__ void wino4_vectors(const IgemmArgs& p, const IgemmGro
 // Persistent: at most one workgroup per CU, each walks the tiles vb = blockIdx.x, + gridDim.x, ...  Between the K loop and the
 // epilogue of a tile the waves request the next tile's first raw patches and filter block (the buffers are free by then) and its
 // epilogue vectors: the DMA latency of a fresh tile and the memory latency of the stores hide behind each other.
-template <int GEO>
+template <int GEO, int FORM>
 __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gyn, int gz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -554,7 +586,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     }
     float* sV = sVb + cur * (4 * kBN4);
     if (!prefetched) {
-      sr = wino4_src<GEO>(p_, grp, tl, gyn, lane, wave);
+      sr = wino4_src<GEO, FORM>(p_, grp, tl, gyn, lane, wave);
       wino4_vectors(p_, grp, tl, sV, tid);   // (published by the K loop's first barrier)
     }
     f32x4 acc[64], accv[8];
@@ -562,13 +594,13 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     for (int j = 0; j < 64; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) accv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wino4_loop<GEO>(p, smem, sr, prefetched, lane, wave, acc, accv);
+    wino4_loop<GEO, FORM>(p, tl, smem, sr, prefetched, lane, wave, acc, accv);
     // (the loop ends with a barrier: every wave is past its last LDS read, raw and filter buffers are free)
     const bool more = vb + (int)gridDim.x < total;
     if (more) {   // the next tile: raw patches 0, 1, 2, filter block 0 and the epilogue vectors
       const Wino4Tile tn = wino4_tile<GEO>(p_, vb + (int)gridDim.x, gx, gyn, gz);
-      sr = wino4_src<GEO>(p_, grp, tn, gyn, lane, wave);
-      wino4_prologue_dma(p_, smem, sr, p_.kchunks, lane, wave);
+      sr = wino4_src<GEO, FORM>(p_, grp, tn, gyn, lane, wave);
+      wino4_prologue_dma<FORM>(p_, smem, sr, p_.kchunks, lane, wave);
       wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * (4 * kBN4), tid);
     }
     wino4_finish<GEO>(p, tl, smem, sV, lane, wave, acc, accv);
@@ -621,15 +653,19 @@ __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const floa
 
 }  // namespace
 
-// the three forms the kernel takes: 0 = none, 1 = 3x3 stride 1 (conv or its transposed twin), 2 = 5x5 stride-2 conv (pad 2, even H / W: four
+// the forms the kernel takes: 0 = none, 1 = 3x3 stride 1 (conv or its transposed twin), 2 = 5x5 stride-2 conv (pad 2, even H / W: four
 // parity sub-filters of 3x3 accumulated), 3 = 5x5 stride-2 transposed conv (pad 2, output = 2 x input: four output phases, each a 3x3
-// stride-1 conv of the input -- elic_layers.py:14-21 up_conv, elic_autoencoder.py:42-52 and their input gradients)
+// stride-1 conv of the input -- elic_layers.py:14-21 up_conv, elic_autoencoder.py:42-52 and their input gradients), 4 = 5x5 stride 1 pad 2
+// (conv or transposed twin: four 3x3 sub-filters over the taps 3 bi + a, 3 bj + b, the last row / column of the padded 6x6 being zero,
+// accumulated over patches displaced by (3 bi, 3 bj) -- the slice transforms of the context model,
+// minnen20_charm_context_model.py:26-38)
 static int wino4_mode(const crdr_conv_desc* d) {
   if (d->wlayout != 0) return 0;
   if (d->kh == 3 && d->kw == 3 && d->stride == 1) {
     const int grow = d->transposed ? 2 - 2 * d->pad : 2 * d->pad - 2;   // (a stride-1 transposed conv = a conv with pad k - 1 - pad)
     return (d->OH == d->H + grow && d->OW == d->W + grow && d->pad >= 0 && d->pad <= 2) ? 1 : 0;
   }
+  if (d->kh == 5 && d->kw == 5 && d->stride == 1 && d->pad == 2) return (d->OH == d->H && d->OW == d->W && d->C >= 12) ? 4 : 0;
   if (d->kh == 5 && d->kw == 5 && d->stride == 2 && d->pad == 2) {
     if (!d->transposed) return (d->H % 2 == 0 && d->W % 2 == 0 && d->OH == d->H / 2 && d->OW == d->W / 2) ? 2 : 0;
     return (d->OH == 2 * d->H && d->OW == 2 * d->W) ? 3 : 0;
@@ -638,15 +674,29 @@ static int wino4_mode(const crdr_conv_desc* d) {
 }
 
 // tile geometry of a launch (W4Geo): by the width of the grid the tiles cover -- the output, or one output phase
-static int wino4_geo(const crdr_conv_desc* d, int mode) { return (mode == 3 ? d->W : d->OW) <= 32 ? 1 : 0; }
+// (geometry 2 -- two whole images of <= 16 x 16 per tile -- for the stride-1 forms only)
+static int wino4_geo(const crdr_conv_desc* d, int mode) {
+  const int gh = mode == 3 ? d->H : d->OH, gw = mode == 3 ? d->W : d->OW;
+  if ((mode == 1 || mode == 4) && gh <= 16 && gw <= 16) return 2;
+  return gw <= 32 ? 1 : 0;
+}
 static int wino4_tile_rows(int geo) { return geo == 0 ? 8 : 16; }
-static int wino4_tile_cols(int geo) { return geo == 0 ? 64 : 32; }
+static int wino4_tile_cols(int geo) { return geo == 0 ? 64 : (geo == 1 ? 32 : 16); }
+// output tiles of a launch (per N tile and output phase) = rows of its column-sum partials
+static int wino4_patches(const crdr_conv_desc* d, int mode) {
+  const int geo = wino4_geo(d, mode), gh = mode == 3 ? d->H : d->OH, gw = mode == 3 ? d->W : d->OW;
+  if (geo == 2) return cdiv(d->N, 2);
+  return d->N * cdiv(gh, wino4_tile_rows(geo)) * cdiv(gw, wino4_tile_cols(geo));
+}
 
 bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok) {
   const int mode = wino4_mode(d);
   if (!mode) return false;
   if (d->C % 4 != 0 || d->ldx % 4 != 0 || d->OC % 4 != 0 || d->ldy % 4 != 0) return false;
-  if ((mode == 3 ? d->W : d->OW) < 24) return false;   // the 8 x 64 / 16 x 32 tile (of the output, or of one output phase) wants wide images
+  {   // the 8 x 64 / 16 x 32 tile (of the output, or of one output phase) wants wide images; two-image tiles want both dimensions >= 9
+    const int gh = mode == 3 ? d->H : d->OH, gw = mode == 3 ? d->W : d->OW;
+    if (wino4_geo(d, mode) == 2 ? (gh < 9 || gw < 9) : gw < 24) return false;
+  }
   if ((d->flags & CRDR_EPI_RES) && d->ldres % 4 != 0) return false;
   if ((d->flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) && d->ldmask % 4 != 0) return false;
   if (d->flags & (CRDR_EPI_GATE | CRDR_EPI_PREADD | CRDR_CONV_BF16X3)) return false;
@@ -660,20 +710,18 @@ bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok) {
 }
 
 size_t wino4_workspace(const crdr_conv_desc* d, int G) {
-  const int nvar = wino4_mode(d) >= 2 ? 4 : 1;   // parity sub-filters / output phases
+  const int nvar = wino4_mode(d) >= 2 ? 4 : 1;   // parity or shifted sub-filters / output phases
   return (size_t)G * cdiv(d->OC, kBN4) * nvar * cdiv(d->C, 4) * kUSlots4 * 16;
 }
 
 int wino4_colsum_rows(const crdr_conv_desc* d) {
   const int mode = wino4_mode(d);
-  const int geo = wino4_geo(d, mode), tr = wino4_tile_rows(geo), tc = wino4_tile_cols(geo);
-  if (mode == 3) return d->N * cdiv(d->H, tr) * cdiv(d->W, tc) * 4;
-  return d->N * cdiv(d->OH, tr) * cdiv(d->OW, tc);
+  return wino4_patches(d, mode) * (mode == 3 ? 4 : 1);
 }
 
 int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s) {
-  CRDR_REQUIRE(wino4_eligible(d, G, a.vec_epi != 0), "conv2d: the F(4x4, 3x3) Winograd kernel takes 3x3 stride-1 and 5x5 stride-2 (pad 2) convolutions of >= 24 "
-               "output (phase) columns with C, OC %% 4 == 0, 16-byte aligned operand rows and no gate / pre-add epilogue");
+  CRDR_REQUIRE(wino4_eligible(d, G, a.vec_epi != 0), "conv2d: the F(4x4, 3x3) Winograd kernel takes 3x3 / 5x5 stride-1 and 5x5 stride-2 (pad 2) convolutions of >= 24 "
+               "output (phase) columns (or whole images of 9..16 pixels a side) with C, OC %% 4 == 0, 16-byte aligned operand rows and no gate / pre-add epilogue");
   const int mode = wino4_mode(d);
   Wino4Taps wt;
   for (int v = 0; v < 4; ++v)
@@ -690,6 +738,17 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
     }
     for (int t = 0; t < 9; ++t) CRDR_REQUIRE(wt.widx[0][t] >= 0, "conv2d: Winograd F(4x4): incomplete 3x3 window");
     si = -dmin;   // the patch starts `si` pixels above / left of its first output pixel
+  } else if (mode == 4) {
+    // taps (dh, dw) relative to the window's first: sub-filter (bi, bj) element (a, b) = tap (3 bi + a, 3 bj + b), absent past the 5th
+    int dmin = 127;
+    for (int t = 0; t < 25; ++t) dmin = std::min(dmin, (int)(signed char)(taps.packed[t] & 0xff));
+    for (int t = 0; t < 25; ++t) {
+      const int v = taps.packed[t];
+      const int dh = (int)(signed char)(v & 0xff) - dmin, dw = (int)(signed char)((v >> 8) & 0xff) - dmin;
+      CRDR_REQUIRE(dh >= 0 && dh < 5 && dw >= 0 && dw < 5, "conv2d: Winograd F(4x4): tap offsets are not a 5x5 window");
+      wt.widx[(dh / 3) * 2 + dw / 3][(dh % 3) * 3 + dw % 3] = v >> 16;
+    }
+    si = -dmin;
   } else if (mode == 2) {
     // out[o] = sum_t w[t] x[2 o - 2 + t], t = 2 a + p: sub-filter (ph, pw) element (a, b) = w[2 a + ph][2 b + pw] over the parity plane
     // x[2 m + ph], a 3-tap 'pad 1' correlation; the pack's tap index of kernel element (r, s) is 5 r + s
@@ -717,13 +776,13 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
     CRDR_CHECK_LAUNCH("wino4_filter_kernel");
   }
   a.w = u;
-  a.nphase = mode == 2 ? 4 : 1;               // parity sub-filters the K loop accumulates
+  a.nphase = (mode == 2 || mode == 4) ? 4 : 1;   // parity / shifted sub-filters the K loop accumulates
   a.kchunks = kchunks * a.nphase;             // sub-steps of a tile
   a.so = mode == 3 ? 2 : 1;                   // output stride (4 output phases = 4 tiles per patch and N tile)
   const int gh = mode == 3 ? d->H : d->OH, gw = mode == 3 ? d->W : d->OW;   // the grid the 8 x 64 tiles cover
   const int geo = wino4_geo(d, mode);
-  a.GH = cdiv(gh, wino4_tile_rows(geo));
-  a.GW = cdiv(gw, wino4_tile_cols(geo));
+  a.GH = geo == 2 ? 1 : cdiv(gh, wino4_tile_rows(geo));
+  a.GW = geo == 2 ? 1 : cdiv(gw, wino4_tile_cols(geo));
   a.si = si;
   a.cs_rows = wino4_colsum_rows(d);
   static const int ncu = [] {
@@ -731,17 +790,18 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
     return n / 8 * 8;
   }();
-  const int gx = d->N * a.GH * a.GW;
+  const int gx = wino4_patches(d, mode);
   const int total = gx * ntile * G * a.so * a.so;
+  using Kern = void (*)(const IgemmArgs, const IgemmGroup, int, int, int);
+  static const Kern kerns[2][3] = {{wino4_kernel<0, 0>, wino4_kernel<1, 0>, wino4_kernel<2, 0>}, {wino4_kernel<0, 1>, wino4_kernel<1, 1>, wino4_kernel<2, 1>}};
   static std::atomic<bool> attr_done;
   if (!attr_done.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int f = 0; f < 2; ++f)
+      for (int g = 0; g < 3; ++g) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[f][g]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.store(true, std::memory_order_release);
   }
   const size_t lds = (size_t)(kLdsFloats4 + 2 * 4 * kBN4) * sizeof(float);
-  if (geo == 0) hipLaunchKernelGGL(wino4_kernel<0>, dim3(std::min(total, ncu)), dim3(kNT4), lds, s, a, grp, gx, ntile, G);
-  else hipLaunchKernelGGL(wino4_kernel<1>, dim3(std::min(total, ncu)), dim3(kNT4), lds, s, a, grp, gx, ntile, G);
+  hipLaunchKernelGGL(kerns[mode == 4 ? 1 : 0][geo], dim3(std::min(total, ncu)), dim3(kNT4), lds, s, a, grp, gx, ntile, G);
   CRDR_CHECK_LAUNCH("wino4_kernel");
   return 0;
 }

@@ -387,14 +387,17 @@ def test_winograd_ids_are_planned_only_for_the_shapes_they_take(lib):
     d5.reserved = base
     assert lib.crdr_conv2d_workspace(C.byref(d5)) == tickets + 1 * 4 * 4 * 16 * 2 * 64 * 16
     # variant 2 = F(4x4, 3x3) (wino4.hip): 3x3 stride 1 with >= 24 output columns (16 x 32-pixel tiles up to 32 columns, 8 x 64 beyond), C and
-    # OC multiples of 4; no 5x5 stride-1 form; workspace =
+    # OC multiples of 4; workspace =
     # tickets + N tiles of 64 x chunks of 4 channels x 36 positions x 4 x 64 floats
     assert plan(desc(96, 96, 64, 3), base + 2) == base + 2
     assert plan(desc(96, 96, 64, 3, transposed=1), base + 2) == base + 2
     assert plan(desc(96, 96, 32, 3), base + 2) == base + 2            # 32 output columns: the 16 x 32 tile geometry
-    assert plan(desc(96, 96, 16, 3), base + 2) == 0                   # 16 output columns
+    assert plan(desc(96, 96, 16, 3), base + 2) == base + 2            # 16 x 16 images: two whole images per tile
+    assert plan(desc(96, 96, 8, 3), base + 2) == 0                    # 8 x 8 images
     assert plan(desc(96, 96, 64, 3, stride=2), base + 2) == 0
-    assert plan(desc(320, 224, 64, 5), base + 2) == 0                 # 5x5 stride 1: no F(4x4) form
+    assert plan(desc(320, 224, 64, 5), base + 2) == base + 2          # 5x5 stride 1 pad 2: four shifted 3x3 sub-filters
+    assert plan(desc(320, 224, 16, 5), base + 2) == base + 2          # (the 16 x 16 stage of the context model)
+    assert plan(desc(8, 224, 64, 5), base + 2) == 0                   # ... of >= 12 input channels
     # 5x5 stride 2 pad 2: conv as four parity sub-filters (even input, >= 24 output columns), transposed conv as four output phases
     assert plan(desc(192, 192, 128, 5, stride=2), base + 2) == base + 2
     assert plan(desc(192, 192, 64, 5, stride=2), base + 2) == base + 2  # 32 output columns

@@ -116,6 +116,9 @@ W4_CASES = [
     ("w4_96_72_narrow_ragged", 3, 96, 21, 27, 72, 1),   # partial tiles both ways (21 = 16 + 5 rows, 27 of 32 columns)
     ("w4_64_64_valid_30", 1, 64, 34, 32, 64, 0),        # pad 0: 32 x 30 outputs
     ("w4_40_36_pad2_28", 1, 40, 12, 28, 36, 2),         # pad 2 (the transposed twin of pad 0): 14 x 30 outputs
+    ("w4_160_160_16", 5, 160, 16, 16, 160, 1),          # 16 x 16 images, two per tile (odd batch: the last tile holds one)
+    ("w4_64_72_13x11", 3, 64, 13, 11, 72, 1),           # ragged images inside the 16 x 16 frame
+    ("w4_32_32_valid16", 2, 32, 16, 16, 32, 0),         # pad 0: 14 x 14 outputs
 ]
 
 
@@ -149,7 +152,7 @@ def test_winograd_f4x4_fwd_dgrad(case):
     print(f"{name}: fwd max err / scale: F(4x4) {e4:.2e}  F(2x2) {e2:.2e}  direct {ed:.2e}")
     _close(out, ref, name + " fwd", rtol=5e-5)
     wq = ops.pack_weight(wd, transpose=True)
-    dx = ops.conv2d_raw(dyd, wq, ci, (3, 3), 1, p, True, (h, w), algo=a4) if w >= 24 else None
+    dx = ops.conv2d_raw(dyd, wq, ci, (3, 3), 1, p, True, (h, w), algo=a4) if (w >= 24 or (9 <= w <= 16 and 9 <= h <= 16)) else None
     if dx is not None:
         _close(dx, xr.grad, name + " dgrad", rtol=5e-5)
     out2 = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=a4)
@@ -216,6 +219,49 @@ def test_winograd_f4x4_5x5_stride2(case):
         wq2 = ops.pack_weight(w2d, transpose=False)    # rows = Cin, cols = Cout
         dx2 = ops.conv2d_raw(dy2.to(dev), wq2, ci, (5, 5), 2, 2, False, (h, w), algo=a4)
         _close(dx2, xr2.grad, name + " convT dgrad", rtol=5e-5)
+
+
+W4K5_CASES = [
+    # name, N, Cin, H, W, Cout   (5x5 stride 1 pad 2 as four shifted 3x3 sub-filters)
+    ("w4k5_320_128_16", 5, 320, 16, 16, 128),         # the context model's stage: two 16 x 16 images per tile, odd batch
+    ("w4k5_32_96_16", 3, 32, 16, 16, 96),
+    ("w4k5_64_64_12x14", 2, 64, 12, 14, 64),          # ragged inside the 16 x 16 frame
+    ("w4k5_96_64_20x70", 1, 96, 20, 70, 64),          # 8 x 64 tiles, ragged both ways
+    ("w4k5_48_80_24x32", 2, 48, 24, 32, 80),          # 16 x 32 tiles
+    ("w4k5_12_8_min", 1, 12, 9, 9, 8),                # smallest channel count taken
+]
+
+
+@pytest.mark.parametrize("case", W4K5_CASES, ids=[c[0] for c in W4K5_CASES])
+def test_winograd_f4x4_5x5_stride1(case):
+    """the 5x5 stride-1 layers (the slice transforms of the context model, minnen20_charm_context_model.py:26-38) through the F(4x4, 3x3)
+    kernel: taps (3 bi + a, 3 bj + b), four sub-filters accumulated over patches displaced by (3 bi, 3 bj); forward and input gradient (the
+    transposed twin) against fp64 torch, bit-identical run to run"""
+    from crdr_amd.hip import ops
+    name, n, ci, h, w, co = case
+    dev = _dev()
+    a4 = _wino_id() + 2
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(co, ci, 5, 5, seed=2, scale=(ci * 25) ** -0.5)
+    b = _rand(co, seed=3)
+    xr = x.double().requires_grad_(True)
+    ref = F.conv2d(xr, wt.double(), b.double(), padding=2)
+    dy = _rand(*ref.shape, seed=4)
+    ref.backward(dy.double())
+    xd, wd, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
+    wp = ops.pack_weight(wd, transpose=False)
+    direct = ops.conv2d_raw(xd, wp, co, (5, 5), 1, 2, False, (h, w), bias=bd, flags=1, algo=1)
+    out = ops.conv2d_raw(xd, wp, co, (5, 5), 1, 2, False, (h, w), bias=bd, flags=1, algo=a4)
+    torch.cuda.synchronize()
+    sc = ref.abs().max().item()
+    print(f"{name}: fwd max err / scale: F(4x4) {(out.cpu().double() - ref.detach()).abs().max().item() / sc:.2e}  "
+          f"direct {(direct.cpu().double() - ref.detach()).abs().max().item() / sc:.2e}")
+    _close(out, ref, name + " fwd", rtol=5e-5)
+    assert torch.equal(out, ops.conv2d_raw(xd, wp, co, (5, 5), 1, 2, False, (h, w), bias=bd, flags=1, algo=a4))
+    if co >= 12:
+        wq = ops.pack_weight(wd, transpose=True)
+        dx = ops.conv2d_raw(dyd, wq, ci, (5, 5), 1, 2, True, (h, w), algo=a4)
+        _close(dx, xr.grad, name + " dgrad", rtol=5e-5)
 
 
 def test_winograd_f4x4_epilogues_slices_groups_colsum():
@@ -296,9 +342,9 @@ def test_winograd_rejects_other_shapes():
         ops.conv2d_raw(x, w3, 32, (3, 3), 2, 1, False, (4, 4), algo=_wino_id())
     with pytest.raises(L.CrdrHipError):   # F(4x4, 3x3): fewer than 24 output columns
         ops.conv2d_raw(x, w3, 32, (3, 3), 1, 1, False, (8, 8), algo=_wino_id() + 2)
-    with pytest.raises(L.CrdrHipError):   # no 5x5 sub-filter form
-        w5 = ops.pack_weight(_rand(32, 32, 5, 5, seed=2).to(dev), transpose=False)
-        ops.conv2d_raw(_rand(1, 32, 8, 64, seed=1).to(dev), w5, 32, (5, 5), 1, 2, False, (8, 64), algo=_wino_id() + 2)
+    with pytest.raises(L.CrdrHipError):   # the 5x5 stride-1 form wants >= 12 input channels
+        w5 = ops.pack_weight(_rand(32, 8, 5, 5, seed=2).to(dev), transpose=False)
+        ops.conv2d_raw(_rand(1, 8, 8, 64, seed=1).to(dev), w5, 32, (5, 5), 1, 2, False, (8, 64), algo=_wino_id() + 2)
 
 
 WG_CASES = [

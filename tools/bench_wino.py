@@ -91,8 +91,8 @@ def main():
         tw = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (kk, kk), 1, kk // 2, False, (hw, hw), bias=b, flags=3, algo=wid), reps=3)
         fl = 2.0 * a.bs * hw * hw * ci * co * kk * kk
         t4 = None
-        if kk == 3 and lib.crdr_conv2d_num_wino_configs() > 2:
-            try:   # F(4x4, 3x3) (wino4.hip): wide images only
+        if lib.crdr_conv2d_num_wino_configs() > 2:
+            try:   # F(4x4, 3x3) (wino4.hip)
                 t4 = ops._time_call(lambda: ops.conv2d_raw(x, wp, co, (kk, kk), 1, kk // 2, False, (hw, hw), bias=b, flags=3, algo=wid + 2), reps=3)
             except L.CrdrHipError:
                 pass
