@@ -265,6 +265,12 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
   int r1 = 1, r0 = 0;   // raw buffer of patch k + 1 / of patch k (= the one patch k + 3 goes to)
   const int Kc = K4 / p.nphase;   // channel chunks per parity sub-filter (stride-2 conv: 4 sub-filters; else 1)
   int ch3 = 3 % Kc, sub3 = 3 / Kc;   // chunk / sub-filter of sub-step k + 3 (counters: no division in the loop)
+  if constexpr (FORM == 1) {   // (12 input channels: the first patch requested inside the loop already belongs to the second sub-filter)
+    if (sub3 > 0 && sub3 < 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub3);
+    }
+  }
   for (int k = 0; k < K4; ++k) {
     // (the two base offsets are made opaque: every LDS read of the sub-step is then `base register + 16-bit immediate`; left visible,
     // the compiler folds the buffer constants into the offsets, overflows the immediate and spends an add per read)
