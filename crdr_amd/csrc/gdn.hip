@@ -117,14 +117,20 @@ __global__ __launch_bounds__(256) void gdn_reparam_bwd_kernel(const float* dgamm
 
 // ------------------------------------------------------------------------------------------------------------
 // Fused forward: ONE kernel reads x once and writes y once (8 B per element of HBM traffic; the four-kernel form above
-// moves 28 B).  A persistent workgroup (4 waves) takes tiles of 128 pixels x all channels: the x tile goes to LDS by
-// LDS-DMA as NB chunk images [128 rows][32 floats] (the igemm A-tile image: 128-byte rows, XOR-swizzled 16-byte slots),
-// gamma_eff streams through LDS in 32-channel K slabs [CP rows][32] (double buffered), A fragments are squared on the way
-// from LDS to the matrix cores (exact fp32 MFMA), and the epilogue -- n = acc + beta, y = x rsqrt(n) or x sqrt(n) -- takes
-// x from the LDS tile again, writes y over it in place and leaves with 16-byte stores of whole 128-byte row segments.
+// moves 28 B).  A persistent workgroup (4 waves, one per SIMD) keeps gamma_eff IN REGISTERS for the whole launch -- wave w owns the
+// output channels [16 NCB w, 16 NCB (w + 1)) and holds their gamma rows as B fragments of v_mfma_f32_16x16x4_f32 (NCB x NS x 4
+// registers per lane: 144 at 192 channels) -- and walks tiles of 64 pixels: the x tile goes to LDS by LDS-DMA as chunk images [64 rows]
+// [32 floats] (the igemm A-tile image: 128-byte rows, XOR-swizzled 16-byte slots), double buffered (the next tile is requested at the
+// top of the current one; counted vmcnt waits keep the previous tile's stores out of the wait), every wave reads each pixel row's 16
+// channels of a K step with one ds_read_b128, squares them on the way to the matrix cores (exact fp32 MFMA; the k order inside a step
+// is the lane group's, the same on both operands), and the epilogue -- n = acc + beta, y = x rsqrt(n) or x sqrt(n) -- takes x from the
+// LDS tile again, writes y over it in place and, after one barrier, the tile leaves with 16-byte stores of whole 128-byte row segments.
+// No barrier and no LDS traffic for gamma inside a tile: the first form of this kernel (128-row tiles, gamma streamed through LDS in
+// six K slabs with a barrier each) ran the mix at 65 - 77 TFLOP/s.
 // Roofline: 2 C^2 FLOP against 8 C bytes per pixel = C / 4 FLOP per byte: at C = 192 the exact-fp32 matrix peak
-// (157 TFLOP/s) caps the op at 3.3 TB/s = 0.41 of the HBM peak, at C = 128 it is HBM-bound.
-// mode 0: y = GDN / IGDN(x); mode 1: y = n (the norm, for the backward pass).  CP = 32 NB <= 192.
+// (157 TFLOP/s) caps the op at 3.3 TB/s = 0.41 of the HBM peak, at C = 128 at 0.61.
+// mode 0: y = GDN / IGDN(x); mode 1: y = n (the norm, for the backward pass).  C <= 192; K and the channel blocks are padded to
+// NS = 4, 8 or 12 steps of 16 (the padding multiplies zeros: x beyond C is zero-filled by the DMA's range check).
 // ------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* gdn_lds_ptr_t;
 struct GdnFusedArgs {
@@ -133,122 +139,173 @@ struct GdnFusedArgs {
   const float* beta;   // beta_eff [C]
   float* y;
   long long M;
-  int C, ldx, ldy, inverse, mode, tiles;
+  int C, CP, ldx, ldy, inverse, mode, tiles;
   unsigned x_bytes, pack_bytes;
 };
 
-template <int NB>
+constexpr int kGdnBM = 64;
+
+template <int VM>
+__device__ __forceinline__ void gdn_wait_barrier() {   // vmcnt(VM) lgkmcnt(0), then the workgroup barrier
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt((VM & 15) | ((VM >> 4) << 14) | 0x70);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NS>
 __global__ __launch_bounds__(256) void gdn_fused_fwd_kernel(const GdnFusedArgs p) {
-  constexpr int CP = 32 * NB, BM = 128;
+  constexpr int BM = kGdnBM, NCB = NS / 4, NBX = NS / 2, XF = NBX * BM * 32;   // NBX chunk images of 32 channels; XF floats per x tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sX = smem;                    // [NB][BM * 32]
-  float* sG = smem + NB * BM * 32;     // [2][CP * 32]
-  float* sBeta = sG + 2 * CP * 32;     // [CP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int frow = lane & 31, fh = lane >> 5;
-  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack), 0, p.pack_bytes, 0x00020000);
-  for (int c = tid; c < CP; c += 256) sBeta[c] = c < p.C ? p.beta[c] : 1.f;
+  float* sX = smem;                    // [2][NBX][BM * 32]
+  float* sBeta = smem + 2 * XF;        // [64 NCB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lg = lane >> 4;
+  const int col0 = wave * 16 * NCB;    // first output channel of this wave
+  if ((int)blockIdx.x >= p.tiles) return;
+  for (int c = tid; c < 64 * NCB; c += 256) sBeta[c] = c < p.C ? p.beta[c] : 1.f;
+  // gamma rows of this wave's channels, once: B[cb][s][e] = gamma[col0 + 16 cb + ln][16 s + 4 lg + e] (rows past the pack: zeros by the range
+  // check; columns past CP inside a row meet x = 0)
+  f32x4 B[NCB][NS];
+  {
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack), 0, p.pack_bytes, 0x00020000);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int row = col0 + 16 * cb + ln, k = 16 * s + 4 * lg;
+        const bool ok = row < p.CP && k < p.CP;
+        B[cb][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? ((unsigned)row * p.CP + k) * 4u : 0x80000000u, 0, 0));
+      }
+  }
   // staging assignment (as igemm): thread fills slot (tid & 7) of rows (tid >> 3) + 32 j with source chunk slot ^ swizzle(row)
   const int srow = tid >> 3;
   const int csrc = (tid & 7) ^ ((srow >> 1) & 7);
-  int fo[4];
+  // tile-independent lane offsets, once per launch (every instruction between two tiles' MFMAs is matrix time lost: the per-tile part
+  // of the address arithmetic was ~1 500 instructions around 576 MFMAs).  Rows past the tensor's end need no test of their own: the
+  // descriptors of a tile end at its last valid row, so the range check drops them.
+  unsigned xoff[NBX][2], yoff[NBX][2];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) fo[kk] = lds_off(frow, kk * 2 + fh);
-  auto fetch_g = [&](int kc, int buf) __attribute__((always_inline)) {   // gamma rows 0..CP-1, columns 32 kc .. +31
-    float* b = sG + buf * CP * 32 + wave * 8 * 32;
+  for (int kc = 0; kc < NBX; ++kc)
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (gdn_lds_ptr_t)(b + j * 32 * 32), 16,
-                                               (int)(((unsigned)(srow + 32 * j) * CP + 32 * kc + csrc * 4) * 4u), 0, 0, 0);
-  };
-  for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
-    const long long m0 = (long long)t * BM;
+    for (int j = 0; j < 2; ++j) {
+      const int row = srow + 32 * j;
+      const int chx = 32 * kc + csrc * 4;                                       // DMA: this lane's source chunk (swizzled)
+      xoff[kc][j] = chx < p.C ? ((unsigned)row * p.ldx + chx) * 4u : 0x80000000u;
+      const int chy = 32 * kc + (((tid & 7) ^ ((row >> 1) & 7)) << 2);           // stores: the channel its LDS slot holds
+      yoff[kc][j] = chy < p.C ? ((unsigned)row * p.ldy + chy) * 4u : 0x80000000u;
+    }
+  int eoff[NCB][4];   // float offset inside an x tile of (row 4 lg + i, channel col0 + 16 cb + ln); row block rb adds 512 rb
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = col0 + 16 * cb + ln;
+      eoff[cb][i] = (ch >> 5) * BM * 32 + lds_off(4 * lg + i, (ch & 31) >> 2) + (ch & 3);
+    }
+  auto tile_rsrc = [&](const float* base, int ld, long long m0) __attribute__((always_inline)) {
     const long long left = p.M - m0;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x) + m0 * p.ldx, 0, (unsigned)std::min<long long>(((left < BM ? left : BM) - 1) * p.ldx * 4ll + p.C * 4ll, 0x7fffffffll), 0x00020000);
-    __syncthreads();   // the previous tile's epilogue is done with sX / sG
-    // x tile: chunk image kc, rows srow + 32 j (rows / channels past the tensor read zeros through the range check)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + m0 * ld, 0,
+                                             (unsigned)std::min<long long>(((left < BM ? left : BM) - 1) * ld * 4ll + p.C * 4ll, 0x7fffffffll), 0x00020000);
+  };
+  // an x tile: chunk image kc, rows srow + 32 j, j < 2: NS requests
+  auto fetch_x = [&](long long m0, int buf) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rx = tile_rsrc(p.x, p.ldx, m0);
 #pragma unroll
-    for (int kc = 0; kc < NB; ++kc) {
-      float* a = sX + kc * BM * 32 + wave * 8 * 32;
+    for (int kc = 0; kc < NBX; ++kc)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = srow + 32 * j, ch = 32 * kc + csrc * 4;
-        const bool ok = (row < left) && (ch < p.C);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (gdn_lds_ptr_t)(a + j * 32 * 32), 16, (int)(ok ? ((unsigned)row * p.ldx + ch) * 4u : 0x80000000u),
-                                                 0, 0, 0);
-      }
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (gdn_lds_ptr_t)(sX + buf * XF + kc * BM * 32 + wave * 8 * 32 + j * 32 * 32), 16, (int)xoff[kc][j], 0, 0, 0);
+  };
+  int t = blockIdx.x, cur = 0;
+  fetch_x((long long)t * BM, 0);
+  bool first = true;
+  for (; t < p.tiles; t += gridDim.x, cur ^= 1) {
+    const long long m0 = (long long)t * BM;
+    const int tn = t + (int)gridDim.x;
+    // this tile's x has landed (everything but the previous tile's NS stores, the youngest requests); every wave is done with the other
+    // buffer (its stores have read their LDS operands)
+    if (first) gdn_wait_barrier<0>();
+    else gdn_wait_barrier<NS>();
+    first = false;
+    if (tn < p.tiles) fetch_x((long long)tn * BM, cur ^ 1);
+    f32x4 acc[4][NCB];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* xt = sX + cur * XF;
+    // NS x 4 groups (K step s, row block rb) of 4 NCB MFMAs; the A fragment of group g + 1 (pixel row 16 rb + ln, channels 16 s + 4 lg .. + 3:
+    // chunk image s >> 1, slot 4 (s & 1) + lg) is requested BEFORE the MFMAs of group g are issued and squared after them -- left to the
+    // compiler every ds_read_b128 sat directly in front of its use with a full lgkmcnt(0) wait (12 MFMAs per exposed LDS latency: 53 %
+    // of the matrix peak)
+    auto a_ptr = [&](int g) __attribute__((always_inline)) {
+      const int s = g >> 2, rb = g & 3;
+      return reinterpret_cast<const f32x4*>(xt + (s >> 1) * BM * 32 + lds_off(16 * rb + ln, 4 * (s & 1) + lg));
+    };
+    f32x4 a_nxt = *a_ptr(0);
+#pragma unroll
+    for (int g = 0; g < NS * 4; ++g) {
+      const int s = g >> 2, rb = g & 3;
+      f32x4 a = a_nxt * a_nxt;
+      if (g + 1 < NS * 4) a_nxt = *a_ptr(g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], B[cb][s][e], acc[rb][cb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    fetch_g(0, 0);
-    f32x16 acc[NB];
+    // epilogue: acc[rb][cb][i] is (row 16 rb + 4 lg + i, channel col0 + 16 cb + ln); x sits in chunk image channel >> 5 at slot
+    // (channel & 31) >> 2 (swizzled), element channel & 3 -- rewritten in place with y
+    // (per channel block: the 16 x values first, then the arithmetic, then the 16 writes -- element by element the compiler must assume a
+    // write aliases the next read and waits on the LDS queue 48 times; the mode switch sits outside the element loops)
+    auto epilogue = [&](auto fn) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+      for (int cb = 0; cb < NCB; ++cb) {
+        const float bta = sBeta[col0 + 16 * cb + ln];
+        float xv[4][4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    __syncthreads();   // (waits for the DMA: x tile and slab 0 have landed)
-#pragma unroll 1
-    for (int kc = 0; kc < NB; ++kc) {
-      if (kc + 1 < NB) fetch_g(kc + 1, (kc + 1) & 1);
-      const float* fa = sX + kc * BM * 32 + wave * 32 * 32;
-      const float* fb = sG + (kc & 1) * CP * 32;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(fa + fo[kk]);
-        a = a * a;
-        f32x4 b[NB];
+          for (int rb = 0; rb < 4; ++rb) xv[i][rb] = xt[eoff[cb][i] + 512 * rb];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) b[j] = *reinterpret_cast<const f32x4*>(fb + fo[kk] + j * 1024);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
+          for (int rb = 0; rb < 4; ++rb) xv[i][rb] = fn(xv[i][rb], acc[rb][cb][i] + bta);
 #pragma unroll
-          for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[j][s2], acc[j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) xt[eoff[cb][i] + 512 * rb] = xv[i][rb];
       }
-      __syncthreads();
-    }
-    // epilogue: accumulator element r of block j is (row (r & 3) + 8 (r >> 2) + 4 fh, column 32 j + frow) of this wave's 32 rows;
-    // x sits in chunk image j at slot frow >> 2 (swizzled), element frow & 3 -- rewritten in place with y
+    };
+    // (v_rsq_f32 / v_sqrt_f32: 1 ulp, one instruction each; the library sqrtf + division pair is ~25 and the epilogue of a wave that owns
+    // its SIMD is not hidden behind anything.  n >= beta_min > 0: no denormal path)
+    if (p.mode) epilogue([](float, float n) { return n; });
+    else if (p.inverse) epilogue([](float xv, float n) { return xv * __builtin_amdgcn_sqrtf(n); });
+    else epilogue([](float xv, float n) { return xv * __builtin_amdgcn_rsqf(n); });
+    gdn_wait_barrier<63>();   // (lgkmcnt(0) + barrier: every wave's y is in the tile; vector memory is not waited for)
+    // 16-byte stores, 8 rows x 128 B per wave instruction: NS per thread, always (so that the wait at the top can count them)
+    const __amdgpu_buffer_rsrc_t ry = tile_rsrc(p.y, p.ldy, m0);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const float bta = sBeta[32 * j + frow];
-      float* img = sX + j * BM * 32 + wave * 32 * 32;
+    for (int kc = 0; kc < NBX; ++kc)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
-        float* q = img + lds_off(row, frow >> 2) + (frow & 3);
-        const float n = acc[j][r] + bta;
-        const float xv = *q;
-        // (v_rsq_f32 / v_sqrt_f32: 1 ulp, one instruction each; the library sqrtf + division pair is ~25 and the epilogue of a wave that
-        // owns its SIMD is not hidden behind anything.  n >= beta_min > 0: no denormal path)
-        *q = p.mode ? n : (p.inverse ? xv * __builtin_amdgcn_sqrtf(n) : xv * __builtin_amdgcn_rsqf(n));
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xt + kc * BM * 32 + (srow + 32 * j) * 32 + (tid & 7) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, yoff[kc][j], 0, 0);
       }
-    }
-    // (the rows are private to the wave: program order is enough) 16-byte stores, 8 rows x 128 B per wave instruction
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + m0 * p.ldy, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const float* img = sX + j * BM * 32 + wave * 32 * 32;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int row = (lane >> 3) + 8 * k, slot = lane & 7;
-        const int grow = wave * 32 + row, ch = 32 * j + ((slot ^ ((row >> 1) & 7)) << 2);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(img + row * 32 + slot * 4);
-        const bool ok = (grow < left) && (ch < p.C);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, ok ? ((unsigned)grow * p.ldy + ch) * 4u : 0x80000000u, 0, 0);
-      }
-    }
   }
 }
 
-template <int NB>
+template <int NS>
 static void gdn_fused_launch(const GdnFusedArgs& a, hipStream_t s) {
-  constexpr int CP = 32 * NB;
-  const size_t lds = ((size_t)NB * 128 * 32 + 2 * CP * 32 + CP) * sizeof(float);
+  const size_t lds = ((size_t)2 * (NS / 2) * kGdnBM * 32 + 64 * (NS / 4)) * sizeof(float);
   static std::atomic<bool> done{false};
   if (!done.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gdn_fused_fwd_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gdn_fused_fwd_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done.store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(gdn_fused_fwd_kernel<NB>, dim3(std::min(a.tiles, 256)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(gdn_fused_fwd_kernel<NS>, dim3(std::min(a.tiles, 256)), dim3(256), lds, s, a);
 }
 
 static inline int grid1(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(cdiv64(n, 256), 1), 8192); }
@@ -306,16 +363,12 @@ static int gdn_fused(const crdr_gdn_desc* d, const GdnLayout& L, char* ws, const
   GdnFusedArgs a;
   a.x = x; a.pack = (const float*)(ws + L.pack_f); a.beta = (const float*)(ws + L.beta_eff); a.y = out;
   a.M = d->M; a.C = d->C; a.ldx = d->ldx; a.ldy = ldo; a.inverse = d->inverse; a.mode = mode;
-  a.tiles = (int)((d->M + 127) / 128);
+  a.tiles = (int)((d->M + kGdnBM - 1) / kGdnBM);
+  a.CP = L.CP;
   a.x_bytes = 0; a.pack_bytes = (unsigned)((size_t)L.CP * L.CP * 4);
-  switch (L.CP / 32) {
-    case 1: gdn_fused_launch<1>(a, as_stream(s)); break;
-    case 2: gdn_fused_launch<2>(a, as_stream(s)); break;
-    case 3: gdn_fused_launch<3>(a, as_stream(s)); break;
-    case 4: gdn_fused_launch<4>(a, as_stream(s)); break;
-    case 5: gdn_fused_launch<5>(a, as_stream(s)); break;
-    default: gdn_fused_launch<6>(a, as_stream(s)); break;
-  }
+  if (d->C <= 64) gdn_fused_launch<4>(a, as_stream(s));
+  else if (d->C <= 128) gdn_fused_launch<8>(a, as_stream(s));
+  else gdn_fused_launch<12>(a, as_stream(s));
   CRDR_CHECK_LAUNCH("gdn_fused_fwd");
   return 0;
 }

@@ -14,4 +14,9 @@ cp gpurun_out/hbm_families.json gpurun_out/pmc_shapes.txt $O/
 timeout 600 python3 tools/fullres_codec.py > $O/fullres_codec.json 2> $O/fullres_codec.err
 timeout 900 python3 tools/fullres_sweep.py > $O/fullres_sweep.json 2> $O/fullres_sweep.err
 timeout 600 python3 bench.py --no-cpu-baseline --steps 100 --warmup 20 --no-secondary > $O/bench_100steps.json 2> /dev/null
+timeout 300 python3 tools/gdn_bw.py > $O/gdn_bandwidth.json 2> /dev/null
+timeout 300 python3 tools/bench_gauss_cond.py > $O/gauss_cond_bandwidth.txt 2> /dev/null
+timeout 600 python3 tools/bench_wino.py > $O/wino_shapes.txt 2> /dev/null
+timeout 600 python3 tools/bench_wino.py --k5s2 >> $O/wino_shapes.txt 2> /dev/null
+timeout 600 python3 tools/bench_wino.py --k5 >> $O/wino_shapes.txt 2> /dev/null
 ls -la $O
