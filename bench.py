@@ -300,14 +300,18 @@ def fused_ops_roofline(tr) -> dict:
         with torch.cuda.graph(g, stream=side):
             for _ in range(reps):
                 fn()
-        g.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps * 1e-3
+        best = None
+        for _ in range(5):   # (the fastest of five replays: these run right after the training loop, while the clocks still move)
+            g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / reps * 1e-3
+            best = t if best is None else min(best, t)
+        return best
 
     def entry(name, nbytes, sec, note):
         out[name] = {"bytes": int(nbytes), "us": round(sec * 1e6, 1), "GBps": round(nbytes / sec / 1e9, 1), "frac_of_8TBps": round(nbytes / sec / 8e12, 4),

@@ -101,7 +101,12 @@ __device__ __forceinline__ void at6(const float m0, const float m1, const float 
 struct Wino4Tile { int gidx, n, oh0, ow0, n0, patch, tn, phase; };   // phase: output phase of a stride-2 transposed conv (0 otherwise)
 
 template <int GEO>
-__device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int gx, int gyn, int gz) {
+__device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int gx, int gyn_, int gz) {
+  // gyn_ < 0: FILTER-STATIONARY order -- the patches of an N tile back to back instead of the N tiles of a patch: where the transformed
+  // filters outweigh the input (the hoisted convs of the context model: 784 MB of filters against 5 MB of latents) each XCD then streams
+  // its share of the filters once instead of all of them (6.5 GB of HBM reads per launch, measured)
+  const bool fstat = gyn_ < 0;
+  const int gyn = fstat ? -gyn_ : gyn_;
   // XCD-aware order (see igemm_kernel.hpp): the hardware deals workgroups round-robin over the 8 XCDs; every XCD walks a contiguous
   // range of (patch, N tile) pairs, the N tiles of a patch back to back (they re-read the patch out of that XCD's L2)
   Wino4Tile t;
@@ -112,8 +117,8 @@ __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int 
   const int r = q - t.gidx * T;
   t.phase = r % nph;
   const int r1 = r / nph;
-  const int tn = r1 % gyn;
-  t.patch = r1 / gyn;
+  const int tn = fstat ? r1 / gx : r1 % gyn;
+  t.patch = fstat ? r1 % gx : r1 / gyn;
   t.tn = tn;
   if constexpr (GEO == 2) {
     t.n = 2 * t.patch;   // (first image of the pair; wave th works on image n + th)
@@ -573,7 +578,8 @@ template <int GEO, int FORM>
 __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gyn, int gz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int total = gx * gyn * gz * p_.so * p_.so;
+  const int gyn_abs = gyn < 0 ? -gyn : gyn;
+  const int total = gx * gyn_abs * gz * p_.so * p_.so;
   float* sVb = smem + kLdsFloats4;   // [2][4][64]: bias, vec2, scale, shift of the current / the next tile
   int cur = 0;
   bool prefetched = false;
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     }
     float* sV = sVb + cur * (4 * kBN4);
     if (!prefetched) {
-      sr = wino4_src<GEO, FORM>(p_, grp, tl, gyn, lane, wave);
+      sr = wino4_src<GEO, FORM>(p_, grp, tl, gyn_abs, lane, wave);
       wino4_vectors(p_, grp, tl, sV, tid);   // (published by the K loop's first barrier)
     }
     f32x4 acc[64], accv[8];
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     const bool more = vb + (int)gridDim.x < total;
     if (more) {   // the next tile: raw patches 0, 1, 2, filter block 0 and the epilogue vectors
       const Wino4Tile tn = wino4_tile<GEO>(p_, vb + (int)gridDim.x, gx, gyn, gz);
-      sr = wino4_src<GEO, FORM>(p_, grp, tn, gyn, lane, wave);
+      sr = wino4_src<GEO, FORM>(p_, grp, tn, gyn_abs, lane, wave);
       wino4_prologue_dma<FORM>(p_, smem, sr, p_.kchunks, lane, wave);
       wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * (4 * kBN4), tid);
     }
@@ -807,7 +813,10 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
     attr_done.store(true, std::memory_order_release);
   }
   const size_t lds = (size_t)(kLdsFloats4 + 2 * 4 * kBN4) * sizeof(float);
-  hipLaunchKernelGGL(kerns[mode == 4 ? 1 : 0][geo], dim3(std::min(total, ncu)), dim3(kNT4), lds, s, a, grp, gx, ntile, G);
+  // tile order: filter-stationary where one pass over the transformed filters is more bytes than one pass over the input
+  const double u_bytes = (double)ntile * a.so * a.so * a.kchunks * (kUSlots4 * 16.0), x_bytes = (double)d->N * d->H * d->W * d->C * 4.0;
+  const int gyn_arg = u_bytes > x_bytes ? -ntile : ntile;
+  hipLaunchKernelGGL(kerns[mode == 4 ? 1 : 0][geo], dim3(std::min(total, ncu)), dim3(kNT4), lds, s, a, grp, gx, gyn_arg, G);
   CRDR_CHECK_LAUNCH("wino4_kernel");
   return 0;
 }
