@@ -237,16 +237,17 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
   const int wino_variant = d->reserved != 0 ? (d->reserved & 0xff) - 1 - kNumCfgs - stream_num_variants() : -1;
   if (wino_variant == 2) {   // forced: the Winograd F(4x4, 3x3) kernel (wino4.hip)
     CRDR_REQUIRE(!fallback && wino4_eligible(d, G, true), "conv2d: forced F(4x4, 3x3) Winograd kernel: not a 3x3 stride-1 convolution it takes");
-    CRDR_REQUIRE(((d->reserved >> 8) & 0xf) == 0, "conv2d: the Winograd kernel has no split-K");
+    const int w4split = ((d->reserved >> 8) & 0xf) + 1;   // K splits per tile (1 = none), reduced inside the launch
+    CRDR_REQUIRE(wino4_split_ok(d, G, w4split), "conv2d: F(4x4, 3x3) Winograd kernel: %d K splits do not fit this shape", w4split);
     pl->wino = 3;
     pl->cfg = -1;
-    a.nsplit = 1;
+    a.nsplit = w4split;
     a.ws_ld = 0;
     pl->grid = dim3(1, 1, 1);
     pl->lds = 0;
     a.cs_ld = round_up(d->OC, 32);
     a.cs_rows = want_cs ? wino4_colsum_rows(d) : 0;
-    pl->ws_bytes = (size_t)CRDR_CONV_TICKETS * sizeof(int) + wino4_workspace(d, G);
+    pl->ws_bytes = (size_t)CRDR_CONV_TICKETS * sizeof(int) + wino4_workspace(d, G, w4split);
     return 0;
   }
   if (wino_variant >= 0 && wino_variant < 2) {  // forced: the Winograd F(2x2, 3x3) kernel (wino.hip); variant 1 = pair tiles for a channel tail <= 32
@@ -396,7 +397,7 @@ extern "C" int crdr_conv2d_colsum_layout(const crdr_conv_desc* d, int G, int* ro
 extern "C" int crdr_conv2d_choose_algo(const crdr_conv_desc* d, int G) {
   Plan pl;
   if (!d || build_plan(d, &pl, G)) return 0;
-  if (pl.wino) return kNumCfgs + 1 + stream_num_variants() + (pl.wino - 1);
+  if (pl.wino) return (kNumCfgs + 1 + stream_num_variants() + (pl.wino - 1)) | ((pl.a.nsplit - 1) << 8);   // (F(4x4): bits 8..11 = K splits - 1)
   if (pl.stream >= 0) return kNumCfgs + 1 + pl.stream;
   int ls = 0;
   while ((1 << ls) < pl.a.nsplit) ++ls;
@@ -465,7 +466,7 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   if (pl.wino) {
     void* prof = profile_begin(as_stream(s));
     if (pl.wino == 3) {
-      if (int rc = wino4_launch(d, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
+      if (int rc = wino4_launch(d, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, a.nsplit, as_stream(s))) return rc;
     } else if (int rc = wino_launch(d, pl.wino - 1, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
     // kind 3 / 5 / 6: filter transform + Winograd F(2x2, 3x3) / F(4x4, 3x3) kernel (6: a 5x5 stride-2 layer through it), direct-convolution
     // flop count

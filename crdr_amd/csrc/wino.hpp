@@ -14,8 +14,9 @@ int wino_launch(const crdr_conv_desc* d, int variant, IgemmArgs a, const IgemmTa
 // Winograd F(4x4, 3x3) path (wino4.hip): variant 2 of the forced Winograd ids.  vec_ok: every operand row is 16-byte aligned (known at
 // launch; planning passes true)
 bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok);
-size_t wino4_workspace(const crdr_conv_desc* d, int G);   // bytes of transformed filters
+size_t wino4_workspace(const crdr_conv_desc* d, int G, int nsplit);   // bytes of transformed filters (+ the partial tiles of a K-split launch)
+bool wino4_split_ok(const crdr_conv_desc* d, int G, int nsplit);      // nsplit K splits per tile (forced id: bits 8..11 = nsplit - 1)
 int wino4_colsum_rows(const crdr_conv_desc* d);
-int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s);
+int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, int nsplit, hipStream_t s);
 
 }  // namespace crdr

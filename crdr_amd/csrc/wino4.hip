@@ -98,7 +98,7 @@ __device__ __forceinline__ void at6(const float m0, const float m1, const float 
   o3 = __builtin_fmaf(8.0f, w, q) + m5;
 }
 
-struct Wino4Tile { int gidx, n, oh0, ow0, n0, patch, tn, phase; };   // phase: output phase of a stride-2 transposed conv (0 otherwise)
+struct Wino4Tile { int gidx, n, oh0, ow0, n0, patch, tn, phase, lin, ks, kbeg, kcnt; };   // lin: index of the tile among the launch's tiles; K split ks works sub-steps [kbeg, kbeg + kcnt)   // phase: output phase of a stride-2 transposed conv (0 otherwise)
 
 template <int GEO>
 __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int gx, int gyn_, int gz) {
@@ -111,8 +111,17 @@ __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int 
   // range of (patch, N tile) pairs, the N tiles of a patch back to back (they re-read the patch out of that XCD's L2)
   Wino4Tile t;
   const int nph = p.so * p.so;   // output phases (4 for a stride-2 transposed conv: each is a stride-1 conv of its own with the same input)
-  const int T = gx * gyn * nph, nwg = T * gz, cpx = nwg >> 3;
-  const int q = vb < cpx * 8 ? (vb & 7) * cpx + (vb >> 3) : vb;
+  // (split K, p.nsplit > 1: the work items are (tile, split), the splits of a tile back to back -- they share the patch)
+  const int T = gx * gyn * nph, S = p.nsplit, nwg = T * gz * S, cpx = nwg >> 3;
+  const int qs = vb < cpx * 8 ? (vb & 7) * cpx + (vb >> 3) : vb;
+  const int q = qs / S;
+  t.ks = qs - q * S;
+  t.lin = q;
+  {
+    const int cnt = (p.kchunks + S - 1) / S;
+    t.kbeg = t.ks * cnt;
+    t.kcnt = min(cnt, p.kchunks - t.kbeg);
+  }
   t.gidx = q / T;
   const int r = q - t.gidx * T;
   t.phase = r % nph;
@@ -195,15 +204,15 @@ __device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, 
 }
 // the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and filter blocks 0, 1 (-> F0, F1)
 template <int FORM>
-__device__ __forceinline__ void wino4_prologue_dma(const IgemmArgs& p, float* smem, const Wino4Src& sr, int K4, int lane, int wave) {
+__device__ __forceinline__ void wino4_prologue_dma(const IgemmArgs& p, float* smem, const Wino4Src& sr, int kbeg, int kcnt, int lane, int wave) {
 #pragma unroll
   for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wino4_dma_raw(smem, sr, kr < K4 ? sr.rx : wino4_empty_rsrc(), j, wino4_raw_soff<FORM>(p, kr), kr, lane, wave);
+    for (int j = 0; j < 4; ++j) wino4_dma_raw(smem, sr, kr < kcnt ? sr.rx : wino4_empty_rsrc(), j, wino4_raw_soff<FORM>(p, kbeg + kr), kr, lane, wave);
 #pragma unroll
   for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
-    for (int j = 0; j < 9; ++j) wino4_dma_filt(smem, sr, kf < K4 ? sr.ru : wino4_empty_rsrc(), j, kf, kf, lane, wave);
+    for (int j = 0; j < 9; ++j) wino4_dma_filt(smem, sr, kf < kcnt ? sr.ru : wino4_empty_rsrc(), j, kbeg + kf, kf, lane, wave);
 }
 
 // K loop of one wave (the only wave of its SIMD: nothing else hides its latencies, so the loop is software pipelined by hand).
@@ -219,7 +228,7 @@ __device__ __forceinline__ void wino4_prologue_dma(const IgemmArgs& p, float* sm
 template <int GEO, int FORM>
 __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& tl, float* smem, Wino4Src& sr, bool prefetched, int lane, int wave,
                                            f32x4 (&acc)[64], f32x4 (&accv)[8]) {
-  const int K4 = p.kchunks;
+  const int K4 = tl.kcnt, kbeg = tl.kbeg;   // this work item's sub-steps: kbeg .. kbeg + K4 - 1 of the tile's p.kchunks
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
   // this lane's raw reads: patch pixel (i, j) of tile (th, tx), channel kg: float offset rbase + ro(i, j) of a raw buffer
   const int rbase = (w4_slot0<GEO>(th) + w4_ty<GEO>(th, tx) * W4Geo<GEO>::PR + w4_tx<GEO>(tx)) * 4 + kg;
@@ -245,7 +254,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
   // younger vector-memory operations -- that tile's stores -- are in flight and need not be waited for); V_0 rows 0..4 and the
   // vertical pass of row 5
   if (!prefetched) {
-    wino4_prologue_dma<FORM>(p, smem, sr, K4, lane, wave);
+    wino4_prologue_dma<FORM>(p, smem, sr, kbeg, K4, lane, wave);
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
   } else {
     __builtin_amdgcn_s_waitcnt(0x8070);   // vmcnt(32)
@@ -268,10 +277,10 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
   }
 
   int r1 = 1, r0 = 0;   // raw buffer of patch k + 1 / of patch k (= the one patch k + 3 goes to)
-  const int Kc = K4 / p.nphase;   // channel chunks per parity sub-filter (stride-2 conv: 4 sub-filters; else 1)
-  int ch3 = 3 % Kc, sub3 = 3 / Kc;   // chunk / sub-filter of sub-step k + 3 (counters: no division in the loop)
+  const int Kc = p.kchunks / p.nphase;   // channel chunks per parity sub-filter (stride-2 conv: 4 sub-filters; else 1)
+  int ch3 = (kbeg + 3) % Kc, sub3 = (kbeg + 3) / Kc;   // chunk / sub-filter of sub-step k + 3 (counters: no division in the loop)
   if constexpr (FORM == 1) {   // (12 input channels: the first patch requested inside the loop already belongs to the second sub-filter)
-    if (sub3 > 0 && sub3 < 4) {
+    if (sub3 != kbeg / Kc && sub3 < 4) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub3);
     }
@@ -326,7 +335,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
       }
       if (s % 5 == 2 && s / 5 < 13) {
         const int q = s / 5;
-        if (q < 9) wino4_dma_filt(smem, sr, ru2, q, k + 2, f2, lane, wave);
+        if (q < 9) wino4_dma_filt(smem, sr, ru2, q, kbeg + k + 2, f2, lane, wave);
         else wino4_dma_raw(smem, sr, rx3, q - 9, soff3, r0, lane, wave);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -363,7 +372,12 @@ __device__ __forceinline__ float acc_read(float v) {
 
 // Output transform + element-wise epilogue + stores of one wave: lane (tile tx of row th, channel group kg) holds M[36] for channels
 // n0 + 32 oh + 16 ob + 4 kg + r, ob < 2, r < 4.  Order of the element-wise operations: epilogue_store of igemm_kernel.hpp.
-template <int GEO>
+// SPLIT (p.nsplit > 1 work items per tile, each over a part of the K range): the output transform is linear, so every work item publishes
+// its transformed partial tile -- 2 x 16 float4 per lane, in the lane's own order: 128 KiB per tile and split -- with write-through
+// stores, takes a ticket on the tile, and the last arriver adds the slabs in split order and runs the epilogue (the hand-off protocol of
+// igemm_kernel.hpp's in-launch split-K: sc1 stores, vmcnt(0), barrier, one agent-scope atomic, acquire, sc1 loads; a workgroup either
+// leaves or reduces, nobody spins).
+template <int GEO, bool SPLIT>
 __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile& tl, float* smem, const float* sV, int lane, int wave, f32x4 (&acc)[64],
                                              f32x4 (&accv)[8]) {
   const int f = p.flags;
@@ -390,6 +404,62 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
     for (int b = 0; b < 4; ++b) pixm |= (img < p.N && so * (oy0 + a) + py < p.OH && so * (ox0 + b) + px < p.OW) ? (1u << (4 * a + b)) : 0u;
   auto soff = [&](int ld, int a, int b) __attribute__((always_inline)) { return so * (a * p.OW + b) * ld * 4; };
   float* sC = smem + kRawBufs * kRF + 2 * kFF;   // column sums: [wave 4][which 2][ob 2][64 lanes][4 r] = 16 KiB in filter buffer F2 (F0, F1 receive the next tile's blocks 0, 1)
+
+  // output transform of channel register r of half ob: s[a][nu] = sum_xi AT[a][xi] M[xi][nu], then Y[a][b] = sum_nu AT[b][nu] s[a][nu]
+  auto out_transform = [&](int ob, float (&yv)[4][4][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sv[4][6];
+#pragma unroll
+      for (int nu = 0; nu < 6; ++nu) {
+        float mcol[6];
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi) {
+          const int blk = 2 * (xi * 6 + nu) + ob;
+          mcol[xi] = blk < 64 ? acc_read(acc[blk < 64 ? blk : 0][r]) : accv[blk >= 64 ? blk - 64 : 0][r];
+        }
+        at6(mcol[0], mcol[1], mcol[2], mcol[3], mcol[4], mcol[5], sv[0][nu], sv[1][nu], sv[2][nu], sv[3][nu]);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) at6(sv[a][0], sv[a][1], sv[a][2], sv[a][3], sv[a][4], sv[a][5], yv[a][0][r], yv[a][1][r], yv[a][2][r], yv[a][3][r]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  __amdgpu_buffer_rsrc_t rws = ry;
+  unsigned slab_bytes = 0;
+  auto slab_off = [&](int ob, int q) __attribute__((always_inline)) { return (unsigned)((((wave * 2 + ob) * 16 + q) * 64 + lane) * 16); };
+  if constexpr (SPLIT) {
+    constexpr unsigned kTileSlab = 4u * 2u * 16u * 64u * 16u;   // bytes of one tile's partial result
+    slab_bytes = (unsigned)p.ws_ld * kTileSlab;                   // one split's slab: every tile of the launch
+    rws = __builtin_amdgcn_make_buffer_rsrc(p.ws + (size_t)tl.lin * (kTileSlab / 4), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+      float yv[4][4][4];
+      out_transform(ob, yv);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const f32x4 v = {yv[q >> 2][q & 3][0], yv[q >> 2][q & 3][1], yv[q >> 2][q & 3][2], yv[q >> 2][q & 3][3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rws, slab_off(ob, q) + (unsigned)tl.ks * slab_bytes, 0, 16 /* sc1 */);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier4();
+    int* sFlag = reinterpret_cast<int*>(smem + kLdsFloats4 + 2 * 4 * kBN4);
+    if (wave == 0 && lane == 0) {
+      int* cnt = p.counters + tl.lin;
+      const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == p.nsplit - 1;
+      if (last) {
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch finds zeros again
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      *sFlag = last;
+    }
+    lds_barrier4();
+    const int last = *sFlag;
+    if (!last) return;   // (workgroup-uniform)
+  }
 
 #pragma unroll
   for (int ob = 0; ob < 2; ++ob) {
@@ -425,24 +495,24 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
     const f32x4 scale = *reinterpret_cast<const f32x4*>(sV + 2 * kBN4 + cl);
     const f32x4 shift = *reinterpret_cast<const f32x4*>(sV + 3 * kBN4 + cl);
     f32x4 cpre = {0.f, 0.f, 0.f, 0.f}, cpost = {0.f, 0.f, 0.f, 0.f};
-    // output transform per channel register r: s[a][nu] = sum_xi AT[a][xi] M[xi][nu], then Y[a][b] = sum_nu AT[b][nu] s[a][nu]
     float yv[4][4][4];   // [a][b][r]
+    if constexpr (SPLIT) {   // the sum of the partial tiles, in split order, four splits of loads in flight
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float sv[4][6];
+      for (int q = 0; q < 16; ++q) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < p.nsplit; s0 += 4) {
+          f32x4 l[4];
 #pragma unroll
-      for (int nu = 0; nu < 6; ++nu) {
-        float mcol[6];
+          for (int j = 0; j < 4; ++j)
+            l[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, s0 + j < p.nsplit ? slab_off(ob, q) + (unsigned)(s0 + j) * slab_bytes : kOobOffset, 0, 16));
 #pragma unroll
-        for (int xi = 0; xi < 6; ++xi) {
-          const int blk = 2 * (xi * 6 + nu) + ob;
-          mcol[xi] = blk < 64 ? acc_read(acc[blk < 64 ? blk : 0][r]) : accv[blk >= 64 ? blk - 64 : 0][r];
+          for (int j = 0; j < 4; ++j) v += l[j];   // (splits past nsplit read zeros: + 0.f is exact)
         }
-        at6(mcol[0], mcol[1], mcol[2], mcol[3], mcol[4], mcol[5], sv[0][nu], sv[1][nu], sv[2][nu], sv[3][nu]);
-      }
 #pragma unroll
-      for (int a = 0; a < 4; ++a) at6(sv[a][0], sv[a][1], sv[a][2], sv[a][3], sv[a][4], sv[a][5], yv[a][0][r], yv[a][1][r], yv[a][2][r], yv[a][3][r]);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 4; ++r) yv[q >> 2][q & 3][r] = v[r];
+      }
+    } else {
+      out_transform(ob, yv);
     }
     // element-wise part: ONE PASS PER EPILOGUE FLAG over 8 outputs pixels at a time (a flag is tested once per half tile, not once per
     // element: every instruction here is matrix time lost)
@@ -553,8 +623,9 @@ __device__ __forceinline__ Wino4Src wino4_src(const IgemmArgs& p, const IgemmGro
   const size_t ublock = (size_t)gyn * nph * p.kchunks * kUSlots4 * 4;   // floats per group: [N tile][output phase][sub-step][2304 slots]
   sr.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (size_t)tl.gidx * ublock, 0, (unsigned)(ublock * 4), 0x00020000);
   sr.u_off0 = (unsigned)(tl.tn * nph + tl.phase) * (unsigned)p.kchunks * (kUSlots4 * 16u);
+  const int sub0 = FORM == 1 ? tl.kbeg / (p.kchunks / p.nphase) : 0;   // (the shifted sub-filter this work item starts in)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, 0);
+  for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub0);
   return sr;
 }
 
@@ -574,12 +645,12 @@ __device__ __forceinline__ void wino4_vectors(const IgemmArgs& p, const IgemmGro
 // Persistent: at most one workgroup per CU, each walks the tiles vb = blockIdx.x, + gridDim.x, ...  Between the K loop and the
 // epilogue of a tile the waves request the next tile's first raw patches and filter block (the buffers are free by then) and its
 // epilogue vectors: the DMA latency of a fresh tile and the memory latency of the stores hide behind each other.
-template <int GEO, int FORM>
+template <int GEO, int FORM, bool SPLIT>
 __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gyn, int gz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gyn_abs = gyn < 0 ? -gyn : gyn;
-  const int total = gx * gyn_abs * gz * p_.so * p_.so;
+  const int total = gx * gyn_abs * gz * p_.so * p_.so * (SPLIT ? p_.nsplit : 1);
   float* sVb = smem + kLdsFloats4;   // [2][4][64]: bias, vec2, scale, shift of the current / the next tile
   int cur = 0;
   bool prefetched = false;
@@ -612,10 +683,10 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     if (more) {   // the next tile: raw patches 0, 1, 2, filter block 0 and the epilogue vectors
       const Wino4Tile tn = wino4_tile<GEO>(p_, vb + (int)gridDim.x, gx, gyn, gz);
       sr = wino4_src<GEO, FORM>(p_, grp, tn, gyn_abs, lane, wave);
-      wino4_prologue_dma<FORM>(p_, smem, sr, p_.kchunks, lane, wave);
+      wino4_prologue_dma<FORM>(p_, smem, sr, tn.kbeg, tn.kcnt, lane, wave);
       wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * (4 * kBN4), tid);
     }
-    wino4_finish<GEO>(p, tl, smem, sV, lane, wave, acc, accv);
+    wino4_finish<GEO, SPLIT>(p, tl, smem, sV, lane, wave, acc, accv);
     prefetched = more;
     cur ^= 1;
     lds_barrier4();   // column-sum area, sV of this tile: free (the stores stay in flight: the next tile's first wait is vmcnt(32))
@@ -701,6 +772,36 @@ static int wino4_patches(const crdr_conv_desc* d, int mode) {
   return d->N * cdiv(gh, wino4_tile_rows(geo)) * cdiv(gw, wino4_tile_cols(geo));
 }
 
+static size_t wino4_filter_bytes(const crdr_conv_desc* d, int G) {
+  const int nvar = wino4_mode(d) >= 2 ? 4 : 1;   // parity or shifted sub-filters / output phases
+  return (size_t)G * cdiv(d->OC, kBN4) * nvar * cdiv(d->C, 4) * kUSlots4 * 16;
+}
+// tiles of a launch (each the ticket of its K splits) and bytes of one tile's published partial result
+static long long wino4_tiles(const crdr_conv_desc* d, int G) {
+  const int mode = wino4_mode(d);
+  return (long long)wino4_patches(d, mode) * cdiv(d->OC, kBN4) * G * (mode == 3 ? 4 : 1);
+}
+constexpr size_t kTileSlabBytes = 4 * 2 * 16 * 64 * 16;
+
+// K splits (1 = none): the K range of a tile -- p.kchunks sub-steps of 4 channels, sub-filters included -- in `nsplit` equal parts
+bool wino4_split_ok(const crdr_conv_desc* d, int G, int nsplit) {
+  if (nsplit == 1) return true;
+  const int mode = wino4_mode(d);
+  if (!mode || nsplit < 1 || nsplit > 16) return false;
+  const int nph = (mode == 2 || mode == 4) ? 4 : 1, Kc = cdiv(d->C, 4), K4 = Kc * nph, cnt = cdiv(K4, nsplit);
+  if (K4 - (nsplit - 1) * cnt < 1) return false;                       // every split has work
+  const long long tiles = wino4_tiles(d, G);
+  if (tiles > CRDR_CONV_TICKETS || tiles * nsplit * (long long)kTileSlabBytes >= (1ll << 31)) return false;
+  if (mode == 4)   // a work item's first three patches share one shifted sub-filter (their lane offsets are derived once)
+    for (int ks = 1; ks < nsplit; ++ks)
+      if ((ks * cnt) % Kc + 3 > Kc && (ks * cnt) % Kc != 0) return false;
+  return true;
+}
+
+size_t wino4_workspace(const crdr_conv_desc* d, int G, int nsplit) {
+  return wino4_filter_bytes(d, G) + (nsplit > 1 ? (size_t)wino4_tiles(d, G) * nsplit * kTileSlabBytes : 0);
+}
+
 bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok) {
   const int mode = wino4_mode(d);
   if (!mode) return false;
@@ -717,21 +818,17 @@ bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok) {
   const long long img = ((long long)d->N * d->H + 8) * d->W * d->ldx * 4;   // one descriptor spans a whole tensor
   const long long oimg = (long long)d->N * d->OH * d->OW * std::max(std::max(d->ldy, d->ldres), d->ldmask) * 4;
   if (img >= (1ll << 31) || oimg >= (1ll << 31)) return false;
-  if ((long long)wino4_workspace(d, G) / G >= (1ll << 31)) return false;
+  if ((long long)wino4_filter_bytes(d, G) / G >= (1ll << 31)) return false;
   return true;
 }
 
-size_t wino4_workspace(const crdr_conv_desc* d, int G) {
-  const int nvar = wino4_mode(d) >= 2 ? 4 : 1;   // parity or shifted sub-filters / output phases
-  return (size_t)G * cdiv(d->OC, kBN4) * nvar * cdiv(d->C, 4) * kUSlots4 * 16;
-}
 
 int wino4_colsum_rows(const crdr_conv_desc* d) {
   const int mode = wino4_mode(d);
   return wino4_patches(d, mode) * (mode == 3 ? 4 : 1);
 }
 
-int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, hipStream_t s) {
+int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, int nsplit, hipStream_t s) {
   CRDR_REQUIRE(wino4_eligible(d, G, a.vec_epi != 0), "conv2d: the F(4x4, 3x3) Winograd kernel takes 3x3 / 5x5 stride-1 and 5x5 stride-2 (pad 2) convolutions of >= 24 "
                "output (phase) columns (or whole images of 9..16 pixels a side) with C, OC %% 4 == 0, 16-byte aligned operand rows and no gate / pre-add epilogue");
   const int mode = wino4_mode(d);
@@ -788,6 +885,9 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
     CRDR_CHECK_LAUNCH("wino4_filter_kernel");
   }
   a.w = u;
+  a.nsplit = nsplit;
+  a.ws = u + wino4_filter_bytes(d, G) / 4;   // partial tiles of a split launch: behind the transformed filters
+  a.ws_ld = (int)wino4_tiles(d, G);
   a.nphase = (mode == 2 || mode == 4) ? 4 : 1;   // parity / shifted sub-filters the K loop accumulates
   a.kchunks = kchunks * a.nphase;             // sub-steps of a tile
   a.so = mode == 3 ? 2 : 1;                   // output stride (4 output phases = 4 tiles per patch and N tile)
@@ -805,18 +905,23 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
   const int gx = wino4_patches(d, mode);
   const int total = gx * ntile * G * a.so * a.so;
   using Kern = void (*)(const IgemmArgs, const IgemmGroup, int, int, int);
-  static const Kern kerns[2][3] = {{wino4_kernel<0, 0>, wino4_kernel<1, 0>, wino4_kernel<2, 0>}, {wino4_kernel<0, 1>, wino4_kernel<1, 1>, wino4_kernel<2, 1>}};
+  static const Kern kerns[2][2][3] = {{{wino4_kernel<0, 0, false>, wino4_kernel<1, 0, false>, wino4_kernel<2, 0, false>},
+                                       {wino4_kernel<0, 1, false>, wino4_kernel<1, 1, false>, wino4_kernel<2, 1, false>}},
+                                      {{wino4_kernel<0, 0, true>, wino4_kernel<1, 0, true>, wino4_kernel<2, 0, true>},
+                                       {wino4_kernel<0, 1, true>, wino4_kernel<1, 1, true>, wino4_kernel<2, 1, true>}}};
   static std::atomic<bool> attr_done;
   if (!attr_done.load(std::memory_order_acquire)) {
-    for (int f = 0; f < 2; ++f)
-      for (int g = 0; g < 3; ++g) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[f][g]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int sp = 0; sp < 2; ++sp)
+      for (int f = 0; f < 2; ++f)
+        for (int g = 0; g < 3; ++g)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[sp][f][g]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.store(true, std::memory_order_release);
   }
-  const size_t lds = (size_t)(kLdsFloats4 + 2 * 4 * kBN4) * sizeof(float);
+  const size_t lds = (size_t)(kLdsFloats4 + 2 * 4 * kBN4 + 4) * sizeof(float);   // (+ the split-K ticket flag)
   // tile order: filter-stationary where one pass over the transformed filters is more bytes than one pass over the input
   const double u_bytes = (double)ntile * a.so * a.so * a.kchunks * (kUSlots4 * 16.0), x_bytes = (double)d->N * d->H * d->W * d->C * 4.0;
   const int gyn_arg = u_bytes > x_bytes ? -ntile : ntile;
-  hipLaunchKernelGGL(kerns[mode == 4 ? 1 : 0][geo], dim3(std::min(total, ncu)), dim3(kNT4), lds, s, a, grp, gx, gyn_arg, G);
+  hipLaunchKernelGGL(kerns[nsplit > 1 ? 1 : 0][mode == 4 ? 1 : 0][geo], dim3(std::min(total * nsplit, ncu)), dim3(kNT4), lds, s, a, grp, gx, gyn_arg, G);
   CRDR_CHECK_LAUNCH("wino4_kernel");
   return 0;
 }

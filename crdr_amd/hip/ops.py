@@ -113,12 +113,19 @@ def _prefer_wino(d, G: int = 1) -> int:
     return algo
 
 
+WINO4_SPLITS = (1, 2, 3, 5, 7, 11, 15)
+
+
 def _stream_ids():
     """Forced-algorithm ids of the streaming 1x1 variants and of the Winograd 3x3 kernel (the library rejects them for other shapes)."""
     lib = L.load()
     n = lib.crdr_conv2d_num_configs()
     ns = lib.crdr_conv2d_num_stream_configs()
-    return [n + 1 + v for v in range(ns)] + ([n + 1 + ns + v for v in range(lib.crdr_conv2d_num_wino_configs())] if WINOGRAD else [])
+    nw = lib.crdr_conv2d_num_wino_configs()
+    ids = [n + 1 + v for v in range(ns)] + ([n + 1 + ns + v for v in range(nw)] if WINOGRAD else [])
+    if WINOGRAD and nw > 2:   # the F(4x4) kernel with 2, 3, 4, 6, 8, 12 or 16 K splits per tile (bits 8..11 = splits - 1): launches with fewer tiles than CUs
+        ids += [(n + 1 + ns + 2) | (v << 8) for v in WINO4_SPLITS]
+    return ids
 
 
 # A candidate may only win if its result agrees with the baseline plan's (algo 0, the built-in plan the parity tests run) on the
@@ -157,7 +164,7 @@ def _autotune(key, ncfg: int, max_log2_split: int, run, extra=(), penalty=None, 
                 continue
             if ref is not None:
                 dis = float((result() - ref).abs().max())
-                tol = TUNE_AGREE["wino4"] if (algo == _wino4_id() and key[0] in ("c", "g", "m")) else agree
+                tol = TUNE_AGREE["wino4"] if ((algo & 0xff) == _wino4_id() and key[0] in ("c", "g", "m")) else agree
                 if not dis <= tol * ref_scale:   # (NaN fails too)
                     TUNE_REJECTED.append((key, algo, dis / (ref_scale + 1e-30)))
                     continue

@@ -408,6 +408,17 @@ def test_winograd_ids_are_planned_only_for_the_shapes_they_take(lib):
     dt.reserved = base + 2
     assert lib.crdr_conv2d_workspace(C.byref(dt)) == 16384 * 4 + 4 * 4 * 64 * 36 * 4 * 64 * 4   # 4 N tiles x 4 phases x 64 chunks x 36 KiB
     assert plan(desc(96, 98, 64, 3), base + 2) == 0                   # OC % 4 != 0
+    # K splits of the F(4x4) kernel: bits 8..11 of the id = splits - 1; workspace + tiles x splits x 128 KiB of partial tiles
+    hoist_t = desc(4256, 320, 16, 5, transposed=1, n=16)              # the hoisted convs' input gradient: 8 image pairs x 5 N tiles = 40 tiles
+    assert plan(hoist_t, (base + 2) | (5 << 8)) == (base + 2) | (5 << 8)
+    u_bytes = 5 * 4 * 1064 * 36 * 4 * 64 * 4                          # 5 N tiles x 4 sub-filters x 1 064 chunks x 36 KiB
+    hoist_t.reserved = base + 2
+    assert lib.crdr_conv2d_workspace(C.byref(hoist_t)) == tickets + u_bytes
+    hoist_t.reserved = (base + 2) | (5 << 8)
+    assert lib.crdr_conv2d_workspace(C.byref(hoist_t)) == tickets + u_bytes + 40 * 6 * 131072
+    assert plan(desc(12, 64, 64, 3), (base + 2) | (3 << 8)) == 0      # 3 sub-steps cannot feed 4 splits
+    assert plan(desc(12, 64, 64, 3), (base + 2) | (2 << 8)) == (base + 2) | (2 << 8)
+    assert plan(desc(24, 64, 16, 5), (base + 2) | (6 << 8)) == 0      # 5x5 stride 1: 7 splits of 24 sub-steps would start 2 sub-steps before a sub-filter's end
     d4 = desc(100, 96, 64, 3)
     d4.reserved = base + 2
     assert lib.crdr_conv2d_workspace(C.byref(d4)) == tickets + 2 * 25 * 36 * 4 * 64 * 4

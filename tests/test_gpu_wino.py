@@ -264,6 +264,50 @@ def test_winograd_f4x4_5x5_stride1(case):
         _close(dx, xr.grad, name + " dgrad", rtol=5e-5)
 
 
+W4SPLIT_CASES = [
+    # name, N, Cin, H, W, Cout, k, transposed, splits   (K splits inside the launch: partial tiles through slabs, last arriver reduces)
+    ("w4sp_hoist_dgrad", 6, 608, 16, 16, 64, 5, 1, 6),      # the shape class it is for: many input channels, few tiles (5x5, two images per tile)
+    ("w4sp_k5_c24_s2", 3, 24, 16, 16, 96, 5, 0, 2),          # splits inside and across the shifted sub-filters
+    ("w4sp_k5_c48_s8", 2, 48, 12, 14, 40, 5, 0, 8),
+    ("w4sp_k3_256_32", 2, 256, 32, 32, 128, 3, 0, 3),        # 3x3, 16 x 32 tiles, uneven split (64 chunks / 3)
+    ("w4sp_k3_96_wide", 1, 96, 9, 70, 72, 3, 0, 4),          # 8 x 64 tiles, ragged
+    ("w4sp_k5s2_conv", 1, 64, 16, 96, 64, -5, 0, 4),         # 5x5 stride-2 conv (parity sub-filters), k = -5 marks stride 2
+    ("w4sp_k5s2_convT", 1, 64, 8, 48, 64, -5, 1, 2),         # 5x5 stride-2 transposed conv (phases)
+]
+
+
+@pytest.mark.parametrize("case", W4SPLIT_CASES, ids=[c[0] for c in W4SPLIT_CASES])
+def test_winograd_f4x4_split_k(case):
+    """the F(4x4) kernel with K splits (forced id | (splits - 1) << 8): equal to float64 within the kernel's bound, to the unsplit launch
+    within fp32 summation order, bit-identical run to run (fixed split order), tickets left at zero (a second launch works), with a
+    bias + ReLU epilogue and column sums taken by the last arriver"""
+    from crdr_amd.hip import ops
+    name, n, ci, h, w, co, k, tr, ns = case
+    dev = _dev()
+    stride = 2 if k < 0 else 1
+    k = abs(k)
+    a4 = _wino_id() + 2
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(*((ci, co, k, k) if tr else (co, ci, k, k)), seed=2, scale=(ci * k * k / stride ** 2) ** -0.5)
+    b = _rand(co, seed=3)
+    if tr:
+        ref = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=stride, padding=k // 2, output_padding=stride - 1)
+    else:
+        ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=k // 2)
+    ref = torch.relu(ref)
+    oh, ow = ref.shape[2:]
+    xd, bd = x.to(dev), b.to(dev)
+    wp = ops.pack_weight(wt.to(dev), transpose=bool(tr))
+    one = ops.conv2d_raw(xd, wp, co, (k, k), stride, k // 2, bool(tr), (oh, ow), bias=bd, flags=3, algo=a4)
+    outs = [ops.conv2d_raw(xd, wp, co, (k, k), stride, k // 2, bool(tr), (oh, ow), bias=bd, flags=3, algo=a4 | ((ns - 1) << 8)) for _ in range(3)]
+    torch.cuda.synchronize()
+    _close(outs[0], ref, name + " split vs fp64", rtol=5e-5)
+    _close(outs[0], one.double(), name + " split vs unsplit", rtol=2e-5)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "split launches differ run to run"
+    after = ops.conv2d_raw(xd, wp, co, (k, k), stride, k // 2, bool(tr), (oh, ow), bias=bd, flags=3, algo=a4)
+    assert torch.equal(after, one), "an unsplit launch after split ones differs (tickets / workspace)"
+
+
 def test_winograd_f4x4_epilogues_slices_groups_colsum():
     """every epilogue the F(4x4) kernel takes: bias + ReLU + vec2 + residual + affine, LeakyReLU, accumulate, ReLU-mask with column sums (the
     input-gradient launches of a conv chain), channel slices in and out, a grouped launch"""
