@@ -418,7 +418,7 @@ def test_winograd_ids_are_planned_only_for_the_shapes_they_take(lib):
     assert lib.crdr_conv2d_workspace(C.byref(hoist_t)) == tickets + u_bytes + 40 * 6 * 131072
     assert plan(desc(12, 64, 64, 3), (base + 2) | (3 << 8)) == 0      # 3 sub-steps cannot feed 4 splits
     assert plan(desc(12, 64, 64, 3), (base + 2) | (2 << 8)) == (base + 2) | (2 << 8)
-    assert plan(desc(24, 64, 16, 5), (base + 2) | (6 << 8)) == 0      # 5x5 stride 1: 7 splits of 24 sub-steps would start 2 sub-steps before a sub-filter's end
+    assert plan(desc(24, 64, 16, 5), (base + 2) | (6 << 8)) == 0      # 24 sub-steps in 7 parts of 4: the last one would be empty
     d4 = desc(100, 96, 64, 3)
     d4.reserved = base + 2
     assert lib.crdr_conv2d_workspace(C.byref(d4)) == tickets + 2 * 25 * 36 * 4 * 64 * 4
