@@ -410,7 +410,8 @@ extern "C" double crdr_conv2d_flops(const crdr_conv_desc* d) {
   return 2.0 * d->N * d->H * d->W * (double)d->OC * d->C * d->kh * d->kw;
 }
 
-static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, void* ws, size_t ws_bytes, crdr_stream_t s) {
+static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, void* ws, size_t ws_bytes, crdr_stream_t s,
+                       float* ucache = nullptr, size_t ucache_bytes = 0, int ucache_valid = 0) {
   Plan pl;
   if (int rc = build_plan(d, &pl, G)) return rc;
   IgemmArgs& a = pl.a;
@@ -466,7 +467,15 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   if (pl.wino) {
     void* prof = profile_begin(as_stream(s));
     if (pl.wino == 3) {
-      if (int rc = wino4_launch(d, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, a.nsplit, as_stream(s))) return rc;
+      // transformed filters: in the workspace, or in the caller's buffer (crdr_conv2d_grouped_ex: kept across launches that share
+      // weights -- `ucache_valid` skips the transform); the partial tiles of a split launch always live in the workspace
+      float* u = (float*)ws + CRDR_CONV_TICKETS;
+      if (ucache) {
+        CRDR_REQUIRE(ucache_bytes >= wino4_workspace(d, G, 1), "conv2d: filter cache of %zu bytes, the launch needs %zu", ucache_bytes, wino4_workspace(d, G, 1));
+        u = ucache;
+      }
+      float* slabs = (float*)ws + CRDR_CONV_TICKETS + wino4_workspace(d, G, 1) / 4;
+      if (int rc = wino4_launch(d, a, pl.t, grp, G, u, slabs, a.nsplit, ucache && ucache_valid, as_stream(s))) return rc;
     } else if (int rc = wino_launch(d, pl.wino - 1, a, pl.t, grp, G, (float*)ws + CRDR_CONV_TICKETS, as_stream(s))) return rc;
     // kind 3 / 5 / 6: filter transform + Winograd F(2x2, 3x3) / F(4x4, 3x3) kernel (6: a 5x5 stride-2 layer through it), direct-convolution
     // flop count
@@ -516,4 +525,18 @@ extern "C" int crdr_conv2d_grouped(const crdr_conv_desc* d, const crdr_conv_io* 
   CRDR_REQUIRE(d && ios, "conv2d_grouped: null descriptor");
   CRDR_REQUIRE(G >= 1 && G <= CRDR_MAX_GROUP, "conv2d_grouped: %d problems (1..%d)", G, CRDR_MAX_GROUP);
   return launch_conv(d, ios, G, ws, ws_bytes, s);
+}
+
+extern "C" size_t crdr_conv2d_filter_cache_bytes(const crdr_conv_desc* d, int G) {
+  Plan pl;
+  if (!d || G < 1 || G > CRDR_MAX_GROUP || build_plan(d, &pl, G) || pl.wino != 3) return 0;
+  return wino4_workspace(d, G, 1);
+}
+
+extern "C" int crdr_conv2d_grouped_ex(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, void* ws, size_t ws_bytes, float* filter_cache,
+                                      size_t filter_cache_bytes, int filter_cache_valid, crdr_stream_t s) {
+  CRDR_REQUIRE(d && ios, "conv2d_grouped_ex: null descriptor");
+  CRDR_REQUIRE(G >= 1 && G <= CRDR_MAX_GROUP, "conv2d_grouped_ex: %d problems (1..%d)", G, CRDR_MAX_GROUP);
+  CRDR_REQUIRE(!filter_cache || (reinterpret_cast<uintptr_t>(filter_cache) & 15) == 0, "conv2d_grouped_ex: the filter cache must be 16-byte aligned");
+  return launch_conv(d, ios, G, ws, ws_bytes, s, filter_cache, filter_cache_bytes, filter_cache_valid);
 }

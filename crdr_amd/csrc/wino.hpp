@@ -17,6 +17,7 @@ bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok);
 size_t wino4_workspace(const crdr_conv_desc* d, int G, int nsplit);   // bytes of transformed filters (+ the partial tiles of a K-split launch)
 bool wino4_split_ok(const crdr_conv_desc* d, int G, int nsplit);      // nsplit K splits per tile (forced id: bits 8..11 = nsplit - 1)
 int wino4_colsum_rows(const crdr_conv_desc* d);
-int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, int nsplit, hipStream_t s);
+int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, float* slabs, int nsplit,
+                 bool filters_ready, hipStream_t s);
 
 }  // namespace crdr

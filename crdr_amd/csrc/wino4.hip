@@ -828,7 +828,8 @@ int wino4_colsum_rows(const crdr_conv_desc* d) {
   return wino4_patches(d, mode) * (mode == 3 ? 4 : 1);
 }
 
-int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, int nsplit, hipStream_t s) {
+int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, float* slabs, int nsplit,
+                 bool filters_ready, hipStream_t s) {
   CRDR_REQUIRE(wino4_eligible(d, G, a.vec_epi != 0), "conv2d: the F(4x4, 3x3) Winograd kernel takes 3x3 / 5x5 stride-1 and 5x5 stride-2 (pad 2) convolutions of >= 24 "
                "output (phase) columns (or whole images of 9..16 pixels a side) with C, OC %% 4 == 0, 16-byte aligned operand rows and no gate / pre-add epilogue");
   const int mode = wino4_mode(d);
@@ -878,7 +879,7 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
   }
   const int nvar = mode >= 2 ? 4 : 1;
   const int ntile = cdiv(d->OC, kBN4), kchunks = cdiv(d->C, 4);
-  {
+  if (!filters_ready) {   // (a caller that kept the transformed filters of these weights from an earlier launch skips this)
     const long long total = (long long)ntile * nvar * kchunks * 256;
     hipLaunchKernelGGL(wino4_filter_kernel, dim3((unsigned)cdiv64(total, 256), G), dim3(256), 0, s, grp, G, a.w, u, d->C, d->OC, d->wrows, d->wcols, kchunks,
                        ntile, nvar, 0, wt);
@@ -886,7 +887,7 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
   }
   a.w = u;
   a.nsplit = nsplit;
-  a.ws = u + wino4_filter_bytes(d, G) / 4;   // partial tiles of a split launch: behind the transformed filters
+  a.ws = slabs;   // partial tiles of a split launch
   a.ws_ld = (int)wino4_tiles(d, G);
   a.nphase = (mode == 2 || mode == 4) ? 4 : 1;   // parity / shifted sub-filters the K loop accumulates
   a.kchunks = kchunks * a.nphase;             // sub-steps of a tile

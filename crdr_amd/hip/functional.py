@@ -46,6 +46,8 @@ class _PackEntry:
 
     def fill(self) -> None:
         lib = L.load()
+        ops.register_persistent_pack(self.dst)
+        ops.filter_scope_invalidate(self.dst.data_ptr())
         if self.mode in (0, 1):
             it = self.item()
             L.check(lib.crdr_pack_weight_item(C.byref(it), ops._stream()), "pack_weight_item")
@@ -71,6 +73,7 @@ def sub_pack(weight: torch.Tensor, j0: int, j1: int, dst: torch.Tensor, dst_off:
     e.rows, e.cols = rows, cols
     assert rows % 8 == 0 and cols % 32 == 0 and rows >= (e.J if transposed else e.I) and cols >= (e.I if transposed else e.J)
     e.dst, e.dst_off, e.dld, e.tstride = dst, 4 * dst_off, dld, tstride
+    ops.register_persistent_pack(dst)
     _pack_entries.append(e)
     _pack_serial += 1
     return e
@@ -148,6 +151,7 @@ class ConvSpec:
                 shape = (ent.T, ops.round32(ent.J), ops.round32(ent.I)) if mode else (ent.T, ops.round32(ent.I), ops.round32(ent.J))
             ent.rows, ent.cols = shape[1], shape[2]
             ent.dst = torch.empty(shape, dtype=torch.float32, device=weight.device)
+            ops.register_persistent_pack(ent.dst)
             self._packs[slot] = ent
             _pack_entries.append(ent)
             _pack_serial += 1
@@ -225,6 +229,7 @@ class PackTable:
     def refill(self) -> None:
         """Refill every pack of the range from the current parameter values and mark them fresh."""
         self._refresh()
+        ops.filter_scope_invalidate()
         if self.entries:
             lib = L.load()
             L.check(lib.crdr_pack_weights_batched(self.items.data_ptr(), self.prefix.data_ptr(), self.meta.data_ptr(),

@@ -114,6 +114,8 @@ SIGNATURES = {
     "crdr_colsum_finish_batched": (_I, [_P, _P, _P, _P, _P, _P]),
     "crdr_conv2d_grouped_workspace": (_SZ, [C.POINTER(ConvDesc), _I]),
     "crdr_conv2d_grouped": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _SZ, _P]),
+    "crdr_conv2d_filter_cache_bytes": (_SZ, [C.POINTER(ConvDesc), _I]),
+    "crdr_conv2d_grouped_ex": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _SZ, _P, _SZ, _I, _P]),
     "crdr_conv2d_wgrad_grouped_workspace": (_SZ, [C.POINTER(WgradDesc), _I]),
     "crdr_conv2d_wgrad_partial_grouped": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _I, _P, _SZ, _P, _P]),
     "crdr_pack_weight_item": (_I, [C.POINTER(PackItem), _P]),

@@ -116,6 +116,65 @@ def _prefer_wino(d, G: int = 1) -> int:
 WINO4_SPLITS = (1, 2, 3, 5, 7, 11, 15)
 
 
+# Transformed filters of the F(4x4) Winograd kernel, kept between launches that share weights: inside `with filter_scope():` a launch that
+# runs that kernel keeps its transformed filters in a tensor of its own, and a later launch in the same scope with the same weight pack(s),
+# descriptor and algorithm skips the transform (crdr_conv2d_grouped_ex).  The scope is the caller's statement that the weights do not change
+# inside it -- the generator's two forward passes of a step (multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:42-47); leaving it drops
+# everything.  Under graph capture the scope must lie inside ONE capture (first use: transform + conv, later uses: conv only, replayed
+# in that order).
+_filter_scope = None
+FILTER_SCOPE_STATS = {"filled": 0, "reused": 0}
+_persistent_packs = {}   # data_ptr -> weakref of a persistent weight-pack buffer (functional._PackEntry.dst): only those are cached by address
+
+
+def register_persistent_pack(t: torch.Tensor) -> None:
+    import weakref
+    _persistent_packs[t.data_ptr()] = weakref.ref(t)
+
+
+def filter_scope_invalidate(ptr=None) -> None:
+    """A weight pack was refilled in place (functional._PackEntry.fill, Packs.refill): transformed filters kept for it are stale."""
+    if _filter_scope:
+        if ptr is None:
+            _filter_scope.clear()
+        else:
+            for k in [k for k in _filter_scope if ptr in k[0]]:
+                del _filter_scope[k]
+
+
+def _is_persistent_pack(ptr: int) -> bool:
+    r = _persistent_packs.get(ptr)
+    t = r() if r is not None else None
+    return t is not None and t.data_ptr() == ptr
+
+
+class filter_scope:
+    def __enter__(self):
+        global _filter_scope
+        self.prev, _filter_scope = _filter_scope, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _filter_scope
+        _filter_scope = self.prev
+        return False
+
+
+def _launch_conv(lib, d, ios, G: int, ws, ws_n, wkeys, device):
+    """crdr_conv2d_grouped, through the filter cache of the enclosing filter_scope where the launch runs the F(4x4) kernel."""
+    if _filter_scope is not None and (d.reserved & 0xFF) == _wino4_id() and all(_is_persistent_pack(int(p_)) for p_ in wkeys):
+        nb = lib.crdr_conv2d_filter_cache_bytes(C.byref(d), G)
+        if nb:
+            key = (tuple(int(p_) for p_ in wkeys), G, d.reserved & 0xFF, d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.kh, d.kw, d.stride, d.pad, d.transposed, d.wrows, d.wcols)
+            ent = _filter_scope.get(key)
+            valid = ent is not None
+            if ent is None:
+                ent = _filter_scope[key] = torch.empty(int(nb) // 4, dtype=torch.float32, device=device)
+            FILTER_SCOPE_STATS["reused" if valid else "filled"] += 1
+            return lib.crdr_conv2d_grouped_ex(C.byref(d), ios, G, ws, ws_n, ent.data_ptr(), int(nb), int(valid), _stream())
+    return lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream())
+
+
 def _stream_ids():
     """Forced-algorithm ids of the streaming 1x1 variants and of the Winograd 3x3 kernel (the library rejects them for other shapes)."""
     lib = L.load()
@@ -429,7 +488,7 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
     nbytes = lib.crdr_conv2d_workspace(C.byref(d))
     ws, ws_n = workspace(nbytes, x.device, conv=True) if nbytes else (None, 0)
     e0 = _prof_begin()
-    L.check(lib.crdr_conv2d(C.byref(d), C.byref(io), ws, ws_n, _stream()), "conv2d")
+    L.check(_launch_conv(lib, d, C.byref(io), 1, ws, ws_n, (wpack.data_ptr(),), x.device), "conv2d")
     _prof_end("igemm", 2.0 * n * (h * w if transposed else oh * ow) * c * oc * k[0] * k[1], e0,
               f"{'T' if transposed else 'C'} {c}->{oc} k{k[0]}s{stride} in{h}x{w} f{flags}",
               4.0 * (n * h * w * c + n * oh * ow * oc * (1 + (res is not None) + 3 * (gate_x is not None)) + k[0] * k[1] * c * oc))
@@ -767,7 +826,7 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
     nbytes = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
     ws, ws_n = workspace(nbytes, device, conv=True) if nbytes else (None, 0)
     e0 = _prof_begin()
-    L.check(lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream()), "conv2d_grouped")
+    L.check(_launch_conv(lib, d, ios, G, ws, ws_n, [ios[g].w for g in range(G)], device), "conv2d_grouped")
     _prof_end("igemm", 2.0 * G * n * h * w * x0.c * oc * k[0] * k[1], e0,
               f"{'T' if transposed else 'C'} {G}x {x0.c}->{oc} k{k[0]} in{h}x{w} f{flags} {label}",
               4.0 * G * (n * h * w * x0.c + n * h * w * oc * (1 + (pres is not None) + (masks is not None) + bool(flags & L.EPI_ACCUM))
@@ -1074,7 +1133,7 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
     nbytes = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
     ws, ws_n = workspace(nbytes, device, conv=True) if nbytes else (None, 0)
     e0 = _prof_begin()
-    L.check(lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream()), "conv2d_grouped")
+    L.check(_launch_conv(lib, d, ios, G, ws, ws_n, [ios[g].w for g in range(G)], device), "conv2d_grouped")
     _prof_end("igemm", 2.0 * G * n * (h * w if transposed else oh * ow) * x0.c * oc * k[0] * k[1], e0,
               f"{'T' if transposed else 'C'} {G}x {x0.c}->{oc} k{k[0]}s{stride} in{h}x{w} f{flags} {label}",
               4.0 * G * (n * h * w * x0.c + n * oh * ow * oc * (1 + (pres is not None) + (masks is not None) + (ress is not None)

@@ -188,6 +188,14 @@ int crdr_colsum_finish_batched(const crdr_colsum_job* jobs, const int64_t* prefi
 #define CRDR_MAX_GROUP 16
 size_t crdr_conv2d_grouped_workspace(const crdr_conv_desc* d, int G);
 int crdr_conv2d_grouped(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, void* ws, size_t ws_bytes, crdr_stream_t s);
+/* The same launch (G = 1: crdr_conv2d) with the Winograd F(4x4) kernel's transformed filters kept in a caller-owned buffer instead of the
+ * workspace: crdr_conv2d_filter_cache_bytes(d, G) bytes (0 unless d->reserved forces that kernel), 16-byte aligned.  With
+ * filter_cache_valid == 0 the launch fills it, with != 0 it trusts it -- for launches that share weights between two updates (the reference runs
+ * its generator twice per step, multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:42-47; cuDNN re-transforms there as well).  The caller
+ * owns validity: same weights, same descriptor, same forced algorithm.  filter_cache == NULL: exactly crdr_conv2d_grouped. */
+size_t crdr_conv2d_filter_cache_bytes(const crdr_conv_desc* d, int G);
+int crdr_conv2d_grouped_ex(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, void* ws, size_t ws_bytes, float* filter_cache,
+                           size_t filter_cache_bytes, int filter_cache_valid, crdr_stream_t s);
 /* algorithmic FLOPs of the call (2 * MACs actually needed, padding taps excluded approx.) for roofline maths */
 double crdr_conv2d_flops(const crdr_conv_desc* d);
 

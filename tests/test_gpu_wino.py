@@ -308,6 +308,36 @@ def test_winograd_f4x4_split_k(case):
     assert torch.equal(after, one), "an unsplit launch after split ones differs (tickets / workspace)"
 
 
+def test_winograd_f4x4_filter_scope():
+    """ops.filter_scope: a second F(4x4) launch with the same persistent weight pack reuses the transformed filters of the first (same
+    bits out); a pack refilled in place invalidates them; temporary packs and launches outside a scope are never cached"""
+    from crdr_amd.hip import ops
+    dev = _dev()
+    a4 = _wino_id() + 2
+    x = _rand(2, 96, 16, 64, seed=1).to(dev)
+    w1, w2 = _rand(64, 96, 3, 3, seed=2, scale=0.03).to(dev), _rand(64, 96, 3, 3, seed=3, scale=0.03).to(dev)
+    wp = ops.pack_weight(w1, transpose=False)
+    call = lambda: ops.conv2d_raw(x, wp, 64, (3, 3), 1, 1, False, (16, 64), algo=a4)
+    ref1 = call()
+    st = ops.FILTER_SCOPE_STATS
+    f0, r0 = st["filled"], st["reused"]
+    with ops.filter_scope():
+        assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0, r0), "a temporary pack must not be cached by address"
+        ops.register_persistent_pack(wp)
+        assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0 + 1, r0)
+        assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0 + 1, r0 + 1)
+        # the pack is refilled in place with other weights (what functional._PackEntry.fill does after telling the scope)
+        wp.copy_(ops.pack_weight(w2, transpose=False))
+        ops.filter_scope_invalidate(wp.data_ptr())
+        out2 = call()
+        assert (st["filled"], st["reused"]) == (f0 + 2, r0 + 1)
+        with ops.filter_scope():   # a nested scope starts empty
+            assert torch.equal(call(), out2) and st["filled"] == f0 + 3
+    assert torch.equal(out2, call()) and st["filled"] == f0 + 3, "outside a scope nothing is cached"
+    ref2 = F.conv2d(x.cpu().double(), w2.cpu().double(), padding=1)
+    _close(out2, ref2, "filter scope after refill", rtol=5e-5)
+
+
 def test_winograd_f4x4_epilogues_slices_groups_colsum():
     """every epilogue the F(4x4) kernel takes: bias + ReLU + vec2 + residual + affine, LeakyReLU, accumulate, ReLU-mask with column sums (the
     input-gradient launches of a conv chain), channel slices in and out, a grouped launch"""
