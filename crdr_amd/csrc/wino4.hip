@@ -1,4 +1,5 @@
-// Winograd F(4x4, 3x3) convolution on the exact-fp32 matrix cores for the 3x3 stride-1 layers at >= 48 output columns
+// Winograd F(4x4, 3x3) convolution on the exact-fp32 matrix cores for the 3x3 stride-1 layers (and, as 3x3 pieces, the 5x5 stride-2 and
+// stride-1 layers: wino4_mode below; tile geometries: W4Geo; K splits inside the launch: wino4_finish)
 // (elic_layers.py:23-36, cheng_nlam.py:31-46, clic21_gvae_discriminator.py:27-40) and their input gradients:
 //   Y = A^T [ (G g G^T) . (B^T d B) ] A   with 6x6 transforms (Lavin & Gray 2016, interpolation points 0, +-1, +-2, inf):
 // 36 element-wise products per 4x4 outputs and channel pair instead of 144 -- 4x fewer MFMAs than the implicit GEMM, 1.78x fewer

@@ -147,12 +147,19 @@ int crdr_conv2d_num_stream_configs(void);
  * that e.g. 96 channels cost 1.5 tiles per patch, not 2.  fp32 arithmetic throughout (data transform +-1, filter transform halves); the
  * sums are associated differently from the direct form.  Rejected unless kh = kw = 3 (or 5, as 2 x 2 sub-filters), stride 1, C % 4 == 0
  * and the epilogue has no GATE / PREADD (grouped: nor VEC2 / AFFINE / MASKOFF).
- * v = 2: F(4x4, 3x3) (wino4.hip): 4x fewer multiply-accumulates than the implicit GEMM, output tiles of 8 x 64 pixels x 64 channels;
- * additionally needs >= 48 output columns, OC % 4 == 0 and 16-byte aligned operand rows.  Its transforms carry the constants 4, 5, 8 and
- * 1/4 .. 1/24: results deviate from float64 by ~5e-6 .. 1e-5 of the output scale (the other kernels: ~1e-6) -- a candidate of the
- * training-side tuner only, never of the built-in plan (the codec runs built-in plans).
+ * v = 2: F(4x4, 3x3) (wino4.hip): 4x fewer multiply-accumulates than the implicit GEMM on a 3x3 stride-1 layer; also takes the 5x5 layers
+ * as 3x3 pieces (2.78x fewer): 5x5 stride-2 pad-2 convolutions of even-sized inputs (four parity sub-filters, elic_autoencoder.py:42-52),
+ * 5x5 stride-2 pad-2 transposed convolutions with output = 2 x input (four output phases, elic_layers.py:14-21), 5x5 stride-1 pad-2 layers
+ * of >= 12 input channels (four shifted sub-filters, minnen20_charm_context_model.py:26-38).  Output tiles of 8 x 64 pixels x 64 channels
+ * (>= 33 output / phase columns), 16 x 32 pixels (24..32 columns) or, for the stride-1 forms, two whole images of 9..16 pixels a side;
+ * needs C % 4 == 0, OC % 4 == 0 and 16-byte aligned operand rows.  Bits 8..11 of the forced id = K splits - 1 (1..16 work items per tile
+ * over equal parts of the K range, reduced inside the launch in split order: bit-identical run to run; the ticket head of the workspace must
+ * be zero, as for the implicit GEMM's split-K).  Its transforms carry the constants 4, 5, 8 and 1/4 .. 1/24: results deviate from float64
+ * by ~5e-6 .. 1.5e-5 of the output scale (the other kernels: ~1e-6) -- a candidate of the training-side tuner only, never of the built-in
+ * plan (the codec runs built-in plans).
  * The transformed filters are rebuilt from the weight pack into the workspace by every launch (crdr_conv2d_workspace with the same
- * `reserved`); CRDR_EPI_COLSUM rows are per output tile (16x16 pixels for v = 0, 1; 8x64 for v = 2), crdr_conv2d_colsum_layout. */
+ * `reserved`; crdr_conv2d_grouped_ex keeps them in a caller's buffer instead); CRDR_EPI_COLSUM rows are per output tile (and phase),
+ * crdr_conv2d_colsum_layout. */
 int crdr_conv2d_num_wino_configs(void);
 /* bytes of workspace crdr_conv2d needs for this problem (split-K partial slabs; may be 0) */
 size_t crdr_conv2d_workspace(const crdr_conv_desc* d);
