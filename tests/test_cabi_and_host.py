@@ -429,3 +429,33 @@ def test_winograd_ids_are_planned_only_for_the_shapes_they_take(lib):
     assert lib.crdr_conv2d_wgrad_workspace(C.byref(wdesc(3, 1))) == 9 * 96 * 64 * 4      # unsplit: one slab of 9 taps
     assert lib.crdr_conv2d_wgrad_workspace(C.byref(wdesc(5, 1))) == 0                     # rejected (0 = planning failed)
     assert lib.crdr_conv2d_wgrad_workspace(C.byref(wdesc(3, 2))) == 0
+
+
+def test_filter_scope_bookkeeping():
+    """ops.filter_scope (host side only, no launches): entries live inside the scope, nested scopes start empty, a refilled pack drops
+    exactly its entries, only registered persistent packs count as cacheable, and a registration dies with its tensor"""
+    import torch
+    from crdr_amd.hip import ops
+    a, b = torch.zeros(64), torch.zeros(64)
+    assert not ops._is_persistent_pack(a.data_ptr())
+    ops.register_persistent_pack(a)
+    assert ops._is_persistent_pack(a.data_ptr()) and not ops._is_persistent_pack(b.data_ptr())
+    assert ops._filter_scope is None
+    ops.filter_scope_invalidate(a.data_ptr())          # outside a scope: nothing to do
+    with ops.filter_scope():
+        sc = ops._filter_scope
+        sc[((a.data_ptr(),), 1, 37)] = "Ua"
+        sc[((a.data_ptr(), b.data_ptr()), 2, 37)] = "Uab"
+        sc[((b.data_ptr(),), 1, 37)] = "Ub"
+        with ops.filter_scope():
+            assert ops._filter_scope == {}
+            ops._filter_scope["x"] = 1
+        assert ops._filter_scope is sc and len(sc) == 3
+        ops.filter_scope_invalidate(a.data_ptr())
+        assert list(sc.values()) == ["Ub"]
+        ops.filter_scope_invalidate()
+        assert sc == {}
+    assert ops._filter_scope is None
+    ptr = a.data_ptr()
+    del a
+    assert not ops._is_persistent_pack(ptr)
