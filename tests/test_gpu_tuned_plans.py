@@ -92,9 +92,13 @@ def _sel(n, cap):
     return sorted(s)
 
 
-def _sample_pixels(n, oh, ow):
-    ys, xs = _sel(oh, 32), _sel(ow, 32)
-    need = -(-4096 // (len(ys) * len(xs)))
+def _sample_pixels(n, oh, ow, work=1):
+    """~4 096 output pixels (borders + an even spread, every image where there are few); `work` = float64 multiply-adds per sampled
+    pixel: the sample shrinks (never below 1 024) where 4 096 of them would cost more than 2e10 on the CPU (the hoisted convs)"""
+    want = max(1024, min(4096, int(2e10 // max(work, 1))))
+    side = 32 if want >= 4096 else 16
+    ys, xs = _sel(oh, side), _sel(ow, side)
+    need = -(-want // (len(ys) * len(xs)))
     ns = _sel(n, max(2, min(n, need)))
     idx = torch.cartesian_prod(torch.tensor(ns), torch.tensor(ys), torch.tensor(xs))
     return idx[:, 0], idx[:, 1], idx[:, 2]
@@ -281,7 +285,7 @@ def _replay_conv(rp, key, algo, seed):
         cscale = max(float(t.abs().max()) for t in csb) + 1e-20
         out["colsum_vs_builtin"] = max(float((a - b).abs().max()) for a, b in zip(cst, csb)) / cscale
     # float64 on the CPU: first and last problem of the group, sampled pixels
-    pix = _sample_pixels(n, oh, ow)
+    pix = _sample_pixels(n, oh, ow, work=c * oc * k[0] * k[1])
     gpix = [t.to(dev) for t in pix]
     geo = (n, h, w, c, oh, ow, oc, k[0], k[1], stride, pad, tr, wlayout)
     e64 = e64b = 0.0
