@@ -57,3 +57,96 @@ def test_f3x3_2x2_weight_gradient_with_unscaled_accumulation():
     assert np.allclose(taps, ref, atol=1e-12)
     f = np.array([1, .5, .5, 1])
     assert np.allclose(ATW @ (u_unscaled * np.outer(f, f)) @ ATW.T, ref, atol=1e-12)
+
+
+# ---- csrc/wino4.hip: F(4x4, 3x3) with the matrices the kernel hard-codes (bt6h, at6, wino4_filter_kernel) and the forms it takes -----------
+BT6 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], float)
+G6 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], float)
+AT6 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], float)
+
+
+def f4(d6, g3):
+    return AT6 @ ((G6 @ g3 @ G6.T) * (BT6 @ d6 @ BT6.T)) @ AT6.T
+
+
+def test_f4x4_3x3_and_its_two_half_transforms():
+    rng = np.random.default_rng(3)
+    d, g = rng.standard_normal((6, 6)), rng.standard_normal((3, 3))
+    assert np.allclose(f4(d, g), corr(d, g), atol=1e-11)
+    # bt6h<0> / bt6h<1>: outputs 0..2 read inputs 0..4, outputs 3..5 read inputs 1..5 (the kernel schedules them separately)
+    assert np.all(BT6[:3, 5] == 0) and np.all(BT6[3:, 0] == 0)
+    x = rng.standard_normal(6)
+    a, b = -4 * x[2] + x[4], -4 * x[1] + x[3]
+    assert np.allclose([4 * x[0] - 5 * x[2] + x[4], a + b, a - b], BT6[:3] @ x)
+    c, e = x[4] - x[2], x[3] - x[1]
+    assert np.allclose([2 * e + c, -2 * e + c, 4 * x[1] - 5 * x[3] + x[5]], BT6[3:] @ x)
+    # at6
+    m = rng.standard_normal(6)
+    p, q, uu, w = m[1] + m[2], m[1] - m[2], m[3] + m[4], m[3] - m[4]
+    assert np.allclose([m[0] + p + uu, 2 * w + q, 4 * uu + p, 8 * w + q + m[5]], AT6 @ m)
+
+
+def test_5x5_stride2_conv_as_four_parity_subfilters():
+    """out[o] = sum_t w[t] x[2 o - 2 + t], t = 2 a + p: sub-filter (ph, pw) element (a, b) = w[2 a + ph][2 b + pw] correlated with the parity
+    plane x[2 m + ph][2 n + pw] at pad 1 (wino4_launch, mode 2)"""
+    rng = np.random.default_rng(4)
+    H = W = 16
+    x, w = rng.standard_normal((H, W)), rng.standard_normal((5, 5))
+    xp = np.pad(x, 2)
+    ref = np.array([[(xp[2 * a:2 * a + 5, 2 * b:2 * b + 5] * w).sum() for b in range(W // 2)] for a in range(H // 2)])
+    out = np.zeros_like(ref)
+    for ph in range(2):
+        for pw in range(2):
+            sub = np.zeros((3, 3))
+            for a in range(3):
+                for b in range(3):
+                    if 2 * a + ph < 5 and 2 * b + pw < 5:
+                        sub[a, b] = w[2 * a + ph, 2 * b + pw]
+            plane = np.pad(x[ph::2, pw::2], 1)
+            for ty in range(0, H // 2, 4):          # F(4x4) tiles of the sub-convolution, accumulated over the four planes
+                for tx in range(0, W // 2, 4):
+                    out[ty:ty + 4, tx:tx + 4] += f4(plane[ty:ty + 6, tx:tx + 6], sub)
+    assert np.allclose(out, ref, atol=1e-10)
+
+
+def test_5x5_stride2_transposed_conv_as_four_output_phases():
+    """out[2 u + py] = sum_a' w[2 (2 - a') + py] in[u - 1 + a']: phase (py, px) is a 3x3 pad-1 correlation of the input with
+    w[2 (2 - a') + py][2 (2 - b') + px] (absent taps zero) written to every second output pixel (wino4_launch, mode 3)"""
+    rng = np.random.default_rng(5)
+    H = W = 8
+    x, w = rng.standard_normal((H, W)), rng.standard_normal((5, 5))
+    ref = np.zeros((2 * H + 4, 2 * W + 4))          # ConvTranspose2d k5 s2 p2 op1: scatter, then crop 2 at the top / left, 1 at the bottom / right
+    for i in range(H):
+        for j in range(W):
+            ref[2 * i:2 * i + 5, 2 * j:2 * j + 5] += x[i, j] * w
+    ref = ref[2:2 + 2 * H, 2:2 + 2 * W]
+    out = np.zeros_like(ref)
+    xp = np.pad(x, 1)
+    for py in range(2):
+        for px in range(2):
+            sub = np.zeros((3, 3))
+            for a in range(3):
+                for b in range(3):
+                    r, c = 2 * (2 - a) + py, 2 * (2 - b) + px
+                    if r < 5 and c < 5:
+                        sub[a, b] = w[r, c]
+            for ty in range(0, H, 4):
+                for tx in range(0, W, 4):
+                    out[py + 2 * ty:py + 2 * ty + 8:2, px + 2 * tx:px + 2 * tx + 8:2] = f4(xp[ty:ty + 6, tx:tx + 6], sub)
+    assert np.allclose(out, ref, atol=1e-10)
+
+
+def test_5x5_stride1_as_four_shifted_subfilters_and_k_splits():
+    """taps (3 bi + a, 3 bj + b): sub-filter (bi, bj) over the patch displaced by (3 bi, 3 bj) (mode 4); and the linearity the K splits rely
+    on: the output transform of a sum of partial products = the sum of the output transforms (wino4_finish, SPLIT)"""
+    rng = np.random.default_rng(6)
+    d, g = rng.standard_normal((9, 9)), rng.standard_normal((5, 5))          # a 4x4 output tile of a 5x5 correlation needs 8x8; the
+    gp = np.zeros((6, 6)); gp[:5, :5] = g                                    # displaced 6x6 windows reach one row / column further
+    y = sum(f4(d[3 * bi:3 * bi + 6, 3 * bj:3 * bj + 6], gp[3 * bi:3 * bi + 3, 3 * bj:3 * bj + 3]) for bi in range(2) for bj in range(2))
+    assert np.allclose(y, corr(d[:8, :8], g), atol=1e-10)
+    C = 12
+    dc, gc = rng.standard_normal((C, 6, 6)), rng.standard_normal((C, 3, 3))
+    prod = np.stack([(G6 @ gc[c] @ G6.T) * (BT6 @ dc[c] @ BT6.T) for c in range(C)])
+    whole = AT6 @ prod.sum(0) @ AT6.T
+    parts = sum(AT6 @ prod[s:s + 4].sum(0) @ AT6.T for s in range(0, C, 4))
+    assert np.allclose(whole, parts, atol=1e-11) and np.allclose(whole, sum(corr(dc[c], gc[c]) for c in range(C)), atol=1e-10)
