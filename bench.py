@@ -239,13 +239,18 @@ def run_stage(a, stage: int, bs: int, steps: int, warmup: int, profile_steps: in
                 "avg_gflop_per_launch": round(fl / n / 1e9, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                 "ms_per_step": round(ms / ps, 2)}
     r0, r3, r5, r6 = raw(0), raw(3), raw(5), raw(6)   # implicit-GEMM / streaming launches, Winograd F(2x2) / F(4x4) / F(4x4)-on-5x5-stride-2 launches (all counted with the direct convolution's flops)
-    r1, r4 = raw(1), raw(4)   # weight-gradient slab launches: direct, Winograd F(3x3, 2x2)
-    ig, wg, sk = (fam(r0[0] + r3[0] + r5[0] + r6[0], r0[1] + r3[1] + r5[1] + r6[1], r0[2] + r3[2] + r5[2] + r6[2]), fam(r1[0] + r4[0], r1[1] + r4[1], r1[2] + r4[2]),
+    r1, r4, r7, r8 = raw(1), raw(4), raw(7), raw(8)   # weight-gradient slab launches: direct, Winograd F(3x3, 2x2), F(3x3, 4x4) on 3x3 / 5x5 layers
+    ig, wg, sk = (fam(r0[0] + r3[0] + r5[0] + r6[0], r0[1] + r3[1] + r5[1] + r6[1], r0[2] + r3[2] + r5[2] + r6[2]), fam(r1[0] + r4[0] + r7[0] + r8[0], r1[1] + r4[1] + r7[1] + r8[1], r1[2] + r4[2] + r7[2] + r8[2]),
                   fam(*raw(2)))
-    if wg is not None and r4[2]:
-        wg["winograd"] = dict(fam(*r4), executed_tflops=round(r4[0] / 2.25 / (r4[1] * 1e-3) / 1e12, 2))
+    if wg is not None and (r4[2] or r7[2] or r8[2]):
+        if r4[2]:
+            wg["winograd"] = dict(fam(*r4), executed_tflops=round(r4[0] / 2.25 / (r4[1] * 1e-3) / 1e12, 2))
+        if r7[2]:
+            wg["winograd_f3x3_4x4"] = dict(fam(*r7), executed_tflops=round(r7[0] / 4.0 / (r7[1] * 1e-3) / 1e12, 2))
+        if r8[2]:
+            wg["winograd_f3x3_4x4_k5"] = dict(fam(*r8), executed_tflops=round(r8[0] * 9.0 / 25.0 / (r8[1] * 1e-3) / 1e12, 2))
         wg["direct"] = fam(*r1)
-        wg["executed_mfma_tflops"] = round((r1[0] + r4[0] / 2.25) / ((r1[1] + r4[1]) * 1e-3) / 1e12, 2)
+        wg["executed_mfma_tflops"] = round((r1[0] + r4[0] / 2.25 + r7[0] / 4.0 + r8[0] * 9.0 / 25.0) / ((r1[1] + r4[1] + r7[1] + r8[1]) * 1e-3) / 1e12, 2)
     if ig is not None and (r3[2] or r5[2] or r6[2]):
         # what the matrix cores execute: a Winograd F(2x2, 3x3) launch does 16 multiply-accumulates per 2x2 outputs and channel pair
         # instead of 36, an F(4x4, 3x3) launch 36 per 4x4 outputs instead of 144 -- effective rates may exceed the MFMA peak, executed
@@ -538,7 +543,7 @@ def main():
             ops.WINOGRAD = False
             for k_, v_ in list(ops._algo_cache.items()):
                 is_w = k_[0] in ("w", "wg", "ws", "wm")
-                if (is_w and (v_ & 0xff) == wlast) or (not is_w and (v_ & 0xff) >= wbase):
+                if (is_w and (v_ & 0xff) >= wlast) or (not is_w and (v_ & 0xff) >= wbase):
                     del ops._algo_cache[k_]
             ops.load_tune_cache(os.path.join(ROOT, "tools", "data", "tune_r3_f.json"), ignore_signature=True)
             dx = run_stage(a, 3, a.bs, min(a.steps, 20), a.warmup, 0)

@@ -505,7 +505,7 @@ static const int kNumWCfgs = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
 struct WPlan {
   WgradArgs a;
   int cfg;
-  int wino;   // 1: the Winograd slab kernel (cfg = -1)
+  int wino;   // 1: the Winograd F(3x3, 2x2) slab kernel, 2: the F(3x3, 4x4) one (cfg = -1)
   dim3 grid;
   size_t lds, ws_bytes;
 };
@@ -551,6 +551,24 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl, int G = 1) {
     }
   }
   pl->wino = 0;
+  if ((d->algo & 0xff) - 1 == kNumWCfgs + 1) {  // forced: the Winograd F(3x3, 4x4) slab kernel (wino4_wgrad.hip), strips of 4 tiles split 2^k ways
+    const bool k3 = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad >= 0 && d->pad <= 2;
+    const bool k5s1 = d->kh == 5 && d->kw == 5 && d->stride == 1 && d->pad == 2;
+    const bool k5s2 = d->kh == 5 && d->kw == 5 && d->stride == 2 && d->pad == 2;
+    CRDR_REQUIRE((k3 || k5s1 || k5s2) && !a.smallj && !(d->algo & CRDR_WGRAD_BF16X3),
+                 "wgrad: the Winograd F(3x3, 4x4) kernel takes 3x3 stride-1 and 5x5 (pad 2, stride 1 or 2) weight gradients with QC > 4 (exact fp32 only)");
+    bs = 1 << ((d->algo >> 8) & 0xf);
+    const long long strips = (long long)d->N * ((d->PH + 3) / 4) * ((d->PW + 15) / 16);
+    CRDR_REQUIRE(strips / bs >= 1, "wgrad: forced split %d too deep for %lld strips", bs, strips);
+    pl->wino = 2; pl->cfg = -1;
+    a.nsplit = bs; a.jtiles = cdiv(d->QC, 32);
+    pl->grid = dim3(cdiv(d->PC, 64) * a.jtiles * (k3 ? 1 : 4), bs, G);
+    pl->lds = 0;
+    a.ngroup = G;
+    a.slab_elems = (long long)bs * a.T * d->PC * d->QC;
+    pl->ws_bytes = (size_t)G * bs * a.T * d->PC * d->QC * sizeof(float);
+    return 0;
+  }
   if ((d->algo & 0xff) - 1 == kNumWCfgs) {  // forced: the Winograd F(3x3, 2x2) slab kernel (wino_wgrad.hip), strips split 2^k ways
     CRDR_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && !a.smallj && !(d->algo & CRDR_WGRAD_BF16X3) && d->pad >= 0 && d->pad <= 2,
                  "wgrad: the Winograd kernel takes 3x3 stride-1 weight gradients with QC > 4 (exact fp32 only)");
@@ -588,7 +606,9 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl, int G = 1) {
 
 using namespace crdr;
 
-extern "C" int crdr_conv2d_wgrad_num_configs(void) { return kNumWCfgs + 1; }   // (+ the Winograd slab kernel, last)
+extern "C" int crdr_conv2d_wgrad_num_configs(void) { return kNumWCfgs + 1; }   // (+ the Winograd F(3x3, 2x2) slab kernel, last)
+// Winograd slab kernels: ids crdr_conv2d_wgrad_num_configs() (F(3x3, 2x2)) .. + crdr_conv2d_wgrad_num_wino_configs() - 1 (F(3x3, 4x4))
+extern "C" int crdr_conv2d_wgrad_num_wino_configs(void) { return 2; }
 
 extern "C" size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d) {
   WPlan pl;
@@ -609,7 +629,11 @@ static int launch_wgrad_slabs(const crdr_wgrad_desc* d, const float* const* ps, 
     grp.p[g] = ps[g]; grp.q[g] = qs[g];
   }
   a.p = ps[0]; a.q = qs[0]; a.ws = (float*)ws;
-  if (pl.wino) {
+  if (pl.wino == 2) {
+    wino4_wgrad_launch(a, grp, pl.grid, as_stream(s));
+    CRDR_CHECK_LAUNCH("wino4_wgrad_kernel");
+    return 0;
+  } else if (pl.wino) {
     wino_wgrad_launch(a, grp, pl.grid, as_stream(s));
     CRDR_CHECK_LAUNCH("wino_wgrad_kernel");
     return 0;
@@ -639,7 +663,7 @@ extern "C" int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const
   hipLaunchKernelGGL(wgrad_reduce, dim3(blocks), dim3(256), 0, as_stream(s), (const float*)ws, g, d->PC, d->QC, d->gI,
                      d->gJ, a.T, a.nsplit, d->accumulate, a.smallj);
   CRDR_CHECK_LAUNCH("wgrad_reduce");
-  profile_end(pl.wino ? 4 : 1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
+  profile_end(pl.wino == 2 ? (d->kh == 5 ? 8 : 7) : pl.wino ? 4 : 1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
   return 0;
 }
 
@@ -653,7 +677,7 @@ extern "C" int crdr_conv2d_wgrad_partial(const crdr_wgrad_desc* d, const float* 
   job->slab = (const float*)slab; job->g = g;
   job->PC = d->PC; job->QC = d->QC; job->gI = d->gI; job->gJ = d->gJ; job->T = a.T; job->nsplit = a.nsplit;
   job->smallj = a.smallj; job->accumulate = d->accumulate; job->gJtot = 0; job->reserved = 0;
-  profile_end(pl.wino ? 4 : 1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
+  profile_end(pl.wino == 2 ? (d->kh == 5 ? 8 : 7) : pl.wino ? 4 : 1, 2.0 * (double)a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
   return 0;
 }
 
@@ -679,7 +703,7 @@ extern "C" int crdr_conv2d_wgrad_partial_grouped(const crdr_wgrad_desc* d, const
     job->PC = d->PC; job->QC = d->QC; job->gI = d->gI; job->gJ = d->gJ; job->T = a.T; job->nsplit = a.nsplit;
     job->smallj = a.smallj; job->accumulate = d->accumulate; job->gJtot = 0; job->reserved = 0;
   }
-  profile_end(pl.wino ? 4 : 1, 2.0 * (double)G * a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
+  profile_end(pl.wino == 2 ? (d->kh == 5 ? 8 : 7) : pl.wino ? 4 : 1, 2.0 * (double)G * a.M * d->gI * d->gJ * a.T, prof, as_stream(s));
   return 0;
 }
 

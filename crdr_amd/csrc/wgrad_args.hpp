@@ -51,5 +51,7 @@ struct WgradArgs {
 // Winograd F(3x3, 2x2) slab kernel (wino_wgrad.hip): same slab layout as wgrad_kernel, grid = (I tiles of 64 x J tiles of 64,
 // strip splits, problems)
 void wino_wgrad_launch(const WgradArgs& a, const WgradGroup& grp, dim3 grid, hipStream_t s);
+// Winograd F(3x3, 4x4) slab kernel (wino4_wgrad.hip): the same, grid = (I tiles of 64 x J tiles of 32, strip splits, problems)
+void wino4_wgrad_launch(const WgradArgs& a, const WgradGroup& grp, dim3 grid, hipStream_t s);
 
 }  // namespace crdr

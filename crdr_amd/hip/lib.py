@@ -105,6 +105,7 @@ SIGNATURES = {
     "crdr_conv2d_num_stream_configs": (_I, []),
     "crdr_conv2d_num_wino_configs": (_I, []),
     "crdr_conv2d_wgrad_num_configs": (_I, []),
+    "crdr_conv2d_wgrad_num_wino_configs": (_I, []),
     "crdr_conv2d_workspace": (_SZ, [C.POINTER(ConvDesc)]),
     "crdr_conv2d_choose_algo": (_I, [C.POINTER(ConvDesc), _I]),
     "crdr_conv2d": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvIO), _P, _SZ, _P]),

@@ -116,6 +116,16 @@ def _prefer_wino(d, G: int = 1) -> int:
 WINO4_SPLITS = (1, 2, 3, 5, 7, 11, 15)
 
 
+def _wgrad_wino4_ids():
+    """Forced ids of the F(3x3, 4x4) weight-gradient slab kernel (wino4_wgrad.hip: the id behind the last wgrad configuration) with its strip
+    splits 1 .. 256; the library refuses them for the shapes it does not take."""
+    lib = L.load()
+    if not WINOGRAD or lib.crdr_conv2d_wgrad_num_wino_configs() < 2:
+        return []
+    nw = lib.crdr_conv2d_wgrad_num_configs()
+    return [(nw + 1) | (ls << 8) for ls in range(9)]
+
+
 # Transformed filters of the F(4x4) Winograd kernel, kept between launches that share weights: inside `with filter_scope():` a launch that
 # runs that kernel keeps its transformed filters in a tensor of its own, and a later launch in the same scope with the same weight pack(s),
 # descriptor and algorithm skips the transform (crdr_conv2d_grouped_ex).  The scope is the caller's statement that the weights do not change
@@ -251,7 +261,7 @@ DEFAULT_TUNE_DB = __import__("os").path.join(__import__("os").path.dirname(__fil
 def _tune_signature() -> str:
     lib = L.load()
     return (f"v{lib.crdr_version()}-c{lib.crdr_conv2d_num_configs()}-s{lib.crdr_conv2d_num_stream_configs()}"
-            f"-w{lib.crdr_conv2d_wgrad_num_configs()}-n{lib.crdr_conv2d_num_wino_configs()}")
+            f"-w{lib.crdr_conv2d_wgrad_num_configs()}+{lib.crdr_conv2d_wgrad_num_wino_configs() - 1}-n{lib.crdr_conv2d_num_wino_configs()}")
 
 
 def save_tune_cache(path: str) -> None:
@@ -533,7 +543,7 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
                     return False
                 w_, wn_ = workspace(nb, p.device)
                 return lib.crdr_conv2d_wgrad(C.byref(d), p.data_ptr(), q.data_ptr(), tmp.data_ptr(), w_, wn_, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, result=lambda: tmp, agree=TUNE_AGREE["wgrad"])
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, extra=_wgrad_wino4_ids(), result=lambda: tmp, agree=TUNE_AGREE["wgrad"])
             d.accumulate = int(accumulate)
         d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
@@ -867,7 +877,7 @@ def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[i
             def finished():   # the trial's slabs reduced into tmp (the jobs accumulate: tmp is zeroed by reset())
                 reduce_jobs_now(jobs_t, device)
                 return tmp
-            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, penalty=lambda: slab[0] / 3.8e9, result=finished,
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, extra=_wgrad_wino4_ids(), penalty=lambda: slab[0] / 3.8e9, result=finished,
                              reset=tmp.zero_, agree=TUNE_AGREE["wgrad"])
         d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)
@@ -904,7 +914,7 @@ def wgrad_split(n: int, h: int, w: int, p: V, q: V, parts, k: Tuple[int, int], p
                     return False
                 w_, wn_ = workspace(nb, device)
                 return lib.crdr_conv2d_wgrad(C.byref(d), p.ptr, q.ptr, tmp.data_ptr(), w_, wn_, _stream()) == 0
-            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, result=lambda: tmp, agree=TUNE_AGREE["wgrad"])
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, extra=_wgrad_wino4_ids(), result=lambda: tmp, agree=TUNE_AGREE["wgrad"])
             d.accumulate = 1
         d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_workspace(C.byref(d))
@@ -1174,7 +1184,7 @@ def wgrad_multi(n: int, ph: int, pw: int, qh: int, qw: int, ps, qs, gs, gi: int,
             def finished():   # the trial's slabs reduced into tmp (the jobs accumulate: tmp is zeroed by reset())
                 reduce_jobs_now(jobs_t, device)
                 return tmp
-            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, penalty=lambda: slab[0] / 3.8e9, result=finished,
+            algo = _autotune(key, lib.crdr_conv2d_wgrad_num_configs(), 8, run, extra=_wgrad_wino4_ids(), penalty=lambda: slab[0] / 3.8e9, result=finished,
                              reset=tmp.zero_, agree=TUNE_AGREE["wgrad"])
         d.algo = _wa(algo)
     nbytes = lib.crdr_conv2d_wgrad_grouped_workspace(C.byref(d), G)

@@ -33,7 +33,8 @@ const char* crdr_arch(void); /* "gfx950" */
  * (0: igemm kernel of a conv forward / input gradient, 1: weight-gradient slab kernel (+ its reduce when not deferred),
  * 2: split-K epilogue kernels, 3: Winograd launches of a conv forward / input gradient -- filter transform + kernel, counted with the
  * direct convolution's FLOPs, 2.25x what the matrix cores execute, 4: Winograd weight-gradient slab launches, likewise, 5: F(4x4, 3x3)
- * Winograd launches of a 3x3 layer (4x what is executed), 6: of a 5x5 stride-2 layer as four 3x3 sub-filters / phases (25/9 x)) of
+ * Winograd launches of a 3x3 layer (4x what is executed), 6: of a 5x5 layer as four 3x3 sub-filters / phases (25/9 x), 7 / 8: F(3x3, 4x4)
+ * Winograd weight-gradient slab launches of 3x3 / 5x5 layers (4x / 25/9 x)) of
  * algorithmic FLOPs and elapsed ms, then clear */
 void crdr_profile_enable(int on);
 int crdr_profile_read(int kind, double* flops, double* ms, long long* launches);
@@ -223,6 +224,10 @@ typedef struct crdr_wgrad_desc {
  * (csrc/wino_wgrad.hip: 16 products per 2x2 tile of P and tap set instead of 36; same slabs, same deferred reduce), accepted for
  * kh = kw = 3, stride 1, QC > 4, exact fp32; its split bits divide the strips of 8 tiles instead of the 32-pixel tiles */
 int crdr_conv2d_wgrad_num_configs(void);
+/* Winograd weight-gradient slab kernels (3x3 stride 1, QC > 4, exact fp32): forced ids crdr_conv2d_wgrad_num_configs() = F(3x3, 2x2)
+ * (wino_wgrad.hip: 2.25x fewer products) and + 1 = F(3x3, 4x4) (wino4_wgrad.hip: 4x fewer; its transforms carry 2, 4, 8 and 1/4 .. 1/24,
+ * deviation from float64 ~1e-5 of the result's scale); bits 8..11 = log2 of the strip splits; same slabs / reduce as the direct kernels */
+int crdr_conv2d_wgrad_num_wino_configs(void);
 size_t crdr_conv2d_wgrad_workspace(const crdr_wgrad_desc* d);
 int crdr_conv2d_wgrad(const crdr_wgrad_desc* d, const float* p, const float* q, float* g, void* ws, size_t ws_bytes,
                       crdr_stream_t s);

@@ -427,6 +427,19 @@ def test_winograd_ids_are_planned_only_for_the_shapes_they_take(lib):
     def wdesc(k, stride):
         return L.WgradDesc(N=2, PH=32, PW=32, PC=96, ldp=96, QH=32, QW=32, QC=64, ldq=64, kh=k, kw=k, stride=stride, pad=k // 2, gI=96, gJ=64, accumulate=0, algo=nw)
     assert lib.crdr_conv2d_wgrad_workspace(C.byref(wdesc(3, 1))) == 9 * 96 * 64 * 4      # unsplit: one slab of 9 taps
+    # the F(3x3, 4x4) slab kernel: the id behind the last configuration; 3x3 stride 1 and 5x5 pad 2 (stride 1 / 2) with QC > 4
+    assert lib.crdr_conv2d_wgrad_num_wino_configs() == 2
+
+    def w4desc(k, stride, algo):
+        d = wdesc(k, stride)
+        d.algo = algo
+        return d
+    assert lib.crdr_conv2d_wgrad_workspace(C.byref(w4desc(3, 1, nw + 1))) == 9 * 96 * 64 * 4
+    assert lib.crdr_conv2d_wgrad_workspace(C.byref(w4desc(3, 1, (nw + 1) | (2 << 8)))) == 4 * 9 * 96 * 64 * 4   # 4 strip splits: 4 slabs
+    assert lib.crdr_conv2d_wgrad_workspace(C.byref(w4desc(5, 1, nw + 1))) == 25 * 96 * 64 * 4
+    assert lib.crdr_conv2d_wgrad_workspace(C.byref(w4desc(5, 2, nw + 1))) == 25 * 96 * 64 * 4
+    assert lib.crdr_conv2d_wgrad_workspace(C.byref(w4desc(3, 2, nw + 1))) == 0                                   # 3x3 stride 2: not taken
+    assert lib.crdr_conv2d_wgrad_workspace(C.byref(w4desc(3, 1, (nw + 1) | (8 << 8)))) == 0                       # 256 splits of 2 x 8 x 2 strips
     assert lib.crdr_conv2d_wgrad_workspace(C.byref(wdesc(5, 1))) == 0                     # rejected (0 = planning failed)
     assert lib.crdr_conv2d_wgrad_workspace(C.byref(wdesc(3, 2))) == 0
 

@@ -430,6 +430,9 @@ def _run_kind(kind, replay):
                 nwino += (algo & 0xFF) > ncfg + nstr   # (the F(4x4) kernel's ids may carry K splits in bits 8..11)
                 nsplit += algo >= 256
             r["wino4"] = bool(kind in ("c", "g", "m") and lib.crdr_conv2d_num_wino_configs() > 2 and (algo & 0xFF) == ncfg + 1 + nstr + 2)
+            if kind.startswith("w"):   # weight-gradient entries: the Winograd slab kernels are the last configuration and the id behind it
+                nwino += (algo & 0xFF) >= lib.crdr_conv2d_wgrad_num_configs()
+                r["wino4"] = (algo & 0xFF) == lib.crdr_conv2d_wgrad_num_configs() + 1   # F(3x3, 4x4): the same transform constants
             tol_plan, tol64 = _tolerances(key, r)
             rows.append({"key": repr(key), "algo": algo, "depth": _depth(key), **{k: v for k, v in r.items()}})
             fails = [n for n, v, t in (("vs_builtin", r["vs_builtin"], tol_plan), ("vs_f64", r["vs_f64"], tol64),

@@ -264,6 +264,56 @@ def test_winograd_f4x4_5x5_stride1(case):
         _close(dx, xr.grad, name + " dgrad", rtol=5e-5)
 
 
+WG5_CASES = [
+    # name, N, Cin, H, W, Cout, stride, log2 split   (5x5 pad 2 weight gradients through the F(3x3, 4x4) slab kernel: four 3x3 sub-problems)
+    ("wg5_s1_hoist", 4, 64, 16, 16, 160, 1, 0),       # the context model's stage
+    ("wg5_s1_ragged", 2, 36, 13, 22, 40, 1, 1),
+    ("wg5_s1_wide", 1, 32, 9, 70, 64, 1, 2),
+    ("wg5_s2_192", 2, 96, 32, 32, 96, 2, 1),           # Conv2d 5x5 s2: P = dy at 16 x 16, Q = x at 32 x 32
+    ("wg5_s2_ragged", 1, 40, 20, 44, 72, 2, 0),
+    ("wg5_s2_c4", 3, 12, 16, 16, 8, 2, 0),
+]
+
+
+@pytest.mark.parametrize("case", WG5_CASES, ids=[c[0] for c in WG5_CASES])
+def test_winograd_wgrad_5x5(case):
+    """5x5 weight gradients through wino4_wgrad.hip: stride 1 as four shifted sub-filters (taps 3 bi + a, 3 bj + b), stride 2 as four parity
+    sub-filters (taps 2 a + ph, 2 b + pw) over the parity planes of the larger operand -- Conv2d (P = dy) and ConvTranspose2d (P = x) -- vs
+    fp64 torch, with accumulation, bit-identical run to run"""
+    from crdr_amd.hip import lib as L
+    from crdr_amd.hip import ops
+    name, n, ci, h, w, co, st, ls = case
+    dev = _dev()
+    algo = (L.load().crdr_conv2d_wgrad_num_configs() + 1) | (ls << 8)
+    x = _rand(n, ci, h, w, seed=1)
+    wt = _rand(co, ci, 5, 5, seed=2, scale=(ci * 25) ** -0.5)
+    xr, wr = x.double(), wt.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride=st, padding=2)
+    dy = _rand(*ref.shape, seed=4)
+    ref.backward(dy.double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    g = torch.zeros(co, ci, 5, 5, device=dev)
+    ops.conv2d_wgrad_raw(dyd, xd, g, (5, 5), st, 2, accumulate=False, algo=algo)
+    gd = torch.zeros_like(g)
+    ops.conv2d_wgrad_raw(dyd, xd, gd, (5, 5), st, 2, accumulate=False, algo=1)
+    sc = wr.grad.abs().max().item()
+    print(f"{name}: wgrad max err / scale: F(3x3,4x4) {(g.cpu().double() - wr.grad).abs().max().item() / sc:.2e}  direct {(gd.cpu().double() - wr.grad).abs().max().item() / sc:.2e}")
+    _close(g, wr.grad, name + " wgrad", rtol=5e-5)
+    g2 = torch.zeros_like(g)
+    ops.conv2d_wgrad_raw(dyd, xd, g2, (5, 5), st, 2, accumulate=False, algo=algo)
+    assert torch.equal(g, g2)
+    ops.conv2d_wgrad_raw(dyd, xd, g, (5, 5), st, 2, accumulate=True, algo=algo)
+    _close(g, 2 * wr.grad, name + " wgrad accumulate", rtol=5e-5)
+    if st == 2 and h % 2 == 0 and w % 2 == 0:   # ConvTranspose2d 5x5 s2 p2 op1: P = x, Q = dy (twice the size)
+        wT = _rand(ci, co, 5, 5, seed=5, scale=(ci * 25 / 4) ** -0.5).double().requires_grad_(True)
+        rT = F.conv_transpose2d(xr, wT, None, stride=2, padding=2, output_padding=1)
+        dyT = _rand(*rT.shape, seed=6)
+        rT.backward(dyT.double())
+        gT = torch.zeros(ci, co, 5, 5, device=dev)
+        ops.conv2d_wgrad_raw(xd, dyT.to(dev), gT, (5, 5), 2, 2, accumulate=False, algo=algo)
+        _close(gT, wT.grad, name + " convT wgrad", rtol=5e-5)
+
+
 W4SPLIT_CASES = [
     # name, N, Cin, H, W, Cout, k, transposed, splits   (K splits inside the launch: partial tiles through slabs, last arriver reduces)
     ("w4sp_hoist_dgrad", 6, 608, 16, 16, 64, 5, 1, 6),      # the shape class it is for: many input channels, few tiles (5x5, two images per tile)
@@ -432,15 +482,18 @@ WG_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 1], ids=["f3x3_2x2", "f3x3_4x4"])
 @pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
-def test_winograd_wgrad(case):
-    """weight gradient through the Winograd F(3x3, 2x2) slab kernel (the last forced wgrad configuration) vs fp64 torch, for the
-    Conv2d and the ConvTranspose2d operand order, with and without accumulation"""
+def test_winograd_wgrad(case, variant):
+    """weight gradient through the Winograd slab kernels -- F(3x3, 2x2) (the last forced wgrad configuration) and F(3x3, 4x4) (the id
+    behind it, wino4_wgrad.hip) -- vs fp64 torch, for the Conv2d and the ConvTranspose2d operand order, with and without accumulation"""
     from crdr_amd.hip import lib as L
     from crdr_amd.hip import ops
     name, n, ci, h, w, co, p, ls = case
     dev = _dev()
-    algo = L.load().crdr_conv2d_wgrad_num_configs() | (ls << 8)
+    if variant and (n * ((h - 2 + 2 * p + 3) // 4) * ((w - 2 + 2 * p + 15) // 16)) >> ls < 1:
+        ls = 0   # (fewer strips of 4 x 16 pixels than the split asks for)
+    algo = (L.load().crdr_conv2d_wgrad_num_configs() + variant) | (ls << 8)
     x = _rand(n, ci, h, w, seed=1)
     wt = _rand(co, ci, 3, 3, seed=2, scale=(ci * 9) ** -0.5)
     xr, wr = x.double(), wt.double().requires_grad_(True)

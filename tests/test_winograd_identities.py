@@ -150,3 +150,52 @@ def test_5x5_stride1_as_four_shifted_subfilters_and_k_splits():
     whole = AT6 @ prod.sum(0) @ AT6.T
     parts = sum(AT6 @ prod[s:s + 4].sum(0) @ AT6.T for s in range(0, C, 4))
     assert np.allclose(whole, parts, atol=1e-11) and np.allclose(whole, sum(corr(dc[c], gc[c]) for c in range(C)), atol=1e-10)
+
+
+# ---- csrc/wino4_wgrad.hip: F(3x3, 4x4), the transposition of F(4x4, 3x3) (same points, same B^T) ---------------------------------------------
+V4 = np.array([[1, 0, 0, 0], [1, 1, 1, 1], [1, -1, 1, -1], [1, 2, 4, 8], [1, -2, 4, -8], [0, 0, 0, 1]], float)   # v4(): rows [1, x, x^2, x^3]
+D6 = np.array([1 / 4, -1 / 6, -1 / 6, 1 / 24, 1 / 24, 1.0])                                                      # left out of the K loop
+AT3 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 1]], float)
+
+
+def wg4(p4, q6):
+    """3x3 taps of the correlation of a 6x6 patch with a 4x4 tile: accumulate (V p V^T) . (B^T q B), scale by D D^T once, then A^T . A"""
+    u = (V4 @ p4 @ V4.T) * (BT6 @ q6 @ BT6.T)
+    return AT3 @ (u * np.outer(D6, D6)) @ AT3.T
+
+
+def test_f3x3_4x4_weight_gradient_and_its_5x5_forms():
+    rng = np.random.default_rng(7)
+    p, q = rng.standard_normal((4, 4)), rng.standard_normal((6, 6))
+    ref = np.array([[(p * q[r:r + 4, s:s + 4]).sum() for s in range(3)] for r in range(3)])
+    assert np.allclose(wg4(p, q), ref, atol=1e-11)
+    # v4() as the kernel evaluates it
+    x = rng.standard_normal(4)
+    e, d, e2, d2 = x[0] + x[2], x[1] + x[3], x[0] + 4 * x[2], x[1] + 4 * x[3]
+    assert np.allclose([x[0], e + d, e - d, e2 + 2 * d2, e2 - 2 * d2, x[3]], V4 @ x)
+    # the scaling commutes with the sum over tiles (it is applied once per workgroup)
+    ps, qs = rng.standard_normal((5, 4, 4)), rng.standard_normal((5, 6, 6))
+    u = sum((V4 @ a @ V4.T) * (BT6 @ b @ BT6.T) for a, b in zip(ps, qs))
+    assert np.allclose(AT3 @ (u * np.outer(D6, D6)) @ AT3.T, sum(wg4(a, b) for a, b in zip(ps, qs)), atol=1e-10)
+    # 5x5 stride 1, pad 2: g[r][s] = sum P[y][x] Q[y - 2 + r][x - 2 + s]; sub-filter (bi, bj) = taps (3 bi + a, 3 bj + b) from the patch displaced
+    # by (3 bi, 3 bj); one 4x4 tile of P at the origin, Q given with its halo (index + 2)
+    P, Q = rng.standard_normal((4, 4)), rng.standard_normal((4 + 7, 4 + 7))
+    ref5 = np.array([[(P * Q[r:r + 4, s:s + 4]).sum() for s in range(5)] for r in range(5)])
+    got5 = np.zeros((5, 5))
+    for bi in range(2):
+        for bj in range(2):
+            g = wg4(P, Q[3 * bi:3 * bi + 6, 3 * bj:3 * bj + 6])
+            na, nb = (2 if bi else 3), (2 if bj else 3)
+            got5[3 * bi:3 * bi + na, 3 * bj:3 * bj + nb] = g[:na, :nb]
+    assert np.allclose(got5, ref5, atol=1e-10)
+    # 5x5 stride 2, pad 2: g[r][s] = sum P[y][x] Q[2 y - 2 + r][2 x - 2 + s], r = 2 a + ph: sub-filter (ph, pw) over the parity plane
+    Q2 = rng.standard_normal((2 * 4 + 5, 2 * 4 + 5))          # index + 2 (halo)
+    ref2 = np.array([[sum(P[y, x] * Q2[2 * y + r, 2 * x + s] for y in range(4) for x in range(4)) for s in range(5)] for r in range(5)])
+    got2 = np.zeros((5, 5))
+    for ph in range(2):
+        for pw in range(2):
+            plane = Q2[ph::2, pw::2][:6, :6]                   # rows 2 (y + a) + ph: patch row u = y + a
+            g = wg4(P, plane)
+            na, nb = (2 if ph else 3), (2 if pw else 3)
+            got2[ph::2, pw::2][:na, :nb] = g[:na, :nb]
+    assert np.allclose(got2, ref2, atol=1e-10)

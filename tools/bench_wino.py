@@ -35,7 +35,7 @@ def main():
             dy = torch.randn(a.bs, co, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
             g = torch.zeros(co, ci, 3, 3, device=dev)
             res = {}
-            for name, cfgs in (("direct", range(0 if a.wino_only else nw - 1)), ("winograd", [nw - 1])):
+            for name, cfgs in (("direct", range(0 if a.wino_only else nw - 1)), ("winograd", [nw - 1]), ("f3x3_4x4", [nw])):
                 best = (1e9, 0, 0)
                 for cfg in cfgs:
                     for ls in range(9):
@@ -46,9 +46,10 @@ def main():
                         best = min(best, (t, cfg, ls))
                 res[name] = best
             fl = 2.0 * a.bs * hw * hw * ci * co * 9
-            d, w = res["direct"], res["winograd"]
+            d, w, w4 = res["direct"], res["winograd"], res["f3x3_4x4"]
             print(f"wgrad {co:4d}x{ci:4d} @{hw:3d}: direct {d[0] * 1e3:8.1f} us ({fl / d[0] / 1e9:6.1f} TF, cfg {d[1]} split {1 << d[2]})   winograd {w[0] * 1e3:8.1f} us "
-                  f"({fl / w[0] / 1e9:6.1f} TF-eq, split {1 << w[2]})   x{d[0] / w[0]:.2f}", flush=True)
+                  f"({fl / w[0] / 1e9:6.1f} TF-eq, split {1 << w[2]})   x{d[0] / w[0]:.2f}   F(3x3,4x4) {w4[0] * 1e3:8.1f} us ({fl / w4[0] / 1e9:6.1f} TF-eq, split {1 << w4[2]}) "
+                  f"x{d[0] / w4[0]:.2f}", flush=True)
         return
     if a.k5s2:
         for tr, ci, co, hw in [(1, 256, 256, 64), (0, 192, 192, 128), (0, 256, 256, 128), (1, 192, 192, 64), (1, 256, 256, 32), (0, 192, 192, 64), (0, 256, 256, 64), (1, 192, 192, 32)]:
