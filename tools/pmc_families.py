@@ -11,7 +11,7 @@ import glob
 import json
 import sys
 
-FAMILIES = [("igemm_kernel", "igemm_kernel"), ("gemm1x1_kernel", "gemm1x1_kernel"), ("wino4_filter_kernel", "wino4_filter_kernel"), ("wino4_kernel", "wino4_kernel"), ("wino_filter_kernel", "wino_filter_kernel"), ("wino_wgrad_kernel", "wino_wgrad_kernel"), ("wino_kernel", "wino_kernel"), ("wgrad_kernel", "wgrad_kernel"), ("wgrad_reduce_batched", "wgrad_reduce_batched_kernel"),
+FAMILIES = [("igemm_kernel", "igemm_kernel"), ("gemm1x1_kernel", "gemm1x1_kernel"), ("wino4_filter_kernel", "wino4_filter_kernel"), ("wino4_kernel", "wino4_kernel"), ("wino_filter_kernel", "wino_filter_kernel"), ("wino_wgrad_kernel", "wino_wgrad_kernel"), ("wino4_wgrad_kernel", "wino4_wgrad_kernel"), ("wino_kernel", "wino_kernel"), ("wgrad_kernel", "wgrad_kernel"), ("wgrad_reduce_batched", "wgrad_reduce_batched_kernel"),
             ("igemm_splitk_epilogue", "igemm_splitk_epilogue"), ("ebwd", "ebwd_kernel"), ("adam_dyn", "adam_dyn_kernel"),
             ("pack_weights_batched", "pack_weights_batched_kernel"), ("colsum_finish", "colsum_finish_"), ("colsum", "colsum_kernel"),
             ("gauss_cond_finish", "gauss_cond_finish_kernel"), ("gauss_cond_fwd", "gauss_cond_fwd_kernel"), ("gauss_cond_bwd", "gauss_cond_bwd_kernel"), ("eb", "eb_"),
