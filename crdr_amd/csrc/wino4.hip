@@ -787,6 +787,7 @@ constexpr size_t kTileSlabBytes = 4 * 2 * 16 * 64 * 16;
 // K splits (1 = none): the K range of a tile -- p.kchunks sub-steps of 4 channels, sub-filters included -- in `nsplit` equal parts
 bool wino4_split_ok(const crdr_conv_desc* d, int G, int nsplit) {
   if (nsplit == 1) return true;
+  if (d->flags & CRDR_CONV_NOSPLIT) return false;   // (the caller's workspace has no zeroed ticket head)
   const int mode = wino4_mode(d);
   if (!mode || nsplit < 1 || nsplit > 16) return false;
   const int nph = (mode == 2 || mode == 4) ? 4 : 1, Kc = cdiv(d->C, 4), K4 = Kc * nph, cnt = cdiv(K4, nsplit);
