@@ -281,6 +281,11 @@ __global__ __launch_bounds__(256) void gdn_fused_fwd_kernel(const GdnFusedArgs p
     };
     // (v_rsq_f32 / v_sqrt_f32: 1 ulp, one instruction each; the library sqrtf + division pair is ~25 and the epilogue of a wave that owns
     // its SIMD is not hidden behind anything.  n >= beta_min > 0: no denormal path)
+    // Every wave's K loop reads ALL channels of the tile as its A operand and the epilogue overwrites the wave's own channels in place:
+    // no wave may start writing before the slowest one has issued -- and received -- its last fragment (the last K step reads exactly
+    // wave 3's channels).  Without this barrier the kernel was correct only while the four waves stayed within one epilogue of each
+    // other, which nothing guarantees beside an RCCL kernel, a second resident workgroup (C <= 128) or a profiler.
+    gdn_wait_barrier<63>();
     if (p.mode) epilogue([](float, float n) { return n; });
     else if (p.inverse) epilogue([](float xv, float n) { return xv * __builtin_amdgcn_sqrtf(n); });
     else epilogue([](float xv, float n) { return xv * __builtin_amdgcn_rsqf(n); });

@@ -38,6 +38,13 @@ namespace crdr {
 namespace {
 
 constexpr int kNT4 = 256;
+#ifdef W4X_STAMPS   // diagnostic build only (tools/experiments): s_memtime at the phase boundaries of every tile, wave 0 of every workgroup
+__device__ unsigned long long w4_stamps[256 * 16 * 8];
+#define W4_STAMP(i) do { if (threadIdx.x == 0 && nt_ < 16) w4_stamps[(blockIdx.x * 16 + nt_) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W4_STAMP(i) do {} while (0)
+#endif
+
 // How the 32 Winograd tiles (4 x 4 outputs each) of an output tile lie over the image -- geometry 0: 2 rows x 16 columns (8 x 64 pixels:
 // images of >= 33 columns), geometry 1: 4 rows x 8 columns (16 x 32 pixels: the 32-column images, where geometry 0 would compute a
 // half-empty tile).  A wave owns 16 of them: tile row th (geometry 0) or tile rows 2 th, 2 th + 1 (geometry 1); lane (tx, kg) -> tile
@@ -69,25 +76,57 @@ __device__ __forceinline__ void lds_barrier4() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// 1-D data transform B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]] on scalars, in two
-// independent halves of 6 operations (outputs 0..2 / 3..5).  Scalars on purpose: packed f32 instructions issued beside MFMAs cost
-// several times their scalar pair on this part (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'); the file is compiled with
-// -fno-slp-vectorize.
-template <int HALF>
-__device__ __forceinline__ void bt6h(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
-                                     float& o0, float& o1, float& o2) {
-  if constexpr (HALF == 0) {
-    const float a = __builtin_fmaf(-4.0f, d2, d4), b = __builtin_fmaf(-4.0f, d1, d3);
-    o0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
-    o1 = a + b;
-    o2 = a - b;
-  } else {
-    const float c = d4 - d2, e = d3 - d1;
-    o0 = __builtin_fmaf(2.0f, e, c);
-    o1 = __builtin_fmaf(-2.0f, e, c);
-    o2 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
-  }
+// 1-D data transform B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]] in PACKED fp32
+// (v_pk_fma_f32 / v_pk_add_f32: two lanes of arithmetic per instruction).  What the issue probe (tools/experiments/issue_probe_gen.py,
+// profiles/r5_issue_probe.txt) says about this part: a wave's own vector instructions do NOT overlap its exact-fp32 MFMAs -- every
+// v_fma_f32 beside v_mfma_f32_16x16x4_f32 costs ~5 cycles of matrix time plus ~7 per gap that holds any (72 gaps with two each: +1 217
+// cycles on 2 304; the same 144 in 9 clusters: +772), a v_pk_fma_f32 costs the same ~5.7 as a scalar one (72 in 9 clusters: +412), while LDS
+// reads and LDS-DMA pieces issued DIRECTLY behind an MFMA are free (behind a VALU instruction they wait for it: +1 050 per sub-step).  So:
+// the transform is written in packed form (72 instead of 144 instructions per sub-step), in 10 clusters, and every memory instruction sits
+// right behind an MFMA.  Same operations in the same association as the scalar form (every step an fma or an exact add): bit-identical.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v pk_fma(f32x2v a, f32x2v b, f32x2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2v pk_bc(float v) { return f32x2v{v, v}; }
+// The clusters are single asm statements: left to itself the compiler turns about a third of the packed operations back into scalar pairs
+// (measured: 41 v_pk_fma_f32 + 38 v_fma_f32 where 60 packed ones were written).  Inside a statement no packed result is read by the very next
+// instruction (gfx950 wants one wait state there -- the compiler inserts it for its own code and, conservatively, behind an asm statement
+// whose outputs the next VALU instruction reads).  Constant pairs live in scalar registers (one scalar source per instruction).
+struct W4Consts { f32x2v k41, k12, kn12, k5; };   // (-4, -1), (1, 2), (-1, -2), (-5, -5)
+// vertical pass, two patch columns at once: D[i] = (d[i][b], d[i][b + 1]) -> T[xi] = (t[xi][b], t[xi][b + 1]): 12 packed operations
+__device__ __forceinline__ void bt6_cols(const f32x2v (&D)[6], f32x2v (&T)[6], const W4Consts& kc) {
+  f32x2v a, b, x, c, e, y;
+  asm volatile(
+      "v_pk_fma_f32 %6, %14, -4.0, %16 op_sel_hi:[1,0,1]\n"     // a = d4 - 4 d2
+      "v_pk_fma_f32 %7, %13, -4.0, %15 op_sel_hi:[1,0,1]\n"     // b = d3 - 4 d1
+      "v_pk_fma_f32 %8, %14, %18, %16 op_sel_hi:[1,0,1]\n"      // x = d4 - 5 d2
+      "v_pk_add_f32 %9, %16, %14 neg_lo:[0,1] neg_hi:[0,1]\n"   // c = d4 - d2
+      "v_pk_add_f32 %10, %15, %13 neg_lo:[0,1] neg_hi:[0,1]\n"  // e = d3 - d1
+      "v_pk_fma_f32 %11, %15, %18, %17 op_sel_hi:[1,0,1]\n"     // y = d5 - 5 d3
+      "v_pk_add_f32 %1, %6, %7\n"                                // t1 = a + b
+      "v_pk_add_f32 %2, %6, %7 neg_lo:[0,1] neg_hi:[0,1]\n"     // t2 = a - b
+      "v_pk_fma_f32 %0, %12, 4.0, %8 op_sel_hi:[1,0,1]\n"       // t0 = 4 d0 + x
+      "v_pk_fma_f32 %3, %10, 2.0, %9 op_sel_hi:[1,0,1]\n"       // t3 = c + 2 e
+      "v_pk_fma_f32 %4, %10, -2.0, %9 op_sel_hi:[1,0,1]\n"      // t4 = c - 2 e
+      "v_pk_fma_f32 %5, %13, 4.0, %11 op_sel_hi:[1,0,1]"         // t5 = 4 d1 + y
+      : "=&v"(T[0]), "=&v"(T[1]), "=&v"(T[2]), "=&v"(T[3]), "=&v"(T[4]), "=&v"(T[5]), "=&v"(a), "=&v"(b), "=&v"(x), "=&v"(c), "=&v"(e), "=&v"(y)
+      : "v"(D[0]), "v"(D[1]), "v"(D[2]), "v"(D[3]), "v"(D[4]), "v"(D[5]), "s"(kc.k5));
 }
+// horizontal pass of one row, inside the vector: P0 = (t0, t1), P1 = (t2, t3), P2 = (t4, t5) -> V[0] = (v0, v5), V[1] = (v1, v3), V[2] = (v2, v4):
+// 6 packed operations (the half selects travel in the instructions' op_sel bits)
+__device__ __forceinline__ void bt6_row(const f32x2v P0, const f32x2v P1, const f32x2v P2, f32x2v (&V)[3], const W4Consts& kc) {
+  f32x2v ac, be, xy;
+  asm volatile(
+      "v_pk_fma_f32 %3, %7, %9, %8 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n"   // (a, c) = t2 (-4, -1) + t4
+      "v_pk_fma_f32 %4, %6, %9, %7 op_sel:[1,0,1] op_sel_hi:[1,1,1]\n"   // (b, e) = t1 (-4, -1) + t3
+      "v_pk_fma_f32 %5, %7, %12, %8 op_sel_hi:[1,0,1]\n"                  // (x, y) = (t4, t5) - 5 (t2, t3)
+      "v_pk_fma_f32 %1, %4, %10, %3\n"                                    // (v1, v3) = (a + b, c + 2 e)
+      "v_pk_fma_f32 %2, %4, %11, %3\n"                                    // (v2, v4) = (a - b, c - 2 e)
+      "v_pk_fma_f32 %0, %6, 4.0, %5 op_sel_hi:[1,0,1]"                    // (v0, v5) = 4 (t0, t1) + (x, y)
+      : "=&v"(V[0]), "=&v"(V[1]), "=&v"(V[2]), "=&v"(ac), "=&v"(be), "=&v"(xy)
+      : "v"(P0), "v"(P1), "v"(P2), "s"(kc.k41), "s"(kc.k12), "s"(kc.kn12), "s"(kc.k5));
+}
+// element y of a transformed row kept as V[0] = (v0, v5), V[1] = (v1, v3), V[2] = (v2, v4)
+__device__ __forceinline__ float v_elem(const f32x2v (&V)[3], int y) { return y == 0 ? V[0].x : y == 1 ? V[1].x : y == 2 ? V[2].x : y == 3 ? V[1].y : y == 4 ? V[2].y : V[0].y; }
 
 // 1-D output transform A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]: 10 operations
 __device__ __forceinline__ void at6(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
@@ -97,6 +136,16 @@ __device__ __forceinline__ void at6(const float m0, const float m1, const float 
   o1 = __builtin_fmaf(2.0f, w, q);
   o2 = __builtin_fmaf(4.0f, u, p);
   o3 = __builtin_fmaf(8.0f, w, q) + m5;
+}
+// the same on two channels at once (packed fp32: the epilogue's vector instructions are not hidden behind anything either -- same
+// operations, same association, bit-identical)
+__device__ __forceinline__ void at6_pk(const f32x2v m0, const f32x2v m1, const f32x2v m2, const f32x2v m3, const f32x2v m4, const f32x2v m5,
+                                       f32x2v& o0, f32x2v& o1, f32x2v& o2, f32x2v& o3) {
+  const f32x2v p = m1 + m2, q = m1 - m2, u = m3 + m4, w = m3 - m4;
+  o0 = m0 + p + u;
+  o1 = pk_fma(pk_bc(2.0f), w, q);
+  o2 = pk_fma(pk_bc(4.0f), u, p);
+  o3 = pk_fma(pk_bc(8.0f), w, q) + m5;
 }
 
 struct Wino4Tile { int gidx, n, oh0, ow0, n0, patch, tn, phase, lin, ks, kbeg, kcnt; };   // lin: index of the tile among the launch's tiles; K split ks works sub-steps [kbeg, kbeg + kcnt)   // phase: output phase of a stride-2 transposed conv (0 otherwise)
@@ -195,13 +244,13 @@ __device__ __forceinline__ int wino4_raw_soff(const IgemmArgs& p, int kr) {
   if (FORM == 1) return ch * 16;   // (the displacement of a shifted sub-filter sits in the lane offsets: wino4_in_off)
   return ch * 16 + ((sub >> 1) * p.W + (sub & 1)) * p.ldx * 4;
 }
-// filter piece 9 wave + j (j = 0..8) of block kf -> filter buffer fbuf
+// filter piece 9 wave + j (j = 0..8) of block kf -> filter buffer fbuf (the piece's displacement is wave-uniform: it travels in the scalar
+// offset, the lane part is the same register for every piece -- no vector add per request)
 __device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, __amdgpu_buffer_rsrc_t ru, int j, int kf, int fbuf, int lane, int wave) {
   const int piece = wave * 9 + j;
-  const unsigned off = (unsigned)((piece * 64 + lane) * 16);
   // (u_off0 is wave-uniform; said so explicitly, or the compiler wraps every request in a waterfall loop over the scalar offset)
-  const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)sr.u_off0) + (unsigned)kf * (kUSlots4 * 16u);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(smem + kRawBufs * kRF + fbuf * kFF + piece * 256), 16, (int)off, (int)so, 0, 0);
+  const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)sr.u_off0) + (unsigned)kf * (kUSlots4 * 16u) + (unsigned)piece * 1024u;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(smem + kRawBufs * kRF + fbuf * kFF + piece * 256), 16, lane * 16, (int)so, 0, 0);
 }
 // the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and filter blocks 0, 1 (-> F0, F1)
 template <int FORM>
@@ -217,18 +266,21 @@ __device__ __forceinline__ void wino4_prologue_dma(const IgemmArgs& p, float* sm
 }
 
 // K loop of one wave (the only wave of its SIMD: nothing else hides its latencies, so the loop is software pipelined by hand).
-// LDS: raw-patch buffers R0..R2, filter buffers F0, F1.  Sub-step k multiplies V_k (registers) with the filters of F[k & 1]; in the
-// shadow of those 72 MFMAs the wave reads raw patch k + 1 from R[(k + 1) % 3] and transforms it into V_{k+1}, and issues the DMA of
-// filter block k + 1 (-> F[(k + 1) & 1], last read in sub-step k - 1; filters come out of L2) and of raw patch k + 3 (-> R[k % 3], last
-// read in sub-step k - 1).  The sub-step ends with vmcnt(13) + barrier: what it requested itself stays in flight, everything older has landed.  72 slots, pinned by sched_barrier:
-//   slot s: MFMA of position j = s / 2 (transform row x = j / 6), channel block s % 2; the two filter fragments of position j + 4
-//   requested at slot 2 j + 1; raw column b (6 pixels) requested in slots 6 b, 6 b + 2, 6 b + 4 (two each), its vertical transform in slots 6 b + 8 and
-//   6 b + 11 (half each); horizontal transform of row x < 5 of V_{k+1} in slots 44 + 5 x and 46 + 5 x -- straight into the registers of
-//   V_k's row x, whose MFMAs (slots 12 x .. 12 x + 11) are done by then; row 5 follows at the top of the next sub-step; DMA instruction
-//   q (9 filter pieces, then 4 raw pieces) at slot 5 q + 2.
+// LDS: raw-patch buffers R0..R2, filter buffers F0..F2.  Sub-step k multiplies V_k (registers) with the filters of F[k % 3]; beside those 72
+// MFMAs the wave reads raw patch k + 1 from R[(k + 1) % 3] and transforms it into V_{k+1}, and issues the DMA of filter block k + 2 and of
+// raw patch k + 3.  The sub-step ends with vmcnt(13) + barrier: what it requested itself stays in flight, everything older has landed.
+// Schedule of a sub-step (round 5, after the issue probe: VALU never hides behind an fp32 MFMA of the same wave, memory instructions do if
+// they are issued directly behind one), 72 slots pinned by sched_barrier:
+//   slot s: MFMA of position j = s / 2 (transform row x = j / 6), channel block s % 2, followed by AT MOST ONE memory instruction --
+//     odd s < 64: the two filter fragments of position j + 4 (one ds_read_b64, four positions ahead of their use);
+//     even s < 36: raw pair r = s / 2 = pixels (i, 2 c), (i, 2 c + 1) of patch row i = r % 6, column pair c = r / 6 (one ds_read2st64_b32);
+//     even s in 36 .. 60: DMA instruction (s - 36) / 2 (9 filter pieces, then 4 raw pieces);
+//   then the slot's VALU cluster, if any: vertical pass of column pair c (12 packed operations) at s = 15 + 12 c; horizontal pass of row
+//     x < 5 of V_{k+1} (6 packed operations) at s = 41, 44, 47, 50, 62 -- straight into the registers of V_k's row x, whose MFMAs (slots 12 x
+//     .. 12 x + 11) are done by then; row 5 follows at the top of the next sub-step.
 template <int GEO, int FORM>
 __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& tl, float* smem, Wino4Src& sr, bool prefetched, int lane, int wave,
-                                           f32x4 (&acc)[64], f32x4 (&accv)[8]) {
+                                           f32x4 (&acc)[64], f32x4 (&accv)[8], int nt_ = 0) {
   const int K4 = tl.kcnt, kbeg = tl.kbeg;   // this work item's sub-steps: kbeg .. kbeg + K4 - 1 of the tile's p.kchunks
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
   // this lane's raw reads: patch pixel (i, j) of tile (th, tx), channel kg: float offset rbase + ro(i, j) of a raw buffer
@@ -238,18 +290,22 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
   // + buffer * kFF + pos * 256
   const int fbase = kRawBufs * kRF + kg * kBN4 + 32 * oh + 2 * tx;
 
-  float t[6][6];   // vertical pass of the patch being transformed: [xi][column]
-  float v[6][6];   // V of the current sub-step (rows 0..4: replaced in place by the next one's during the sub-step)
-  float dcol[2][6];   // raw pixels of one patch column, double buffered by column parity
-  auto vread = [&](const float* rp, int b, int i) __attribute__((always_inline)) { dcol[b & 1][i] = rp[ro(i, b)]; };
-  auto vpass0 = [&](int b) __attribute__((always_inline)) {
-    bt6h<0>(dcol[b & 1][0], dcol[b & 1][1], dcol[b & 1][2], dcol[b & 1][3], dcol[b & 1][4], dcol[b & 1][5], t[0][b], t[1][b], t[2][b]);
+  const W4Consts kc = {f32x2v{-4.0f, -1.0f}, f32x2v{1.0f, 2.0f}, f32x2v{-1.0f, -2.0f}, f32x2v{-5.0f, -5.0f}};
+  f32x2v T[6][3];      // vertical pass of the patch being transformed: T[xi][c] = (t[xi][2 c], t[xi][2 c + 1])
+  f32x2v V[6][3];      // V of the current sub-step, row x as (v0, v5), (v1, v3), (v2, v4) (rows 0..4: replaced in place by the next one's during the sub-step)
+  f32x2v D[2][6];      // raw pixels of one column pair, double buffered by the pair's parity: D[c & 1][i] = (d[i][2 c], d[i][2 c + 1])
+  // (the two pixels are one class apart -- 1 KiB = 4 x 64 floats: one ds_read2st64_b32; columns 2 c, 2 c + 1 never straddle a slot)
+  auto vread = [&](const float* rp, int r) __attribute__((always_inline)) {
+    const int c = r / 6, i = r - 6 * c;
+    D[c & 1][i] = f32x2v{rp[ro(i, 2 * c)], rp[ro(i, 2 * c + 1)]};
   };
-  auto vpass1 = [&](int b) __attribute__((always_inline)) {
-    bt6h<1>(dcol[b & 1][0], dcol[b & 1][1], dcol[b & 1][2], dcol[b & 1][3], dcol[b & 1][4], dcol[b & 1][5], t[3][b], t[4][b], t[5][b]);
+  auto vpass = [&](int c) __attribute__((always_inline)) {
+    f32x2v t6[6];
+    bt6_cols(D[c & 1], t6, kc);
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) T[xi][c] = t6[xi];
   };
-  auto hpass0 = [&](int x) __attribute__((always_inline)) { bt6h<0>(t[x][0], t[x][1], t[x][2], t[x][3], t[x][4], t[x][5], v[x][0], v[x][1], v[x][2]); };
-  auto hpass1 = [&](int x) __attribute__((always_inline)) { bt6h<1>(t[x][0], t[x][1], t[x][2], t[x][3], t[x][4], t[x][5], v[x][3], v[x][4], v[x][5]); };
+  auto hpass = [&](int x) __attribute__((always_inline)) { bt6_row(T[x][0], T[x][1], T[x][2], V[x], kc); };
 
   // ---- prologue: filter block 0 and patches 0, 1, 2 (requested by the previous tile's epilogue where there was one: then at least 32
   // younger vector-memory operations -- that tile's stores -- are in flight and need not be waited for); V_0 rows 0..4 and the
@@ -264,17 +320,13 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
   {
     const float* rp = smem + rbase;
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
+    for (int c = 0; c < 3; ++c) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) vread(rp, b, i);
-      vpass0(b);
-      vpass1(b);
+      for (int i = 0; i < 6; ++i) vread(rp, 6 * c + i);
+      vpass(c);
     }
 #pragma unroll
-    for (int x = 0; x < 5; ++x) {
-      hpass0(x);
-      hpass1(x);
-    }
+    for (int x = 0; x < 5; ++x) hpass(x);
   }
 
   int r1 = 1, r0 = 0;   // raw buffer of patch k + 1 / of patch k (= the one patch k + 3 goes to)
@@ -286,6 +338,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
       for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub3);
     }
   }
+  W4_STAMP(2);
   for (int k = 0; k < K4; ++k) {
     // (the two base offsets are made opaque: every LDS read of the sub-step is then `base register + 16-bit immediate`; left visible,
     // the compiler folds the buffer constants into the offsets, overflows the immediate and spends an add per read)
@@ -304,42 +357,38 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
       uf[j][0] = u2[0];
       uf[j][1] = u2[1];
     }
-    hpass0(5);   // row 5 of V_k (its vertical pass was done during the previous sub-step; its MFMAs are the last ones)
-    hpass1(5);
+    hpass(5);   // row 5 of V_k (its vertical pass was done during the previous sub-step; its MFMAs are the last ones)
     __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(full)
     for (int s = 0; s < 72; ++s) {
       const int j = s >> 1, ob = s & 1, x = j / 6, y = j - 6 * x;
       // 72 blocks x 4 = 288 accumulator registers: 64 blocks in the accumulation half of the register file, the last 8 (positions 32..35)
       // pinned to ordinary vector registers (left to the compiler they bounce between the two files: 72 moves per sub-step)
-      if (s < 64) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[j & 7][ob], v[x][y], acc[s], 0, 0, 0);
-      else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[s - 64]) : "v"(uf[j & 7][ob]), "v"(v[x][y]));
+      if (s < 64) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[j & 7][ob], v_elem(V[x], y), acc[s], 0, 0, 0);
+      else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[s - 64]) : "v"(uf[j & 7][ob]), "v"(v_elem(V[x], y)));
+      // the slot's memory instruction, directly behind the MFMA
       if (ob == 1 && j + 4 < 36) {   // four positions (8 slots) ahead of their use
         const f32x2 u2 = *reinterpret_cast<const f32x2*>(fp + (j + 4) * 256);
         uf[(j + 4) & 7][0] = u2[0];
         uf[(j + 4) & 7][1] = u2[1];
       }
-      if (s < 36 && (s & 1) == 0) {   // raw column b = s / 6, pixels s % 6 and s % 6 + 1: same slot row, classes 4 KiB apart = one ds_read2st64_b32
-        vread(rp, s / 6, s % 6);
-        vread(rp, s / 6, s % 6 + 1);
-      }
-      // vertical pass of column b: outputs 0..2 (inputs 0..4, the last one requested at slot 6 b + 4) at slot 6 b + 8, outputs 3..5
-      // (inputs 1..5) at slot 6 b + 11; the column buffer is overwritten from slot 6 b + 12 (input 0) / 6 b + 13 (input 1) on
-      if (s >= 8 && s < 44) {
-        if ((s - 8) % 6 == 0) vpass0((s - 8) / 6);
-        if ((s - 8) % 6 == 3) vpass1((s - 8) / 6);
-      }
-      // horizontal pass of row x < 5 at slots 44 + 5 x and 46 + 5 x (the row's MFMAs ended at slot 12 x + 11)
-      if (s >= 44 && s < 69) {
-        if ((s - 44) % 5 == 0) hpass0((s - 44) / 5);
-        if ((s - 44) % 5 == 2) hpass1((s - 44) / 5);
-      }
-      if (s % 5 == 2 && s / 5 < 13) {
-        const int q = s / 5;
+      if (ob == 0 && s < 36) vread(rp, s >> 1);
+      if (ob == 0 && s >= 36 && s <= 60) {
+        const int q = (s - 36) >> 1;
         if (q < 9) wino4_dma_filt(smem, sr, ru2, q, kbeg + k + 2, f2, lane, wave);
         else wino4_dma_raw(smem, sr, rx3, q - 9, soff3, r0, lane, wave);
       }
       __builtin_amdgcn_sched_barrier(0);
+      // the slot's VALU cluster
+      if (s == 15) vpass(0);
+      if (s == 27) vpass(1);
+      if (s == 39) vpass(2);
+      if (s == 41) hpass(0);
+      if (s == 44) hpass(1);
+      if (s == 47) hpass(2);
+      if (s == 50) hpass(3);
+      if (s == 62) hpass(4);
+      if (s == 15 || s == 27 || s == 39 || s == 41 || s == 44 || s == 47 || s == 50 || s == 62) __builtin_amdgcn_sched_barrier(0);
     }
     r0 = r1;
     r1 = r1 == 2 ? 0 : r1 + 1;
@@ -378,10 +427,23 @@ __device__ __forceinline__ float acc_read(float v) {
 // stores, takes a ticket on the tile, and the last arriver adds the slabs in split order and runs the epilogue (the hand-off protocol of
 // igemm_kernel.hpp's in-launch split-K: sc1 stores, vmcnt(0), barrier, one agent-scope atomic, acquire, sc1 loads; a workgroup either
 // leaves or reduces, nobody spins).
-template <int GEO, bool SPLIT>
+// Epilogue classes: the flags a launch MAY carry, as a compile-time superset (the kernel tests `p.flags & FM`, so the passes of every other
+// flag disappear from the code: the general epilogue is 51 KB of instructions beside a 2 KB loop -- a 128-channel tile ran 5.6 us faster
+// with only its own flags compiled in).  0: bias / (Leaky)ReLU / vec2 / affine (no operand tensors), 1: + residual, 2: the input-gradient
+// launches of a conv chain (ReLU masks, column sums, accumulate), 3: everything.
+constexpr int kW4EpiA = CRDR_EPI_BIAS | CRDR_EPI_RELU | CRDR_EPI_LRELU | CRDR_EPI_VEC2 | CRDR_EPI_AFFINE;
+constexpr int kW4EpiC = CRDR_EPI_BIAS | CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK | CRDR_EPI_MASKOFF | CRDR_EPI_COLSUM | CRDR_EPI_ACCUM;
+constexpr int kW4EpiAll = kW4EpiA | kW4EpiC | CRDR_EPI_RES;
+constexpr int w4_epi_mask(int cls) { return cls == 0 ? kW4EpiA : cls == 1 ? (kW4EpiA | CRDR_EPI_RES) : cls == 2 ? kW4EpiC : kW4EpiAll; }
+constexpr int w4_epi_class(int flags) {
+  const int f = flags & kW4EpiAll;
+  return (f & ~w4_epi_mask(0)) == 0 ? 0 : (f & ~w4_epi_mask(1)) == 0 ? 1 : (f & ~w4_epi_mask(2)) == 0 ? 2 : 3;
+}
+
+template <int GEO, bool SPLIT, int FM>
 __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile& tl, float* smem, const float* sV, int lane, int wave, f32x4 (&acc)[64],
                                              f32x4 (&accv)[8]) {
-  const int f = p.flags;
+  const int f = p.flags & FM;
   const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
   const bool do_cs = (f & CRDR_EPI_COLSUM) != 0, accum = (f & CRDR_EPI_ACCUM) != 0;
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
@@ -406,23 +468,36 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
   auto soff = [&](int ld, int a, int b) __attribute__((always_inline)) { return so * (a * p.OW + b) * ld * 4; };
   float* sC = smem + kRawBufs * kRF + 2 * kFF;   // column sums: [wave 4][which 2][ob 2][64 lanes][4 r] = 16 KiB in filter buffer F2 (F0, F1 receive the next tile's blocks 0, 1)
 
-  // output transform of channel register r of half ob: s[a][nu] = sum_xi AT[a][xi] M[xi][nu], then Y[a][b] = sum_nu AT[b][nu] s[a][nu]
+  // output transform of half ob, two channel registers (r, r + 1) at a time in packed fp32: s[a][nu] = sum_xi AT[a][xi] M[xi][nu], then
+  // Y[a][b] = sum_nu AT[b][nu] s[a][nu]
   auto out_transform = [&](int ob, float (&yv)[4][4][4]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float sv[4][6];
+    for (int rp = 0; rp < 2; ++rp) {
+      f32x2v sv[4][6];
 #pragma unroll
       for (int nu = 0; nu < 6; ++nu) {
-        float mcol[6];
+        f32x2v mcol[6];
 #pragma unroll
         for (int xi = 0; xi < 6; ++xi) {
           const int blk = 2 * (xi * 6 + nu) + ob;
-          mcol[xi] = blk < 64 ? acc_read(acc[blk < 64 ? blk : 0][r]) : accv[blk >= 64 ? blk - 64 : 0][r];
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            mcol[xi][e] = blk < 64 ? acc_read(acc[blk < 64 ? blk : 0][2 * rp + e]) : accv[blk >= 64 ? blk - 64 : 0][2 * rp + e];
         }
-        at6(mcol[0], mcol[1], mcol[2], mcol[3], mcol[4], mcol[5], sv[0][nu], sv[1][nu], sv[2][nu], sv[3][nu]);
+        at6_pk(mcol[0], mcol[1], mcol[2], mcol[3], mcol[4], mcol[5], sv[0][nu], sv[1][nu], sv[2][nu], sv[3][nu]);
       }
 #pragma unroll
-      for (int a = 0; a < 4; ++a) at6(sv[a][0], sv[a][1], sv[a][2], sv[a][3], sv[a][4], sv[a][5], yv[a][0][r], yv[a][1][r], yv[a][2][r], yv[a][3][r]);
+      for (int a = 0; a < 4; ++a) {
+        f32x2v y0, y1, y2, y3;
+        at6_pk(sv[a][0], sv[a][1], sv[a][2], sv[a][3], sv[a][4], sv[a][5], y0, y1, y2, y3);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          yv[a][0][2 * rp + e] = y0[e];
+          yv[a][1][2 * rp + e] = y1[e];
+          yv[a][2][2 * rp + e] = y2[e];
+          yv[a][3][2 * rp + e] = y3[e];
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -472,8 +547,9 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
                    base_m = (pix00 * (unsigned)p.ldmask + (unsigned)c0) * 4u;
     auto voff = [&](unsigned base, int a, int b) __attribute__((always_inline)) { return ((okm >> (4 * a + b)) & 1u) ? base : kOobOffset; };
     // residual / mask / accumulate operands, 8 pixels (two output rows) at a time.  Launches carry at most one of them as a rule (the
-    // ReLU mask of an input-gradient conv, the residual of a forward one): that one is requested for both halves up front and its
-    // latency hides behind the output transform; with several present they are fetched where they are used.
+    // ReLU mask of an input-gradient conv, the residual of a forward one): that one's first half is requested up front and its latency
+    // hides behind the output transform, the second half behind the first half's arithmetic; with several present they are fetched where
+    // they are used.
     const int nopnd = (has_res ? 1 : 0) + (has_mask ? 1 : 0) + (accum ? 1 : 0);
     f32x4 opnd[2][8];
     auto fetch = [&](f32x4 (&dst)[8], __amdgpu_buffer_rsrc_t rs, unsigned base, int ld, int hf) __attribute__((always_inline)) {
@@ -483,14 +559,12 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
         dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff(base, a, b), soff(ld, a, b), 0));
       }
     };
-    if (nopnd == 1) {
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        if (has_res) fetch(opnd[hf], rr, base_r, p.ldres, hf);
-        else if (has_mask) fetch(opnd[hf], rm, base_m, p.ldmask, hf);
-        else fetch(opnd[hf], ry, base_y, p.ldy, hf);
-      }
-    }
+    auto fetch_single = [&](int hf) __attribute__((always_inline)) {
+      if (has_res) fetch(opnd[hf], rr, base_r, p.ldres, hf);
+      else if (has_mask) fetch(opnd[hf], rm, base_m, p.ldmask, hf);
+      else fetch(opnd[hf], ry, base_y, p.ldy, hf);
+    };
+    if (nopnd == 1) fetch_single(0);   // (half 1 follows behind half 0's arithmetic: 32 registers less across the output transform)
     const f32x4 bias = *reinterpret_cast<const f32x4*>(sV + 0 * kBN4 + cl);
     const f32x4 vec2 = *reinterpret_cast<const f32x4*>(sV + 1 * kBN4 + cl);
     const f32x4 scale = *reinterpret_cast<const f32x4*>(sV + 2 * kBN4 + cl);
@@ -519,6 +593,7 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
     // element: every instruction here is matrix time lost)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
+      if (nopnd == 1 && hf == 0) fetch_single(1);
       f32x4 o[8];
       bool pix_ok[8];
 #pragma unroll
@@ -646,7 +721,7 @@ __device__ __forceinline__ void wino4_vectors(const IgemmArgs& p, const IgemmGro
 // Persistent: at most one workgroup per CU, each walks the tiles vb = blockIdx.x, + gridDim.x, ...  Between the K loop and the
 // epilogue of a tile the waves request the next tile's first raw patches and filter block (the buffers are free by then) and its
 // epilogue vectors: the DMA latency of a fresh tile and the memory latency of the stores hide behind each other.
-template <int GEO, int FORM, bool SPLIT>
+template <int GEO, int FORM, bool SPLIT, int EC>
 __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const IgemmGroup grp, int gx, int gyn, int gz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -656,7 +731,11 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
   int cur = 0;
   bool prefetched = false;
   Wino4Src sr;
+  int nt_ = -1;
+  (void)nt_;
   for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+    ++nt_;
+    W4_STAMP(0);
     // (per-lane constants are re-derived per tile instead of staying live across the register-hungry epilogue)
     int lane = lane_, wave = wave_;
     asm volatile("" : "+v"(lane));
@@ -678,16 +757,24 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     for (int j = 0; j < 64; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) accv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wino4_loop<GEO, FORM>(p, tl, smem, sr, prefetched, lane, wave, acc, accv);
+    W4_STAMP(1);
+    wino4_loop<GEO, FORM>(p, tl, smem, sr, prefetched, lane, wave, acc, accv, nt_);
+    W4_STAMP(3);
     // (the loop ends with a barrier: every wave is past its last LDS read, raw and filter buffers are free)
     const bool more = vb + (int)gridDim.x < total;
     if (more) {   // the next tile: raw patches 0, 1, 2, filter block 0 and the epilogue vectors
       const Wino4Tile tn = wino4_tile<GEO>(p_, vb + (int)gridDim.x, gx, gyn, gz);
-      sr = wino4_src<GEO, FORM>(p_, grp, tn, gyn_abs, lane, wave);
-      wino4_prologue_dma<FORM>(p_, smem, sr, tn.kbeg, tn.kcnt, lane, wave);
+      // (the vectors FIRST: their global loads are waited for with vmcnt(0) before they go to LDS, and vector-memory operations retire in
+      // issue order -- behind the 30 DMA requests that wait would sit out the whole DMA latency: 9 000 cycles per tile by the stamps)
       wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * (4 * kBN4), tid);
+      W4_STAMP(6);
+      sr = wino4_src<GEO, FORM>(p_, grp, tn, gyn_abs, lane, wave);
+      W4_STAMP(7);
+      wino4_prologue_dma<FORM>(p_, smem, sr, tn.kbeg, tn.kcnt, lane, wave);
     }
-    wino4_finish<GEO, SPLIT>(p, tl, smem, sV, lane, wave, acc, accv);
+    W4_STAMP(4);
+    wino4_finish<GEO, SPLIT, w4_epi_mask(EC)>(p, tl, smem, sV, lane, wave, acc, accv);
+    W4_STAMP(5);
     prefetched = more;
     cur ^= 1;
     lds_barrier4();   // column-sum area, sV of this tile: free (the stores stay in flight: the next tile's first wait is vmcnt(32))
@@ -908,25 +995,33 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
   const int gx = wino4_patches(d, mode);
   const int total = gx * ntile * G * a.so * a.so;
   using Kern = void (*)(const IgemmArgs, const IgemmGroup, int, int, int);
-  static const Kern kerns[2][2][3] = {{{wino4_kernel<0, 0, false>, wino4_kernel<1, 0, false>, wino4_kernel<2, 0, false>},
-                                       {wino4_kernel<0, 1, false>, wino4_kernel<1, 1, false>, wino4_kernel<2, 1, false>}},
-                                      {{wino4_kernel<0, 0, true>, wino4_kernel<1, 0, true>, wino4_kernel<2, 0, true>},
-                                       {wino4_kernel<0, 1, true>, wino4_kernel<1, 1, true>, wino4_kernel<2, 1, true>}}};
+#define W4_ROW(SP, F, E) {wino4_kernel<0, F, SP, E>, wino4_kernel<1, F, SP, E>, wino4_kernel<2, F, SP, E>}
+#define W4_CLS(E) {{W4_ROW(false, 0, E), W4_ROW(false, 1, E)}, {W4_ROW(true, 0, E), W4_ROW(true, 1, E)}}
+  static const Kern kerns[4][2][2][3] = {W4_CLS(0), W4_CLS(1), W4_CLS(2), W4_CLS(3)};   // [epilogue class][split][form][geometry]
+#undef W4_CLS
+#undef W4_ROW
   static std::atomic<bool> attr_done;
   if (!attr_done.load(std::memory_order_acquire)) {
-    for (int sp = 0; sp < 2; ++sp)
-      for (int f = 0; f < 2; ++f)
-        for (int g = 0; g < 3; ++g)
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[sp][f][g]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int ec = 0; ec < 4; ++ec)
+      for (int sp = 0; sp < 2; ++sp)
+        for (int f = 0; f < 2; ++f)
+          for (int g = 0; g < 3; ++g)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[ec][sp][f][g]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.store(true, std::memory_order_release);
   }
   const size_t lds = (size_t)(kLdsFloats4 + 2 * 4 * kBN4 + 4) * sizeof(float);   // (+ the split-K ticket flag)
   // tile order: filter-stationary where one pass over the transformed filters is more bytes than one pass over the input
   const double u_bytes = (double)ntile * a.so * a.so * a.kchunks * (kUSlots4 * 16.0), x_bytes = (double)d->N * d->H * d->W * d->C * 4.0;
   const int gyn_arg = u_bytes > x_bytes ? -ntile : ntile;
-  hipLaunchKernelGGL(kerns[nsplit > 1 ? 1 : 0][mode == 4 ? 1 : 0][geo], dim3(std::min(total * nsplit, ncu)), dim3(kNT4), lds, s, a, grp, gx, gyn_arg, G);
+  hipLaunchKernelGGL(kerns[w4_epi_class(a.flags)][nsplit > 1 ? 1 : 0][mode == 4 ? 1 : 0][geo], dim3(std::min(total * nsplit, ncu)), dim3(kNT4), lds, s, a, grp, gx, gyn_arg, G);
   CRDR_CHECK_LAUNCH("wino4_kernel");
   return 0;
 }
+
+#ifdef W4X_STAMPS
+extern "C" int crdr_w4_stamps(unsigned long long* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(w4_stamps), sizeof(w4_stamps));
+}
+#endif
 
 }  // namespace crdr

@@ -47,6 +47,7 @@ class _PackEntry:
     def fill(self) -> None:
         lib = L.load()
         ops.register_persistent_pack(self.dst)
+        ops.bump_pack_version(self.dst.data_ptr())
         ops.filter_scope_invalidate(self.dst.data_ptr())
         if self.mode in (0, 1):
             it = self.item()
@@ -229,6 +230,8 @@ class PackTable:
     def refill(self) -> None:
         """Refill every pack of the range from the current parameter values and mark them fresh."""
         self._refresh()
+        for ptr in {e.dst.data_ptr() for e in self.entries}:
+            ops.bump_pack_version(ptr)
         ops.filter_scope_invalidate()
         if self.entries:
             lib = L.load()

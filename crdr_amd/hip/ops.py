@@ -133,23 +133,38 @@ def _wgrad_wino4_ids():
 # everything.  Under graph capture the scope must lie inside ONE capture (first use: transform + conv, later uses: conv only, replayed
 # in that order).
 _filter_scope = None
+_filter_scope_stack = []   # the enclosing scopes' dicts, outermost first (filter_scope_invalidate walks all of them)
 FILTER_SCOPE_STATS = {"filled": 0, "reused": 0}
 _persistent_packs = {}   # data_ptr -> weakref of a persistent weight-pack buffer (functional._PackEntry.dst): only those are cached by address
+_pack_versions = {}      # data_ptr -> how often that buffer was (re)written: every writer of a registered pack bumps it (bump_pack_version), and a
+#                          kept set of transformed filters is only reused while the versions it was derived from are still the current ones
 
 
 def register_persistent_pack(t: torch.Tensor) -> None:
     import weakref
     _persistent_packs[t.data_ptr()] = weakref.ref(t)
+    _pack_versions.setdefault(t.data_ptr(), 0)
+
+
+def bump_pack_version(ptr: int) -> None:
+    """The pack buffer at `ptr` is being rewritten in place (functional._PackEntry.fill, PackTable.refill, or any future writer): whatever
+    was derived from its previous content is stale from here on, whether or not anybody calls filter_scope_invalidate."""
+    _pack_versions[ptr] = _pack_versions.get(ptr, 0) + 1
+
+
+def pack_version(ptr: int) -> int:
+    return _pack_versions.get(ptr, 0)
 
 
 def filter_scope_invalidate(ptr=None) -> None:
-    """A weight pack was refilled in place (functional._PackEntry.fill, Packs.refill): transformed filters kept for it are stale."""
-    if _filter_scope:
+    """A weight pack was refilled in place (functional._PackEntry.fill, PackTable.refill): transformed filters kept for it are stale -- in
+    the innermost scope and in every scope around it."""
+    for sc in _filter_scope_stack:
         if ptr is None:
-            _filter_scope.clear()
+            sc.clear()
         else:
-            for k in [k for k in _filter_scope if ptr in k[0]]:
-                del _filter_scope[k]
+            for k in [k for k in sc if isinstance(k, tuple) and ptr in k[0]]:
+                del sc[k]
 
 
 def _is_persistent_pack(ptr: int) -> bool:
@@ -162,10 +177,12 @@ class filter_scope:
     def __enter__(self):
         global _filter_scope
         self.prev, _filter_scope = _filter_scope, {}
+        _filter_scope_stack.append(_filter_scope)
         return self
 
     def __exit__(self, *exc):
         global _filter_scope
+        _filter_scope_stack.pop()
         _filter_scope = self.prev
         return False
 
@@ -176,12 +193,16 @@ def _launch_conv(lib, d, ios, G: int, ws, ws_n, wkeys, device):
         nb = lib.crdr_conv2d_filter_cache_bytes(C.byref(d), G)
         if nb:
             key = (tuple(int(p_) for p_ in wkeys), G, d.reserved & 0xFF, d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.kh, d.kw, d.stride, d.pad, d.transposed, d.wrows, d.wcols)
+            # (the key leaves the K-split bits of the algorithm id out on purpose: the block layout of the transformed filters does not
+            # depend on the split count -- wino4_filter_bytes / wino4_filter_kernel take no nsplit)
+            vers = tuple(pack_version(int(p_)) for p_ in wkeys)
             ent = _filter_scope.get(key)
-            valid = ent is not None
+            valid = ent is not None and ent[1] == vers   # derived from the packs' CURRENT content, not merely from the same addresses
             if ent is None:
-                ent = _filter_scope[key] = torch.empty(int(nb) // 4, dtype=torch.float32, device=device)
+                ent = (torch.empty(int(nb) // 4, dtype=torch.float32, device=device), vers)
+            _filter_scope[key] = (ent[0], vers)
             FILTER_SCOPE_STATS["reused" if valid else "filled"] += 1
-            return lib.crdr_conv2d_grouped_ex(C.byref(d), ios, G, ws, ws_n, ent.data_ptr(), int(nb), int(valid), _stream())
+            return lib.crdr_conv2d_grouped_ex(C.byref(d), ios, G, ws, ws_n, ent[0].data_ptr(), int(nb), int(valid), _stream())
     return lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream())
 
 

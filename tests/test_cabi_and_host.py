@@ -468,7 +468,22 @@ def test_filter_scope_bookkeeping():
         assert list(sc.values()) == ["Ub"]
         ops.filter_scope_invalidate()
         assert sc == {}
-    assert ops._filter_scope is None
+        # a refill announced from INSIDE a nested scope reaches the scopes around it too
+        sc[((a.data_ptr(),), 1, 37)] = "Ua"
+        sc[((b.data_ptr(),), 1, 37)] = "Ub"
+        with ops.filter_scope():
+            ops._filter_scope[((a.data_ptr(),), 1, 37)] = "Ua-inner"
+            ops.filter_scope_invalidate(a.data_ptr())
+            assert ops._filter_scope == {}
+        assert list(sc.values()) == ["Ub"]
+        with ops.filter_scope():
+            ops.filter_scope_invalidate()
+        assert sc == {}
+    assert ops._filter_scope is None and ops._filter_scope_stack == []
+    # every writer of a registered pack bumps its version; what was derived from an older version is not reused (ops._launch_conv)
+    v0 = ops.pack_version(a.data_ptr())
+    ops.bump_pack_version(a.data_ptr())
+    assert ops.pack_version(a.data_ptr()) == v0 + 1 and ops.pack_version(b.data_ptr()) == 0
     ptr = a.data_ptr()
     del a
     assert not ops._is_persistent_pack(ptr)

@@ -55,3 +55,36 @@ def test_balle18_transforms_build_and_run():
     keys = set(enc.state_dict())
     assert {"conv.0.weight", "conv.1.beta", "conv.1.gamma", "conv.1.beta_reparam.pedestal", "conv.1.gamma_reparam.lower_bound.bound",
             "conv.6.bias"} <= keys
+
+
+@pytest.mark.parametrize("c", [192, 128])
+def test_gdn_forward_is_stable_beside_a_loaded_chip(c):
+    """The fused forward rewrites its x tile in place while the four waves of a workgroup read ALL channels of it: the waves must meet at a
+    barrier between the matrix loop and the epilogue.  More tiles than CUs, a second stream keeping the chip unevenly busy (and, at 128
+    channels, two workgroups per CU): every run must equal the float64 value of the op and the unloaded run bit for bit."""
+    from crdr_amd.models.layer.gdn import GDN
+    d = dev()
+    m = GDN(c)
+    g = torch.Generator().manual_seed(7 + c)
+    with torch.no_grad():
+        m.gamma.copy_(torch.sqrt(torch.rand(c, c, generator=g) * 0.02 + 2.0 ** -36))
+        m.beta.copy_(torch.sqrt(torch.rand(c, generator=g) + 0.5))
+    m.to(d)
+    x = (torch.randn(8, c, 96, 96, generator=g) * 2.0).to(d).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y0 = m(x).clone()
+        xd = x.double()
+        ped = 2.0 ** -36
+        gam = (torch.clamp(m.gamma.double(), min=2.0 ** -18) ** 2 - ped)
+        bet = (torch.clamp(m.beta.double(), min=(1e-6 + ped) ** 0.5) ** 2 - ped)
+        ref = xd / torch.sqrt(torch.einsum("ij,njhw->nihw", gam, xd * xd) + bet.view(1, -1, 1, 1))
+        assert float((y0.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+        side = torch.cuda.Stream(device=d)
+        a = torch.randn(4096, 4096, device=d)
+        for rep in range(12):
+            with torch.cuda.stream(side):
+                for _ in range(1 + rep % 3):
+                    a = torch.tanh(a @ a * 1e-3)
+            y = m(x)
+            assert torch.equal(y, y0), f"run {rep} differs from the unloaded run"
+        torch.cuda.synchronize()

@@ -383,7 +383,18 @@ def test_winograd_f4x4_filter_scope():
         assert (st["filled"], st["reused"]) == (f0 + 2, r0 + 1)
         with ops.filter_scope():   # a nested scope starts empty
             assert torch.equal(call(), out2) and st["filled"] == f0 + 3
-    assert torch.equal(out2, call()) and st["filled"] == f0 + 3, "outside a scope nothing is cached"
+        # a writer that only bumps the pack's version (no invalidate call at all): the kept filters are NOT reused
+        wp.copy_(ops.pack_weight(w1, transpose=False))
+        ops.bump_pack_version(wp.data_ptr())
+        assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0 + 4, r0 + 1)
+        assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0 + 4, r0 + 2)
+        # a refill announced inside a nested scope drops the enclosing scope's entry as well
+        with ops.filter_scope():
+            wp.copy_(ops.pack_weight(w2, transpose=False))
+            ops.bump_pack_version(wp.data_ptr())
+            ops.filter_scope_invalidate(wp.data_ptr())
+        assert torch.equal(call(), out2) and (st["filled"], st["reused"]) == (f0 + 5, r0 + 2)
+    assert torch.equal(out2, call()) and st["filled"] == f0 + 5, "outside a scope nothing is cached"
     ref2 = F.conv2d(x.cpu().double(), w2.cpu().double(), padding=1)
     _close(out2, ref2, "filter scope after refill", rtol=5e-5)
 
