@@ -451,19 +451,25 @@ def main():
             traffic = round(fams_.get("conv_fwd_dgrad", fams_["igemm_kernel"])["hbm_bytes_per_launch"])
             traffic_src = (f"HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step at q = 2 "
                            f"with this library version ({os.path.relpath(tp, ROOT)})")
-    roof = {"bound": "mfma", "achieved": ig["tflops"] if ig else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None, "traffic": traffic, "traffic_source": traffic_src,
+    # `achieved` / `frac`: what the matrix cores EXECUTE (a Winograd launch counted with the products it really issues), so that the one-line
+    # JSON cannot be read as MFMA utilisation where it is arithmetic reduction; the algorithmic (direct-convolution) rate SURVEY 8(d) defines
+    # travels beside it as `achieved_effective` / `frac_effective`
+    ex_tf = ig.get("executed_mfma_tflops", ig["tflops"]) if ig else None
+    roof = {"bound": "mfma", "achieved": ex_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ex_tf / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None,
+            "achieved_effective": ig["tflops"] if ig else None, "frac_effective": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None,
+            "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": round(main_run["alg_bytes_per_igemm_launch"]) if main_run["alg_bytes_per_igemm_launch"] else None,
             "flop_convention": "dense: 2 * Cin * Cout * kh * kw per output pixel (input pixel for transposed convs), zero-padding taps at "
                                "the borders included (5x5 at 16x16: 14 % of the counted taps multiply padding)",
             "kernel": "igemm_kernel<*> + gemm1x1_kernel<*> + wino_kernel + wino4_kernel (conv / convT forward + input-gradient launches incl. grouped "
                       "ones: tiled implicit GEMM, the streaming 1x1 kernel and, where the tuner found them faster, the Winograd F(2x2,3x3) / "
                       "F(4x4,3x3) kernels with their filter transforms; v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32)",
-            "effective_rate_note": "`achieved` / `frac` price the ALGORITHMIC (direct-convolution) flops of every launch against the fp32 MFMA "
-                                   "peak, as SURVEY 8(d) defines the unit; a Winograd launch executes 2.25x (F(2x2)), 4x (F(4x4)) or 25/9 x (F(4x4) on a 5x5 stride-2 layer) fewer multiply-accumulates than it is "
-                                   "credited with, so this is an effective rate (a single Winograd launch may exceed 1.0). What the matrix cores "
-                                   "actually execute is detail.executed_mfma_tflops (frac_executed below); detail.direct / detail.winograd split "
-                                   "the family.",
+            "effective_rate_note": "`achieved` / `frac` are the multiply-accumulates the matrix cores EXECUTE over HIP-event time against the fp32 MFMA "
+                                   "peak.  `achieved_effective` / `frac_effective` price the ALGORITHMIC (direct-convolution) flops of every launch, "
+                                   "the unit SURVEY 8(d) defines: a Winograd launch executes 2.25x (F(2x2)), 4x (F(4x4)) or 25/9 x (F(4x4) on a 5x5 "
+                                   "layer) fewer multiply-accumulates than it is credited with there, so the effective rate of a single Winograd "
+                                   "launch may exceed 1.0.  detail.direct / detail.winograd* split the family.",
             "frac_executed": round(ig["executed_mfma_tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig and "executed_mfma_tflops" in ig else None,
             "measured_over": f"{a.profile_steps} eager steps after the timed region, rate index cycled (HIP events around each launch, on its stream)",
             "detail": ig, "wgrad_kernel": wg,
@@ -554,6 +560,33 @@ def main():
             ops._algo_cache.clear(); ops._algo_cache.update(saved); ops.WINOGRAD = saved_flag
         except Exception as e:
             line["stage3_direct_only"] = {"error": repr(e)[:300]}
+    if ws == 1 and a.stage == 3 and not a.no_secondary:
+        # fourth line: the same fp32 step with only the F(4x4, 3x3) / F(3x3, 4x4) kernels taken out (F(2x2) + direct kernels: the round-3 plan
+        # set) -- what the round-4/5 kernels are worth on their own
+        try:
+            tr = None
+            torch.cuda.empty_cache()
+            lib_ = __import__("crdr_amd.hip.lib", fromlist=["x"]).load()
+            w4 = lib_.crdr_conv2d_num_configs() + 1 + lib_.crdr_conv2d_num_stream_configs() + 2
+            wg4 = lib_.crdr_conv2d_wgrad_num_configs() + 1
+            saved = dict(ops._algo_cache)
+            saved_w4 = ops.WINO4
+            ops.WINO4 = False
+            for k_, v_ in list(ops._algo_cache.items()):
+                is_w = k_[0] in ("w", "wg", "ws", "wm")
+                if (is_w and (v_ & 0xff) == wg4) or (not is_w and (v_ & 0xff) == w4):
+                    del ops._algo_cache[k_]
+            ops.load_tune_cache(os.path.join(ROOT, "tools", "data", "tune_r3_f.json"), ignore_signature=True)
+            nx = run_stage(a, 3, a.bs, min(a.steps, 20), a.warmup, 0)
+            nx.pop("trainer")
+            line["stage3_no_f4x4"] = {"metric": f"stage-3 training img/s at {a.size}x{a.size}", "value": round(nx["value"], 3), "unit": "img/s",
+                                      "ms_per_step": round(nx["ms_per_step"], 2), "steps": min(a.steps, 20), "warmup": a.warmup, "dtype": "fp32",
+                                      "config": {"workload": f"config/crdr_stage_3.yaml -b {a.bs}, F(4x4, 3x3) / F(3x3, 4x4) kernels off (F(2x2) + direct)"}}
+            ops._algo_cache.clear(); ops._algo_cache.update(saved); ops.WINO4 = saved_w4
+        except Exception as e:
+            line["stage3_no_f4x4"] = {"error": repr(e)[:300]}
+    if ops.TUNE_REJECTED:   # candidates the tuner refused because they disagreed with the built-in plan (a silently de-tuned database is visible)
+        line["tune_rejected"] = {"count": len(ops.TUNE_REJECTED), "first": [[repr(k), int(a_), float(f"{d:.3g}")] for k, a_, d in ops.TUNE_REJECTED[:8]]}
     if ws == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.stage, a.size)
     save_tuning()

@@ -236,7 +236,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
   pl->wino = 0;
   const int wino_variant = d->reserved != 0 ? (d->reserved & 0xff) - 1 - kNumCfgs - stream_num_variants() : -1;
   if (wino_variant == 2) {   // forced: the Winograd F(4x4, 3x3) kernel (wino4.hip)
-    CRDR_REQUIRE(!fallback && wino4_eligible(d, G, true), "conv2d: forced F(4x4, 3x3) Winograd kernel: not a 3x3 stride-1 convolution it takes");
+    CRDR_REQUIRE(!fallback && wino4_eligible(d, G, true), "conv2d: forced F(4x4, 3x3) Winograd kernel: not a 3x3 / 5x5 stride-1 or 5x5 stride-2 convolution it takes (wino4_eligible)");
     const int w4split = ((d->reserved >> 8) & 0xf) + 1;   // K splits per tile (1 = none), reduced inside the launch
     CRDR_REQUIRE(wino4_split_ok(d, G, w4split), "conv2d: F(4x4, 3x3) Winograd kernel: %d K splits do not fit this shape", w4split);
     pl->wino = 3;

@@ -14,8 +14,14 @@
 // strips (a strip = 4 consecutive tiles of one tile row = 4 x 16 pixels of P and the 6 x 18 pixels of Q around them = ONE k-step of
 // v_mfma_f32_16x16x4_f32: lane group kg holds tile kg).  Wave (iw, jw): P channels 32 iw .. + 31 (two blocks of 16), Q channels 16 jw .. + 15:
 // 72 accumulator blocks (position x P block).  A strip is one LDS stage ([pixel][channels], exactly the NHWC memory layout, LDS-DMA, double
-// buffered); a lane reads its channels' 2 x 16 + 36 raw values with ds_read_b32, transforms them in registers (V: 9 operations per 1-D
-// transform, B^T: 12) and feeds them as the A (P side) and B (Q side) operands of 72 MFMAs.  Epilogue: pure register arithmetic per lane
+// buffered); a lane reads its channels' 2 x 16 + 36 raw values as 34 pairs (ds_read2_b32: the two P channel blocks of a pixel, two
+// neighbouring Q pixels), transforms them in registers in PACKED fp32 (V: 8 operations per 1-D transform, over the two channel blocks at
+// once; B^T: wino4_xform.hpp) and feeds them as the A (P side) and B (Q side) operands of 72 MFMAs.
+// Round 5 (the issue probe, tools/experiments/issue_probe_gen.py: a wave's vector instructions never hide behind its own fp32 MFMAs, its LDS
+// reads and DMA requests do when they sit directly behind one): a k-step is [transforms of strip s: 152 packed instructions] [MFMAs 0..35]
+// [vmcnt(0) + barrier: strip s + 1 has landed, everybody is done reading strip s] [MFMAs 36..71, each followed by one of: the 8 DMA
+// requests of strip s + 2, the 34 raw reads of strip s + 1].  Before: 324 scalar transform instructions + 68 reads in front of 72 bare MFMAs
+// (matrix pipe 37 % busy).  Epilogue: pure register arithmetic per lane
 // (it holds all 36 positions of its (i, j) pairs), written into the slab of this split -- the layout of wgrad_kernel's slabs
 // ([split][tap][PC][QC]), so the deferred fixed-order reduce (wgrad_reduce_batched) and everything behind it are unchanged.
 //
@@ -27,9 +33,11 @@
 // In both, Q row u / column c of a strip is image pixel qs (4 tr + u) + oy / qs (16 sc + c) + ox with (qs, oy, ox) per sub-problem.
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "common.hpp"
 #include "wgrad_args.hpp"
+#include "wino4_xform.hpp"
 
 namespace crdr {
 
@@ -44,27 +52,22 @@ constexpr int kPieces = kUsed / 4;                         // 16-byte pieces (1 
 constexpr int kPasses = (kPieces + 255) / 256;             // 8 (the last one partial: its wave 1 is half used)
 constexpr int kStage = ((kPieces + 63) / 64) * 64 * 4;     // floats per stage, whole wave instructions (7 680)
 
-// V p: rows [1, x, x^2, x^3] at x = 0, 1, -1, 2, -2, inf
-__device__ __forceinline__ void v4(const float p0, const float p1, const float p2, const float p3, float (&o)[6]) {
-  const float e = p0 + p2, d = p1 + p3;
-  const float e2 = __builtin_fmaf(4.0f, p2, p0), d2 = __builtin_fmaf(4.0f, p3, p1);
+// V p: rows [1, x, x^2, x^3] at x = 0, 1, -1, 2, -2, inf, on two channel blocks at once (packed fp32; o[0] = p0 and o[5] = p3 are the inputs)
+__device__ __forceinline__ void v4_pk(const f32x2v p0, const f32x2v p1, const f32x2v p2, const f32x2v p3, f32x2v (&o)[6]) {
+  f32x2v e, d, e2, d2;
+  asm volatile(
+      "v_pk_add_f32 %4, %8, %10\n"                             // e  = p0 + p2
+      "v_pk_add_f32 %5, %9, %11\n"                             // d  = p1 + p3
+      "v_pk_fma_f32 %6, %10, 4.0, %8 op_sel_hi:[1,0,1]\n"      // e2 = p0 + 4 p2
+      "v_pk_fma_f32 %7, %11, 4.0, %9 op_sel_hi:[1,0,1]\n"      // d2 = p1 + 4 p3
+      "v_pk_add_f32 %0, %4, %5\n"                              // o1 = e + d
+      "v_pk_add_f32 %1, %4, %5 neg_lo:[0,1] neg_hi:[0,1]\n"    // o2 = e - d
+      "v_pk_fma_f32 %2, %7, 2.0, %6 op_sel_hi:[1,0,1]\n"       // o3 = e2 + 2 d2
+      "v_pk_fma_f32 %3, %7, -2.0, %6 op_sel_hi:[1,0,1]"         // o4 = e2 - 2 d2
+      : "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(e), "=&v"(d), "=&v"(e2), "=&v"(d2)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
   o[0] = p0;
-  o[1] = e + d;
-  o[2] = e - d;
-  o[3] = __builtin_fmaf(2.0f, d2, e2);
-  o[4] = __builtin_fmaf(-2.0f, d2, e2);
   o[5] = p3;
-}
-// B^T d (wino4.hip's data transform)
-__device__ __forceinline__ void bt6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5, float (&o)[6]) {
-  const float a = __builtin_fmaf(-4.0f, d2, d4), b = __builtin_fmaf(-4.0f, d1, d3);
-  o[0] = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
-  o[1] = a + b;
-  o[2] = a - b;
-  const float c = d4 - d2, e = d3 - d1;
-  o[3] = __builtin_fmaf(2.0f, e, c);
-  o[4] = __builtin_fmaf(-2.0f, e, c);
-  o[5] = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
 }
 
 __device__ __forceinline__ float acc_read(float v) {
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void wino4_wgrad_kernel(const WgradArgs p_, co
 
   // staging: piece S = tid + 256 pass -> P: [row 4][col 16][16 pieces], Q: [row 6][col 18][8 pieces]
   int s_row[kPasses], s_col[kPasses];
-  bool s_isp[kPasses];
+  static_assert(kPFloats / 4 == 4 * 256, "staging passes 0..3 are P pieces, 4..7 Q pieces");
   unsigned s_off[kPasses];
 #pragma unroll
   for (int j = 0; j < kPasses; ++j) {
@@ -106,45 +109,68 @@ __global__ __launch_bounds__(256) void wino4_wgrad_kernel(const WgradArgs p_, co
     const bool isp = Sx < kPFloats / 4;
     const int px = isp ? Sx >> 4 : (Sx - kPFloats / 4) >> 3;
     const int ch = isp ? (Sx & 15) * 4 : ((Sx - kPFloats / 4) & 7) * 4;
-    s_isp[j] = isp;
     s_row[j] = isp ? px >> 4 : px / 18;
     s_col[j] = isp ? px & 15 : px - (px / 18) * 18;
     // lane part of the byte offsets (strip (n, tr, sc) = (0, 0, 0)); the strip's displacement is uniform
     if (isp) s_off[j] = i0 + ch < p.PC ? (unsigned)(((s_row[j] * p.PW + s_col[j]) * p.ldp + i0 + ch) * 4) : kOob;
-    else s_off[j] = j0 + ch < p.QC ? (unsigned)((((qs * s_row[j] + oy) * p.QW + qs * s_col[j] + ox) * p.ldq + j0 + ch) * 4) : kOob;   // (may wrap: added to the strip's displacement)
+    // (Q: relative to the patch's first pixel -- never negative; the patch origin (oy, ox) travels with the strip's scalar displacement)
+    else s_off[j] = j0 + ch < p.QC ? (unsigned)(((qs * s_row[j] * p.QW + qs * s_col[j]) * p.ldq + j0 + ch) * 4) : kOob;
     if (Sx >= kPieces) s_off[j] = kOob;
   }
+  // the last pass is partial (pieces 1 792 .. 1 887: waves 0 and 1): waves 2 and 3 repeat their pass 6 instead -- every wave issues the same
+  // number of requests and the request sequence has no branch in it
+  const int last_pass = wave < 2 ? kPasses - 1 : kPasses - 2;
+  if (wave >= 2) { s_off[kPasses - 1] = s_off[kPasses - 2]; s_row[kPasses - 1] = s_row[kPasses - 2]; s_col[kPasses - 1] = s_col[kPasses - 2]; }
   int f_n, f_tr, f_sc;   // strip counters of the NEXT strip to fetch: no division in the loop
   {
     const int n = s0 / (TR * SC), rem = s0 - n * (TR * SC);
     f_n = n; f_tr = rem / SC; f_sc = rem - f_tr * SC;
   }
-  auto fetch = [&](int buf) __attribute__((always_inline)) {
-    const int n = f_n, tr = f_tr, sc = f_sc;
+  // DMA requests of one strip, one at a time (request j of this wave = staging pass j): fetch_begin() takes the next strip's counters,
+  // fetch_piece(j) issues pass j.  `live` false (past the workgroup's last strip): an empty descriptor -- zeros land in a stage nobody reads.
+  int fn = 0, ftr = 0, fsc = 0;
+  unsigned f_dp = 0, f_dq = 0;
+  bool f_inner = true, f_live = true;
+  auto fetch_begin = [&](bool live) __attribute__((always_inline)) {
+    fn = f_n; ftr = f_tr; fsc = f_sc;
     if (++f_sc == SC) { f_sc = 0; if (++f_tr == TR) { f_tr = 0; ++f_n; } }
-    float* st = smem + buf * kStage;
-    const unsigned dp = (unsigned)((((n * p.PH + 4 * tr) * p.PW + 16 * sc) * p.ldp) * 4);
-    const unsigned dq = (unsigned)((((n * p.QH + qs * 4 * tr) * p.QW + qs * 16 * sc) * p.ldq) * 4);
+    f_live = live;
+    f_dp = (unsigned)((((fn * p.PH + 4 * ftr) * p.PW + 16 * fsc) * p.ldp) * 4);
     // interior strip: its 4 x 16 pixels of P and the 6 x 18 pixels of Q around them all lie inside the images
-    const bool inner = 4 * tr + 4 <= p.PH && 16 * sc + 16 <= p.PW && qs * 4 * tr + oy >= 0 && qs * (4 * tr + 5) + oy < p.QH &&
-                       qs * 16 * sc + ox >= 0 && qs * (16 * sc + 17) + ox < p.QW;
+    f_inner = 4 * ftr + 4 <= p.PH && 16 * fsc + 16 <= p.PW && qs * 4 * ftr + oy >= 0 && qs * (4 * ftr + 5) + oy < p.QH &&
+              qs * 16 * fsc + ox >= 0 && qs * (16 * fsc + 17) + ox < p.QW;
+    // (signed: the first patch pixel of an edge strip may lie above / left of the image -- those strips add it per lane below)
+    f_dq = (unsigned)((((fn * p.QH + qs * 4 * ftr + oy) * p.QW + qs * 16 * fsc + ox) * p.ldq) * 4);
+  };
+  // per-lane offsets of the strip taken by fetch_begin: the staging offsets themselves for an interior strip (its displacement travels in
+  // the requests' scalar offsets); for an edge strip -- the only place with vector arithmetic and a branch, kept OUT of the MFMA sequence
+  // so that that stays one basic block -- out-of-image pixels get an out-of-range offset and the Q displacement (which may point above /
+  // left of the image) is added per lane
+  unsigned off8[kPasses];
+  unsigned f_sq = 0;   // scalar offset of the Q requests
+  auto fetch_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < kPasses; ++j) {
-      if (j * 256 + wave * 64 >= kPieces) break;   // (wave-uniform)
-      unsigned off = s_off[j];
-      if (!inner) {
-        if (s_isp[j]) {
-          const int a = 4 * tr + s_row[j], b = 16 * sc + s_col[j];
-          if (!(a < p.PH && b < p.PW)) off = kOob;
+    for (int j = 0; j < kPasses; ++j) off8[j] = s_off[j];
+    f_sq = f_dq;
+    if (!f_inner) {
+      f_sq = 0;
+#pragma unroll
+      for (int j = 0; j < kPasses; ++j) {
+        if (j < 4) {
+          const int a = 4 * ftr + s_row[j], b = 16 * fsc + s_col[j];
+          if (!(a < p.PH && b < p.PW)) off8[j] = kOob;
         } else {
-          const int a = qs * (4 * tr + s_row[j]) + oy, b = qs * (16 * sc + s_col[j]) + ox;
-          if (!((unsigned)a < (unsigned)p.QH && (unsigned)b < (unsigned)p.QW)) off = kOob;
+          const int a = qs * (4 * ftr + s_row[j]) + oy, b = qs * (16 * fsc + s_col[j]) + ox;
+          off8[j] = ((unsigned)a < (unsigned)p.QH && (unsigned)b < (unsigned)p.QW && s_off[j] != kOob) ? s_off[j] + f_dq : kOob;
         }
       }
-      if (s_isp[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr_t)(st + (j * 256 + wave * 64) * 4), 16, (int)off, (int)dp, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr_t)(st + (j * 256 + wave * 64) * 4), 16, (int)(off == kOob ? kOob : off + dq), 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto fetch_piece = [&](int buf, int j) __attribute__((always_inline)) {
+    const int jd = j == kPasses - 1 ? last_pass : j;   // (destination pass)
+    float* st = smem + buf * kStage;
+    const __amdgpu_buffer_rsrc_t rl = f_live ? (j < 4 ? rp : rq) : __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_ptr_t)(st + (jd * 256 + wave * 64) * 4), 16, (int)off8[j], (int)(j < 4 ? f_dp : f_sq), 0, 0);
   };
 
   f32x4 acc[64], accv[8];
@@ -155,55 +181,107 @@ __global__ __launch_bounds__(256) void wino4_wgrad_kernel(const WgradArgs p_, co
 
   const int m = lane & 15, kg = lane >> 4;
   const int pb = (4 * kg) * kPC + 32 * iw + m, qb = kPFloats + (4 * kg) * kQC + 16 * jw + m;   // this lane's tile / channel inside the P / Q images
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const float* st = smem + buf * kStage;
-    float A[2][6][6], B[6][6];
-    // P side: V p V^T of the lane's tile for its two channel blocks
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-      float t[6][4];   // vertical pass: [xi][column]
+  const W4Consts kc = {f32x2v{-4.0f, -1.0f}, f32x2v{1.0f, 2.0f}, f32x2v{-1.0f, -2.0f}, f32x2v{-5.0f, -5.0f}};
+  f32x2v PR[4][4];   // raw P: [row][column] = (channel block 0, channel block 1) of the lane's tile
+  f32x2v QR[3][6];   // raw Q: [column pair c][row] = pixels (row, 2 c), (row, 2 c + 1) of the lane's patch
+  f32x2v Ap[6][6];   // V p V^T: [xi][nu] = (block 0, block 1)
+  f32x2v Vq[6][3];   // B^T q B: row xi as (v0, v5), (v1, v3), (v2, v4)
+  // raw read r of a strip (34 of them): 0..15 P pixel (r / 4, r % 4), 16..33 Q pair (column pair (r - 16) / 6, row (r - 16) % 6)
+  auto raw_read = [&](const float* st, int r) __attribute__((always_inline)) {
+    if (r < 16) {
+      const int u = r >> 2, v = r & 3;
+      PR[u][v] = f32x2v{st[pb + (u * 16 + v) * kPC], st[pb + (u * 16 + v) * kPC + 16]};
+    } else {
+      const int c = (r - 16) / 6, u = (r - 16) - 6 * c;
+      QR[c][u] = f32x2v{st[qb + (u * 18 + 2 * c) * kQC], st[qb + (u * 18 + 2 * c + 1) * kQC]};
+    }
+  };
+  auto transforms = [&]() __attribute__((always_inline)) {
+    {   // P side: V p V^T, both channel blocks at once
+      f32x2v t[6][4];   // vertical pass: [xi][column]
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        float o[6];
-        v4(st[pb + (0 * 16 + v) * kPC + 16 * ib], st[pb + (1 * 16 + v) * kPC + 16 * ib], st[pb + (2 * 16 + v) * kPC + 16 * ib],
-           st[pb + (3 * 16 + v) * kPC + 16 * ib], o);
+        f32x2v o[6];
+        v4_pk(PR[0][v], PR[1][v], PR[2][v], PR[3][v], o);
 #pragma unroll
         for (int x = 0; x < 6; ++x) t[x][v] = o[x];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int x = 0; x < 6; ++x) v4(t[x][0], t[x][1], t[x][2], t[x][3], A[ib][x]);
+      for (int x = 0; x < 6; ++x) v4_pk(t[x][0], t[x][1], t[x][2], t[x][3], Ap[x]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // Q side: B^T q B of the lane's patch
-    {
-      float t[6][6];
+    {   // Q side: B^T q B
+      f32x2v T[6][3];
 #pragma unroll
-      for (int v = 0; v < 6; ++v) {
-        float o[6];
-        bt6(st[qb + (0 * 18 + v) * kQC], st[qb + (1 * 18 + v) * kQC], st[qb + (2 * 18 + v) * kQC], st[qb + (3 * 18 + v) * kQC],
-            st[qb + (4 * 18 + v) * kQC], st[qb + (5 * 18 + v) * kQC], o);
+      for (int c = 0; c < 3; ++c) {
+        f32x2v t6[6];
+        bt6_cols(QR[c], t6, kc);
 #pragma unroll
-        for (int x = 0; x < 6; ++x) t[x][v] = o[x];
+        for (int x = 0; x < 6; ++x) T[x][c] = t6[x];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int x = 0; x < 6; ++x) bt6(t[x][0], t[x][1], t[x][2], t[x][3], t[x][4], t[x][5], B[x]);
+      for (int x = 0; x < 6; ++x) bt6_row(T[x][0], T[x][1], T[x][2], Vq[x], kc);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 72; ++s) {
-      const int pos = s >> 1, ib = s & 1, x = pos / 6, y = pos - 6 * x;
-      if (s < 64) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ib][x][y], B[x][y], acc[s], 0, 0, 0);
-      else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[s - 64]) : "v"(A[ib][x][y]), "v"(B[x][y]));
-    }
-    __builtin_amdgcn_sched_barrier(0);
   };
-  if (s0 < s1) fetch(0);
-  __syncthreads();
+  auto mfma_slot = [&](int s) __attribute__((always_inline)) {
+    const int pos = s >> 1, ib = s & 1, x = pos / 6, y = pos - 6 * x;
+    const float av = ib ? Ap[x][y].y : Ap[x][y].x;
+    if (s < 64) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v_elem(Vq[x], y), acc[s], 0, 0, 0);
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[s - 64]) : "v"(av), "v"(v_elem(Vq[x], y)));
+  };
+  // ---- prologue: strip s0 into stage 0, then strip s0 + 1 into stage 1 (in flight while strip s0 is read and transformed)
+  if (s0 < s1) {
+    fetch_begin(true);
+    fetch_offsets();
+#pragma unroll
+    for (int j = 0; j < kPasses; ++j) fetch_piece(0, j);
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
+    __syncthreads();
+    fetch_begin(s0 + 1 < s1);
+    fetch_offsets();
+#pragma unroll
+    for (int j = 0; j < kPasses; ++j) fetch_piece(1, j);
+#pragma unroll
+    for (int r = 0; r < 34; ++r) raw_read(smem, r);
+  }
   for (int s = s0; s < s1; ++s) {
     const int buf = (s - s0) & 1;
-    if (s + 1 < s1) fetch(buf ^ 1);
-    compute(buf);
-    __syncthreads();
+    const float* stn = smem + (buf ^ 1) * kStage;   // strip s + 1
+    // (the offsets of strip s + 2 first: the only branch of the k-step -- edge strips -- then everything below is ONE basic block; with
+    // the branch between the two MFMA halves the register allocator copied every accumulator of the first half, 140 moves per k-step)
+    fetch_begin(s + 2 < s1);
+    fetch_offsets();
+    __builtin_amdgcn_sched_barrier(0);
+    transforms();
+#pragma unroll
+    for (int t = 0; t < 36; ++t) {
+      mfma_slot(t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // strip s + 1 has landed (requested one k-step ago), and every wave is done reading strip s (its raw reads were the last thing of the
+    // previous k-step): stage `buf` is free for strip s + 2
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 36; t < 72; ++t) {
+      mfma_slot(t);
+      // the slot's memory instructions, directly behind the MFMA: 8 DMA requests of strip s + 2, then the 34 raw reads of strip s + 1
+      // (34 + 8 = 42 in 36 slots: the first six read slots take two)
+      const int q = t - 36;
+      if (q < kPasses) fetch_piece(buf, q);
+      else {
+        const int r0 = q - kPasses < 6 ? 2 * (q - kPasses) : (q - kPasses) + 6;
+        raw_read(stn, r0);
+        if (q - kPasses < 6) raw_read(stn, r0 + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+  // (the reads behind the last k-step's MFMAs fetched a stage nobody needs; nothing is waited for)
 
   // ---- output transform g = A^T (D U D) A per (i, j) pair of the lane: accumulator element r of block (pos, ib) is
   // (i = i0 + 32 iw + 16 ib + 4 kg + r, j = j0 + 16 jw + m)

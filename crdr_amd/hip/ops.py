@@ -88,6 +88,7 @@ def _time_call(fn, reps: int = 2) -> float:
 
 
 WINOGRAD = __import__("os").environ.get("CRDR_WINOGRAD", "1") != "0"   # 0: the tuner never offers the Winograd kernel
+WINO4 = __import__("os").environ.get("CRDR_WINO4", "1") != "0"         # 0: ... never the F(4x4, 3x3) / F(3x3, 4x4) kernels (F(2x2) stays)
 
 
 # Tests: every convolution a Winograd kernel accepts takes it (without the tuner, whose choice is per shape and speed): the
@@ -120,7 +121,7 @@ def _wgrad_wino4_ids():
     """Forced ids of the F(3x3, 4x4) weight-gradient slab kernel (wino4_wgrad.hip: the id behind the last wgrad configuration) with its strip
     splits 1 .. 256; the library refuses them for the shapes it does not take."""
     lib = L.load()
-    if not WINOGRAD or lib.crdr_conv2d_wgrad_num_wino_configs() < 2:
+    if not WINOGRAD or not WINO4 or lib.crdr_conv2d_wgrad_num_wino_configs() < 2:
         return []
     nw = lib.crdr_conv2d_wgrad_num_configs()
     return [(nw + 1) | (ls << 8) for ls in range(9)]
@@ -187,6 +188,25 @@ class filter_scope:
         return False
 
 
+WINO4_DEMOTED = [0]   # launches whose tuned / preferred F(4x4) plan was dropped because an epilogue operand was not 16-byte aligned
+
+
+def _demote_if_misaligned(d, ios, G: int, explicit: bool) -> None:
+    """The F(4x4) kernel's epilogue works with 16-byte accesses.  A plan id out of the perf database (or ops.PREFER_WINOGRAD) is keyed by shape
+    and strides, not by pointer alignment: for an output / residual / mask view at a channel offset that is not a multiple of 4 floats the
+    launch would be refused by the library (it hard-fails an id it cannot honour, which is right for an EXPLICITLY forced one).  Such a
+    launch takes the built-in plan instead."""
+    if explicit or (d.reserved & 0xFF) != _wino4_id():
+        return
+    for g in range(G):
+        for f_ in ("y", "res", "mask"):
+            p_ = getattr(ios[g], f_)
+            if p_ and int(p_) % 16:
+                d.reserved = 0
+                WINO4_DEMOTED[0] += 1
+                return
+
+
 def _launch_conv(lib, d, ios, G: int, ws, ws_n, wkeys, device):
     """crdr_conv2d_grouped, through the filter cache of the enclosing filter_scope where the launch runs the F(4x4) kernel."""
     if _filter_scope is not None and (d.reserved & 0xFF) == _wino4_id() and all(_is_persistent_pack(int(p_)) for p_ in wkeys):
@@ -212,8 +232,8 @@ def _stream_ids():
     n = lib.crdr_conv2d_num_configs()
     ns = lib.crdr_conv2d_num_stream_configs()
     nw = lib.crdr_conv2d_num_wino_configs()
-    ids = [n + 1 + v for v in range(ns)] + ([n + 1 + ns + v for v in range(nw)] if WINOGRAD else [])
-    if WINOGRAD and nw > 2:   # the F(4x4) kernel with 2, 3, 4, 6, 8, 12 or 16 K splits per tile (bits 8..11 = splits - 1): launches with fewer tiles than CUs
+    ids = [n + 1 + v for v in range(ns)] + ([n + 1 + ns + v for v in range(nw if WINO4 else min(nw, 2))] if WINOGRAD else [])
+    if WINOGRAD and WINO4 and nw > 2:   # the F(4x4) kernel with 2, 3, 4, 6, 8, 12 or 16 K splits per tile (bits 8..11 = splits - 1): launches with fewer tiles than CUs
         ids += [(n + 1 + ns + 2) | (v << 8) for v in WINO4_SPLITS]
     return ids
 
@@ -225,6 +245,7 @@ def _stream_ids():
 TUNE_AGREE = {"conv": 2e-5, "wgrad": 2e-4, "wino4": 6e-5}   # wino4: the F(4x4, 3x3) Winograd kernel (transform constants up to 8 and 1/24:
 #                                                              5e-6 .. 1e-5 of the output scale against float64, tests/test_gpu_wino.py)
 TUNE_REJECTED = []   # (key, algo, measured disagreement) of every candidate refused
+TUNE_SKIPPED = []    # keys whose tuning was put off because the call's result was all zero (no scale to compare candidates against)
 
 
 def _wino4_id() -> int:
@@ -245,6 +266,12 @@ def _autotune(key, ncfg: int, max_log2_split: int, run, extra=(), penalty=None, 
     fresh(0)
     ref = result().detach().clone() if result is not None else None
     ref_scale = float(ref.abs().max()) if ref is not None else 0.0
+    if ref is not None and not ref_scale > 1e-30:
+        # the operands of this call happen to give an all-zero (or denormal) result -- a zero gradient at warm-up, a masked branch: nothing
+        # can be compared against it, and caching the baseline plan for the key would silently de-tune it.  Keep the built-in plan for THIS
+        # call only; the next call with the same key tunes on its own operands.
+        TUNE_SKIPPED.append(key)
+        return 0
     best, best_t = 0, _time_call(lambda: run(0)) + (penalty() if penalty else 0.0)
     base_t = best_t
     cands = [(c + 1) | (ls << 8) for c in range(ncfg) for ls in range(max_log2_split + 1)] + list(extra)
@@ -500,7 +527,8 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
             ldg = oc
         d.ldg = ldg
         io.gx, io.gt, io.sig = gate_x.data_ptr(), gate_t.data_ptr(), sig_out.data_ptr()
-    if algo or FORCED_CONV_ALGO:
+    explicit = bool(algo or FORCED_CONV_ALGO)
+    if explicit:
         d.reserved = algo or FORCED_CONV_ALGO
     elif _prefer_wino(d):
         d.reserved = _prefer_wino(d)
@@ -516,6 +544,7 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
             algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids(), result=lambda: out_t,
                              agree=TUNE_AGREE["conv"])
         d.reserved = algo
+    _demote_if_misaligned(d, (io,), 1, explicit)
     nbytes = lib.crdr_conv2d_workspace(C.byref(d))
     ws, ws_n = workspace(nbytes, x.device, conv=True) if nbytes else (None, 0)
     e0 = _prof_begin()
@@ -854,6 +883,7 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
         d.reserved = algo
     elif GP != G:
         d.reserved = lib.crdr_conv2d_choose_algo(C.byref(d), GP)
+    _demote_if_misaligned(d, ios, G, bool(FORCED_CONV_ALGO))
     nbytes = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
     ws, ws_n = workspace(nbytes, device, conv=True) if nbytes else (None, 0)
     e0 = _prof_begin()
@@ -1155,6 +1185,7 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
             algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids(), result=lambda: scratch, reset=reset,
                              agree=TUNE_AGREE["conv"])
         d.reserved = algo
+    _demote_if_misaligned(d, ios, G, bool(FORCED_CONV_ALGO))
     out = None
     if colsum:
         bufs, rows, ld, _ = cs_alloc()

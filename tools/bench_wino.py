@@ -28,6 +28,8 @@ def main():
     lib = L.load()
     wid = lib.crdr_conv2d_num_configs() + 1 + lib.crdr_conv2d_num_stream_configs()
     dev = torch.device("cuda:0")
+    if a.shapes:
+        SHAPES[:] = [tuple(int(v) for v in t.split(",")) for t in a.shapes.split(";")]
     if a.wgrad:
         nw = lib.crdr_conv2d_wgrad_num_configs()
         for ci, co, hw in SHAPES:
@@ -73,8 +75,6 @@ def main():
             print(f"{'T' if tr else 'C'} {ci:4d}->{co:4d} k5s2 in{hw:3d}: direct {best[0] * 1e3:8.1f} us ({fl / best[0] / 1e9:6.1f} TF, cfg {best[1]})   F(4x4) {t4 * 1e3:8.1f} us "
                   f"({fl / t4 / 1e9:6.1f} TF-eq) x{best[0] / t4:.2f}   max rel diff {err:.2e}", flush=True)
         return
-    if a.shapes:
-        SHAPES[:] = [tuple(int(v) for v in t.split(",")) for t in a.shapes.split(";")]
     kk, shapes = (5, [(320, 4256, 16), (320, 2016, 16), (32, 4032, 16), (32, 2240, 16), (224, 128, 16), (320, 224, 16), (128, 224, 16)]) if a.k5 else (3, SHAPES)
     for ci, co, hw in shapes:
         x = torch.randn(a.bs, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
