@@ -1,12 +1,13 @@
 // Winograd F(4x4, 3x3) convolution on the exact-fp32 matrix cores for the 3x3 stride-1 layers (and, as 3x3 pieces, the 5x5 stride-2 and
 // stride-1 layers: wino4_mode below; tile geometries: W4Geo; K splits inside the launch: wino4_finish)
 // (elic_layers.py:23-36, cheng_nlam.py:31-46, clic21_gvae_discriminator.py:27-40) and their input gradients:
-//   Y = A^T [ (G g G^T) . (B^T d B) ] A   with 6x6 transforms (Lavin & Gray 2016, interpolation points 0, +-1, +-2, inf):
+//   Y = A^T [ (G g G^T) . (B^T d B) ] A   with 6x6 transforms (Lavin & Gray 2016; interpolation points 0, +-3/4, +-5/4, inf since round 5:
+//   wino4_xform.hpp says why):
 // 36 element-wise products per 4x4 outputs and channel pair instead of 144 -- 4x fewer MFMAs than the implicit GEMM, 1.78x fewer
 // than the F(2x2, 3x3) kernel of wino.hip.  Arithmetic is fp32 throughout (the filter transform is evaluated in double and rounded
-// once); the transforms carry the constants 4, 5, 8 and 1/4 ... 1/24, so the result deviates from the direct form by ~5e-6 .. 1e-5
-// of the output scale at 96 .. 256 input channels (the direct kernels: ~1e-6): a tuner candidate for TRAINING launches only (the
-// codec never runs tuned plans), behind the forced-algorithm id of Winograd variant 2, tests/test_gpu_wino.py.
+// once); with the round-5 points the result deviates from float64 by ~1.5e-6 .. 5e-6 of the output scale at 96 .. 1 024 accumulated
+// channels (the points 0, +-1, +-2 of rounds 3-4: 5e-6 .. 2.3e-5; the direct kernels: ~1e-6 .. 4e-6): a tuner candidate for TRAINING launches
+// only (the codec never runs tuned plans), behind the forced-algorithm id of Winograd variant 2, tests/test_gpu_wino.py.
 //
 // One output tile = 8 rows x 64 columns of output pixels (2 x 16 Winograd tiles of 4 x 4) of one image x 64 output channels, on FOUR
 // waves (one per SIMD: 512 registers each), all running the SAME code: wave (th, oh) owns the 16 tiles of tile row th x the 32
@@ -28,6 +29,7 @@
 //   the wave issues 72 MFMAs; the work is laid out by hand in 72 slots of one MFMA + its share of loads / transform / DMA.
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "common.hpp"
 #include "igemm_args.hpp"
@@ -77,24 +79,15 @@ __device__ __forceinline__ void lds_barrier4() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// 1-D output transform A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]: 10 operations
-__device__ __forceinline__ void at6(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
-                                    float& o0, float& o1, float& o2, float& o3) {
-  const float p = m1 + m2, q = m1 - m2, u = m3 + m4, w = m3 - m4;
-  o0 = m0 + p + u;
-  o1 = __builtin_fmaf(2.0f, w, q);
-  o2 = __builtin_fmaf(4.0f, u, p);
-  o3 = __builtin_fmaf(8.0f, w, q) + m5;
-}
-// the same on two channels at once (packed fp32: the epilogue's vector instructions are not hidden behind anything either -- same
-// operations, same association, bit-identical)
+// 1-D output transform A^T = [[1, 1, 1, 1, 1, 0], [0, a, -a, b, -b, 0], [0, a2, a2, b2, b2, 0], [0, a3, -a3, b3, -b3, 1]] (wino4_xform.hpp: a = 3/4,
+// b = 5/4), two channels at once in packed fp32 (the epilogue's vector instructions are not hidden behind anything either): 13 operations
 __device__ __forceinline__ void at6_pk(const f32x2v m0, const f32x2v m1, const f32x2v m2, const f32x2v m3, const f32x2v m4, const f32x2v m5,
                                        f32x2v& o0, f32x2v& o1, f32x2v& o2, f32x2v& o3) {
   const f32x2v p = m1 + m2, q = m1 - m2, u = m3 + m4, w = m3 - m4;
   o0 = m0 + p + u;
-  o1 = pk_fma(pk_bc(2.0f), w, q);
-  o2 = pk_fma(pk_bc(4.0f), u, p);
-  o3 = pk_fma(pk_bc(8.0f), w, q) + m5;
+  o1 = pk_fma(pk_bc(kWb), w, pk_bc(kWa) * q);
+  o2 = pk_fma(pk_bc(kWb2), u, pk_bc(kWa2) * p);
+  o3 = pk_fma(pk_bc(kWb3), w, pk_bc(kWa3) * q) + m5;
 }
 
 struct Wino4Tile { int gidx, n, oh0, ow0, n0, patch, tn, phase, lin, ks, kbeg, kcnt; };   // lin: index of the tile among the launch's tiles; K split ks works sub-steps [kbeg, kbeg + kcnt)   // phase: output phase of a stride-2 transposed conv (0 otherwise)
@@ -201,23 +194,34 @@ __device__ __forceinline__ void wino4_dma_filt(float* smem, const Wino4Src& sr, 
   const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)sr.u_off0) + (unsigned)kf * (kUSlots4 * 16u) + (unsigned)piece * 1024u;
   __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(smem + kRawBufs * kRF + fbuf * kFF + piece * 256), 16, lane * 16, (int)so, 0, 0);
 }
-// the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and filter blocks 0, 1 (-> F0, F1)
+// the requests a tile starts with: raw patches 0, 1, 2 (-> R0, R1, R2) and filter blocks 0, 1 (-> F0, F1): 30 per wave; request i: 0..11 raw
+// piece i % 4 of patch i / 4, 12..29 filter piece (i - 12) % 9 of block (i - 12) / 9
+constexpr int kW4PrologueReqs = 30;
+template <int FORM>
+__device__ __forceinline__ void wino4_prologue_req(const IgemmArgs& p, float* smem, const Wino4Src& sr, int kbeg, int kcnt, int lane, int wave, int i) {
+  if (i < 12) {
+    const int kr = i >> 2;
+    wino4_dma_raw(smem, sr, kr < kcnt ? sr.rx : wino4_empty_rsrc(), i & 3, wino4_raw_soff<FORM>(p, kbeg + kr), kr, lane, wave);
+  } else {
+    const int kf = (i - 12) / 9;
+    wino4_dma_filt(smem, sr, kf < kcnt ? sr.ru : wino4_empty_rsrc(), (i - 12) - 9 * kf, kbeg + kf, kf, lane, wave);
+  }
+}
 template <int FORM>
 __device__ __forceinline__ void wino4_prologue_dma(const IgemmArgs& p, float* smem, const Wino4Src& sr, int kbeg, int kcnt, int lane, int wave) {
 #pragma unroll
-  for (int kr = 0; kr < 3; ++kr)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wino4_dma_raw(smem, sr, kr < kcnt ? sr.rx : wino4_empty_rsrc(), j, wino4_raw_soff<FORM>(p, kbeg + kr), kr, lane, wave);
-#pragma unroll
-  for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-    for (int j = 0; j < 9; ++j) wino4_dma_filt(smem, sr, kf < kcnt ? sr.ru : wino4_empty_rsrc(), j, kbeg + kf, kf, lane, wave);
+  for (int i = 0; i < kW4PrologueReqs; ++i) wino4_prologue_req<FORM>(p, smem, sr, kbeg, kcnt, lane, wave, i);
 }
+// the next tile's first requests, handed to the epilogue of the current one: issued back to back they hold the wave for ~160 cycles each (the
+// CU's load path takes 1 KiB per request: 4 800 - 5 000 cycles per tile by the stamps, tools/experiments/w4_stamps.py); spread through the
+// vector arithmetic of the first half's output transform they cost their issue slots
+struct Wino4Next { bool more; int kbeg, kcnt; };
 
 // K loop of one wave (the only wave of its SIMD: nothing else hides its latencies, so the loop is software pipelined by hand).
 // LDS: raw-patch buffers R0..R2, filter buffers F0..F2.  Sub-step k multiplies V_k (registers) with the filters of F[k % 3]; beside those 72
 // MFMAs the wave reads raw patch k + 1 from R[(k + 1) % 3] and transforms it into V_{k+1}, and issues the DMA of filter block k + 2 and of
-// raw patch k + 3.  The sub-step ends with vmcnt(13) + barrier: what it requested itself stays in flight, everything older has landed.
+// raw patch k + 3.  Slot 65 of the sub-step is vmcnt(13) + barrier: what it requested itself stays in flight, everything older has landed; the
+// last six MFMAs cover the reads of the next sub-step's first four filter fragments.
 // Schedule of a sub-step (round 5, after the issue probe: VALU never hides behind an fp32 MFMA of the same wave, memory instructions do if
 // they are issued directly behind one), 72 slots pinned by sched_barrier:
 //   slot s: MFMA of position j = s / 2 (transform row x = j / 6), channel block s % 2, followed by AT MOST ONE memory instruction --
@@ -239,7 +243,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
   // + buffer * kFF + pos * 256
   const int fbase = kRawBufs * kRF + kg * kBN4 + 32 * oh + 2 * tx;
 
-  const W4Consts kc = {f32x2v{-4.0f, -1.0f}, f32x2v{1.0f, 2.0f}, f32x2v{-1.0f, -2.0f}, f32x2v{-5.0f, -5.0f}};
+  const W4Consts kc = w4_consts();
   f32x2v T[6][3];      // vertical pass of the patch being transformed: T[xi][c] = (t[xi][2 c], t[xi][2 c + 1])
   f32x2v V[6][3];      // V of the current sub-step, row x as (v0, v5), (v1, v3), (v2, v4) (rows 0..4: replaced in place by the next one's during the sub-step)
   f32x2v D[2][6];      // raw pixels of one column pair, double buffered by the pair's parity: D[c & 1][i] = (d[i][2 c], d[i][2 c + 1])
@@ -278,6 +282,14 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
     for (int x = 0; x < 5; ++x) hpass(x);
   }
 
+  float uf[9][2];   // filter fragments of positions j .. j + 3 in flight (ring of 9, indexed j % 9: 36 = 0 mod 9, so the next sub-step's
+  //                   positions 0..3 land in entries the current one has long left); alive across sub-steps
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 u2 = *reinterpret_cast<const f32x2*>(smem + fbase + j * 256);   // (filter block 0 of the tile: buffer 0)
+    uf[j][0] = u2[0];
+    uf[j][1] = u2[1];
+  }
   int r1 = 1, r0 = 0;   // raw buffer of patch k + 1 / of patch k (= the one patch k + 3 goes to)
   const int Kc = p.kchunks / p.nphase;   // channel chunks per parity sub-filter (stride-2 conv: 4 sub-filters; else 1)
   int ch3 = (kbeg + 3) % Kc, sub3 = (kbeg + 3) / Kc;   // chunk / sub-filter of sub-step k + 3 (counters: no division in the loop)
@@ -299,13 +311,9 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
     const __amdgpu_buffer_rsrc_t ru2 = k + 2 < K4 ? sr.ru : wino4_empty_rsrc(), rx3 = k + 3 < K4 ? sr.rx : wino4_empty_rsrc();
     const int soff3 = FORM == 1 ? ch3 * 16 : ch3 * 16 + ((sub3 >> 1) * p.W + (sub3 & 1)) * p.ldx * 4;   // (sub3 = 0 unless the conv is the stride-2 form)
     const int f2 = r1 == 2 ? 0 : r1 + 1;                  // buffer of filter block k + 2
-    float uf[8][2];   // filter fragments of positions j .. j + 3 in flight (ring of 8, indexed j & 7)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x2 u2 = *reinterpret_cast<const f32x2*>(fp + j * 256);
-      uf[j][0] = u2[0];
-      uf[j][1] = u2[1];
-    }
+    int fpno = fbase + r1 * kFF;
+    asm volatile("" : "+v"(fpno));
+    const float* fpn = smem + fpno;                       // filter block k + 1 (its first four positions are fetched at the end of this sub-step)
     hpass(5);   // row 5 of V_k (its vertical pass was done during the previous sub-step; its MFMAs are the last ones)
     __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(full)
@@ -313,13 +321,18 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
       const int j = s >> 1, ob = s & 1, x = j / 6, y = j - 6 * x;
       // 72 blocks x 4 = 288 accumulator registers: 64 blocks in the accumulation half of the register file, the last 8 (positions 32..35)
       // pinned to ordinary vector registers (left to the compiler they bounce between the two files: 72 moves per sub-step)
-      if (s < 64) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[j & 7][ob], v_elem(V[x], y), acc[s], 0, 0, 0);
-      else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[s - 64]) : "v"(uf[j & 7][ob]), "v"(v_elem(V[x], y)));
+      if (s < 64) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[j % 9][ob], v_elem(V[x], y), acc[s], 0, 0, 0);
+      else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[s - 64]) : "v"(uf[j % 9][ob]), "v"(v_elem(V[x], y)));
       // the slot's memory instruction, directly behind the MFMA
       if (ob == 1 && j + 4 < 36) {   // four positions (8 slots) ahead of their use
         const f32x2 u2 = *reinterpret_cast<const f32x2*>(fp + (j + 4) * 256);
-        uf[(j + 4) & 7][0] = u2[0];
-        uf[(j + 4) & 7][1] = u2[1];
+        uf[(j + 4) % 9][0] = u2[0];
+        uf[(j + 4) % 9][1] = u2[1];
+      }
+      if (s >= 66 && s < 70) {   // behind the sub-step's barrier (slot 65): positions 0..3 of the NEXT sub-step's filter block
+        const f32x2 u2 = *reinterpret_cast<const f32x2*>(fpn + (s - 66) * 256);
+        uf[s - 66][0] = u2[0];
+        uf[s - 66][1] = u2[1];
       }
       if (ob == 0 && s < 36) vread(rp, s >> 1);
       if (ob == 0 && s >= 36 && s <= 60) {
@@ -338,6 +351,15 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
       if (s == 50) hpass(3);
       if (s == 62) hpass(4);
       if (s == 15 || s == 27 || s == 39 || s == 41 || s == 44 || s == 47 || s == 50 || s == 62) __builtin_amdgcn_sched_barrier(0);
+      if (s == 65) {
+        // the sub-step's barrier sits HERE, not at its end: the 13 requests of this sub-step (filter block k + 2, patch k + 3: slots 36 .. 60)
+        // stay in flight, everything older (filter block k + 1, patch k + 2) has landed; every wave is past its last read of filter block k
+        // (slot 63) and of patch k + 1 (slot 34), which the next sub-step's requests overwrite.  The six MFMAs behind it cover the latency of
+        // the next sub-step's first filter fragments -- with the barrier at the end the first MFMA of every sub-step waited for its operands
+        __builtin_amdgcn_s_waitcnt(0x007D);   // vmcnt(13) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     r0 = r1;
     r1 = r1 == 2 ? 0 : r1 + 1;
@@ -351,12 +373,10 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
         }
       }
     }
-    // the 13 requests of this sub-step (filter block k + 2, patch k + 3) stay in flight; everything older (filter block k + 1, patch
-    // k + 2) has landed
-    __builtin_amdgcn_s_waitcnt(0x007D);   // vmcnt(13) lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
+  // (the last sub-step's barrier is 6 MFMAs back: what follows -- the next tile's requests into the raw / filter buffers, the epilogue -- touches
+  // no LDS a wave could still be reading for a purpose: the four fragment reads behind that barrier fetched a block nobody multiplies)
   // (the dead tail requests -- zeros for sub-steps past the last -- that may still be in flight go to raw buffers; whatever is requested
   // into those next comes from the same wave and lands behind them)
 }
@@ -389,9 +409,9 @@ constexpr int w4_epi_class(int flags) {
   return (f & ~w4_epi_mask(0)) == 0 ? 0 : (f & ~w4_epi_mask(1)) == 0 ? 1 : (f & ~w4_epi_mask(2)) == 0 ? 2 : 3;
 }
 
-template <int GEO, bool SPLIT, int FM>
+template <int GEO, int FORM, bool SPLIT, int FM>
 __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile& tl, float* smem, const float* sV, int lane, int wave, f32x4 (&acc)[64],
-                                             f32x4 (&accv)[8]) {
+                                             f32x4 (&accv)[8], const Wino4Src& srn, const Wino4Next nx) {
   const int f = p.flags & FM;
   const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
   const bool do_cs = (f & CRDR_EPI_COLSUM) != 0, accum = (f & CRDR_EPI_ACCUM) != 0;
@@ -419,12 +439,21 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
 
   // output transform of half ob, two channel registers (r, r + 1) at a time in packed fp32: s[a][nu] = sum_xi AT[a][xi] M[xi][nu], then
   // Y[a][b] = sum_nu AT[b][nu] s[a][nu]
-  auto out_transform = [&](int ob, float (&yv)[4][4][4]) __attribute__((always_inline)) {
+  // (`reqs`: the 30 requests of the next tile ride in this call, three every two of its 20 arithmetic groups)
+  auto next_reqs = [&](int grp) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = (3 * grp) / 2; i < (3 * (grp + 1)) / 2; ++i) wino4_prologue_req<FORM>(p, smem, srn, nx.kbeg, nx.kcnt, lane, wave, i);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto out_transform = [&](int ob, float (&yv)[4][4][4], auto reqs_c) __attribute__((always_inline)) {
+    constexpr bool REQS = decltype(reqs_c)::value;
 #pragma unroll
     for (int rp = 0; rp < 2; ++rp) {
       f32x2v sv[4][6];
 #pragma unroll
       for (int nu = 0; nu < 6; ++nu) {
+        if constexpr (REQS) next_reqs(10 * rp + nu);
         f32x2v mcol[6];
 #pragma unroll
         for (int xi = 0; xi < 6; ++xi) {
@@ -437,6 +466,7 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
+        if constexpr (REQS) next_reqs(10 * rp + 6 + a);
         f32x2v y0, y1, y2, y3;
         at6_pk(sv[a][0], sv[a][1], sv[a][2], sv[a][3], sv[a][4], sv[a][5], y0, y1, y2, y3);
 #pragma unroll
@@ -454,13 +484,14 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
   unsigned slab_bytes = 0;
   auto slab_off = [&](int ob, int q) __attribute__((always_inline)) { return (unsigned)((((wave * 2 + ob) * 16 + q) * 64 + lane) * 16); };
   if constexpr (SPLIT) {
+    if (nx.more) wino4_prologue_dma<FORM>(p, smem, srn, nx.kbeg, nx.kcnt, lane, wave);
     constexpr unsigned kTileSlab = 4u * 2u * 16u * 64u * 16u;   // bytes of one tile's partial result
     slab_bytes = (unsigned)p.ws_ld * kTileSlab;                   // one split's slab: every tile of the launch
     rws = __builtin_amdgcn_make_buffer_rsrc(p.ws + (size_t)tl.lin * (kTileSlab / 4), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob) {
       float yv[4][4][4];
-      out_transform(ob, yv);
+      out_transform(ob, yv, std::false_type{});
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const f32x4 v = {yv[q >> 2][q & 3][0], yv[q >> 2][q & 3][1], yv[q >> 2][q & 3][2], yv[q >> 2][q & 3][3]};
@@ -535,8 +566,10 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
 #pragma unroll
         for (int r = 0; r < 4; ++r) yv[q >> 2][q & 3][r] = v[r];
       }
+    } else if (ob == 0 && nx.more) {   // (wave-uniform; the other half and the last tile of a workgroup: the plain form)
+      out_transform(ob, yv, std::true_type{});
     } else {
-      out_transform(ob, yv);
+      out_transform(ob, yv, std::false_type{});
     }
     // element-wise part: ONE PASS PER EPILOGUE FLAG over 8 outputs pixels at a time (a flag is tested once per half tile, not once per
     // element: every instruction here is matrix time lost)
@@ -711,6 +744,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     W4_STAMP(3);
     // (the loop ends with a barrier: every wave is past its last LDS read, raw and filter buffers are free)
     const bool more = vb + (int)gridDim.x < total;
+    Wino4Next nx{false, 0, 0};
     if (more) {   // the next tile: raw patches 0, 1, 2, filter block 0 and the epilogue vectors
       const Wino4Tile tn = wino4_tile<GEO>(p_, vb + (int)gridDim.x, gx, gyn, gz);
       // (the vectors FIRST: their global loads are waited for with vmcnt(0) before they go to LDS, and vector-memory operations retire in
@@ -719,10 +753,10 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
       W4_STAMP(6);
       sr = wino4_src<GEO, FORM>(p_, grp, tn, gyn_abs, lane, wave);
       W4_STAMP(7);
-      wino4_prologue_dma<FORM>(p_, smem, sr, tn.kbeg, tn.kcnt, lane, wave);
+      nx = Wino4Next{true, tn.kbeg, tn.kcnt};
     }
     W4_STAMP(4);
-    wino4_finish<GEO, SPLIT, w4_epi_mask(EC)>(p, tl, smem, sV, lane, wave, acc, accv);
+    wino4_finish<GEO, FORM, SPLIT, w4_epi_mask(EC)>(p, tl, smem, sV, lane, wave, acc, accv, sr, nx);
     W4_STAMP(5);
     prefetched = more;
     cur ^= 1;
@@ -730,7 +764,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
   }
 }
 
-// Filter transform U = G g G^T, G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]], evaluated in double
+// Filter transform U = G g G^T, G = rows [1, p_j, p_j^2] / N_j at the points 0, +-a, +-b and [0, 0, 1] (wino4_xform.hpp), evaluated in double
 // and rounded once, from the implicit-GEMM weight pack (tap-major [tap][wrows][wcols]) into the block layout of wino4_kernel:
 // [N tile of 64][chunk of 4 channels][position 36][channel 4][oh 2][tx 16][ob 2], output channel = 32 oh + 16 ob + tx.
 struct Wino4Taps { int widx[4][9]; };   // [variant][3 a + b]: weight-pack tap of sub-filter element (a, b), -1 = zero
@@ -758,8 +792,9 @@ __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const floa
       const int wi = tp.widx[var][a * 3 + b];
       g9[a][b] = (live && wi >= 0) ? (double)w[((size_t)wi * wrows + oc) * wcols + c] : 0.0;
     }
-  const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  const double wa = kWa, wb = kWb;
+  const double G[6][3] = {{1.0 / kWN0, 0.0, 0.0}, {1.0 / kWNa, wa / kWNa, wa * wa / kWNa}, {1.0 / kWNa, -wa / kWNa, wa * wa / kWNa},
+                          {1.0 / kWNb, wb / kWNb, wb * wb / kWNb}, {1.0 / kWNb, -wb / kWNb, wb * wb / kWNb}, {0.0, 0.0, 1.0}};
   float* dst = u + ((size_t)g * ntile * nvar * kchunks + (size_t)blk) * (kUSlots4 * 4) + (size_t)c4 * kBN4 + (oc64 >> 5) * 32 + (oc64 & 15) * 2 + ((oc64 >> 4) & 1);
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {

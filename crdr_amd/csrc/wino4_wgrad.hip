@@ -5,8 +5,8 @@
 //
 // Cut P (dy of a Conv2d) into 4 x 4 tiles and Q (x) into the 6 x 6 patches they meet: per tile the 3 x 3 taps are the correlation of the patch
 // with the tile, which minimal filtering does in 36 products instead of 144:
-//   g = sum_tiles A^T [ (G p G^T) . (B^T q B) ] A,   A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,1]],   B^T = wino4.hip's,
-//   G = D V,  V = rows [1, x, x^2, x^3] at x = 0, 1, -1, 2, -2 and [0,0,0,1],  D = diag(1/4, -1/6, -1/6, 1/24, 1/24, 1)
+//   g = sum_tiles A^T [ (G p G^T) . (B^T q B) ] A,   A^T = [[1,1,1,1,1,0],[0,a,-a,b,-b,0],[0,a2,a2,b2,b2,1]],   B^T = wino4.hip's,
+//   G = D V,  V = rows [1, x, x^2, x^3] at x = 0, +-a, +-b and [0,0,0,1],  D = diag(1 / N_j)   (points: wino4_xform.hpp, a = 3/4, b = 5/4)
 // i.e. 36 GEMMs [I x tiles] . [tiles x J] whose reduction axis is the tile index, and ONE output transform per workgroup.  D is left out of
 // the K loop: the accumulators carry (V p V^T) . (B^T q B) and the output transform scales position (xi, nu) by D[xi] D[nu] once.
 //
@@ -52,20 +52,21 @@ constexpr int kPieces = kUsed / 4;                         // 16-byte pieces (1 
 constexpr int kPasses = (kPieces + 255) / 256;             // 8 (the last one partial: its wave 1 is half used)
 constexpr int kStage = ((kPieces + 63) / 64) * 64 * 4;     // floats per stage, whole wave instructions (7 680)
 
-// V p: rows [1, x, x^2, x^3] at x = 0, 1, -1, 2, -2, inf, on two channel blocks at once (packed fp32; o[0] = p0 and o[5] = p3 are the inputs)
-__device__ __forceinline__ void v4_pk(const f32x2v p0, const f32x2v p1, const f32x2v p2, const f32x2v p3, f32x2v (&o)[6]) {
-  f32x2v e, d, e2, d2;
+// V p: rows [1, x, x^2, x^3] at x = 0, +-a, +-b, inf (wino4_xform.hpp: a = 3/4, b = 5/4), on two channel blocks at once (packed fp32; o[0] = p0
+// and o[5] = p3 are the inputs): rows +-a = E_a +- a D_a with E_a = p0 + a2 p2, D_a = p1 + a2 p3
+__device__ __forceinline__ void v4_pk(const f32x2v p0, const f32x2v p1, const f32x2v p2, const f32x2v p3, f32x2v (&o)[6], const W4Consts& kc) {
+  f32x2v ea, da, eb, db;
   asm volatile(
-      "v_pk_add_f32 %4, %8, %10\n"                             // e  = p0 + p2
-      "v_pk_add_f32 %5, %9, %11\n"                             // d  = p1 + p3
-      "v_pk_fma_f32 %6, %10, 4.0, %8 op_sel_hi:[1,0,1]\n"      // e2 = p0 + 4 p2
-      "v_pk_fma_f32 %7, %11, 4.0, %9 op_sel_hi:[1,0,1]\n"      // d2 = p1 + 4 p3
-      "v_pk_add_f32 %0, %4, %5\n"                              // o1 = e + d
-      "v_pk_add_f32 %1, %4, %5 neg_lo:[0,1] neg_hi:[0,1]\n"    // o2 = e - d
-      "v_pk_fma_f32 %2, %7, 2.0, %6 op_sel_hi:[1,0,1]\n"       // o3 = e2 + 2 d2
-      "v_pk_fma_f32 %3, %7, -2.0, %6 op_sel_hi:[1,0,1]"         // o4 = e2 - 2 d2
-      : "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(e), "=&v"(d), "=&v"(e2), "=&v"(d2)
-      : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+      "v_pk_fma_f32 %4, %10, %14, %8 op_sel_hi:[1,0,1]\n"                     // E_a = p0 + a2 p2
+      "v_pk_fma_f32 %5, %11, %14, %9 op_sel_hi:[1,0,1]\n"                     // D_a = p1 + a2 p3
+      "v_pk_fma_f32 %6, %10, %14, %8 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"      // E_b = p0 + b2 p2
+      "v_pk_fma_f32 %7, %11, %14, %9 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"      // D_b = p1 + b2 p3
+      "v_pk_fma_f32 %0, %5, %12, %4 op_sel_hi:[1,0,1]\n"                      // o1 = E_a + a D_a
+      "v_pk_fma_f32 %1, %5, %13, %4 op_sel_hi:[1,0,1]\n"                      // o2 = E_a - a D_a
+      "v_pk_fma_f32 %2, %7, %12, %6 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"       // o3 = E_b + b D_b
+      "v_pk_fma_f32 %3, %7, %13, %6 op_sel:[0,1,0] op_sel_hi:[1,1,1]"          // o4 = E_b - b D_b
+      : "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(ea), "=&v"(da), "=&v"(eb), "=&v"(db)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(kc.k2), "s"(kc.k3), "s"(kc.k5));
   o[0] = p0;
   o[5] = p3;
 }
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void wino4_wgrad_kernel(const WgradArgs p_, co
 
   const int m = lane & 15, kg = lane >> 4;
   const int pb = (4 * kg) * kPC + 32 * iw + m, qb = kPFloats + (4 * kg) * kQC + 16 * jw + m;   // this lane's tile / channel inside the P / Q images
-  const W4Consts kc = {f32x2v{-4.0f, -1.0f}, f32x2v{1.0f, 2.0f}, f32x2v{-1.0f, -2.0f}, f32x2v{-5.0f, -5.0f}};
+  const W4Consts kc = w4_consts();
   f32x2v PR[4][4];   // raw P: [row][column] = (channel block 0, channel block 1) of the lane's tile
   f32x2v QR[3][6];   // raw Q: [column pair c][row] = pixels (row, 2 c), (row, 2 c + 1) of the lane's patch
   f32x2v Ap[6][6];   // V p V^T: [xi][nu] = (block 0, block 1)
@@ -202,13 +203,13 @@ __global__ __launch_bounds__(256) void wino4_wgrad_kernel(const WgradArgs p_, co
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         f32x2v o[6];
-        v4_pk(PR[0][v], PR[1][v], PR[2][v], PR[3][v], o);
+        v4_pk(PR[0][v], PR[1][v], PR[2][v], PR[3][v], o, kc);
 #pragma unroll
         for (int x = 0; x < 6; ++x) t[x][v] = o[x];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int x = 0; x < 6; ++x) v4_pk(t[x][0], t[x][1], t[x][2], t[x][3], Ap[x]);
+      for (int x = 0; x < 6; ++x) v4_pk(t[x][0], t[x][1], t[x][2], t[x][3], Ap[x], kc);
       __builtin_amdgcn_sched_barrier(0);
     }
     {   // Q side: B^T q B
@@ -287,12 +288,12 @@ __global__ __launch_bounds__(256) void wino4_wgrad_kernel(const WgradArgs p_, co
   // (i = i0 + 32 iw + 16 ib + 4 kg + r, j = j0 + 16 jw + m)
   float* slab = p.ws + (size_t)gidx * p.slab_elems + (size_t)split * p.T * p.PC * p.QC;
   const int jc = j0 + 16 * jw + m;
-  const float D[6] = {0.25f, -1.0f / 6, -1.0f / 6, 1.0f / 24, 1.0f / 24, 1.0f};
+  const double D[6] = {1.0 / kWN0, 1.0 / kWNa, 1.0 / kWNa, 1.0 / kWNb, 1.0 / kWNb, 1.0};   // 1 / N_j (wino4_xform.hpp), left out of the K loop
 #pragma unroll
   for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float sv[3][6];   // A^T (D U D), rows a, columns nu
+      float sv[3][6];   // A^T (D U D), rows a, columns nu;  A^T = [[1, 1, 1, 1, 1, 0], [0, a, -a, b, -b, 0], [0, a2, a2, b2, b2, 1]]
 #pragma unroll
       for (int nu = 0; nu < 6; ++nu) {
         float u[6];
@@ -300,18 +301,18 @@ __global__ __launch_bounds__(256) void wino4_wgrad_kernel(const WgradArgs p_, co
         for (int xi = 0; xi < 6; ++xi) {
           const int blk = 2 * (xi * 6 + nu) + ib;
           const float raw = blk < 64 ? acc_read(acc[blk < 64 ? blk : 0][r]) : accv[blk >= 64 ? blk - 64 : 0][r];
-          u[xi] = raw * (D[xi] * D[nu]);
+          u[xi] = raw * (float)(D[xi] * D[nu]);
         }
         const float pp = u[1] + u[2], qq = u[1] - u[2], uu = u[3] + u[4], ww = u[3] - u[4];
         sv[0][nu] = u[0] + pp + uu;
-        sv[1][nu] = __builtin_fmaf(2.0f, ww, qq);
-        sv[2][nu] = __builtin_fmaf(4.0f, uu, pp) + u[5];
+        sv[1][nu] = __builtin_fmaf(kWb, ww, kWa * qq);
+        sv[2][nu] = __builtin_fmaf(kWb2, uu, kWa2 * pp) + u[5];
       }
       const int i = i0 + 32 * iw + 16 * ib + 4 * kg + r;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float pp = sv[a][1] + sv[a][2], qq = sv[a][1] - sv[a][2], uu = sv[a][3] + sv[a][4], ww = sv[a][3] - sv[a][4];
-        const float g0 = sv[a][0] + pp + uu, g1 = __builtin_fmaf(2.0f, ww, qq), g2 = __builtin_fmaf(4.0f, uu, pp) + sv[a][5];
+        const float g0 = sv[a][0] + pp + uu, g1 = __builtin_fmaf(kWb, ww, kWa * qq), g2 = __builtin_fmaf(kWb2, uu, kWa2 * pp) + sv[a][5];
         if (i < p.PC && jc < p.QC && a < na) {
           const int t0 = tap0 + tstep * (a * p.kw);
           slab[((size_t)t0 * p.PC + i) * p.QC + jc] = g0;

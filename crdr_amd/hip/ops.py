@@ -242,8 +242,8 @@ def _stream_ids():
 # very operands it is timed on: max |candidate - baseline| <= TUNE_AGREE[kind] x max |baseline|.  Two correct plans differ by fp32
 # summation order only (measured over every entry of the shipped database: profiles/r4_plan_replay.json); a mis-tiled edge, a
 # wrong split reduce or a stale workspace is orders of magnitude above that and must not ship because it is fast.
-TUNE_AGREE = {"conv": 2e-5, "wgrad": 2e-4, "wino4": 6e-5}   # wino4: the F(4x4, 3x3) Winograd kernel (transform constants up to 8 and 1/24:
-#                                                              5e-6 .. 1e-5 of the output scale against float64, tests/test_gpu_wino.py)
+TUNE_AGREE = {"conv": 2e-5, "wgrad": 2e-4, "wino4": 2e-5}   # wino4: the F(4x4, 3x3) Winograd kernel (round 5 points 0, +-3/4, +-5/4: 0.4e-6 .. 5e-6 of
+#                                                              the output scale against float64, tests/test_gpu_wino.py; 6e-5 with round 4's 0, +-1, +-2)
 TUNE_REJECTED = []   # (key, algo, measured disagreement) of every candidate refused
 TUNE_SKIPPED = []    # keys whose tuning was put off because the call's result was all zero (no scale to compare candidates against)
 

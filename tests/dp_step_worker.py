@@ -19,6 +19,28 @@ os.environ.setdefault("CRDR_ALLOW_RANDOM_LPIPS", "1")
 
 
 def main():
+    """One variant (`OUT.pt [options]`) or several in ONE process (`--batch SPEC.json`: a list of {"out": path, "args": [options]}): the
+    GPU suite's child-process tests used to start 18 interpreters of ~10 s each (import, library load, trainer build) for variants that
+    differ in a flag; variants of one kind (all plain, or all on the 1-rank process group) now share a process, each with a fresh
+    trainer, freshly seeded generators and its own dump."""
+    if len(sys.argv) >= 3 and sys.argv[1] == "--batch":
+        import gc
+        import json
+        import torch
+        with open(sys.argv[2]) as f:
+            specs = json.load(f)
+        for spec in specs:
+            run_one([spec["out"]] + list(spec["args"]), last=spec is specs[-1])
+            gc.collect()
+            torch.cuda.empty_cache()
+        return
+    run_one(sys.argv[1:], last=True)
+
+
+_dist_ready = []
+
+
+def run_one(argv, last=True):
     ap = argparse.ArgumentParser()
     ap.add_argument("out")
     ap.add_argument("--graphs", action="store_true")
@@ -33,14 +55,18 @@ def main():
     ap.add_argument("--forced-algo", type=int, default=0, help="ops.FORCED_CONV_ALGO: one conv plan whatever the batch size (runs at different "
                     "per-process batch sizes then share the fp32 summation order)")
     ap.add_argument("--report-qbpp", action="store_true", help="no training: per-image quantised bpp of the global batch at --fixed-q")
-    a = ap.parse_args()
+    ap.add_argument("--straddle-target", action="store_true", help="target rate between the two half-batch means of the quantised bpp of the "
+                    "global batch (computed here, before training, from the seeded parameters): the lambda_A / lambda_B switch is straddled")
+    a = ap.parse_args(argv)
     import torch
     from crdr_amd.trainer import build_trainer
     from crdr_amd.trainer import dist as D
     from tests.golden.seeded_weights import seeded_input
     from tests.test_gpu_step import _opt, _seed_params
     from crdr_amd.hip import ops
-    local = D.init_from_env()
+    if not _dist_ready:
+        _dist_ready.append(D.init_from_env())
+    local = _dist_ready[0]
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     ops.FORCED_CONV_ALGO = a.forced_algo
@@ -72,6 +98,19 @@ def main():
                  "z": seeded_input("dp.noise.z", (a.global_bs, 192, 1, 1), 0.5)[sl].to(device)}
     else:
         x = seeded_input("image", (2, 3, 64, 64)).to(device)
+    target_used = a.target_rate
+    if a.straddle_target:   # (needs --shard --fixed-q: the whole global batch through the seeded model, no training)
+        gx = seeded_input("dp.image", (a.global_bs, 3, 64, 64)).to(device)
+        gn = {"y": seeded_input("dp.noise.y", (a.global_bs, 320, 4, 4), 0.5).to(device),
+              "z": seeded_input("dp.noise.z", (a.global_bs, 192, 1, 1), 0.5).to(device)}
+        with torch.no_grad():
+            qb = tr.comp_model.run_model(gx, rate_ind=float(a.fixed_q), beta=2.56, is_train=True, noise=gn)["qbpp"].detach().double().cpu()
+        lo, hi = sorted([float(qb[: a.global_bs // 2].mean()), float(qb[a.global_bs // 2:].mean())])
+        target_used = lo + 0.25 * (hi - lo)
+        rl = tr.rate_loss
+        rl.target_rate = [target_used] * len(rl.target_rate) if isinstance(rl.target_rate, list) else target_used
+        tr.comp_model.context_model.seed_noise(1234)
+        torch.manual_seed(0)
     if a.report_qbpp:
         with torch.no_grad():
             out = tr.comp_model.run_model(x, rate_ind=float(a.fixed_q), beta=2.56, is_train=True, noise=noise)
@@ -108,9 +147,11 @@ def main():
              "G": {k: p.detach().cpu() for k, p in tr.comp_model.named_parameters()},
              "D": {k: p.detach().cpu() for k, p in tr.discriminator.named_parameters()} if a.stage == 3 else {},
              "staged": bool(tr._staged()),
-             "graphs": len(tr.graphs)}
+             "graphs": len(tr.graphs), "target": target_used,
+             "probe_qbpp": qb if a.straddle_target else None}
     torch.save(state, a.out + (f".rank{D.rank()}" if a.shard and D.is_dist() else ""))
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
+    tr.g_optimizer.step = g_step
+    if last and torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

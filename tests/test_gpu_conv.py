@@ -23,7 +23,7 @@ def _rand(*shape, seed=0, scale=1.0):
     return (torch.rand(*shape, generator=g) * 2 - 1) * scale
 
 
-def _close(got, ref, what, rtol=2e-4):
+def _close(got, ref, what, rtol=2e-5):   # (exact-fp32 kernels measure ~1e-6 of the output scale against float64: SURVEY 8d gate (1) with a factor of two)
     got = got.detach().cpu().double()
     ref = ref.detach().cpu().double()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)

@@ -20,21 +20,48 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_worker(out, force_dist, graphs, extra=()):
+def _run_batch(tmp, force_dist, variants):
+    """ONE child process for all `variants` ({name: [worker options]}) of one kind -- plain, or on the 1-rank RCCL process group
+    (CRDR_FORCE_DIST=1) -- each with a fresh trainer and freshly seeded generators (tests/dp_step_worker.py --batch); -> {name: dump}"""
+    import json
     env = dict(os.environ, CRDR_FORCE_DIST="1" if force_dist else "0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "tests.dp_step_worker", str(out)] + (["--graphs"] if graphs else []) + list(extra)
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    tag = "dp" if force_dist else "plain"
+    spec = [{"out": str(tmp / f"{tag}_{name}.pt"), "args": list(args)} for name, args in variants.items()]
+    spec_path = tmp / f"{tag}_spec.json"
+    spec_path.write_text(json.dumps(spec))
+    r = subprocess.run([sys.executable, "-m", "tests.dp_step_worker", "--batch", str(spec_path)], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
-    return torch.load(out, map_location="cpu", weights_only=False)
+    return {name: torch.load(sp["out"], map_location="cpu", weights_only=False) for name, sp in zip(variants, spec)}
+
+
+STRADDLE = ("--stage", "3", "--fixed-q", "2", "--global-bs", "4", "--forced-algo", "1", "--graphs", "--shard", "--straddle-target")
+
+
+@pytest.fixture(scope="module")
+def dp_runs(tmp_path_factory):
+    """Every child-process variant of this file, in TWO processes (round 4: eighteen, 212 s of the suite): the plain runs in one, the
+    runs on the 1-rank RCCL group in the other.  Keys: (kind, name)."""
+    tmp = tmp_path_factory.mktemp("dp_runs")
+    staged = {"stage1": ("--stage", "1"), "stage3-lambdaB": ("--stage", "3", "--target-rate", "100.0"),
+              "stage3-target0.5": ("--stage", "3", "--target-rate", "0.5")}
+    plain = {"graphs": ["--graphs"], "eager": [], "straddle": list(STRADDLE)}
+    dp = {"graphs": ["--graphs"], "eager": [], "draw_a": ["--draw-conditions", "--iters", "4"], "draw_b": ["--draw-conditions", "--iters", "4"]}
+    for name, extra in staged.items():
+        plain["staged_" + name] = ["--graphs", *extra]
+        dp["staged_" + name] = ["--graphs", *extra]
+        dp["single_" + name] = ["--graphs", *extra, "--no-buckets"]
+    out = {("plain", k): v for k, v in _run_batch(tmp, False, plain).items()}
+    out.update({("dp", k): v for k, v in _run_batch(tmp, True, dp).items()})
+    return out
 
 
 @pytest.mark.parametrize("graphs", [True, False])
-def test_trainer_dp_path_on_one_rank_rccl_is_bit_identical(tmp_path, graphs):
-    plain = _run_worker(tmp_path / "plain.pt", False, graphs)
-    dp = _run_worker(tmp_path / "dp.pt", True, graphs)
+def test_trainer_dp_path_on_one_rank_rccl_is_bit_identical(dp_runs, graphs):
+    plain, dp = dp_runs[("plain", "graphs" if graphs else "eager")], dp_runs[("dp", "graphs" if graphs else "eager")]
     assert plain["dist"] is False and dp["dist"] is True and dp["world"] == 1
     if graphs:
         assert dp["graphs"] >= 4, "the data-parallel run did not capture its segments"
@@ -47,18 +74,15 @@ def test_trainer_dp_path_on_one_rank_rccl_is_bit_identical(tmp_path, graphs):
             assert torch.equal(plain[part][k], dp[part][k]), (part, k)
 
 
-@pytest.mark.parametrize("stage,target", [(1, None), (3, 100.0), (3, 0.5)], ids=["stage1", "stage3-lambdaB", "stage3-target0.5"])
-def test_staged_backward_and_global_rate_switch_are_bit_identical(tmp_path, stage, target):
+@pytest.mark.parametrize("name", ["stage1", "stage3-lambdaB", "stage3-target0.5"])
+def test_staged_backward_and_global_rate_switch_are_bit_identical(dp_runs, name):
     """Config #4 semantics on one rank, HIP graphs on: the data-parallel generator step -- forward graph | all-reduce of the
     mean qbpp (lambda_A / lambda_B on the GLOBAL mean, rate_loss.py:172-175) | backward in three captured pieces with one
     asynchronous gradient bucket each -- against (a) the same path with one bucket behind an unstaged backward and (b) the
     plain single-GPU run: same logs, bit-identical parameters.  target 100 forces the lambda_B branch, 0.5 sits among the
     seeded model's qbpp values; stage 1 (crdr_stage_1.yaml: HificRateLoss, target 1.5) is the path where the all-reduce is
     otherwise fully exposed."""
-    extra = ("--stage", str(stage)) + (("--target-rate", str(target)) if target is not None else ())
-    plain = _run_worker(tmp_path / "plain.pt", False, True, extra)
-    staged = _run_worker(tmp_path / "staged.pt", True, True, extra)
-    single = _run_worker(tmp_path / "single.pt", True, True, extra + ("--no-buckets",))
+    plain, staged, single = dp_runs[("plain", "staged_" + name)], dp_runs[("dp", "staged_" + name)], dp_runs[("dp", "single_" + name)]
     assert staged["staged"] is True and single["staged"] is False and plain["staged"] is False
     assert staged["graphs"] >= single["graphs"] + 3, (staged["graphs"], single["graphs"])
     for other in (single, plain):
@@ -71,11 +95,10 @@ def test_staged_backward_and_global_rate_switch_are_bit_identical(tmp_path, stag
                 assert torch.equal(other[part][k], staged[part][k]), (part, k)
 
 
-def test_dp_ranks_draw_shared_conditions(tmp_path):
+def test_dp_ranks_draw_shared_conditions(dp_runs):
     """with the trainer drawing (q, beta) itself, the data-parallel path uses the seeded shared generators
-    (same sequence on every rank): two runs give identical logs"""
-    a = _run_worker(tmp_path / "a.pt", True, False, ("--draw-conditions", "--iters", "4"))
-    b = _run_worker(tmp_path / "b.pt", True, False, ("--draw-conditions", "--iters", "4"))
+    (same sequence on every rank): two runs (fresh trainers) give identical logs"""
+    a, b = dp_runs[("dp", "draw_a")], dp_runs[("dp", "draw_b")]
     assert [l["qbpp"] for l in a["logs"]] == [l["qbpp"] for l in b["logs"]]
     assert len({round(l["qbpp"], 6) for l in a["logs"]}) > 1, "the rate index never changed over 4 draws"
 
@@ -196,44 +219,31 @@ def _by_module(layout, got, ref):
 
 
 @pytest.mark.parametrize("world", [1, 2])
-def test_two_rank_rccl_staged_step(tmp_path, world):
+def test_two_rank_rccl_staged_step(tmp_path, dp_runs, world):
     """Stage 3, HIP graphs on, staged generator step (forward graph | all-reduce of the mean qbpp | three backward graphs with one
     asynchronous RCCL bucket each), a global batch of 4 seeded images with explicit noise split over `world` ranks:
 
-    * the lambda_A / lambda_B switch is STRADDLED: the target rate sits between the two half-batch means of the quantised bpp, so a
-      rank deciding on its local mean would take the other branch than the global mean does (rate_loss.py:172-175 at global batch);
+    * the lambda_A / lambda_B switch is STRADDLED: the target rate sits between the two half-batch means of the quantised bpp (every
+      process derives it from the seeded parameters before it trains, dp_step_worker --straddle-target), so a rank deciding on its
+      local mean would take the other branch than the global mean does (rate_loss.py:172-175 at global batch);
     * all ranks hold bit-identical generator and discriminator parameters after 5 iterations;
     * the all-reduced gradients of iteration 1 equal the one-GPU run of the whole batch within the data-parallel identity's
       tolerances (test_dp_identity_on_the_real_trainer: 2e-5 behind the quantiser, encoder 5e-3, mean / scale transforms 5e-4) --
       a rank on the wrong lambda branch would be off by the ratio lambda_A / lambda_B in the rate gradient."""
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs (have {torch.cuda.device_count()})")
-    q, gbs = 2, 4
-    common = ("--stage", "3", "--fixed-q", str(q), "--global-bs", str(gbs), "--forced-algo", "1")
-    # per-image quantised bpp of the global batch (one GPU, no training) -> a target between the half-batch means
-    probe = tmp_path / "probe.pt"
-    env = dict(os.environ, CRDR_FORCE_DIST="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-        env.pop(k, None)
-    r = subprocess.run([sys.executable, "-m", "tests.dp_step_worker", str(probe), "--shard", "--report-qbpp", *common], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    qb = torch.load(probe, weights_only=False)["qbpp"].double()
+    gbs = 4
+    # the whole batch on one GPU, plain (no process group): the reference the ranks must reproduce
+    ref = dp_runs[("plain", "straddle")]
+    assert ref["dist"] is False
+    qb, target = ref["probe_qbpp"], ref["target"]
     lo, hi = sorted([float(qb[: gbs // 2].mean()), float(qb[gbs // 2:].mean())])
     assert hi - lo > 1e-4 * hi, ("the two halves of the seeded batch have the same mean qbpp", lo, hi)
     glob = float(qb.mean())
-    target = lo + 0.25 * (hi - lo)          # lo < target < global mean < hi: global decision lambda_A, the low half alone would say lambda_B
-    assert lo < target < glob < hi
-    extra = common + ("--target-rate", repr(target))
-    # the whole batch on one GPU, plain (no process group): the reference the ranks must reproduce
-    single = tmp_path / "single.pt"
-    r = subprocess.run([sys.executable, "-m", "tests.dp_step_worker", str(single), "--graphs", "--shard", *extra], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stderr[-3000:]
-    ref = torch.load(single, map_location="cpu", weights_only=False)
-    assert ref["dist"] is False
-    ranks = _launch_ranks(tmp_path / "dp.pt", world, extra, 29650 + world)
+    assert lo < target < glob < hi      # global decision lambda_A, the low half alone would say lambda_B
+    ranks = _launch_ranks(tmp_path / "dp.pt", world, [x for x in STRADDLE if x not in ("--graphs", "--shard")], 29650 + world)
     assert all(s["dist"] and s["world"] == world and s["staged"] for s in ranks)
+    assert all(s["target"] == target for s in ranks), ([s["target"] for s in ranks], target)
     assert all(s["graphs"] >= 7 for s in ranks), [s["graphs"] for s in ranks]
     assert all(lg is not None for s in ranks for lg in s["logs"]), "an iteration was skipped"
     if world == 2:   # the straddle is real on the ranks' own logs (iteration 1: the probe's parameters)

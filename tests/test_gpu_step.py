@@ -150,7 +150,7 @@ def test_stage3_step_128_winograd_f4x4():
 # with direct / F(2x2) plans (forward noise ~1e-6), 9.7e-3 at stage 1 / bs 8 once the tuner's F(4x4, 3x3) Winograd launches (forward
 # noise ~6e-6, tests/test_gpu_wino.py) run the analysis transform's 3x3 layers.  Everything behind the quantiser is unaffected (the
 # rounding absorbs the noise: decoder / context model / hyper-decoder errors are the same with both plan sets, profiles/r4_parity_margins.json).
-UPSTREAM_TUNED_TOL = 2e-2
+UPSTREAM_TUNED_TOL = 8e-3   # (round 4: 2e-2 for the F(4x4) kernels at the points 0, +-1, +-2; round 5's points carry ~1/4 of that forward noise)
 
 
 def _upstream(name: str) -> bool:

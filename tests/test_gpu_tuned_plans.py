@@ -9,8 +9,10 @@ the deferred weight-gradient reduce and the column-sum partial rows the training
 
  (i)  with the built-in plan's result on the same operands: max |tuned - builtin| <= 1e-5 of the output scale (two correct fp32
       summation orders), and
- (ii) with float64 torch on the CPU on a strided sample of >= 4 096 output pixels that includes all four borders and the
-      first / last image (weight gradients: a 32 x 32 sample of (out, in) channel pairs, all taps, full reduction).
+ (ii) with float64 stock torch on a strided sample of >= 4 096 output pixels that includes all four borders and the first / last image
+      (weight gradients: a 32 x 32 sample of (out, in) channel pairs, all taps, full reduction).  The float64 products run where the
+      operands live (ATen's float64 matmul on the device); for every 8th entry they run a second time entirely on the CPU and the two
+      references must agree to 1e-11 (round 4 spent 190 s of the suite's 1 056 s in CPU dgemm here).
 
 The autotuner is not allowed to run here: an entry whose reconstructed key misses the database fails the test.
 """
@@ -104,13 +106,17 @@ def _sample_pixels(n, oh, ow, work=1):
     return idx[:, 0], idx[:, 1], idx[:, 2]
 
 
-def _conv_ref64(xb, wp, geo, pix):
+def _conv_ref64(xb, wp, geo, pix, on_cpu=False):
     """float64 accumulator of the convolution at the sampled output pixels.  xb: [N,H,W,ld] float32; wp: pack [T][wrows][wcols]
-    (wlayout 0) or [1][wrows][4T..] (wlayout 1), on any device: the sampled input rows are GATHERED where the tensors live (a copy,
-    no arithmetic) and every product and sum runs in float64 on the CPU; -> [P][OC] float64"""
+    (wlayout 0) or [1][wrows][4T..] (wlayout 1), on any device: the sampled input rows are gathered, converted to float64 and
+    multiplied by stock torch WHERE THE TENSORS LIVE (float64 matmul of ATen: an implementation that shares nothing with the kernels
+    under test; on the GPU box 140 grouped entries took 118 s of CPU dgemm, round 4) -- `on_cpu` forces every product and sum onto
+    the CPU instead (the replay does that for every 8th entry and requires the two float64 results to agree to 1e-11);
+    -> [P][OC] float64 on the CPU"""
     n, h, w, c, oh, ow, oc, kh, kw, stride, pad, transposed, wlayout = geo
     pn, py, px = pix
-    acc = torch.zeros((pn.numel(), oc), dtype=torch.float64)
+    dev = torch.device("cpu") if on_cpu else xb.device
+    acc = torch.zeros((pn.numel(), oc), dtype=torch.float64, device=dev)
     x2d = xb.reshape(n * h * w, xb.shape[-1])
     for r in range(kh):
         for s in range(kw):
@@ -126,13 +132,13 @@ def _conv_ref64(xb, wp, geo, pix):
                 continue
             t = r * kw + s
             rows = ((pn[ok] * h + iy[ok]) * w + ix[ok]).to(x2d.device)
-            patch = x2d.index_select(0, rows)[:, :c].cpu().double()            # [P'][c]
+            patch = x2d.index_select(0, rows)[:, :c].to(dev).double()          # [P'][c]
             if wlayout == 1:
-                wt = wp[0, :oc, 4 * t:4 * t + c].cpu().double()                # [oc][c]
+                wt = wp[0, :oc, 4 * t:4 * t + c].to(dev).double()              # [oc][c]
             else:
-                wt = wp[t, :oc, :c].cpu().double()
-            acc[ok] += patch @ wt.t()
-    return acc
+                wt = wp[t, :oc, :c].to(dev).double()
+            acc[ok.to(dev)] += patch @ wt.t()
+    return acc.cpu()
 
 
 def _epilogue64(v, flags, o, pix, oc):
@@ -291,6 +297,11 @@ def _replay_conv(rp, key, algo, seed):
     e64 = e64b = 0.0
     for g in sorted({0, G - 1}):
         acc = _conv_ref64(xs[g], wps[g], geo, pix)
+        if seed % 8000 == 0 and g == 0:   # every 8th entry: the same reference with every product and sum on the CPU
+            acc_cpu = _conv_ref64(xs[g], wps[g], geo, pix, on_cpu=True)
+            dd = float((acc - acc_cpu).abs().max()) / (float(acc_cpu.abs().max()) + 1e-300)
+            assert dd <= 1e-11, f"{key}: float64 references on the device and on the CPU disagree by {dd:.3e}"
+            out["f64_device_vs_cpu"] = dd
         o = {"y0": y0[g]}
         for name, lst in opn.items():
             o[name] = lst[g if len(lst) > 1 else 0]
@@ -311,12 +322,14 @@ def _replay_conv(rp, key, algo, seed):
     return out
 
 
-def _wgrad_ref64(pb, qb, geo, isel, jsel):
-    """g[i][j][t] = sum P[n,a,b,i] Q[n, a*stride - pad + r, b*stride - pad + s, j] in float64 for i in isel, j in jsel"""
+def _wgrad_ref64(pb, qb, geo, isel, jsel, on_cpu=False):
+    """g[i][j][t] = sum P[n,a,b,i] Q[n, a*stride - pad + r, b*stride - pad + s, j] in float64 for i in isel, j in jsel (stock torch float64 where
+    the operands live; `on_cpu`: everything on the CPU -- see _conv_ref64)"""
     n, ph, pw, qh, qw, kh, kw, stride, pad = geo
-    P = pb.index_select(-1, torch.tensor(isel, device=pb.device)).cpu().double().reshape(-1, len(isel))   # [M][I'] (channel gather on the operand's device)
-    Q = qb.index_select(-1, torch.tensor(jsel, device=qb.device)).cpu().double()
-    out = torch.zeros((len(isel), len(jsel), kh * kw), dtype=torch.float64)
+    dev = torch.device("cpu") if on_cpu else pb.device
+    P = pb.index_select(-1, torch.tensor(isel, device=pb.device)).to(dev).double().reshape(-1, len(isel))   # [M][I'] (channel gather on the operand's device)
+    Q = qb.index_select(-1, torch.tensor(jsel, device=qb.device)).to(dev).double()
+    out = torch.zeros((len(isel), len(jsel), kh * kw), dtype=torch.float64, device=dev)
     ext = pad + kh + kw + stride   # zero border wide enough for every tap of every dense pixel
     Qp = torch.nn.functional.pad(Q, (0, 0, ext, ext, ext, ext))
     for r in range(kh):
@@ -324,7 +337,7 @@ def _wgrad_ref64(pb, qb, geo, isel, jsel):
             y0, x0 = ext - pad + r, ext - pad + s
             g = Qp[:, y0:y0 + stride * (ph - 1) + 1:stride, x0:x0 + stride * (pw - 1) + 1:stride]   # Q[n, a*stride - pad + r, b*stride - pad + s]
             out[:, :, r * kw + s] = P.t() @ g.reshape(-1, len(jsel))
-    return out
+    return out.cpu()
 
 
 def _replay_wgrad(rp, key, algo, seed):
@@ -376,6 +389,10 @@ def _replay_wgrad(rp, key, algo, seed):
     e = eb = 0.0
     for g in sorted({0, G - 1}):
         ref = _wgrad_ref64(ps[g], qs[g], (n, ph, pw, qh, qw, k[0], k[1], stride, pad), isel, jsel)
+        if seed % 8000 == 0 and g == 0:
+            ref_cpu = _wgrad_ref64(ps[g], qs[g], (n, ph, pw, qh, qw, k[0], k[1], stride, pad), isel, jsel, on_cpu=True)
+            dd = float((ref - ref_cpu).abs().max()) / (float(ref_cpu.abs().max()) + 1e-300)
+            assert dd <= 1e-11, f"{key}: float64 references on the device and on the CPU disagree by {dd:.3e}"
         rs = float(ref.abs().max()) + 1e-20
         pick = lambda t: t.cpu().double().reshape(gi, gj, T)[isel][:, jsel]
         e = max(e, float((pick(gt[g]) - ref).abs().max()) / rs)
@@ -403,8 +420,8 @@ def _tolerances(key, r):
     wg = key[0].startswith("w")
     plan = max(TOL_PLAN, (1.5e-7 if not wg else 2.5e-7) * depth ** 0.5)
     f64 = TOL_F64_BF16X3 if r["bf16x3"] else TOL_F64
-    if r.get("wino4"):   # the F(4x4, 3x3) Winograd kernel: transform constants up to 8 and 1/24 (tests/test_gpu_wino.py: 5e-6 .. 1e-5 against float64)
-        plan, f64 = 6e-5, 6e-5
+    if r.get("wino4"):   # the F(4x4, 3x3) / F(3x3, 4x4) Winograd kernels (points 0, +-3/4, +-5/4: tests/test_gpu_wino.py measures 0.4e-6 .. 5.2e-6
+        plan, f64 = max(plan, 2e-5), 2e-5   # against float64; round 4's points 0, +-1, +-2 needed 6e-5 here)
     if os.environ.get("CRDR_PLAN_REPLAY_MEASURE") == "1":   # first measurement of a new database: gross errors only
         plan, f64 = 1e-3, 3e-3
     return plan, f64

@@ -126,7 +126,7 @@ W4_CASES = [
 def test_winograd_f4x4_fwd_dgrad(case):
     """Winograd F(4x4, 3x3) kernel (csrc/wino4.hip, Winograd variant 2) against fp64 torch: forward and input gradient.  Its transforms
     carry the constants 4, 5, 8, 1/24: the deviation from fp64 is ~8x the direct kernel's (numpy model: 5e-6 .. 1e-5 of the output
-    scale at 96 .. 256 channels) and is gated at 5e-5; the measured errors of the three kernels are printed."""
+    scale at 96 .. 256 channels) and is gated at 2e-5 (round 5: interpolation points 0, +-3/4, +-5/4; the 5e-5 of round 4 belonged to 0, +-1, +-2); the measured errors of the three kernels are printed."""
     from crdr_amd.hip import ops
     name, n, ci, h, w, co, p = case
     dev = _dev()
@@ -150,11 +150,11 @@ def test_winograd_f4x4_fwd_dgrad(case):
     e2 = (w2.cpu().double() - ref.detach()).abs().max().item() / sc
     ed = (direct.cpu().double() - ref.detach()).abs().max().item() / sc
     print(f"{name}: fwd max err / scale: F(4x4) {e4:.2e}  F(2x2) {e2:.2e}  direct {ed:.2e}")
-    _close(out, ref, name + " fwd", rtol=5e-5)
+    _close(out, ref, name + " fwd", rtol=2e-5)
     wq = ops.pack_weight(wd, transpose=True)
     dx = ops.conv2d_raw(dyd, wq, ci, (3, 3), 1, p, True, (h, w), algo=a4) if (w >= 24 or (9 <= w <= 16 and 9 <= h <= 16)) else None
     if dx is not None:
-        _close(dx, xr.grad, name + " dgrad", rtol=5e-5)
+        _close(dx, xr.grad, name + " dgrad", rtol=2e-5)
     out2 = ops.conv2d_raw(xd, wp, co, (3, 3), 1, p, False, (oh, ow), bias=bd, flags=1, algo=a4)
     assert torch.equal(out, out2), "not deterministic"
 
@@ -198,12 +198,12 @@ def test_winograd_f4x4_5x5_stride2(case):
         sc = ref.abs().max().item()
         print(f"{name}: conv s2 fwd max err / scale: F(4x4) {(out.cpu().double() - ref.detach()).abs().max().item() / sc:.2e}  "
               f"direct {(direct.cpu().double() - ref.detach()).abs().max().item() / sc:.2e}")
-        _close(out, ref, name + " conv fwd", rtol=5e-5)
+        _close(out, ref, name + " conv fwd", rtol=2e-5)
         assert torch.equal(out, ops.conv2d_raw(xd, wp, co, (5, 5), 2, 2, False, (oh, ow), bias=bd, flags=1, algo=a4))
         # its input gradient: a transposed stride-2 launch (output = the conv's input grid, phases of oh x ow)
         wq = ops.pack_weight(wd, transpose=True)
         dx = ops.conv2d_raw(dyd, wq, ci, (5, 5), 2, 2, True, (h, w), algo=a4)
-        _close(dx, xr.grad, name + " conv dgrad", rtol=5e-5)
+        _close(dx, xr.grad, name + " conv dgrad", rtol=2e-5)
     # ConvTranspose2d 5x5 s2 p2 op1: forward + input gradient
     if w >= 24:
         wt2 = _rand(ci, co, 5, 5, seed=5, scale=(ci * 25 / 4) ** -0.5)
@@ -215,10 +215,10 @@ def test_winograd_f4x4_5x5_stride2(case):
         w2d = wt2.to(dev)
         wp2 = ops.pack_weight(w2d, transpose=True)     # rows = Cout, cols = Cin
         out2 = ops.conv2d_raw(xd, wp2, co, (5, 5), 2, 2, True, (oh2, ow2), bias=bd, flags=1, algo=a4)
-        _close(out2, ref2, name + " convT fwd", rtol=5e-5)
+        _close(out2, ref2, name + " convT fwd", rtol=2e-5)
         wq2 = ops.pack_weight(w2d, transpose=False)    # rows = Cin, cols = Cout
         dx2 = ops.conv2d_raw(dy2.to(dev), wq2, ci, (5, 5), 2, 2, False, (h, w), algo=a4)
-        _close(dx2, xr2.grad, name + " convT dgrad", rtol=5e-5)
+        _close(dx2, xr2.grad, name + " convT dgrad", rtol=2e-5)
 
 
 W4K5_CASES = [
@@ -256,12 +256,12 @@ def test_winograd_f4x4_5x5_stride1(case):
     sc = ref.abs().max().item()
     print(f"{name}: fwd max err / scale: F(4x4) {(out.cpu().double() - ref.detach()).abs().max().item() / sc:.2e}  "
           f"direct {(direct.cpu().double() - ref.detach()).abs().max().item() / sc:.2e}")
-    _close(out, ref, name + " fwd", rtol=5e-5)
+    _close(out, ref, name + " fwd", rtol=2e-5)
     assert torch.equal(out, ops.conv2d_raw(xd, wp, co, (5, 5), 1, 2, False, (h, w), bias=bd, flags=1, algo=a4))
     if co >= 12:
         wq = ops.pack_weight(wd, transpose=True)
         dx = ops.conv2d_raw(dyd, wq, ci, (5, 5), 1, 2, True, (h, w), algo=a4)
-        _close(dx, xr.grad, name + " dgrad", rtol=5e-5)
+        _close(dx, xr.grad, name + " dgrad", rtol=2e-5)
 
 
 WG5_CASES = [
@@ -298,12 +298,12 @@ def test_winograd_wgrad_5x5(case):
     ops.conv2d_wgrad_raw(dyd, xd, gd, (5, 5), st, 2, accumulate=False, algo=1)
     sc = wr.grad.abs().max().item()
     print(f"{name}: wgrad max err / scale: F(3x3,4x4) {(g.cpu().double() - wr.grad).abs().max().item() / sc:.2e}  direct {(gd.cpu().double() - wr.grad).abs().max().item() / sc:.2e}")
-    _close(g, wr.grad, name + " wgrad", rtol=5e-5)
+    _close(g, wr.grad, name + " wgrad", rtol=2e-5)
     g2 = torch.zeros_like(g)
     ops.conv2d_wgrad_raw(dyd, xd, g2, (5, 5), st, 2, accumulate=False, algo=algo)
     assert torch.equal(g, g2)
     ops.conv2d_wgrad_raw(dyd, xd, g, (5, 5), st, 2, accumulate=True, algo=algo)
-    _close(g, 2 * wr.grad, name + " wgrad accumulate", rtol=5e-5)
+    _close(g, 2 * wr.grad, name + " wgrad accumulate", rtol=2e-5)
     if st == 2 and h % 2 == 0 and w % 2 == 0:   # ConvTranspose2d 5x5 s2 p2 op1: P = x, Q = dy (twice the size)
         wT = _rand(ci, co, 5, 5, seed=5, scale=(ci * 25 / 4) ** -0.5).double().requires_grad_(True)
         rT = F.conv_transpose2d(xr, wT, None, stride=2, padding=2, output_padding=1)
@@ -311,7 +311,7 @@ def test_winograd_wgrad_5x5(case):
         rT.backward(dyT.double())
         gT = torch.zeros(ci, co, 5, 5, device=dev)
         ops.conv2d_wgrad_raw(xd, dyT.to(dev), gT, (5, 5), 2, 2, accumulate=False, algo=algo)
-        _close(gT, wT.grad, name + " convT wgrad", rtol=5e-5)
+        _close(gT, wT.grad, name + " convT wgrad", rtol=2e-5)
 
 
 W4SPLIT_CASES = [
@@ -351,7 +351,7 @@ def test_winograd_f4x4_split_k(case):
     one = ops.conv2d_raw(xd, wp, co, (k, k), stride, k // 2, bool(tr), (oh, ow), bias=bd, flags=3, algo=a4)
     outs = [ops.conv2d_raw(xd, wp, co, (k, k), stride, k // 2, bool(tr), (oh, ow), bias=bd, flags=3, algo=a4 | ((ns - 1) << 8)) for _ in range(3)]
     torch.cuda.synchronize()
-    _close(outs[0], ref, name + " split vs fp64", rtol=5e-5)
+    _close(outs[0], ref, name + " split vs fp64", rtol=2e-5)
     _close(outs[0], one.double(), name + " split vs unsplit", rtol=2e-5)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "split launches differ run to run"
     after = ops.conv2d_raw(xd, wp, co, (k, k), stride, k // 2, bool(tr), (oh, ow), bias=bd, flags=3, algo=a4)
@@ -396,7 +396,7 @@ def test_winograd_f4x4_filter_scope():
         assert torch.equal(call(), out2) and (st["filled"], st["reused"]) == (f0 + 5, r0 + 2)
     assert torch.equal(out2, call()) and st["filled"] == f0 + 5, "outside a scope nothing is cached"
     ref2 = F.conv2d(x.cpu().double(), w2.cpu().double(), padding=1)
-    _close(out2, ref2, "filter scope after refill", rtol=5e-5)
+    _close(out2, ref2, "filter scope after refill", rtol=2e-5)
 
 
 def test_winograd_f4x4_epilogues_slices_groups_colsum():
@@ -421,15 +421,15 @@ def test_winograd_f4x4_epilogues_slices_groups_colsum():
     out = ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (h, w), bias=b, flags=flags, vec2=v2, res=res, scale=sc, shift=sh,
                          out=owide[:, 8:8 + co], algo=a4)
     torch.cuda.synchronize()
-    _close(out, ref, "epilogues", rtol=5e-5)
+    _close(out, ref, "epilogues", rtol=2e-5)
     assert float(owide[:, :8].abs().max()) == 0.0 and float(owide[:, 8 + co:].abs().max()) == 0.0
     out = ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (h, w), bias=b, flags=L.EPI_BIAS | L.EPI_LRELU, algo=a4)
-    _close(out, F.leaky_relu(z, 0.2), "lrelu", rtol=5e-5)
+    _close(out, F.leaky_relu(z, 0.2), "lrelu", rtol=2e-5)
     # accumulate into an existing tensor
     acc0 = _rand(n, co, h, w, seed=12).to(dev).contiguous(memory_format=torch.channels_last)
     acc = acc0.clone()
     ops.conv2d_raw(x, wp, co, (3, 3), 1, 1, False, (h, w), bias=b, flags=L.EPI_BIAS | L.EPI_ACCUM, out=acc, algo=a4)
-    _close(acc, z + acc0.double(), "accumulate", rtol=5e-5)
+    _close(acc, z + acc0.double(), "accumulate", rtol=2e-5)
     # grouped launch with ReLU mask + column sums (conv_multi: what a chain's input-gradient launches look like), against the built-in plan
     G = 2
     xs = [_rand(n, h, w, ci, seed=20 + g).to(dev) for g in range(G)]
@@ -457,11 +457,11 @@ def test_winograd_f4x4_epilogues_slices_groups_colsum():
     yb, cb = run(1)
     y4, c4 = run(a4)
     for g in range(G):
-        _close(y4[g], yb[g], f"grouped masked output {g}", rtol=5e-5)
-        _close(c4[g], cb[g], f"grouped column sums {g}", rtol=5e-5)
+        _close(y4[g], yb[g], f"grouped masked output {g}", rtol=2e-5)
+        _close(c4[g], cb[g], f"grouped column sums {g}", rtol=2e-5)
         refg = F.conv2d(xs[g].permute(0, 3, 1, 2).double().cpu(), ws_[g][:, :co, :ci].permute(1, 2, 0).reshape(co, ci, 3, 3).double().cpu(), padding=1)
         refg = torch.where(masks[g].permute(0, 3, 1, 2).cpu() > 0, refg, torch.zeros_like(refg))
-        _close(y4[g].permute(0, 3, 1, 2), refg, f"grouped masked output {g} vs fp64", rtol=5e-5)
+        _close(y4[g].permute(0, 3, 1, 2), refg, f"grouped masked output {g} vs fp64", rtol=2e-5)
 
 
 def test_winograd_rejects_other_shapes():
