@@ -1,4 +1,4 @@
-"""Data-parallel logic on CPU with the gloo backend (world_size 2): flat-buffer averaging, rank-consistent skip
+"""Data-parallel logic on CPU with the gloo backend (world_size 2 and 4): flat-buffer averaging, rank-consistent skip
 decisions, identical per-iteration (q, beta) draws on every rank, and the DP identity itself -- averaging the
 per-rank gradients of the step's loss over shards equals the single-process gradient over the whole batch
 (computed with the CPU oracle, so no GPU is needed)."""
@@ -31,18 +31,26 @@ def _worker(rank, world, port, q):
     try:
         assert D.is_dist() and D.world_size() == world and D.rank() == rank
         # 1) flat-buffer mean
+        mean_rank1 = (world + 1) / 2.0   # mean of rank + 1 over the ranks
         bufs = [torch.full((5,), float(rank + 1)), torch.arange(3.0) * (rank + 1)]
         D.all_reduce_mean_(bufs)
-        assert torch.allclose(bufs[0], torch.full((5,), 1.5)) and torch.allclose(bufs[1], torch.arange(3.0) * 1.5)
+        assert torch.allclose(bufs[0], torch.full((5,), mean_rank1)) and torch.allclose(bufs[1], torch.arange(3.0) * mean_rank1)
         # 1b) the asynchronous form the stage-3 trainer uses (gradient buffers mean-reduced, skip flag max-reduced)
         gb, flag = torch.full((7,), float(2 * rank)), torch.tensor([float(rank)])
         sync = D.AsyncGradSync([gb], [flag])
         sync.wait()
-        assert torch.allclose(gb, torch.full((7,), 1.0)) and float(flag) == 1.0
+        assert torch.allclose(gb, torch.full((7,), float(world - 1))) and float(flag) == float(world - 1)
+        # 1c) the mean is exact for rank counts that are not 2: a value every rank holds comes back bit for bit (world a power of two: the
+        # division is exact; the sum of equal addends is exact below 2^24 x ulp)
+        same = torch.tensor([0.1, 1.0 / 3.0, 1e-7, 123456.789])
+        keep = same.clone()
+        D.all_reduce_mean_([same])
+        assert torch.equal(same, keep), (same, keep)
         # 2) skip decision is an OR over ranks; scalar mean
         assert D.any_rank_true(rank == 1, torch.device("cpu")) is True
+        assert D.any_rank_true(rank == world - 1, torch.device("cpu")) is True
         assert D.any_rank_true(False, torch.device("cpu")) is False
-        assert abs(float(D.all_reduce_scalars_mean(torch.tensor(float(rank)))) - 0.5) < 1e-6
+        assert abs(float(D.all_reduce_scalars_mean(torch.tensor(float(rank)))) - (world - 1) / 2.0) < 1e-6
         # 3) identical condition draws (same seeded generators as the stage-3 trainer)
         import numpy as np
         g = torch.Generator().manual_seed(0)
@@ -63,7 +71,8 @@ def _worker(rank, world, port, q):
         full = {k: v.clone().requires_grad_(True) for k, v in w.items()}
         loss_fn(full, x).backward()
         mine = {k: v.clone().requires_grad_(True) for k, v in w.items()}
-        loss_fn(mine, x[rank * 2:(rank + 1) * 2]).backward()
+        per = 4 // world
+        loss_fn(mine, x[rank * per:(rank + 1) * per]).backward()
         flat = torch.cat([mine[k].grad.reshape(-1) for k in sorted(mine)])
         D.all_reduce_mean_([flat])
         ref_flat = torch.cat([full[k].grad.reshape(-1) for k in sorted(full)])
@@ -132,7 +141,7 @@ def _staged_step_check(rank, world, D):
 
     torch.manual_seed(11)
     x = torch.randn(4, 3, 8, 8)
-    x[2:] *= 3.0   # rank 1's shard has the larger rate: the local means straddle the target
+    x[2:] *= 3.0   # the upper half of the batch (rank 1 of 2, ranks 2 and 3 of 4) has the larger rate: the local means straddle the target
     probe, _ = None, None
     with torch.no_grad():
         out = Toy().run_model(x)
@@ -146,7 +155,8 @@ def _staged_step_check(rank, world, D):
         assert [sum(b.numel() for b in p) for p in pieces] == [sum(q.numel() for q in m.parameters()) for m in
                                                                (tr.comp_model.decoder, tr.comp_model.context_model)] + \
             [sum(q.numel() for n, q in tr.comp_model.named_parameters() if n.split(".")[0] not in ("decoder", "context_model"))]
-        ctx, syncs = tr._run_generator_staged(lambda name, fn: fn(), x[rank * 2:(rank + 1) * 2], {}, None, 1)
+        per = 4 // world
+        ctx, syncs = tr._run_generator_staged(lambda name, fn: fn(), x[rank * per:(rank + 1) * per], {}, None, 1)
         for sy in syncs:
             sy.wait()
         # reference: one unstaged backward over the whole batch with the switch on the global mean
@@ -158,17 +168,27 @@ def _staged_step_check(rank, world, D):
         want_lambda = 2.0 if mid > target else 0.5
         assert abs(float(rate) - want_lambda * mid) < 1e-5 * max(1.0, mid)
         assert torch.allclose(flat, ref_flat, rtol=1e-4, atol=1e-6), (target, float((flat - ref_flat).abs().max()))
-        assert float(ctx["bad"]) == 0.0 and abs(float(ctx["losses"]["rate"]) - want_lambda * float(q_all[rank * 2:(rank + 1) * 2].mean())) < 1e-4 * hi
+        assert float(ctx["bad"]) == 0.0 and abs(float(ctx["losses"]["rate"]) - want_lambda * float(q_all[rank * per:(rank + 1) * per].mean())) < 1e-4 * hi
 
 
-def test_dp_two_ranks_gloo():
+def _run_world(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_dp_two_ranks_gloo():
+    _run_world(2)
+
+
+def test_dp_four_ranks_gloo():
+    """the same checks on four ranks: shards of one image each, bucket partition and AVG for a rank count that is not 2, the rate switch
+    straddled by ranks 0 / 1 (below) and 2 / 3 (above the target)"""
+    _run_world(4)

@@ -145,11 +145,14 @@ def test_stage3_step_128_winograd_f4x4():
 
 # Gradient bound of the parameter groups UPSTREAM of the quantiser (analysis transform, hyper-encoder) under the shipped plan set.
 # Their forward activations differ from the oracle's by fp32 summation-order noise; a pre-activation within that noise of zero flips its
-# ReLU mask in the backward pass, and every flipped element adds a rank-one term to the weight gradients above it, weighted by the
-# heavy-tailed -1/(p ln 2) rate gradients (p down to the 1e-9 floor under seeded random weights): measured 1.2e-3 on the hyper-encoder
-# with direct / F(2x2) plans (forward noise ~1e-6), 9.7e-3 at stage 1 / bs 8 once the tuner's F(4x4, 3x3) Winograd launches (forward
-# noise ~6e-6, tests/test_gpu_wino.py) run the analysis transform's 3x3 layers.  Everything behind the quantiser is unaffected (the
-# rounding absorbs the noise: decoder / context model / hyper-decoder errors are the same with both plan sets, profiles/r4_parity_margins.json).
+# ReLU mask in the backward pass, and every flipped element adds a finite rank-one term to the weight gradients above it.  Behind the
+# quantiser the rounding absorbs the noise.  tests/test_conditioning.py reproduces this on the CPU oracle ALONE (float64, noise of the
+# kernels' size injected behind the analysis convolutions, shared rounding decisions): 1e-6 of the output scale -> 1.2e-3 upstream,
+# 6e-6 -> 3.3e-3, 25 .. 50x less behind the quantiser, 25x less with the clean run's masks imposed -- the figures the GPU measured (1.2e-3 on
+# the hyper-encoder with direct / F(2x2) plans; 2.6e-3 .. 9.7e-3 with the F(4x4) kernels at the round-4 points, forward noise ~6e-6;
+# profiles/r4_parity_margins.json).  (Round 4 also blamed the heavy-tailed rate gradient for the size of the jumps; the CPU test finds the
+# same discrepancy with the rate term off, so that part is withdrawn.)  Round 5's interpolation points bring the F(4x4) kernels' noise to
+# ~1.5e-6 (tests/test_gpu_wino.py), hence the tighter cap.
 UPSTREAM_TUNED_TOL = 8e-3   # (round 4: 2e-2 for the F(4x4) kernels at the points 0, +-1, +-2; round 5's points carry ~1/4 of that forward noise)
 
 

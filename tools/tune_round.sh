@@ -1,11 +1,11 @@
 #!/bin/bash
 # Rebuild the shipped perf database on the GPU box (run from the repo root): the 3x3 / 5x5 launches are timed again (cold caches,
 # best of 3) on top of the shipped entries -- every candidate now also has to agree with the built-in plan's result (ops._autotune) --
-# then one confirmation run; copy gpurun_out/tune_r4.json to crdr_amd/hip/tune_gfx950.json.
+# then one confirmation run; copy gpurun_out/tune_r5.json to crdr_amd/hip/tune_gfx950.json.
 set -x
 export TMPDIR=/tmp
 export CRDR_TUNE_ROUNDS=3 CRDR_TUNE_COLD=1
-timeout 2400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --bf16x3 --tune-db none --retune-k3 crdr_amd/hip/tune_gfx950.json --save-tune-db gpurun_out/tune_r4.json --tune-log gpurun_out/tune_r4.log --shape-table gpurun_out/r4_tune_shapes.txt > gpurun_out/bench_tune.log 2> gpurun_out/bench_tune.err
+timeout 2400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --bf16x3 --tune-db none --retune-k3 crdr_amd/hip/tune_gfx950.json --save-tune-db gpurun_out/tune_r5.json --tune-log gpurun_out/tune_r5.log --shape-table gpurun_out/r5_tune_shapes.txt > gpurun_out/bench_tune.log 2> gpurun_out/bench_tune.err
 cut -c1-300 gpurun_out/bench_tune.log; tail -2 gpurun_out/bench_tune.err
-timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary --tune-db gpurun_out/tune_r4.json > gpurun_out/bench_tuned.log 2>> gpurun_out/bench_tune.err
+timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary --tune-db gpurun_out/tune_r5.json > gpurun_out/bench_tuned.log 2>> gpurun_out/bench_tune.err
 cut -c1-400 gpurun_out/bench_tuned.log
