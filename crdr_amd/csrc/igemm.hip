@@ -533,6 +533,20 @@ extern "C" size_t crdr_conv2d_filter_cache_bytes(const crdr_conv_desc* d, int G)
   return wino4_workspace(d, G, 1);
 }
 
+extern "C" int crdr_conv2d_filter_item(const crdr_conv_desc* d, int G, crdr_w4_filter_item* item) {
+  CRDR_REQUIRE(d && item, "conv2d_filter_item: null pointer");
+  CRDR_REQUIRE(G >= 1 && G <= CRDR_MAX_GROUP, "conv2d_filter_item: %d problems (1..%d)", G, CRDR_MAX_GROUP);
+  Plan pl;
+  if (int rc = build_plan(d, &pl, G)) return rc;
+  CRDR_REQUIRE(pl.wino == 3, "conv2d_filter_item: the descriptor's `reserved` does not force the F(4x4, 3x3) kernel");
+  return wino4_filter_item(d, pl.t, G, item);
+}
+
+extern "C" int crdr_w4_filters_batched(const crdr_w4_filter_item* items, const int64_t* prefix, const int64_t* meta, crdr_stream_t s) {
+  CRDR_REQUIRE(items && prefix && meta, "w4_filters_batched: null pointer");
+  return wino4_filters_batched(items, reinterpret_cast<const long long*>(prefix), reinterpret_cast<const long long*>(meta), as_stream(s));
+}
+
 extern "C" int crdr_conv2d_grouped_ex(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, void* ws, size_t ws_bytes, float* filter_cache,
                                       size_t filter_cache_bytes, int filter_cache_valid, crdr_stream_t s) {
   CRDR_REQUIRE(d && ios, "conv2d_grouped_ex: null descriptor");

@@ -17,6 +17,8 @@ bool wino4_eligible(const crdr_conv_desc* d, int G, bool vec_ok);
 size_t wino4_workspace(const crdr_conv_desc* d, int G, int nsplit);   // bytes of transformed filters (+ the partial tiles of a K-split launch)
 bool wino4_split_ok(const crdr_conv_desc* d, int G, int nsplit);      // nsplit K splits per tile (forced id: bits 8..11 = nsplit - 1)
 int wino4_colsum_rows(const crdr_conv_desc* d);
+int wino4_filter_item(const crdr_conv_desc* d, const IgemmTaps& taps, int G, crdr_w4_filter_item* it);   // crdr_conv2d_filter_item
+int wino4_filters_batched(const crdr_w4_filter_item* items, const long long* prefix, const long long* meta, hipStream_t s);
 int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, float* slabs, int nsplit,
                  bool filters_ready, hipStream_t s);
 

@@ -768,19 +768,12 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
 // and rounded once, from the implicit-GEMM weight pack (tap-major [tap][wrows][wcols]) into the block layout of wino4_kernel:
 // [N tile of 64][chunk of 4 channels][position 36][channel 4][oh 2][tx 16][ob 2], output channel = 32 oh + 16 ob + tx.
 struct Wino4Taps { int widx[4][9]; };   // [variant][3 a + b]: weight-pack tap of sub-filter element (a, b), -1 = zero
-__global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const float* w0, float* u, int Cin, int Cout, int wrows, int wcols, int kchunks,
-                                    int ntile, int nvar, int var_inner, Wino4Taps tp) {
-  // one thread per (N tile, variant, chunk, oc, channel c of the chunk); variant = parity sub-filter of a stride-2 conv (blocks of one
-  // tile: [sub][chunk], var_inner = 0 ... the K loop walks them) or output phase of a stride-2 transposed conv ([phase][chunk] as well,
-  // each phase being a tile of its own); consecutive threads read consecutive input channels of one weight-pack row
-  const long long total = (long long)ntile * nvar * kchunks * 256;
-  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= total) return;
-  (void)var_inner;
-  const int g = blockIdx.y;
-  const float* w = ngroup > 1 ? grp.w[g] : w0;
-  const int c4 = (int)(id & 3), oc64 = (int)((id >> 2) & 63);
-  const long long blk = id >> 8;   // (N tile, variant, chunk)
+// one thread: (unit blk = (N tile, variant, chunk), oc, channel c of the chunk); variant = parity sub-filter of a stride-2 conv (blocks of one
+// tile: [sub][chunk] ... the K loop walks them) or output phase of a stride-2 transposed conv ([phase][chunk] as well, each phase being a
+// tile of its own); consecutive threads read consecutive input channels of one weight-pack row
+__device__ __forceinline__ void wino4_filter_thread(const float* w, float* ug, long long blk, int t256, int Cin, int Cout, int wrows, int wcols,
+                                                    int kchunks, int nvar, const int (&widx)[4][9]) {
+  const int c4 = t256 & 3, oc64 = (t256 >> 2) & 63;
   const int kc = (int)(blk % kchunks), var = (int)((blk / kchunks) % nvar), ct = (int)(blk / ((long long)kchunks * nvar));
   const int oc = ct * kBN4 + oc64, c = kc * 4 + c4;
   const bool live = oc < Cout && c < Cin;
@@ -789,13 +782,13 @@ __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const floa
   for (int a = 0; a < 3; ++a)
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-      const int wi = tp.widx[var][a * 3 + b];
+      const int wi = widx[var][a * 3 + b];
       g9[a][b] = (live && wi >= 0) ? (double)w[((size_t)wi * wrows + oc) * wcols + c] : 0.0;
     }
   const double wa = kWa, wb = kWb;
   const double G[6][3] = {{1.0 / kWN0, 0.0, 0.0}, {1.0 / kWNa, wa / kWNa, wa * wa / kWNa}, {1.0 / kWNa, -wa / kWNa, wa * wa / kWNa},
                           {1.0 / kWNb, wb / kWNb, wb * wb / kWNb}, {1.0 / kWNb, -wb / kWNb, wb * wb / kWNb}, {0.0, 0.0, 1.0}};
-  float* dst = u + ((size_t)g * ntile * nvar * kchunks + (size_t)blk) * (kUSlots4 * 4) + (size_t)c4 * kBN4 + (oc64 >> 5) * 32 + (oc64 & 15) * 2 + ((oc64 >> 4) & 1);
+  float* dst = ug + (size_t)blk * (kUSlots4 * 4) + (size_t)c4 * kBN4 + (oc64 >> 5) * 32 + (oc64 & 15) * 2 + ((oc64 >> 4) & 1);
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
     double t[3];
@@ -803,6 +796,35 @@ __global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const floa
     for (int b = 0; b < 3; ++b) t[b] = G[xi][0] * g9[0][b] + G[xi][1] * g9[1][b] + G[xi][2] * g9[2][b];
 #pragma unroll
     for (int nu = 0; nu < 6; ++nu) dst[(size_t)(xi * 6 + nu) * 256] = (float)(G[nu][0] * t[0] + G[nu][1] * t[1] + G[nu][2] * t[2]);
+  }
+}
+__global__ void wino4_filter_kernel(const IgemmGroup grp, int ngroup, const float* w0, float* u, int Cin, int Cout, int wrows, int wcols, int kchunks,
+                                    int ntile, int nvar, int var_inner, Wino4Taps tp) {
+  const long long total = (long long)ntile * nvar * kchunks * 256;
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  (void)var_inner;
+  const int g = blockIdx.y;
+  const float* w = ngroup > 1 ? grp.w[g] : w0;
+  wino4_filter_thread(w, u + (size_t)g * ntile * nvar * kchunks * (kUSlots4 * 4), id >> 8, (int)(id & 255), Cin, Cout, wrows, wcols, kchunks, nvar, tp.widx);
+}
+// every filter cache of an optimiser in one launch (crdr_w4_filters_batched): a workgroup = one unit (256 threads) at a time, units dealt
+// round robin over a persistent grid; the item of a unit by binary search over the prefix table (block-uniform)
+__global__ __launch_bounds__(256) void wino4_filter_batched_kernel(const crdr_w4_filter_item* items, const long long* prefix, const long long* meta) {
+  const int n = (int)meta[0];
+  const long long total = meta[1];
+  for (long long gu = blockIdx.x; gu < total; gu += gridDim.x) {
+    int lo = 0, hi = n - 1;   // last item with prefix[item] <= gu
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= gu) lo = mid; else hi = mid - 1;
+    }
+    const crdr_w4_filter_item& it = items[lo];
+    const long long ul = gu - prefix[lo];
+    const long long per = (long long)it.ntile * it.nvar * it.kchunks;   // units of one problem of the group
+    const int g = (int)(ul / per);
+    wino4_filter_thread(it.w[g], it.u + (size_t)g * per * (kUSlots4 * 4), ul - (long long)g * per, (int)threadIdx.x, it.Cin, it.Cout, it.wrows, it.wcols,
+                        it.kchunks, it.nvar, it.widx);
   }
 }
 
@@ -901,15 +923,12 @@ int wino4_colsum_rows(const crdr_conv_desc* d) {
   return wino4_patches(d, mode) * (mode == 3 ? 4 : 1);
 }
 
-int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, float* slabs, int nsplit,
-                 bool filters_ready, hipStream_t s) {
-  CRDR_REQUIRE(wino4_eligible(d, G, a.vec_epi != 0), "conv2d: the F(4x4, 3x3) Winograd kernel takes 3x3 / 5x5 stride-1 and 5x5 stride-2 (pad 2) convolutions of >= 24 "
-               "output (phase) columns (or whole images of 9..16 pixels a side) with C, OC %% 4 == 0, 16-byte aligned operand rows and no gate / pre-add epilogue");
+// which weight-pack tap feeds element (a, b) of sub-filter / phase v, and how far above / left of its first output pixel the patch starts
+static int wino4_taps(const crdr_conv_desc* d, const IgemmTaps& taps, Wino4Taps& wt, int& si) {
   const int mode = wino4_mode(d);
-  Wino4Taps wt;
   for (int v = 0; v < 4; ++v)
     for (int t = 0; t < 9; ++t) wt.widx[v][t] = -1;
-  int si = 1;
+  si = 1;
   if (mode == 1) {
     int dmin = 127;
     for (int t = 0; t < 9; ++t) dmin = std::min(dmin, (int)(signed char)(taps.packed[t] & 0xff));
@@ -950,6 +969,40 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
           if (r < 5 && c < 5) wt.widx[ph][a2 * 3 + b2] = r * 5 + c;
         }
   }
+  return 0;
+}
+
+// description of one filter cache for the batched rebuild (crdr_conv2d_filter_item): everything but the pointers
+int wino4_filter_item(const crdr_conv_desc* d, const IgemmTaps& taps, int G, crdr_w4_filter_item* it) {
+  CRDR_REQUIRE(wino4_eligible(d, G, true), "conv2d_filter_item: not a convolution the F(4x4, 3x3) kernel takes");
+  Wino4Taps wt;
+  int si = 1;
+  if (int rc = wino4_taps(d, taps, wt, si)) return rc;
+  const int mode = wino4_mode(d);
+  for (int g = 0; g < CRDR_MAX_GROUP; ++g) it->w[g] = nullptr;
+  it->u = nullptr;
+  it->G = G; it->Cin = d->C; it->Cout = d->OC; it->wrows = d->wrows; it->wcols = d->wcols;
+  it->kchunks = cdiv(d->C, 4); it->ntile = cdiv(d->OC, kBN4); it->nvar = mode >= 2 ? 4 : 1;
+  for (int v = 0; v < 4; ++v)
+    for (int t = 0; t < 9; ++t) it->widx[v][t] = wt.widx[v][t];
+  it->units = (long long)G * it->ntile * it->nvar * it->kchunks;
+  return 0;
+}
+
+int wino4_filters_batched(const crdr_w4_filter_item* items, const long long* prefix, const long long* meta, hipStream_t s) {
+  hipLaunchKernelGGL(wino4_filter_batched_kernel, dim3(4096), dim3(256), 0, s, items, prefix, meta);
+  CRDR_CHECK_LAUNCH("wino4_filter_batched_kernel");
+  return 0;
+}
+
+int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, const IgemmGroup& grp, int G, float* u, float* slabs, int nsplit,
+                 bool filters_ready, hipStream_t s) {
+  CRDR_REQUIRE(wino4_eligible(d, G, a.vec_epi != 0), "conv2d: the F(4x4, 3x3) Winograd kernel takes 3x3 / 5x5 stride-1 and 5x5 stride-2 (pad 2) convolutions of >= 24 "
+               "output (phase) columns (or whole images of 9..16 pixels a side) with C, OC %% 4 == 0, 16-byte aligned operand rows and no gate / pre-add epilogue");
+  const int mode = wino4_mode(d);
+  Wino4Taps wt;
+  int si = 1;
+  if (int rc = wino4_taps(d, taps, wt, si)) return rc;
   const int nvar = mode >= 2 ? 4 : 1;
   const int ntile = cdiv(d->OC, kBN4), kchunks = cdiv(d->C, 4);
   if (!filters_ready) {   // (a caller that kept the transformed filters of these weights from an earlier launch skips this)

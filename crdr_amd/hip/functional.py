@@ -48,7 +48,6 @@ class _PackEntry:
         lib = L.load()
         ops.register_persistent_pack(self.dst)
         ops.bump_pack_version(self.dst.data_ptr())
-        ops.filter_scope_invalidate(self.dst.data_ptr())
         if self.mode in (0, 1):
             it = self.item()
             L.check(lib.crdr_pack_weight_item(C.byref(it), ops._stream()), "pack_weight_item")
@@ -198,6 +197,7 @@ class PackTable:
         self.prefix = torch.zeros(self.CAP + 1, dtype=torch.int64, device=flat.device)
         self.meta = torch.zeros(2, dtype=torch.int64, device=flat.device)
         self.entries, self.singles = [], []
+        self.filters = None
         self._seen = -1
 
     def _refresh(self) -> None:
@@ -232,7 +232,6 @@ class PackTable:
         self._refresh()
         for ptr in {e.dst.data_ptr() for e in self.entries}:
             ops.bump_pack_version(ptr)
-        ops.filter_scope_invalidate()
         if self.entries:
             lib = L.load()
             L.check(lib.crdr_pack_weights_batched(self.items.data_ptr(), self.prefix.data_ptr(), self.meta.data_ptr(),
@@ -241,6 +240,10 @@ class PackTable:
             e.fill()
         for e in self.entries + self.singles:
             e.key = _current_key(e.weight)
+        # ... and, behind the packs, every transformed-filter cache of the F(4x4) kernel derived from them: one launch (ops.FilterTable)
+        if self.filters is None:
+            self.filters = ops.FilterTable(self.device)
+        self.filters.refill({e.dst.data_ptr() for e in self.entries + self.singles})
 
 
 def _flags(bias, act, vec2, res, gate, affine) -> int:

@@ -60,6 +60,11 @@ class PackItem(C.Structure):
         "I", "J", "T", "rows", "cols", "mode", "srcJ", "dld")] + [("tstride", C.c_int64)]
 
 
+class W4FilterItem(C.Structure):  # mirrors struct crdr_w4_filter_item (312 bytes)
+    _fields_ = [("w", c_void_p * 16), ("u", c_void_p)] + [(n, C.c_int32) for n in (
+        "G", "Cin", "Cout", "wrows", "wcols", "kchunks", "ntile", "nvar")] + [("widx", (C.c_int32 * 9) * 4), ("units", C.c_int64)]
+
+
 class GdnDesc(C.Structure):
     _fields_ = [("M", C.c_int64)] + [(n, C.c_int32) for n in ("C", "ldx", "ldy", "inverse")] + [
         ("beta_min", C.c_float), ("reparam_offset", C.c_float)]
@@ -117,6 +122,8 @@ SIGNATURES = {
     "crdr_conv2d_grouped": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _SZ, _P]),
     "crdr_conv2d_filter_cache_bytes": (_SZ, [C.POINTER(ConvDesc), _I]),
     "crdr_conv2d_grouped_ex": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _SZ, _P, _SZ, _I, _P]),
+    "crdr_conv2d_filter_item": (_I, [C.POINTER(ConvDesc), _I, C.POINTER(W4FilterItem)]),
+    "crdr_w4_filters_batched": (_I, [_P, _P, _P, _P]),
     "crdr_conv2d_wgrad_grouped_workspace": (_SZ, [C.POINTER(WgradDesc), _I]),
     "crdr_conv2d_wgrad_partial_grouped": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _I, _P, _SZ, _P, _P]),
     "crdr_pack_weight_item": (_I, [C.POINTER(PackItem), _P]),

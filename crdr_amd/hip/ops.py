@@ -127,18 +127,26 @@ def _wgrad_wino4_ids():
     return [(nw + 1) | (ls << 8) for ls in range(9)]
 
 
-# Transformed filters of the F(4x4) Winograd kernel, kept between launches that share weights: inside `with filter_scope():` a launch that
-# runs that kernel keeps its transformed filters in a tensor of its own, and a later launch in the same scope with the same weight pack(s),
-# descriptor and algorithm skips the transform (crdr_conv2d_grouped_ex).  The scope is the caller's statement that the weights do not change
-# inside it -- the generator's two forward passes of a step (multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:42-47); leaving it drops
-# everything.  Under graph capture the scope must lie inside ONE capture (first use: transform + conv, later uses: conv only, replayed
-# in that order).
-_filter_scope = None
-_filter_scope_stack = []   # the enclosing scopes' dicts, outermost first (filter_scope_invalidate walks all of them)
-FILTER_SCOPE_STATS = {"filled": 0, "reused": 0}
+# Transformed filters of the F(4x4) Winograd kernel as PERSISTENT packs (round 5).  A launch that runs that kernel on registered weight packs
+# (functional._PackEntry.dst: buffers that live as long as their layer and are refilled in place) keeps its transformed filters in a tensor of
+# its own, keyed by (pack addresses, descriptor, algorithm) and stamped with the packs' version counters: a later launch with the same key
+# whose packs still carry those versions skips the transform (crdr_conv2d_grouped_ex, filter_cache_valid = 1); if any writer has touched a
+# pack since (bump_pack_version -- every writer bumps), the launch re-transforms into the same tensor.  The packs of an optimiser are
+# refilled by ONE launch behind its update (functional.PackTable.refill); refill_filters() then rebuilds every filter cache derived from
+# them with ONE more launch (crdr_w4_filters_batched) and stamps them current -- so inside a training step no convolution launch
+# transforms anything (round 4: 80.8 transform launches, 2.1 ms per stage-3 step; the generator's second forward pass and the
+# discriminator's passes reused filters only inside an explicit `filter_scope`).
+# Under graph capture nothing new is cached (a tensor born inside a capture belongs to that graph's pool): a launch whose cache does not
+# exist yet transforms into the workspace as before; the warm-up iterations in front of every capture create the caches.
+FILTER_SCOPE_STATS = {"filled": 0, "reused": 0, "batched": 0}
 _persistent_packs = {}   # data_ptr -> weakref of a persistent weight-pack buffer (functional._PackEntry.dst): only those are cached by address
-_pack_versions = {}      # data_ptr -> how often that buffer was (re)written: every writer of a registered pack bumps it (bump_pack_version), and a
-#                          kept set of transformed filters is only reused while the versions it was derived from are still the current ones
+_pack_versions = {}      # data_ptr -> how often that buffer was (re)written: every writer of a registered pack bumps it (bump_pack_version)
+_filter_cache = {}       # key -> _FilterCache
+_filter_serial = [0]     # bumped when _filter_cache grows (FilterTable re-reads it)
+
+
+class _FilterCache:
+    __slots__ = ("u", "wkeys", "versions", "item", "nbytes")
 
 
 def register_persistent_pack(t: torch.Tensor) -> None:
@@ -149,7 +157,7 @@ def register_persistent_pack(t: torch.Tensor) -> None:
 
 def bump_pack_version(ptr: int) -> None:
     """The pack buffer at `ptr` is being rewritten in place (functional._PackEntry.fill, PackTable.refill, or any future writer): whatever
-    was derived from its previous content is stale from here on, whether or not anybody calls filter_scope_invalidate."""
+    was derived from its previous content is stale from here on."""
     _pack_versions[ptr] = _pack_versions.get(ptr, 0) + 1
 
 
@@ -158,14 +166,11 @@ def pack_version(ptr: int) -> int:
 
 
 def filter_scope_invalidate(ptr=None) -> None:
-    """A weight pack was refilled in place (functional._PackEntry.fill, PackTable.refill): transformed filters kept for it are stale -- in
-    the innermost scope and in every scope around it."""
-    for sc in _filter_scope_stack:
-        if ptr is None:
-            sc.clear()
-        else:
-            for k in [k for k in sc if isinstance(k, tuple) and ptr in k[0]]:
-                del sc[k]
+    """Drop the filter caches derived from the pack at `ptr` (all of them: None).  Not needed for correctness -- the version stamps decide --
+    but it frees the memory of caches whose pack is gone."""
+    for k in [k for k, e in _filter_cache.items() if ptr is None or ptr in e.wkeys]:
+        del _filter_cache[k]
+    _filter_serial[0] += 1
 
 
 def _is_persistent_pack(ptr: int) -> bool:
@@ -175,17 +180,60 @@ def _is_persistent_pack(ptr: int) -> bool:
 
 
 class filter_scope:
+    """Kept for callers of rounds 3-4 (the trainer wrapped the generator's two forward passes in one): the caches are persistent now and
+    valid by version, inside or outside a scope; entering / leaving changes nothing."""
+
     def __enter__(self):
-        global _filter_scope
-        self.prev, _filter_scope = _filter_scope, {}
-        _filter_scope_stack.append(_filter_scope)
         return self
 
     def __exit__(self, *exc):
-        global _filter_scope
-        _filter_scope_stack.pop()
-        _filter_scope = self.prev
         return False
+
+
+class FilterTable:
+    """The filter caches derived from a set of weight packs (an optimiser's), rebuilt by one launch: device-side item table of fixed
+    capacity, rewritten in place when new caches appear, so a HIP graph that captured the launch keeps covering everything."""
+    CAP = 1024
+    ITEM = C.sizeof(L.W4FilterItem)
+
+    def __init__(self, device):
+        self.device = device
+        self.items = torch.zeros(self.CAP * self.ITEM, dtype=torch.uint8, device=device)
+        self.prefix = torch.zeros(self.CAP + 1, dtype=torch.int64, device=device)
+        self.meta = torch.zeros(2, dtype=torch.int64, device=device)
+        self.entries = []
+        self._seen = -1
+        self._packs = frozenset()
+
+    def _refresh(self, pack_ptrs) -> None:
+        pack_ptrs = frozenset(pack_ptrs)
+        if self._seen == _filter_serial[0] and pack_ptrs == self._packs:
+            return
+        ents = [e for e in _filter_cache.values() if e.u.device == self.device and all(p_ in pack_ptrs for p_ in e.wkeys)]
+        if [id(e) for e in ents] != [id(e) for e in self.entries]:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FilterTable: new filter caches appeared during graph capture (run eager warm-up iterations first)")
+            assert len(ents) <= self.CAP, len(ents)
+            raw, pre = bytearray(), [0]
+            for e in ents:
+                raw += bytes(e.item)
+                pre.append(pre[-1] + int(e.item.units))
+            if ents:
+                self.items[:len(raw)].copy_(torch.frombuffer(raw, dtype=torch.uint8))
+            self.prefix[:len(pre)].copy_(torch.tensor(pre, dtype=torch.int64))
+            self.meta.copy_(torch.tensor([len(ents), pre[-1]], dtype=torch.int64))
+            self.entries = ents
+        self._seen, self._packs = _filter_serial[0], pack_ptrs
+
+    def refill(self, pack_ptrs) -> None:
+        """Rebuild every cache derived from `pack_ptrs` (just refilled) and stamp it with the packs' current versions."""
+        self._refresh(pack_ptrs)
+        if self.entries:
+            lib = L.load()
+            L.check(lib.crdr_w4_filters_batched(self.items.data_ptr(), self.prefix.data_ptr(), self.meta.data_ptr(), _stream()), "w4_filters_batched")
+            FILTER_SCOPE_STATS["batched"] += len(self.entries)
+            for e in self.entries:
+                e.versions = tuple(pack_version(p_) for p_ in e.wkeys)
 
 
 WINO4_DEMOTED = [0]   # launches whose tuned / preferred F(4x4) plan was dropped because an epilogue operand was not 16-byte aligned
@@ -208,22 +256,62 @@ def _demote_if_misaligned(d, ios, G: int, explicit: bool) -> None:
 
 
 def _launch_conv(lib, d, ios, G: int, ws, ws_n, wkeys, device):
-    """crdr_conv2d_grouped, through the filter cache of the enclosing filter_scope where the launch runs the F(4x4) kernel."""
-    if _filter_scope is not None and (d.reserved & 0xFF) == _wino4_id() and all(_is_persistent_pack(int(p_)) for p_ in wkeys):
-        nb = lib.crdr_conv2d_filter_cache_bytes(C.byref(d), G)
-        if nb:
-            key = (tuple(int(p_) for p_ in wkeys), G, d.reserved & 0xFF, d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.kh, d.kw, d.stride, d.pad, d.transposed, d.wrows, d.wcols)
-            # (the key leaves the K-split bits of the algorithm id out on purpose: the block layout of the transformed filters does not
-            # depend on the split count -- wino4_filter_bytes / wino4_filter_kernel take no nsplit)
-            vers = tuple(pack_version(int(p_)) for p_ in wkeys)
-            ent = _filter_scope.get(key)
-            valid = ent is not None and ent[1] == vers   # derived from the packs' CURRENT content, not merely from the same addresses
-            if ent is None:
-                ent = (torch.empty(int(nb) // 4, dtype=torch.float32, device=device), vers)
-            _filter_scope[key] = (ent[0], vers)
+    """crdr_conv2d_grouped, through the persistent filter cache where the launch runs the F(4x4) kernel on registered weight packs."""
+    if (d.reserved & 0xFF) == _wino4_id() and all(_is_persistent_pack(int(p_)) for p_ in wkeys):
+        # (the key leaves the K-split bits of the algorithm id out on purpose: the block layout of the transformed filters does not depend
+        # on the split count -- wino4_filter_bytes / wino4_filter_thread take no nsplit)
+        wk = tuple(int(p_) for p_ in wkeys)
+        key = (wk, G, d.reserved & 0xFF, d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.kh, d.kw, d.stride, d.pad, d.transposed, d.wrows, d.wcols)
+        ent = _filter_cache.get(key)
+        if ent is None and not torch.cuda.is_current_stream_capturing():
+            nb = int(lib.crdr_conv2d_filter_cache_bytes(C.byref(d), G))
+            if nb:
+                ent = _FilterCache()
+                ent.u = torch.empty(nb // 4, dtype=torch.float32, device=device)
+                ent.wkeys, ent.versions, ent.nbytes = wk, None, nb
+                ent.item = L.W4FilterItem()
+                L.check(lib.crdr_conv2d_filter_item(C.byref(d), G, C.byref(ent.item)), "conv2d_filter_item")
+                for g in range(G):
+                    ent.item.w[g] = wk[g]
+                ent.item.u = ent.u.data_ptr()
+                _filter_cache[key] = ent
+                _filter_serial[0] += 1
+        if ent is not None:
+            vers = tuple(pack_version(p_) for p_ in wk)
+            valid = ent.versions == vers   # derived from the packs' CURRENT content, not merely from the same addresses
+            ent.versions = vers
             FILTER_SCOPE_STATS["reused" if valid else "filled"] += 1
-            return lib.crdr_conv2d_grouped_ex(C.byref(d), ios, G, ws, ws_n, ent[0].data_ptr(), int(nb), int(valid), _stream())
+            return lib.crdr_conv2d_grouped_ex(C.byref(d), ios, G, ws, ws_n, ent.u.data_ptr(), ent.nbytes, int(valid), _stream())
     return lib.crdr_conv2d_grouped(C.byref(d), ios, G, ws, ws_n, _stream())
+
+
+# Tuner trials of the F(4x4) kernel: in the step its transformed filters are rebuilt once per optimiser update by the batched launch, not in
+# front of the convolution, so a candidate is timed with its filters in place (a scratch cache filled by the first trial launch) and charged
+# the share of the batched rebuild it causes: the cache's bytes at the rate that launch runs at (~4.8 GB per ms).
+_tune_filters = {}
+_tune_w4_penalty = [0.0]
+
+
+def _tune_conv_launch(lib, d, ios, G: int, w_, wn_, device) -> bool:
+    """ios: one lib.ConvIO (G = 1) or a ctypes array of G of them"""
+    _tune_w4_penalty[0] = 0.0
+    if isinstance(ios, L.ConvIO):
+        ios = (L.ConvIO * 1)(ios)
+    if (d.reserved & 0xFF) != _wino4_id():
+        return lib.crdr_conv2d_grouped(C.byref(d), ios, G, w_, wn_, _stream()) == 0
+    nb = int(lib.crdr_conv2d_filter_cache_bytes(C.byref(d), G))
+    if not nb:
+        return lib.crdr_conv2d_grouped(C.byref(d), ios, G, w_, wn_, _stream()) == 0
+    key = (tuple(int(ios[g].w) for g in range(G)), G, d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.kh, d.kw, d.stride, d.pad, d.transposed, d.wrows, d.wcols)
+    ent = _tune_filters.get(key)
+    if ent is None or ent.numel() * 4 < nb:
+        _tune_filters.clear()   # (one shape is tuned at a time: the previous shape's scratch is garbage)
+        ent = _tune_filters[key] = torch.empty(nb // 4, dtype=torch.float32, device=device)
+        valid = 0
+    else:
+        valid = 1
+    _tune_w4_penalty[0] = nb / 4.8e9
+    return lib.crdr_conv2d_grouped_ex(C.byref(d), ios, G, w_, wn_, ent.data_ptr(), nb, valid, _stream()) == 0
 
 
 def _stream_ids():
@@ -540,9 +628,9 @@ def conv2d_raw(x: torch.Tensor, wpack: torch.Tensor, oc: int, k: Tuple[int, int]
                 d.reserved = a
                 nb = lib.crdr_conv2d_workspace(C.byref(d))
                 w_, wn_ = workspace(nb, x.device, conv=True) if nb else (None, 0)
-                return lib.crdr_conv2d(C.byref(d), C.byref(io), w_, wn_, _stream()) == 0
+                return _tune_conv_launch(lib, d, io, 1, w_, wn_, x.device)
             algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids(), result=lambda: out_t,
-                             agree=TUNE_AGREE["conv"])
+                             agree=TUNE_AGREE["conv"], penalty=lambda: _tune_w4_penalty[0])
         d.reserved = algo
     _demote_if_misaligned(d, (io,), 1, explicit)
     nbytes = lib.crdr_conv2d_workspace(C.byref(d))
@@ -877,9 +965,9 @@ def conv_group(n: int, h: int, w: int, xs, wpacks, ys, oc: int, k: Tuple[int, in
                 d.reserved = a
                 nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
                 w_, wn_ = workspace(nb, device, conv=True) if nb else (None, 0)
-                return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
+                return _tune_conv_launch(lib, d, tio, G, w_, wn_, device)
             algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids(), result=lambda: scratch, reset=reset,
-                             agree=TUNE_AGREE["conv"])
+                             agree=TUNE_AGREE["conv"], penalty=lambda: _tune_w4_penalty[0])
         d.reserved = algo
     elif GP != G:
         d.reserved = lib.crdr_conv2d_choose_algo(C.byref(d), GP)
@@ -1181,9 +1269,9 @@ def conv_multi(n: int, h: int, w: int, oh: int, ow: int, xs, wpacks, ys, oc: int
                         tio[g].cs = bufs[g]
                 nb = lib.crdr_conv2d_grouped_workspace(C.byref(d), G)
                 w_, wn_ = workspace(nb, device, conv=True) if nb else (None, 0)
-                return lib.crdr_conv2d_grouped(C.byref(d), tio, G, w_, wn_, _stream()) == 0
+                return _tune_conv_launch(lib, d, tio, G, w_, wn_, device)
             algo = _autotune(key, lib.crdr_conv2d_num_configs(), 4, run, extra=_stream_ids(), result=lambda: scratch, reset=reset,
-                             agree=TUNE_AGREE["conv"])
+                             agree=TUNE_AGREE["conv"], penalty=lambda: _tune_w4_penalty[0])
         d.reserved = algo
     _demote_if_misaligned(d, ios, G, bool(FORCED_CONV_ALGO))
     out = None

@@ -155,9 +155,9 @@ int crdr_conv2d_num_stream_configs(void);
  * (>= 33 output / phase columns), 16 x 32 pixels (24..32 columns) or, for the stride-1 forms, two whole images of 9..16 pixels a side;
  * needs C % 4 == 0, OC % 4 == 0 and 16-byte aligned operand rows.  Bits 8..11 of the forced id = K splits - 1 (1..16 work items per tile
  * over equal parts of the K range, reduced inside the launch in split order: bit-identical run to run; the ticket head of the workspace must
- * be zero, as for the implicit GEMM's split-K).  Its transforms carry the constants 4, 5, 8 and 1/4 .. 1/24: results deviate from float64
- * by ~5e-6 .. 1.5e-5 of the output scale (the other kernels: ~1e-6) -- a candidate of the training-side tuner only, never of the built-in
- * plan (the codec runs built-in plans).
+ * be zero, as for the implicit GEMM's split-K).  Interpolation points 0, +-3/4, +-5/4, infinity (round 5; rounds 3-4: 0, +-1, +-2): results
+ * deviate from float64 by ~0.4e-6 .. 5e-6 of the output scale (the direct kernels: ~1e-6 .. 4e-6) -- still a candidate of the training-side
+ * tuner only, never of the built-in plan (the codec runs built-in plans).
  * The transformed filters are rebuilt from the weight pack into the workspace by every launch (crdr_conv2d_workspace with the same
  * `reserved`; crdr_conv2d_grouped_ex keeps them in a caller's buffer instead); CRDR_EPI_COLSUM rows are per output tile (and phase),
  * crdr_conv2d_colsum_layout. */
@@ -202,6 +202,23 @@ int crdr_conv2d_grouped(const crdr_conv_desc* d, const crdr_conv_io* ios, int G,
  * its generator twice per step, multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:42-47; cuDNN re-transforms there as well).  The caller
  * owns validity: same weights, same descriptor, same forced algorithm.  filter_cache == NULL: exactly crdr_conv2d_grouped. */
 size_t crdr_conv2d_filter_cache_bytes(const crdr_conv_desc* d, int G);
+/* Transformed filters as PERSISTENT packs (round 5): they go stale exactly when the weight packs they are derived from do -- right behind an
+ * optimiser's update -- so every filter cache of that optimiser is rebuilt by ONE launch behind crdr_pack_weights_batched instead of one
+ * transform launch in front of every convolution (round 4: 80.8 launches, 2.1 ms per stage-3 step).
+ * crdr_conv2d_filter_item fills the description of one cache (a HOST struct; everything but the pointers `w[g]` -- the G weight packs, the
+ * launch's crdr_conv_io.w -- and `u`, the cache of crdr_conv2d_filter_cache_bytes(d, G) bytes) for a descriptor whose `reserved` forces
+ * the F(4x4) kernel.  crdr_w4_filters_batched takes DEVICE arrays like crdr_pack_weights_batched: item k owns the work units (one per
+ * problem, 64-channel N tile, sub-filter / phase and 4-channel chunk: `units`) numbered [prefix[k], prefix[k+1]); meta = {number of items,
+ * prefix[number of items]}.  A launch that finds its cache filled this way passes filter_cache_valid != 0 to crdr_conv2d_grouped_ex. */
+typedef struct crdr_w4_filter_item {
+  const float* w[16]; /* CRDR_MAX_GROUP source packs (the first G used) */
+  float* u;
+  int32_t G, Cin, Cout, wrows, wcols, kchunks, ntile, nvar;
+  int32_t widx[4][9]; /* [sub-filter / phase][3 a + b]: tap of the weight pack, -1 = zero */
+  int64_t units;      /* G * ntile * nvar * kchunks */
+} crdr_w4_filter_item;
+int crdr_conv2d_filter_item(const crdr_conv_desc* d, int G, crdr_w4_filter_item* item);
+int crdr_w4_filters_batched(const crdr_w4_filter_item* items, const int64_t* prefix, const int64_t* meta, crdr_stream_t s);
 int crdr_conv2d_grouped_ex(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, void* ws, size_t ws_bytes, float* filter_cache,
                            size_t filter_cache_bytes, int filter_cache_valid, crdr_stream_t s);
 /* algorithmic FLOPs of the call (2 * MACs actually needed, padding taps excluded approx.) for roofline maths */

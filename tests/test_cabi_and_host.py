@@ -444,46 +444,38 @@ def test_winograd_ids_are_planned_only_for_the_shapes_they_take(lib):
     assert lib.crdr_conv2d_wgrad_workspace(C.byref(wdesc(3, 2))) == 0
 
 
-def test_filter_scope_bookkeeping():
-    """ops.filter_scope (host side only, no launches): entries live inside the scope, nested scopes start empty, a refilled pack drops
-    exactly its entries, only registered persistent packs count as cacheable, and a registration dies with its tensor"""
+def test_filter_cache_bookkeeping():
+    """ops' persistent filter caches (host side only, no launches): only registered persistent packs count as cacheable, a registration dies
+    with its tensor, every writer of a pack bumps its version, filter_scope is a no-op kept for older callers, and dropping the caches of a
+    pack drops exactly those"""
     import torch
     from crdr_amd.hip import ops
     a, b = torch.zeros(64), torch.zeros(64)
     assert not ops._is_persistent_pack(a.data_ptr())
     ops.register_persistent_pack(a)
     assert ops._is_persistent_pack(a.data_ptr()) and not ops._is_persistent_pack(b.data_ptr())
-    assert ops._filter_scope is None
-    ops.filter_scope_invalidate(a.data_ptr())          # outside a scope: nothing to do
-    with ops.filter_scope():
-        sc = ops._filter_scope
-        sc[((a.data_ptr(),), 1, 37)] = "Ua"
-        sc[((a.data_ptr(), b.data_ptr()), 2, 37)] = "Uab"
-        sc[((b.data_ptr(),), 1, 37)] = "Ub"
-        with ops.filter_scope():
-            assert ops._filter_scope == {}
-            ops._filter_scope["x"] = 1
-        assert ops._filter_scope is sc and len(sc) == 3
-        ops.filter_scope_invalidate(a.data_ptr())
-        assert list(sc.values()) == ["Ub"]
-        ops.filter_scope_invalidate()
-        assert sc == {}
-        # a refill announced from INSIDE a nested scope reaches the scopes around it too
-        sc[((a.data_ptr(),), 1, 37)] = "Ua"
-        sc[((b.data_ptr(),), 1, 37)] = "Ub"
-        with ops.filter_scope():
-            ops._filter_scope[((a.data_ptr(),), 1, 37)] = "Ua-inner"
-            ops.filter_scope_invalidate(a.data_ptr())
-            assert ops._filter_scope == {}
-        assert list(sc.values()) == ["Ub"]
-        with ops.filter_scope():
-            ops.filter_scope_invalidate()
-        assert sc == {}
-    assert ops._filter_scope is None and ops._filter_scope_stack == []
-    # every writer of a registered pack bumps its version; what was derived from an older version is not reused (ops._launch_conv)
     v0 = ops.pack_version(a.data_ptr())
     ops.bump_pack_version(a.data_ptr())
     assert ops.pack_version(a.data_ptr()) == v0 + 1 and ops.pack_version(b.data_ptr()) == 0
+    keep = dict(ops._filter_cache)
+    try:
+        ops._filter_cache.clear()
+        for name, wk in (("Ua", (a.data_ptr(),)), ("Uab", (a.data_ptr(), b.data_ptr())), ("Ub", (b.data_ptr(),))):
+            e = ops._FilterCache()
+            e.wkeys, e.u, e.versions, e.item, e.nbytes = wk, name, None, None, 0
+            ops._filter_cache[(wk, len(wk), 37)] = e
+        with ops.filter_scope():
+            with ops.filter_scope():
+                assert len(ops._filter_cache) == 3
+        serial = ops._filter_serial[0]
+        ops.filter_scope_invalidate(a.data_ptr())
+        assert [e.u for e in ops._filter_cache.values()] == ["Ub"] and ops._filter_serial[0] > serial
+        ops.filter_scope_invalidate()
+        assert ops._filter_cache == {}
+    finally:
+        ops._filter_cache.clear()
+        ops._filter_cache.update(keep)
     ptr = a.data_ptr()
     del a
     assert not ops._is_persistent_pack(ptr)
+

@@ -358,45 +358,62 @@ def test_winograd_f4x4_split_k(case):
     assert torch.equal(after, one), "an unsplit launch after split ones differs (tickets / workspace)"
 
 
-def test_winograd_f4x4_filter_scope():
-    """ops.filter_scope: a second F(4x4) launch with the same persistent weight pack reuses the transformed filters of the first (same
-    bits out); a pack refilled in place invalidates them; temporary packs and launches outside a scope are never cached"""
+def test_winograd_f4x4_persistent_filter_caches():
+    """ops' persistent filter caches: a second F(4x4) launch with the same registered weight pack reuses the transformed filters of the first
+    (same bits out), inside or outside a filter_scope; a pack rewritten in place is noticed through its version counter alone; temporary
+    packs are never cached; and the batched rebuild behind a pack refill (ops.FilterTable: one launch for every cache derived from a set of
+    packs) leaves exactly what the per-launch transform would have written, stamped current"""
     from crdr_amd.hip import ops
     dev = _dev()
     a4 = _wino_id() + 2
     x = _rand(2, 96, 16, 64, seed=1).to(dev)
+    x5 = _rand(2, 32, 16, 16, seed=4).to(dev)
     w1, w2 = _rand(64, 96, 3, 3, seed=2, scale=0.03).to(dev), _rand(64, 96, 3, 3, seed=3, scale=0.03).to(dev)
+    w5a, w5b = _rand(96, 32, 5, 5, seed=5, scale=0.03).to(dev), _rand(96, 32, 5, 5, seed=6, scale=0.03).to(dev)
     wp = ops.pack_weight(w1, transpose=False)
+    wp5 = ops.pack_weight(w5a, transpose=False)
     call = lambda: ops.conv2d_raw(x, wp, 64, (3, 3), 1, 1, False, (16, 64), algo=a4)
-    ref1 = call()
+    call5 = lambda: ops.conv2d_raw(x5, wp5, 96, (5, 5), 1, 2, False, (16, 16), algo=a4)
+    ref1, ref5a = call(), call5()
     st = ops.FILTER_SCOPE_STATS
     f0, r0 = st["filled"], st["reused"]
+    assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0, r0), "a temporary pack must not be cached by address"
+    ops.register_persistent_pack(wp)
+    ops.register_persistent_pack(wp5)
+    assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0 + 1, r0)
     with ops.filter_scope():
-        assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0, r0), "a temporary pack must not be cached by address"
-        ops.register_persistent_pack(wp)
-        assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0 + 1, r0)
         assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0 + 1, r0 + 1)
-        # the pack is refilled in place with other weights (what functional._PackEntry.fill does after telling the scope)
-        wp.copy_(ops.pack_weight(w2, transpose=False))
-        ops.filter_scope_invalidate(wp.data_ptr())
-        out2 = call()
-        assert (st["filled"], st["reused"]) == (f0 + 2, r0 + 1)
-        with ops.filter_scope():   # a nested scope starts empty
-            assert torch.equal(call(), out2) and st["filled"] == f0 + 3
-        # a writer that only bumps the pack's version (no invalidate call at all): the kept filters are NOT reused
-        wp.copy_(ops.pack_weight(w1, transpose=False))
-        ops.bump_pack_version(wp.data_ptr())
-        assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0 + 4, r0 + 1)
-        assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0 + 4, r0 + 2)
-        # a refill announced inside a nested scope drops the enclosing scope's entry as well
-        with ops.filter_scope():
-            wp.copy_(ops.pack_weight(w2, transpose=False))
-            ops.bump_pack_version(wp.data_ptr())
-            ops.filter_scope_invalidate(wp.data_ptr())
-        assert torch.equal(call(), out2) and (st["filled"], st["reused"]) == (f0 + 5, r0 + 2)
-    assert torch.equal(out2, call()) and st["filled"] == f0 + 5, "outside a scope nothing is cached"
-    ref2 = F.conv2d(x.cpu().double(), w2.cpu().double(), padding=1)
-    _close(out2, ref2, "filter scope after refill", rtol=2e-5)
+    assert torch.equal(call(), ref1) and (st["filled"], st["reused"]) == (f0 + 1, r0 + 2)
+    # a writer that only bumps the pack's version (what functional._PackEntry.fill / PackTable.refill do): the kept filters are NOT reused
+    wp.copy_(ops.pack_weight(w2, transpose=False))
+    ops.bump_pack_version(wp.data_ptr())
+    out2 = call()
+    assert (st["filled"], st["reused"]) == (f0 + 2, r0 + 2)
+    assert torch.equal(call(), out2) and (st["filled"], st["reused"]) == (f0 + 2, r0 + 3)
+    _close(out2, F.conv2d(x.cpu().double(), w2.cpu().double(), padding=1), "filter cache after a refill", rtol=2e-5)
+    # the batched rebuild: both packs rewritten, ONE launch rebuilds both caches (3x3: one sub-filter; 5x5 stride 1: four), the next
+    # launches trust them and give the bits a fresh per-launch transform gives
+    assert torch.equal(call5(), ref5a)                                    # (creates the 5x5 cache)
+    wp.copy_(ops.pack_weight(w1, transpose=False))
+    wp5.copy_(ops.pack_weight(w5b, transpose=False))
+    ops.bump_pack_version(wp.data_ptr())
+    ops.bump_pack_version(wp5.data_ptr())
+    table = ops.FilterTable(dev)
+    b0 = st["batched"]
+    table.refill({wp.data_ptr(), wp5.data_ptr()})
+    assert st["batched"] == b0 + 2 and len(table.entries) == 2
+    f1, r1 = st["filled"], st["reused"]
+    got3, got5 = call(), call5()
+    assert (st["filled"], st["reused"]) == (f1, r1 + 2), "the launches behind the batched rebuild transformed again"
+    assert torch.equal(got3, ref1)
+    fresh5 = ops.conv2d_raw(x5, ops.pack_weight(w5b, transpose=False), 96, (5, 5), 1, 2, False, (16, 16), algo=a4)   # temporary pack: per-launch transform
+    assert torch.equal(got5, fresh5)
+    _close(got5, F.conv2d(x5.cpu().double(), w5b.cpu().double(), padding=2), "5x5 behind the batched rebuild", rtol=2e-5)
+    # a rebuild for OTHER packs leaves these caches alone; rebuilding again is idempotent
+    table.refill({wp.data_ptr(), wp5.data_ptr()})
+    assert torch.equal(call(), ref1) and torch.equal(call5(), fresh5)
+    ops.filter_scope_invalidate(wp.data_ptr())
+    ops.filter_scope_invalidate(wp5.data_ptr())
 
 
 def test_winograd_f4x4_epilogues_slices_groups_colsum():
