@@ -157,6 +157,9 @@ PATTERNS = [
     "pk72x72", "pk72x9", "ar144x9", "ar288x1", "st32", "cv144x9+st32", "nomfma:st32", "nomfma:cv144x1", "nomfma:ar288x1", "nomfma:ldsf+ldsr",
     "nomfma:dma13", "nomfma:dma52",
     # two waves per SIMD, 36 MFMA slots each: does one wave's VALU hide under the other's MFMAs?
+    # the current one-wave loop's mix and the two-wave form of it (per wave: half the positions = 36 MFMAs, half the transform)
+    "pk72x9+ldsf+ldsr+dma13", "pk78x10+ldsf+ldsr+dma13", "pk36x5+ldsf128+ldsr+dma13",
+    "w2:pk36x5+ldsf+ldsr+dma7", "w2:pk36x3+ldsf+ldsr+dma7", "w2:pk36x9+ldsf+ldsr+dma7", "w2:pk36x5", "w2:pk72x5+ldsf+ldsr+dma7", "w2:pk18x3+ldsf+ldsr+dma7",
     "w2:mfma", "w2:valu36", "w2:valu72", "w2:valu144", "w2:cv72x4", "w2:cv144x4", "w2:valu72+ldsf+ldsr+dma13", "w2:cv144x4+ldsf+ldsr+dma13",
 ]
 

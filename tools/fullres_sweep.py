@@ -45,8 +45,9 @@ def seed_interp_ca(model) -> None:
             if name.startswith("encoder"):
                 lvl = torch.arange(L, device=prm.device, dtype=prm.dtype).view(L, 1, 1, 1, 1)
                 if name.endswith("weight"):
-                    off, slope = 0.5 * noise[:1], 0.12 + 0.08 * torch.sigmoid(4.0 * noise[1:2])     # slope in (0.12, 0.20) per channel
-                    prm.copy_(base - 0.3 + off + lvl * slope)
+                    # nine stages multiply: ~0.97^9 of the identity's latent scale at q = 0 (still codes non-zero symbols), ~1.09^9 at q = 4
+                    off, slope = 0.3 * noise[:1], 0.03 + 0.03 * torch.sigmoid(4.0 * noise[1:2])     # slope in (0.03, 0.06) per channel and level
+                    prm.copy_(base + off + (lvl - 1.0) * slope)
                 else:
                     prm.copy_((0.1 * noise[:1]).expand_as(prm))
             else:
