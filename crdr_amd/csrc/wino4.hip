@@ -282,6 +282,9 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
     for (int x = 0; x < 5; ++x) hpass(x);
   }
 
+#ifdef W4X_STAMPS
+  unsigned long long seg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   float uf[9][2];   // filter fragments of positions j .. j + 3 in flight (ring of 9, indexed j % 9: 36 = 0 mod 9, so the next sub-step's
   //                   positions 0..3 land in entries the current one has long left); alive across sub-steps
 #pragma unroll
@@ -300,24 +303,55 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
     }
   }
   W4_STAMP(2);
-  for (int k = 0; k < K4; ++k) {
-    // (the two base offsets are made opaque: every LDS read of the sub-step is then `base register + 16-bit immediate`; left visible,
+  // per-sub-step scalar state, computed one sub-step AHEAD behind the last MFMAs of the previous one (slots 66 .. 70): ~30 scalar instructions
+  // and three address adds used to sit at the loop top, where nothing covers them -- the matrix pipe ran dry for ~150 cycles per sub-step
+  // (in-loop stamps, tools/experiments/w4_stamps.py)
+  struct SubState {
+    int rpo, fpo, fpno;                  // float offsets of raw patch k + 1, filter block k, filter block k + 1 (opaque to the compiler, see below)
+    __amdgpu_buffer_rsrc_t ru2, rx3;     // descriptors of the requests for filter block k + 2 / raw patch k + 3 (empty past the last sub-step)
+    int soff3, f2;                       // scalar offset of raw patch k + 3; buffer of filter block k + 2
+  };
+  auto sub_state = [&](int k, int r0_, int r1_, int ch3_, int sub3_) __attribute__((always_inline)) {
+    SubState st;
+    // (the base offsets are made opaque: every LDS read of the sub-step is then `base register + 16-bit immediate`; left visible,
     // the compiler folds the buffer constants into the offsets, overflows the immediate and spends an add per read)
-    int rpo = rbase + r1 * kRF, fpo = fbase + r0 * kFF;
-    asm volatile("" : "+v"(rpo));
-    asm volatile("" : "+v"(fpo));
-    const float* rp = smem + rpo;                         // raw patch k + 1
-    const float* fp = smem + fpo;                         // filter block k (the filter ring turns with the raw ring: block k in buffer k % 3)
-    const __amdgpu_buffer_rsrc_t ru2 = k + 2 < K4 ? sr.ru : wino4_empty_rsrc(), rx3 = k + 3 < K4 ? sr.rx : wino4_empty_rsrc();
-    const int soff3 = FORM == 1 ? ch3 * 16 : ch3 * 16 + ((sub3 >> 1) * p.W + (sub3 & 1)) * p.ldx * 4;   // (sub3 = 0 unless the conv is the stride-2 form)
-    const int f2 = r1 == 2 ? 0 : r1 + 1;                  // buffer of filter block k + 2
-    int fpno = fbase + r1 * kFF;
-    asm volatile("" : "+v"(fpno));
-    const float* fpn = smem + fpno;                       // filter block k + 1 (its first four positions are fetched at the end of this sub-step)
+    st.rpo = rbase + r1_ * kRF;
+    st.fpo = fbase + r0_ * kFF;
+    st.fpno = fbase + r1_ * kFF;
+    asm volatile("" : "+v"(st.rpo));
+    asm volatile("" : "+v"(st.fpo));
+    asm volatile("" : "+v"(st.fpno));
+    st.ru2 = k + 2 < K4 ? sr.ru : wino4_empty_rsrc();
+    st.rx3 = k + 3 < K4 ? sr.rx : wino4_empty_rsrc();
+    st.soff3 = FORM == 1 ? ch3_ * 16 : ch3_ * 16 + ((sub3_ >> 1) * p.W + (sub3_ & 1)) * p.ldx * 4;   // (sub3 = 0 unless the conv is the stride-2 form)
+    st.f2 = r1_ == 2 ? 0 : r1_ + 1;
+    return st;
+  };
+  SubState cur = sub_state(0, r0, r1, ch3, sub3), nxt = cur;
+  for (int k = 0; k < K4; ++k) {
+    const float* rp = smem + cur.rpo;                     // raw patch k + 1
+    const float* fp = smem + cur.fpo;                     // filter block k (the filter ring turns with the raw ring: block k in buffer k % 3)
+    const __amdgpu_buffer_rsrc_t ru2 = cur.ru2, rx3 = cur.rx3;
+    const int soff3 = cur.soff3, f2 = cur.f2;
+    const float* fpn = smem + cur.fpno;                   // filter block k + 1 (its first four positions are fetched at the end of this sub-step)
+    bool newsub = false;                                  // the requests of sub-step k + 1 start a new shifted sub-filter (FORM 1)
+#ifdef W4X_STAMPS
+    unsigned long long seg_t = __builtin_amdgcn_s_memtime();
+#define W4_SEG(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); seg_acc[i] += now_ - seg_t; seg_t = now_; } while (0)
+#else
+#define W4_SEG(i) do {} while (0)
+#endif
     hpass(5);   // row 5 of V_k (its vertical pass was done during the previous sub-step; its MFMAs are the last ones)
     __builtin_amdgcn_sched_barrier(0);
+    W4_SEG(0);
 #pragma clang loop unroll(full)
     for (int s = 0; s < 72; ++s) {
+      if (s == 15) W4_SEG(1);
+      if (s == 27) W4_SEG(2);
+      if (s == 39) W4_SEG(3);
+      if (s == 51) W4_SEG(4);
+      if (s == 65) W4_SEG(5);
+      if (s == 66) W4_SEG(6);
       const int j = s >> 1, ob = s & 1, x = j / 6, y = j - 6 * x;
       // 72 blocks x 4 = 288 accumulator registers: 64 blocks in the accumulation half of the register file, the last 8 (positions 32..35)
       // pinned to ordinary vector registers (left to the compiler they bounce between the two files: 72 moves per sub-step)
@@ -328,6 +362,16 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
         const f32x2 u2 = *reinterpret_cast<const f32x2*>(fp + (j + 4) * 256);
         uf[(j + 4) % 9][0] = u2[0];
         uf[(j + 4) % 9][1] = u2[1];
+      }
+      if (s == 70) {   // the next sub-step's scalar state, behind an MFMA (the ring turns, the chunk / sub-filter counters advance)
+        r0 = r1;
+        r1 = r1 == 2 ? 0 : r1 + 1;
+        if (++ch3 == Kc) {
+          ch3 = 0;
+          ++sub3;
+          newsub = true;
+        }
+        nxt = sub_state(k + 1, r0, r1, ch3, sub3);
       }
       if (s >= 66 && s < 70) {   // behind the sub-step's barrier (slot 65): positions 0..3 of the NEXT sub-step's filter block
         const f32x2 u2 = *reinterpret_cast<const f32x2*>(fpn + (s - 66) * 256);
@@ -361,20 +405,20 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    r0 = r1;
-    r1 = r1 == 2 ? 0 : r1 + 1;
-    if (++ch3 == Kc) {
-      ch3 = 0;
-      ++sub3;
-      if constexpr (FORM == 1) {   // the patches requested from here on belong to the next shifted sub-filter: its padding pattern
-        if (sub3 < 4) {
+    cur = nxt;
+    if constexpr (FORM == 1) {   // the patches requested from here on belong to the next shifted sub-filter: its padding pattern
+      if (newsub && sub3 < 4) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub3);
-        }
+        for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub3);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    W4_SEG(7);
   }
+#ifdef W4X_STAMPS
+  if (threadIdx.x == 0 && nt_ == 1)
+    for (int i = 0; i < 8; ++i) w4_stamps[(blockIdx.x * 16 + 8) * 8 + i] = seg_acc[i];
+#endif
   // (the last sub-step's barrier is 6 MFMAs back: what follows -- the next tile's requests into the raw / filter buffers, the epilogue -- touches
   // no LDS a wave could still be reading for a purpose: the four fragment reads behind that barrier fetched a block nobody multiplies)
   // (the dead tail requests -- zeros for sub-steps past the last -- that may still be in flight go to raw buffers; whatever is requested

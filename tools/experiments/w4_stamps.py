@@ -26,6 +26,14 @@ torch.cuda.synchronize()
 buf = np.zeros(256 * 16 * 8, dtype=np.uint64)
 assert raw.crdr_w4_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
 st = buf.reshape(256, 16, 8).astype(np.int64)
+seg = st[:, 8]
+if (seg > 0).any():
+    nsub = (ci + 3) // 4 * (4 if k == 5 else 1)
+    names = ["top (row 5 pass)", "slots 0-14", "15-26 (+vpass 0)", "27-38 (+vpass 1)", "39-50 (+vpass 2, hpass 0-2)", "51-64 (+hpass 3)", "65 (wait + barrier)", "66-71 (+hpass 4 at 62.. see code)"]
+    print("in-loop segments, median cycles per sub-step (second tile of each workgroup, wave 0):")
+    for i, nm in enumerate(names):
+        print(f"   {nm:34s} {float(np.median(seg[:, i])) / nsub:8.1f}")
+    print(f"   {'sum':34s} {float(np.median(seg.sum(1))) / nsub:8.1f}")
 print(f"{ci}->{co} k{k} @{hw}: median shader cycles per phase (wave 0 of each workgroup)")
 print(" tile   setup  prologue      loop  next-req  epilogue   to-next")
 for t in range(16):
