@@ -572,11 +572,14 @@ def main():
             saved = dict(ops._algo_cache)
             saved_w4 = ops.WINO4
             ops.WINO4 = False
-            for k_, v_ in list(ops._algo_cache.items()):
+            # the plan set tuned WITHOUT those kernels (tools/tune_round.sh, CRDR_WINO4=0: the tuner's choice among F(2x2) and the direct kernels for
+            # every 3x3 / 5x5 shape); whatever it lacks keeps the shipped choice unless that is an F(4x4) id
+            ops._algo_cache.clear()
+            ops.load_tune_cache(os.path.join(ROOT, "tools", "data", "tune_r5_no_f4x4.json"))
+            for k_, v_ in saved.items():
                 is_w = k_[0] in ("w", "wg", "ws", "wm")
-                if (is_w and (v_ & 0xff) == wg4) or (not is_w and (v_ & 0xff) == w4):
-                    del ops._algo_cache[k_]
-            ops.load_tune_cache(os.path.join(ROOT, "tools", "data", "tune_r3_f.json"), ignore_signature=True)
+                if not ((is_w and (v_ & 0xff) == wg4) or (not is_w and (v_ & 0xff) == w4)):
+                    ops._algo_cache.setdefault(k_, v_)
             nx = run_stage(a, 3, a.bs, min(a.steps, 20), a.warmup, 0)
             nx.pop("trainer")
             line["stage3_no_f4x4"] = {"metric": f"stage-3 training img/s at {a.size}x{a.size}", "value": round(nx["value"], 3), "unit": "img/s",

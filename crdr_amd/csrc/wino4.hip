@@ -41,12 +41,6 @@ namespace crdr {
 namespace {
 
 constexpr int kNT4 = 256;
-#ifdef W4X_STAMPS   // diagnostic build only (tools/experiments): s_memtime at the phase boundaries of every tile, wave 0 of every workgroup
-__device__ unsigned long long w4_stamps[256 * 16 * 8];
-#define W4_STAMP(i) do { if (threadIdx.x == 0 && nt_ < 16) w4_stamps[(blockIdx.x * 16 + nt_) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define W4_STAMP(i) do {} while (0)
-#endif
 
 // How the 32 Winograd tiles (4 x 4 outputs each) of an output tile lie over the image -- geometry 0: 2 rows x 16 columns (8 x 64 pixels:
 // images of >= 33 columns), geometry 1: 4 rows x 8 columns (16 x 32 pixels: the 32-column images, where geometry 0 would compute a
@@ -233,7 +227,7 @@ struct Wino4Next { bool more; int kbeg, kcnt; };
 //     .. 12 x + 11) are done by then; row 5 follows at the top of the next sub-step.
 template <int GEO, int FORM>
 __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& tl, float* smem, Wino4Src& sr, bool prefetched, int lane, int wave,
-                                           f32x4 (&acc)[64], f32x4 (&accv)[8], int nt_ = 0) {
+                                           f32x4 (&acc)[64], f32x4 (&accv)[8]) {
   const int K4 = tl.kcnt, kbeg = tl.kbeg;   // this work item's sub-steps: kbeg .. kbeg + K4 - 1 of the tile's p.kchunks
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
   // this lane's raw reads: patch pixel (i, j) of tile (th, tx), channel kg: float offset rbase + ro(i, j) of a raw buffer
@@ -282,9 +276,6 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
     for (int x = 0; x < 5; ++x) hpass(x);
   }
 
-#ifdef W4X_STAMPS
-  unsigned long long seg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
   float uf[9][2];   // filter fragments of positions j .. j + 3 in flight (ring of 9, indexed j % 9: 36 = 0 mod 9, so the next sub-step's
   //                   positions 0..3 land in entries the current one has long left); alive across sub-steps
 #pragma unroll
@@ -302,7 +293,6 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
       for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub3);
     }
   }
-  W4_STAMP(2);
   // per-sub-step scalar state, computed one sub-step AHEAD behind the last MFMAs of the previous one (slots 66 .. 70): ~30 scalar instructions
   // and three address adds used to sit at the loop top, where nothing covers them -- the matrix pipe ran dry for ~150 cycles per sub-step
   // (in-loop stamps, tools/experiments/w4_stamps.py)
@@ -335,23 +325,10 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
     const int soff3 = cur.soff3, f2 = cur.f2;
     const float* fpn = smem + cur.fpno;                   // filter block k + 1 (its first four positions are fetched at the end of this sub-step)
     bool newsub = false;                                  // the requests of sub-step k + 1 start a new shifted sub-filter (FORM 1)
-#ifdef W4X_STAMPS
-    unsigned long long seg_t = __builtin_amdgcn_s_memtime();
-#define W4_SEG(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); seg_acc[i] += now_ - seg_t; seg_t = now_; } while (0)
-#else
-#define W4_SEG(i) do {} while (0)
-#endif
     hpass(5);   // row 5 of V_k (its vertical pass was done during the previous sub-step; its MFMAs are the last ones)
     __builtin_amdgcn_sched_barrier(0);
-    W4_SEG(0);
 #pragma clang loop unroll(full)
     for (int s = 0; s < 72; ++s) {
-      if (s == 15) W4_SEG(1);
-      if (s == 27) W4_SEG(2);
-      if (s == 39) W4_SEG(3);
-      if (s == 51) W4_SEG(4);
-      if (s == 65) W4_SEG(5);
-      if (s == 66) W4_SEG(6);
       const int j = s >> 1, ob = s & 1, x = j / 6, y = j - 6 * x;
       // 72 blocks x 4 = 288 accumulator registers: 64 blocks in the accumulation half of the register file, the last 8 (positions 32..35)
       // pinned to ordinary vector registers (left to the compiler they bounce between the two files: 72 moves per sub-step)
@@ -413,12 +390,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    W4_SEG(7);
   }
-#ifdef W4X_STAMPS
-  if (threadIdx.x == 0 && nt_ == 1)
-    for (int i = 0; i < 8; ++i) w4_stamps[(blockIdx.x * 16 + 8) * 8 + i] = seg_acc[i];
-#endif
   // (the last sub-step's barrier is 6 MFMAs back: what follows -- the next tile's requests into the raw / filter buffers, the epilogue -- touches
   // no LDS a wave could still be reading for a purpose: the four fragment reads behind that barrier fetched a block nobody multiplies)
   // (the dead tail requests -- zeros for sub-steps past the last -- that may still be in flight go to raw buffers; whatever is requested
@@ -757,11 +729,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
   int cur = 0;
   bool prefetched = false;
   Wino4Src sr;
-  int nt_ = -1;
-  (void)nt_;
   for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
-    ++nt_;
-    W4_STAMP(0);
     // (per-lane constants are re-derived per tile instead of staying live across the register-hungry epilogue)
     int lane = lane_, wave = wave_;
     asm volatile("" : "+v"(lane));
@@ -783,9 +751,7 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     for (int j = 0; j < 64; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) accv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    W4_STAMP(1);
-    wino4_loop<GEO, FORM>(p, tl, smem, sr, prefetched, lane, wave, acc, accv, nt_);
-    W4_STAMP(3);
+    wino4_loop<GEO, FORM>(p, tl, smem, sr, prefetched, lane, wave, acc, accv);
     // (the loop ends with a barrier: every wave is past its last LDS read, raw and filter buffers are free)
     const bool more = vb + (int)gridDim.x < total;
     Wino4Next nx{false, 0, 0};
@@ -794,14 +760,10 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
       // (the vectors FIRST: their global loads are waited for with vmcnt(0) before they go to LDS, and vector-memory operations retire in
       // issue order -- behind the 30 DMA requests that wait would sit out the whole DMA latency: 9 000 cycles per tile by the stamps)
       wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * (4 * kBN4), tid);
-      W4_STAMP(6);
       sr = wino4_src<GEO, FORM>(p_, grp, tn, gyn_abs, lane, wave);
-      W4_STAMP(7);
       nx = Wino4Next{true, tn.kbeg, tn.kcnt};
     }
-    W4_STAMP(4);
     wino4_finish<GEO, FORM, SPLIT, w4_epi_mask(EC)>(p, tl, smem, sV, lane, wave, acc, accv, sr, nx);
-    W4_STAMP(5);
     prefetched = more;
     cur ^= 1;
     lds_barrier4();   // column-sum area, sV of this tile: free (the stores stay in flight: the next tile's first wait is vmcnt(32))
@@ -1099,10 +1061,5 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
   return 0;
 }
 
-#ifdef W4X_STAMPS
-extern "C" int crdr_w4_stamps(unsigned long long* dst) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(w4_stamps), sizeof(w4_stamps));
-}
-#endif
 
 }  // namespace crdr

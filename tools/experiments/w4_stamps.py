@@ -34,6 +34,12 @@ if (seg > 0).any():
     for i, nm in enumerate(names):
         print(f"   {nm:34s} {float(np.median(seg[:, i])) / nsub:8.1f}")
     print(f"   {'sum':34s} {float(np.median(seg.sum(1))) / nsub:8.1f}")
+ep = st[:, 9]
+if (ep[:, 4] > 0).any():
+    e = ep[ep[:, 4] > 0]
+    med = lambda a: float(np.median(a))
+    print(f"epilogue of the second tile: output transform of half 0 (+ next tile's requests) {med(e[:, 1]):.0f}, its element-wise part + 16 stores "
+          f"{med(e[:, 2] - e[:, 1]):.0f}, output transform of half 1 {med(e[:, 3] - e[:, 2]):.0f}, its element-wise part + stores {med(e[:, 4] - e[:, 3]):.0f}")
 print(f"{ci}->{co} k{k} @{hw}: median shader cycles per phase (wave 0 of each workgroup)")
 print(" tile   setup  prologue      loop  next-req  epilogue   to-next")
 for t in range(16):

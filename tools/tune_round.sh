@@ -1,7 +1,8 @@
 #!/bin/bash
 # Rebuild the shipped perf database on the GPU box (run from the repo root): the 3x3 / 5x5 launches are timed again (cold caches,
-# best of 3) on top of the shipped entries -- every candidate now also has to agree with the built-in plan's result (ops._autotune) --
-# then one confirmation run; copy gpurun_out/tune_r5.json to crdr_amd/hip/tune_gfx950.json.
+# best of 3) on top of the shipped entries -- every candidate also has to agree with the built-in plan's result (ops._autotune) --
+# then one confirmation run; copy gpurun_out/tune_r5.json to crdr_amd/hip/tune_gfx950.json.  A second database without the
+# F(4x4, 3x3) / F(3x3, 4x4) kernels (CRDR_WINO4=0: F(2x2) + direct) for bench.py's `stage3_no_f4x4` line: tools/data/tune_r5_no_f4x4.json.
 set -x
 export TMPDIR=/tmp
 export CRDR_TUNE_ROUNDS=3 CRDR_TUNE_COLD=1
@@ -9,3 +10,5 @@ timeout 2400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --bf16x3 --
 cut -c1-300 gpurun_out/bench_tune.log; tail -2 gpurun_out/bench_tune.err
 timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary --tune-db gpurun_out/tune_r5.json > gpurun_out/bench_tuned.log 2>> gpurun_out/bench_tune.err
 cut -c1-400 gpurun_out/bench_tuned.log
+CRDR_WINO4=0 timeout 1800 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --tune-db none --retune-k3 crdr_amd/hip/tune_gfx950.json --save-tune-db gpurun_out/tune_r5_no_f4x4.json > gpurun_out/bench_tune_no_f4x4.log 2>> gpurun_out/bench_tune.err
+cut -c1-300 gpurun_out/bench_tune_no_f4x4.log
