@@ -136,23 +136,30 @@ __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int 
 // FORM 1 (a 5x5 stride-1 layer as four 3x3 sub-filters, taps 3 bi + a, 3 bj + b): sub-filter `sub` = (bi, bj) reads the patch displaced by
 // (3 bi, 3 bj) pixels; whether a pixel is padding then depends on the sub-filter, so the lane offsets are re-derived when the K loop
 // moves to the next one (four times per tile).
-template <int GEO, int FORM>
-__device__ __forceinline__ unsigned wino4_in_off(const IgemmArgs& p, const Wino4Tile& t, int piece, int lane, int sub) {
+// (the slot decode depends on the lane and the piece only: wino4_piece_geo does it once per kernel -- pi | pj << 8 | image of the pair << 16 |
+// slot in use << 17 --, wino4_in_off finishes it per tile / sub-filter: the decode was two thirds of the 1 700 cycles a tile spent here)
+template <int GEO>
+__device__ __forceinline__ unsigned wino4_piece_geo(int piece, int lane) {
   using G = W4Geo<GEO>;
   const int S = piece * 64 + lane;
   const int cls = S / kClsSlots, r2f = S - cls * kClsSlots;
   const int img = GEO == 2 ? r2f >> 5 : 0, r2 = GEO == 2 ? r2f & 31 : r2f;
   const int R = r2 / G::PR, Cc = r2 - R * G::PR;
   const int ci = cls >> 2, cj = cls & 3;
-  const int pi = 4 * R + ci + (FORM == 1 ? 3 * (sub >> 1) : 0), pj = 4 * Cc + cj + (FORM == 1 ? 3 * (sub & 1) : 0);
+  const bool used = S < kInUsed4 && r2 < (GEO == 2 ? 25 : G::USED);
+  return (unsigned)(4 * R + ci) | ((unsigned)(4 * Cc + cj) << 8) | ((unsigned)img << 16) | ((used ? 1u : 0u) << 17);
+}
+template <int GEO, int FORM>
+__device__ __forceinline__ unsigned wino4_in_off(const IgemmArgs& p, const Wino4Tile& t, unsigned geo, int sub) {
+  using G = W4Geo<GEO>;
+  const int pi = (int)(geo & 0xff) + (FORM == 1 ? 3 * (sub >> 1) : 0), pj = (int)((geo >> 8) & 0xff) + (FORM == 1 ? 3 * (sub & 1) : 0);
   const int pmax_i = 4 * G::TY + 2 + (FORM == 1 ? 3 * (sub >> 1) : 0), pmax_j = 4 * G::TX + 2 + (FORM == 1 ? 3 * (sub & 1) : 0);
-  const int n = t.n + img;
+  const int n = t.n + (int)((geo >> 16) & 1);
   // (5x5 stride-2 conv as four parity sub-filters: plane pixel m of parity (ph, pw) is image pixel 2 m + parity; the parity displacement
   // is wave-uniform and travels in the request's scalar offset; H and W are even there, so validity does not depend on the parity)
   const int ist = (FORM == 0 && p.nphase == 4) ? 2 : 1;
   const int ih = ist * (t.oh0 - p.si + pi), iw = ist * (t.ow0 - p.si + pj);
-  const bool ok = S < kInUsed4 && r2 < (GEO == 2 ? 25 : G::USED) && pi < pmax_i && pj < pmax_j && n < p.N && (unsigned)ih < (unsigned)p.H &&
-                  (unsigned)iw < (unsigned)p.W;
+  const bool ok = ((geo >> 17) & 1) && pi < pmax_i && pj < pmax_j && n < p.N && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
   return ok ? (unsigned)((((n * p.H + ih) * p.W + iw) * p.ldx) * 4) : kOobOffset;
 }
 
@@ -227,7 +234,7 @@ struct Wino4Next { bool more; int kbeg, kcnt; };
 //     .. 12 x + 11) are done by then; row 5 follows at the top of the next sub-step.
 template <int GEO, int FORM>
 __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& tl, float* smem, Wino4Src& sr, bool prefetched, int lane, int wave,
-                                           f32x4 (&acc)[64], f32x4 (&accv)[8]) {
+                                           f32x4 (&acc)[64], f32x4 (&accv)[8], const unsigned (&geo)[4]) {
   const int K4 = tl.kcnt, kbeg = tl.kbeg;   // this work item's sub-steps: kbeg .. kbeg + K4 - 1 of the tile's p.kchunks
   const int tx = lane & 15, kg = lane >> 4, th = wave >> 1, oh = wave & 1;
   // this lane's raw reads: patch pixel (i, j) of tile (th, tx), channel kg: float offset rbase + ro(i, j) of a raw buffer
@@ -290,7 +297,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
   if constexpr (FORM == 1) {   // (12 input channels: the first patch requested inside the loop already belongs to the second sub-filter)
     if (sub3 != kbeg / Kc && sub3 < 4) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub3);
+      for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, geo[j], sub3);
     }
   }
   // per-sub-step scalar state, computed one sub-step AHEAD behind the last MFMAs of the previous one (slots 66 .. 70): ~30 scalar instructions
@@ -386,7 +393,7 @@ __device__ __forceinline__ void wino4_loop(const IgemmArgs& p, const Wino4Tile& 
     if constexpr (FORM == 1) {   // the patches requested from here on belong to the next shifted sub-filter: its padding pattern
       if (newsub && sub3 < 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub3);
+        for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, geo[j], sub3);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -688,7 +695,7 @@ __device__ __forceinline__ void wino4_finish(const IgemmArgs& p, const Wino4Tile
 
 // DMA sources of tile tl (group pointers resolved)
 template <int GEO, int FORM>
-__device__ __forceinline__ Wino4Src wino4_src(const IgemmArgs& p, const IgemmGroup& grp, const Wino4Tile& tl, int gyn, int lane, int wave) {
+__device__ __forceinline__ Wino4Src wino4_src(const IgemmArgs& p, const IgemmGroup& grp, const Wino4Tile& tl, int gyn, const unsigned (&geo)[4]) {
   Wino4Src sr;
   const float* x = p.ngroup > 1 ? grp.x[tl.gidx] : p.x;
   sr.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)((((unsigned long long)p.N * p.H * p.W - 1) * p.ldx + p.Cin) * 4ull), 0x00020000);
@@ -699,20 +706,32 @@ __device__ __forceinline__ Wino4Src wino4_src(const IgemmArgs& p, const IgemmGro
   sr.u_off0 = (unsigned)(tl.tn * nph + tl.phase) * (unsigned)p.kchunks * (kUSlots4 * 16u);
   const int sub0 = FORM == 1 ? tl.kbeg / (p.kchunks / p.nphase) : 0;   // (the shifted sub-filter this work item starts in)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, wave + 4 * j, lane, sub0);
+  for (int j = 0; j < 4; ++j) sr.a_off[j] = wino4_in_off<GEO, FORM>(p, tl, geo[j], sub0);
   return sr;
 }
 
-// per-column epilogue vectors of tile tl -> sV[4][64] (bias, vec2, scale, shift)
-__device__ __forceinline__ void wino4_vectors(const IgemmArgs& p, const IgemmGroup& grp, const Wino4Tile& tl, float* sV, int tid) {
+// per-column epilogue vectors of tile tl -> sV[4][64] (bias, vec2, scale, shift), in two halves: the loads are issued, something else is done
+// while they are in flight (the next tile's source set-up), then they go to LDS
+struct Wino4Vec { float v[4]; };
+__device__ __forceinline__ Wino4Vec wino4_vectors_load(const IgemmArgs& p, const IgemmGroup& grp, const Wino4Tile& tl, int tid) {
+  Wino4Vec r = {{0.f, 0.f, 1.f, 0.f}};
   if (tid < kBN4) {
     const int f0 = p.flags;
     const bool live = tl.n0 + tid < p.Cout;
     const float* bias = p.ngroup > 1 ? grp.bias[tl.gidx] : p.bias;
-    sV[0 * kBN4 + tid] = (live && (f0 & CRDR_EPI_BIAS)) ? bias[tl.n0 + tid] : 0.f;
-    sV[1 * kBN4 + tid] = (live && (f0 & (CRDR_EPI_VEC2 | CRDR_EPI_MASKOFF))) ? p.vec2[tl.n0 + tid] : 0.f;
-    sV[2 * kBN4 + tid] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.scale[tl.n0 + tid] : 1.f;
-    sV[3 * kBN4 + tid] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[tl.n0 + tid] : 0.f;
+    if (live && (f0 & CRDR_EPI_BIAS)) r.v[0] = bias[tl.n0 + tid];
+    if (live && (f0 & (CRDR_EPI_VEC2 | CRDR_EPI_MASKOFF))) r.v[1] = p.vec2[tl.n0 + tid];
+    if (live && (f0 & CRDR_EPI_AFFINE)) {
+      r.v[2] = p.scale[tl.n0 + tid];
+      r.v[3] = p.shift[tl.n0 + tid];
+    }
+  }
+  return r;
+}
+__device__ __forceinline__ void wino4_vectors_store(const Wino4Vec& r, float* sV, int tid) {
+  if (tid < kBN4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sV[k * kBN4 + tid] = r.v[k];
   }
 }
 
@@ -729,6 +748,9 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
   int cur = 0;
   bool prefetched = false;
   Wino4Src sr;
+  unsigned geo[4];   // this lane's slots of the four raw pieces of its wave (tile independent)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) geo[j] = wino4_piece_geo<GEO>(wave_ + 4 * j, lane_);
   for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
     // (per-lane constants are re-derived per tile instead of staying live across the register-hungry epilogue)
     int lane = lane_, wave = wave_;
@@ -743,24 +765,26 @@ __global__ __launch_bounds__(kNT4) void wino4_kernel(const IgemmArgs p_, const I
     }
     float* sV = sVb + cur * (4 * kBN4);
     if (!prefetched) {
-      sr = wino4_src<GEO, FORM>(p_, grp, tl, gyn_abs, lane, wave);
-      wino4_vectors(p_, grp, tl, sV, tid);   // (published by the K loop's first barrier)
+      const Wino4Vec vec = wino4_vectors_load(p_, grp, tl, tid);
+      sr = wino4_src<GEO, FORM>(p_, grp, tl, gyn_abs, geo);
+      wino4_vectors_store(vec, sV, tid);   // (published by the K loop's first barrier)
     }
     f32x4 acc[64], accv[8];
 #pragma unroll
     for (int j = 0; j < 64; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) accv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wino4_loop<GEO, FORM>(p, tl, smem, sr, prefetched, lane, wave, acc, accv);
+    wino4_loop<GEO, FORM>(p, tl, smem, sr, prefetched, lane, wave, acc, accv, geo);
     // (the loop ends with a barrier: every wave is past its last LDS read, raw and filter buffers are free)
     const bool more = vb + (int)gridDim.x < total;
     Wino4Next nx{false, 0, 0};
     if (more) {   // the next tile: raw patches 0, 1, 2, filter block 0 and the epilogue vectors
       const Wino4Tile tn = wino4_tile<GEO>(p_, vb + (int)gridDim.x, gx, gyn, gz);
-      // (the vectors FIRST: their global loads are waited for with vmcnt(0) before they go to LDS, and vector-memory operations retire in
-      // issue order -- behind the 30 DMA requests that wait would sit out the whole DMA latency: 9 000 cycles per tile by the stamps)
-      wino4_vectors(p_, grp, tn, sVb + (cur ^ 1) * (4 * kBN4), tid);
-      sr = wino4_src<GEO, FORM>(p_, grp, tn, gyn_abs, lane, wave);
+      // (the vectors' loads FIRST -- vector-memory operations retire in issue order: behind the next tile's requests their wait would sit out
+      // the whole DMA latency, 9 000 cycles per tile by the stamps -- and the source set-up while they are in flight)
+      const Wino4Vec vec = wino4_vectors_load(p_, grp, tn, tid);
+      sr = wino4_src<GEO, FORM>(p_, grp, tn, gyn_abs, geo);
+      wino4_vectors_store(vec, sVb + (cur ^ 1) * (4 * kBN4), tid);
       nx = Wino4Next{true, tn.kbeg, tn.kcnt};
     }
     wino4_finish<GEO, FORM, SPLIT, w4_epi_mask(EC)>(p, tl, smem, sV, lane, wave, acc, accv, sr, nx);
