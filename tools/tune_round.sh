@@ -1,7 +1,11 @@
 #!/bin/bash
 # Rebuild the shipped perf database on the GPU box (run from the repo root): the 3x3 / 5x5 launches are timed again (cold caches,
 # best of 3) on top of the shipped entries -- every candidate also has to agree with the built-in plan's result (ops._autotune) --
-# then one confirmation run; copy gpurun_out/tune_r5.json to crdr_amd/hip/tune_gfx950.json.  A second database without the
+# then one confirmation run and the ACCEPTANCE run: the two full-size oracle steps and the plan replay on the candidate database (the
+# gradients upstream of the quantiser amplify the kernels' 1e-6 rounding differences through ReLU-mask flips, tests/test_conditioning.py:
+# which masks flip depends on the plan set, and of two databases tuned on the same kernels one measured 3e-3 there and the other 9.4e-3
+# against the 8e-3 cap -- a candidate that fails is NOT shipped, the previous database stays).  Only a candidate with
+# gpurun_out/tune_accept.log ending in `rc=0` is copied to crdr_amd/hip/tune_gfx950.json.  A second database without the
 # F(4x4, 3x3) / F(3x3, 4x4) kernels (CRDR_WINO4=0: F(2x2) + direct) for bench.py's `stage3_no_f4x4` line: tools/data/tune_r5_no_f4x4.json.
 set -x
 export TMPDIR=/tmp
@@ -10,5 +14,8 @@ timeout 2400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --bf16x3 --
 cut -c1-300 gpurun_out/bench_tune.log; tail -2 gpurun_out/bench_tune.err
 timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary --tune-db gpurun_out/tune_r5.json > gpurun_out/bench_tuned.log 2>> gpurun_out/bench_tune.err
 cut -c1-400 gpurun_out/bench_tuned.log
+cp crdr_amd/hip/tune_gfx950.json /tmp/tune_shipped.json && cp gpurun_out/tune_r5.json crdr_amd/hip/tune_gfx950.json
+timeout 1500 python -m pytest -x -q -m gpu tests/test_gpu_step.py -k "256_tuned or every_tuned" tests/test_gpu_tuned_plans.py > gpurun_out/tune_accept.log 2>&1; echo "rc=$?" >> gpurun_out/tune_accept.log
+cp /tmp/tune_shipped.json crdr_amd/hip/tune_gfx950.json; tail -4 gpurun_out/tune_accept.log
 CRDR_WINO4=0 timeout 1800 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --tune-db none --retune-k3 crdr_amd/hip/tune_gfx950.json --save-tune-db gpurun_out/tune_r5_no_f4x4.json > gpurun_out/bench_tune_no_f4x4.log 2>> gpurun_out/bench_tune.err
 cut -c1-300 gpurun_out/bench_tune_no_f4x4.log
