@@ -10,69 +10,96 @@
 namespace crdr {
 
 // BEGIN GENERATED (gen_igemm_parts.py)
-extern template __global__ void igemm_kernel<4, 1, 1, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 3, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 4, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 5, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 6, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 7, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 3, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 4, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 3, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 4, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 3, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 2, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 2, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 1, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 3, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 1, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 2, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 2, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 2, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 1, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 2, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 1, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 2, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 2, 1, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 3, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 4, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 5, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 6, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 7, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 3, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 4, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 3, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 4, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 3, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 2, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 2, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 1, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 3, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 3, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 4, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 5, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 6, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 7, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 3, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 4, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 3, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 4, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 3, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 3, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 1, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 3, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 4, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 5, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 6, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 7, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 3, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 4, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 3, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 4, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 3, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 3, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 3, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 4, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 5, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 6, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 7, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 3, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 4, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 3, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 4, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 3, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 3, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
 // END GENERATED
 
 // ------------------------------------------------------------------------------------------------------------
@@ -83,9 +110,10 @@ struct TileCfg {
   void (*kern)(const IgemmArgs, const IgemmTaps, const IgemmGroup);
   void (*kern_smallc)(const IgemmArgs, const IgemmTaps, const IgemmGroup);  // tap-major variant (Cin <= 4), nullptr where not built
   void (*kern_bf3)(const IgemmArgs, const IgemmTaps, const IgemmGroup);     // split-bf16 products (CRDR_CONV_BF16X3)
+  void (*kern_fast)(const IgemmArgs, const IgemmTaps, const IgemmGroup);    // unsplit launches on the straight-line epilogue: the kernel without its split-K / general-epilogue code
 };
-#define CFG(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false, false>, nullptr, igemm_kernel<a, b, c, d, false, true>}
-#define CFGS(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false, false>, igemm_kernel<a, b, c, d, true, false>, igemm_kernel<a, b, c, d, false, true>}
+#define CFG(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false, false>, nullptr, igemm_kernel<a, b, c, d, false, true>, igemm_kernel<a, b, c, d, false, false, true>}
+#define CFGS(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false, false>, igemm_kernel<a, b, c, d, true, false>, igemm_kernel<a, b, c, d, false, true>, igemm_kernel<a, b, c, d, false, false, true>}
 static const TileCfg kCfgs[] = {
     // BM=128 family (one 32-row strip per wave), BN = 32..224
     CFGS(4, 1, 1, 1), CFGS(4, 1, 1, 2), CFG(4, 1, 1, 3), CFG(4, 1, 1, 4), CFG(4, 1, 1, 5), CFG(4, 1, 1, 6),
@@ -193,6 +221,12 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
         }
       }
     tp.tap_begin[ph] = (short)nt;
+  }
+  {  // power-of-two grids: the kernel splits GEMM rows with shifts (igemm_kernel.hpp, split_row)
+    const long long hw = (long long)a.GH * a.GW;
+    const bool p2 = a.GW > 0 && hw > 0 && hw < (1ll << 30) && (a.GW & (a.GW - 1)) == 0 && (hw & (hw - 1)) == 0;
+    a.gw_sh = p2 ? __builtin_ctz((unsigned)a.GW) : -1;
+    a.hw_sh = p2 ? __builtin_ctzll((unsigned long long)hw) : -1;
   }
   {  // extents of the range-checked buffer descriptors (the input's is re-based per workgroup: any size)
     const long long xb = (((long long)d->N * d->H * d->W - 1) * d->ldx + d->C) * 4;
@@ -500,9 +534,10 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
     return 0;
   }
   const TileCfg& t = kCfgs[pl.cfg];
-  const int variant = a.smallc ? 1 : ((d->flags & CRDR_CONV_BF16X3) ? 2 : 0);   // (RGB-input layers stay exact: K is tiny there)
-  auto kern = variant == 1 ? t.kern_smallc : (variant == 2 ? t.kern_bf3 : t.kern);
-  static std::atomic<bool> attr_done[3][64];
+  // (RGB-input layers stay exact: K is tiny there); 3: the FAST form of the plain kernel (same arithmetic, same order: bit-identical results)
+  const int variant = a.smallc ? 1 : ((d->flags & CRDR_CONV_BF16X3) ? 2 : ((a.fast_epi && a.nsplit == 1) ? 3 : 0));
+  auto kern = variant == 1 ? t.kern_smallc : (variant == 2 ? t.kern_bf3 : (variant == 3 ? t.kern_fast : t.kern));
+  static std::atomic<bool> attr_done[4][64];
   if (!attr_done[variant][pl.cfg].load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[variant][pl.cfg].store(true, std::memory_order_release);

@@ -36,6 +36,8 @@ struct IgemmArgs {
   int nphase, nsplit;
   int kchunks;
   int ws_ld;  // columns of a partial slab row (= gridDim.y * BN)
+  int hw_sh, gw_sh;  // log2(GH * GW), log2(GW) when both are powers of two (every layer of the model but the 15 / 31 / 63-pixel ones), else -1:
+                     // the tiled kernel then splits a GEMM row into (image, grid row, grid column) with shifts instead of integer divisions
   int vec_epi;  // 1: y / res / gx / gt / sig rows are 16-byte aligned -> vector epilogue
   int m_inner;   // 1: consecutive workgroups walk the M tiles of one (N tile, phase/split) -- weight-heavy shapes (see build_plan)
   int fast_epi;  // 1: vec_epi, Cout % 4 == 0, unsplit, no gate / pre-add / accumulate: straight-line buffer-op epilogue

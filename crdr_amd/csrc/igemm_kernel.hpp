@@ -57,6 +57,26 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, 
   *dst = v;
 }
 
+// GEMM row m -> (image n, grid row a, grid column b).  gfx950 has no integer divide: a division by a runtime value is ~25 scalar or ~20
+// vector instructions behind a v_rcp_f32, and a tile used to run 8 of them per thread in front of its first request plus two per 16-byte
+// output group in the epilogue of a phased (stride-2 transposed) launch -- on the discriminator's k3 s2 input gradients, whose phases have K
+// loops of 2 .. 8 K-tiles, that was most of the tile's time (PMC: waves 26 % "active" at 36 % MFMA busy).  Power-of-two grids take shifts
+// (the branch is workgroup-uniform).
+__device__ __forceinline__ void split_row(const IgemmArgs& p, int m, int& n, int& a, int& b) {
+  if (p.hw_sh >= 0) {
+    n = m >> p.hw_sh;
+    const int rem = m & ((1 << p.hw_sh) - 1);
+    a = rem >> p.gw_sh;
+    b = rem & ((1 << p.gw_sh) - 1);
+  } else {
+    const int hw = p.GH * p.GW;
+    n = m / hw;
+    const int rem = m - n * hw;
+    a = rem / p.GW;
+    b = rem - a * p.GW;
+  }
+}
+
 // Staging is LDS-DMA: `buffer_load_dwordx4 ... lds` moves 16 bytes per lane straight from global memory into LDS
 // (1 KiB = 8 tile rows per wave instruction, lane-linear destination), so the K loop carries no staging registers,
 // no ds_write pass and no zero-fill selects: rows / channel chunks / taps that fall outside the tensor get a byte
@@ -67,7 +87,12 @@ __device__ __forceinline__ void epilogue_store(const IgemmArgs& p, size_t opix, 
 // K-loop stages of a tile configuration (host and kernel agree through this): see the kernel.
 // BF3: the products run as split-bf16 triples on the bf16 matrix path (common.hpp, split_bf16x8): same staging, same K order,
 // same epilogues -- only the fragment-to-MFMA step differs.
-template <int WM, int WN, int MB, int NB, bool SMALLC, bool BF3 = false>
+// FAST: the launch is unsplit and takes the straight-line epilogue (p.fast_epi, p.nsplit == 1 -- the host checks): the split-K hand-off and
+// the general epilogue are not compiled in.  The full kernel is ~16 k instructions (~125 KB) beside a 64 KB instruction cache shared by two
+// CUs; a tile walks its prologue and epilogue once, so every tile re-fetched most of what it executed outside the K loop -- a constant
+// ~6.8 us of CU time per tile whatever its K (C 64->64 k3 s2: 22.9 us per tile for 18 K-tiles of 0.9 us; its transposed twin with four
+// times the tiles: the same 6.7 us per tile), i.e. most of the time of every launch whose tiles have short K loops.
+template <int WM, int WN, int MB, int NB, bool SMALLC, bool BF3 = false, bool FAST = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
   constexpr int BM = 32 * WM * MB, BN = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;  // 16-byte pieces per thread per K-tile
@@ -105,18 +130,20 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   // problem of a grouped launch (workgroup-uniform): its pointers replace the ones in the argument block
   IgemmArgs p = p_;
-  const int zper = p.nphase * p.nsplit;
+  const int nsplit = FAST ? 1 : p.nsplit;
+  const int zper = p.nphase * nsplit;
   const int gidx = tile_z / zper;
   tile_z -= gidx * zper;
   if (p.ngroup > 1) {
     p.x = grp.x[gidx]; p.w = grp.w[gidx]; p.y = grp.y[gidx];
     p.bias = grp.bias[gidx]; p.pre = grp.pre[gidx]; p.mask = grp.mask[gidx]; p.res = grp.res[gidx]; p.cs = grp.cs[gidx];
   }
-  const int phase = tile_z / p.nsplit, split = tile_z % p.nsplit;
+  const int phase = nsplit == 1 ? tile_z : tile_z / nsplit, split = nsplit == 1 ? 0 : tile_z % nsplit;
   const int tb = tp.tap_begin[phase], te = tp.tap_begin[phase + 1];
   const int ntap = te - tb;
   const int KT = SMALLC ? p.kchunks : ntap * p.kchunks;
-  const int it0 = (int)((long long)KT * split / p.nsplit), it1 = (int)((long long)KT * (split + 1) / p.nsplit);
+  // (KT <= 25 taps x 133 chunks, split < 64: 32-bit products; a 64-bit division is ~150 instructions here)
+  const int it0 = nsplit == 1 ? 0 : KT * split / nsplit, it1 = nsplit == 1 ? KT : KT * (split + 1) / nsplit;
   const int poh = tp.poh[phase], pow_ = tp.pow[phase];
   const int H = p.H, W = p.W, ldx = p.ldx, Cin = p.Cin, kchunks = p.kchunks;
 
@@ -132,8 +159,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   // have to span one tile (+ halo) and the tensor itself may be of any size.
   long long base_pix;
   {
-    const int hw0 = p.GH * p.GW;
-    const int nn = m0 / hw0, rem0 = m0 - nn * hw0, a0 = rem0 / p.GW, b0 = rem0 - a0 * p.GW;
+    int nn, a0, b0;
+    split_row(p, m0, nn, a0, b0);
     base_pix = (long long)(nn * H + a0 * p.si) * W + b0 * p.si + mintap;
     base_pix = base_pix < 0 ? 0 : base_pix;
   }
@@ -151,8 +178,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
 #pragma unroll
   for (int j = 0; j < AV; ++j) {
     const int m = m0 + srow + j * RPP;
-    const int hw = p.GH * p.GW;
-    const int n = m / hw, rem = m - n * hw, a = rem / p.GW, b = rem - a * p.GW;
+    int n, a, b;
+    split_row(p, m, n, a, b);
     const bool ok = (m < p.M) && (a * p.so + poh < p.OH) && (b * p.so + pow_ < p.OW);
     a_ih[j] = ok ? a * p.si : -(1 << 24);  // a dead row fails every bounds test below
     a_iw[j] = ok ? b * p.si : 0;
@@ -319,7 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   };
   if (it0 < it1) fetch(0);
   // (behind the first DMA so that their latencies overlap; the barrier below publishes both)
-  if (p.fast_epi) {
+  if (FAST || p.fast_epi) {
     const int f0 = p.flags;
     for (int c = tid; c < BN; c += NT) {
       const bool live = n0 + c < p.Cout;
@@ -348,7 +375,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   constexpr int CLD = 32 * G;                 // floats per staged row
   float* sC = smem + wave * (32 * CLD);       // per-wave [32][CLD]
   const int f = p.flags;
-  const int hw = p.GH * p.GW;
   const bool direct = (p.nphase == 1) && (p.so == 1);  // output pixel index == GEMM row
   const bool vec = p.vec_epi != 0;
 
@@ -358,7 +384,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   // write-back needed), every storing wave drains vmcnt, the workgroup barrier, then ONE lane takes the ticket with an
   // agent-scope atomic; the workgroup whose ticket is nsplit - 1 acquires (buffer_inv sc1) and reads all slabs with sc1 loads
   // in split order.  Placement independent, no spinning: a workgroup either leaves or reduces.
-  const bool splitk = p.nsplit > 1;
+  const bool splitk = !FAST && p.nsplit > 1;
   const unsigned slab_bytes = splitk ? (unsigned)((size_t)p.M * p.ws_ld * 4u) : 0u;
   __amdgpu_buffer_rsrc_t rws = rw;
   if (splitk)
@@ -444,11 +470,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
   // groups get an out-of-range offset, loads return 0 and stores are dropped -- relative to this tile's first output pixel;
   // bias / vec2 / scale / shift come from sV.  The code is straight-line: no wait on a store anywhere, one wait per batch of
   // four row groups on the res / mask operands.  Arithmetic and order are those of the general path below.
-  if (p.fast_epi) {
+  if (FAST || p.fast_epi) {
     const bool has_res = (f & CRDR_EPI_RES) != 0, has_mask = (f & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) != 0;
     long long opix0 = m0;
     if (!direct) {
-      const int n = m0 / hw, rem = m0 - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
+      int n, ga, gb;
+      split_row(p, m0, n, ga, gb);
       opix0 = ((long long)n * p.OH + ga * p.so + poh) * p.OW + gb * p.so + pow_;
     }
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + opix0 * p.ldy, 0, 0x7fffffff, 0x00020000);
@@ -485,7 +512,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
           unsigned rel = (unsigned)(m - m0);
           if (!direct) {
             const int mm = live_row ? m : m0;
-            const int n = mm / hw, rem = mm - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
+            int n, ga, gb;
+            split_row(p, mm, n, ga, gb);
             const int oh = ga * p.so + poh, ow = gb * p.so + pow_;
             live_row = live_row && (oh < p.OH) && (ow < p.OW);
             rel = (unsigned)((((long long)n * p.OH + oh) * p.OW + ow) - opix0);
@@ -624,6 +652,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
     }
     return;
   }
+  if constexpr (!FAST) {
   // one pass = GC column blocks [JG, JG+GC) of accumulator row-block I (all compile-time so acc stays in registers)
   auto pass = [&](auto I_, auto JG_, auto GC_) __attribute__((always_inline)) {
     constexpr int I = decltype(I_)::value, JG = decltype(JG_)::value, GC = decltype(GC_)::value;
@@ -650,7 +679,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
         size_t opix = (size_t)m;
         if (!direct) {
           const int mm = live_row ? m : 0;
-          const int n = mm / hw, rem = mm - n * hw, ga = rem / p.GW, gb = rem - ga * p.GW;
+          int n, ga, gb;
+          split_row(p, mm, n, ga, gb);
           const int oh = ga * p.so + poh, ow = gb * p.so + pow_;
           live_row = live_row && (oh < p.OH) && (ow < p.OW);
           opix = ((size_t)n * p.OH + oh) * p.OW + ow;
@@ -764,6 +794,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_,
       if (n0 + c < p.Cout) dst[(size_t)which * p.cs_ld + n0 + c] = v;
     }
   }
+  }   // !FAST
 }
 
 }  // namespace crdr
