@@ -69,6 +69,62 @@ __global__ __launch_bounds__(256) void ebwd_kernel(const EbwdArgs p) {
   }
 }
 
+// Narrow tensors (C <= 4: the RGB ends of the generator and the discriminator), no gate: one thread per ROW.  The generic kernel's 64
+// channel lanes leave 61 of 64 idle there (258 us for the 16 x 3 x 256 x 256 image gradient of the step, 0.05 TB/s).  Same per-element
+// arithmetic; the rows of a block are summed per thread (stride 256) and then over the threads in a fixed tree.
+__global__ __launch_bounds__(256) void ebwd_kernel_narrow(const EbwdArgs p) {
+  __shared__ float red[16][256];   // [4 sums x 4 channels][thread]
+  const int f = p.d.flags, C = p.d.C, tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+  const int64_t r1 = r0 + p.rows_per_block < p.d.M ? r0 + p.rows_per_block : p.d.M;
+  float s[4][4];
+  float sc[4], sh[4], v2[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bool live = c < C;
+    sc[c] = (live && (f & CRDR_EPI_AFFINE)) ? p.io.scale[c] : 1.f;
+    sh[c] = (live && (f & CRDR_EPI_AFFINE)) ? p.io.shift[c] : 0.f;
+    v2[c] = (live && (f & CRDR_EPI_VEC2)) ? p.io.vec2[c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k][c] = 0.f;
+  }
+  const bool need_out = f & (CRDR_EPI_AFFINE | CRDR_EPI_RELU | CRDR_EPI_LRELU);
+  for (int64_t m = r0 + tid; m < r1; m += 256) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c >= C) continue;
+      float g = p.io.dout[m * p.d.lddout + c];
+      float o = need_out ? p.io.out[m * p.d.ldout + c] : 0.f;
+      if (f & CRDR_EPI_AFFINE) {
+        const float u = (o - sh[c]) / sc[c];
+        s[2][c] += g * u;
+        s[3][c] += g;
+        g *= sc[c];
+        o = u;
+        if (f & CRDR_EPI_RES) p.io.gres[m * p.d.ldgres + c] = g;
+      }
+      if (f & CRDR_EPI_VEC2) s[1][c] += g;
+      if (f & CRDR_EPI_RELU) g = (o - v2[c]) > 0.f ? g : 0.f;
+      if (f & CRDR_EPI_LRELU) g = o > 0.f ? g : 0.2f * g;
+      if (p.io.dz) p.io.dz[m * p.d.lddz + c] = g;
+      s[0][c] += g;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[k * 4 + c][tid] = s[k][c];
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (tid < w) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[e][tid] += red[e][tid + w];
+    }
+    __syncthreads();
+  }
+  if (tid < 16 && (tid & 3) < C) p.partial[((size_t)blockIdx.x * 4 + (tid >> 2)) * C + (tid & 3)] = red[tid][0];
+}
+
 // Vector path (C % 4 == 0, all strides % 4 == 0): 16 B per lane.  block = 16 channel-quads (64 channels) x 16 rows;
 // grid (strips, ceil(C/64)).  Each thread keeps 4 sums x 4 channels; rows are reduced through LDS in fixed order.
 __global__ __launch_bounds__(256) void ebwd_kernel_v4(const EbwdArgs p) {
@@ -501,13 +557,14 @@ __global__ __launch_bounds__(256) void adam_dyn_kernel(float* p, const float* g,
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float* x, float* y, int N, int H, int W, int C,
                                                              int OH, int OW) {
-  const int64_t total = (int64_t)N * OH * OW * C;
-  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
-    const int c = (int)(e % C);
-    int64_t r = e / C;
-    const int ow = (int)(r % OW); r /= OW;
-    const int oh = (int)(r % OH);
-    const int n = (int)(r / OH);
+  // (32-bit element index, checked by the host: a 64-bit division is ~150 instructions on this ISA and there were three per element)
+  const unsigned total = (unsigned)N * OH * OW * C;
+  for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+    unsigned r = e / (unsigned)C;
+    const int c = (int)(e - r * C);
+    unsigned q = r / (unsigned)OW;
+    const int ow = (int)(r - q * OW);
+    const int n = (int)(q / (unsigned)OH), oh = (int)(q - (unsigned)n * OH);
     float best = -INFINITY;
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) {
@@ -520,13 +577,13 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float* x, flo
 // gather form: dx[pixel] = sum over the (<=4) windows containing it whose argmax (first max in scan order) is it
 __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* x, const float* dy, float* dx, int N, int H,
                                                              int W, int C, int OH, int OW) {
-  const int64_t total = (int64_t)N * H * W * C;
-  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
-    const int c = (int)(e % C);
-    int64_t r = e / C;
-    const int iw = (int)(r % W); r /= W;
-    const int ih = (int)(r % H);
-    const int n = (int)(r / H);
+  const unsigned total = (unsigned)N * H * W * C;
+  for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+    unsigned r = e / (unsigned)C;
+    const int c = (int)(e - r * C);
+    unsigned q = r / (unsigned)W;
+    const int iw = (int)(r - q * W);
+    const int n = (int)(q / (unsigned)H), ih = (int)(q - (unsigned)n * H);
     float acc = 0.f;
     for (int oh = (ih >= 2 ? (ih - 1) / 2 : 0); oh <= ih / 2 && oh < OH; ++oh)
       for (int ow = (iw >= 2 ? (iw - 1) / 2 : 0); ow <= iw / 2 && ow < OW; ++ow) {
@@ -754,33 +811,61 @@ __global__ __launch_bounds__(1024) void linear_group_bwd_x_kernel(int M, int I, 
     }
 }
 
-// gather half of the GEMM + scatter formulation of RGB-output transposed ops (see crdr_col2im_rgb)
+// gather half of the GEMM + scatter formulation of RGB-output transposed ops (see crdr_col2im_rgb).  SF = 2: stride 2 (the decoder's last layer):
+// the taps that reach an output pixel are those of its parity -- (kh / 2 + 1) x (kw / 2 + 1) candidates instead of kh x kw, shifts instead of
+// the `% S`, `/ S` of the general form; the pixel index is decoded in 32 bits (the host checks the extent).  The general form spent its time
+// in integer divisions (three 64-bit ones per pixel, four 32-bit ones per tap: 97 us for 16 x 256 x 256 pixels, 1.1 TB/s).
+template <int SF>   // SF = 1 / 2: stride known at compile time (every tap / the taps of the pixel's parity, no divisions); 0: any stride
 __global__ __launch_bounds__(256) void col2im_rgb_kernel(const float* cols, int ldc, int N, int H, int W, int kh, int kw, int S,
                                                          int P, const float* bias, float* out, int ldo, int OH, int OW, int C) {
-  const long long total = (long long)N * OH * OW;
-  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
-    const int ow = (int)(e % OW);
-    const long long r2 = e / OW;
-    const int oh = (int)(r2 % OH), n = (int)(r2 / OH);
+  const unsigned total = (unsigned)N * OH * OW;
+  const f32x4 b4 = {bias ? bias[0] : 0.f, (bias && C > 1) ? bias[1] : 0.f, (bias && C > 2) ? bias[2] : 0.f, (bias && C > 3) ? bias[3] : 0.f};
+  for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+    const unsigned r2 = e / (unsigned)OW;
+    const int ow = (int)(e - r2 * OW);
+    const int n = (int)(r2 / (unsigned)OH), oh = (int)(r2 - (unsigned)n * OH);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < kh; ++r) {
-      const int th = oh + P - r;
-      if (th < 0 || th % S) continue;
-      const int ih = th / S;
-      if (ih >= H) continue;
-      for (int s = 0; s < kw; ++s) {
-        const int tw = ow + P - s;
-        if (tw < 0 || tw % S) continue;
-        const int iw = tw / S;
-        if (iw >= W) continue;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(cols + ((size_t)(n * H + ih) * W + iw) * ldc + 4 * (r * kw + s));
-        acc += v;
+    const float* base = cols + (size_t)n * H * W * ldc;
+    if constexpr (SF == 1) {
+      for (int r = 0; r < kh; ++r) {
+        const int ih = oh + P - r;
+        if (ih < 0 || ih >= H) continue;
+        for (int s = 0; s < kw; ++s) {
+          const int iw = ow + P - s;
+          if (iw < 0 || iw >= W) continue;
+          acc += *reinterpret_cast<const f32x4*>(base + ((size_t)ih * W + iw) * ldc + 4 * (r * kw + s));
+        }
+      }
+    } else if constexpr (SF == 2) {
+      for (int r = (oh + P) & 1; r < kh; r += 2) {
+        const int ih = (oh + P - r) >> 1;
+        if (oh + P - r < 0 || ih >= H) continue;
+        for (int s = (ow + P) & 1; s < kw; s += 2) {
+          const int iw = (ow + P - s) >> 1;
+          if (ow + P - s < 0 || iw >= W) continue;
+          acc += *reinterpret_cast<const f32x4*>(base + ((size_t)ih * W + iw) * ldc + 4 * (r * kw + s));
+        }
+      }
+    } else {
+      for (int r = 0; r < kh; ++r) {
+        const int th = oh + P - r;
+        if (th < 0 || th % S) continue;
+        const int ih = th / S;
+        if (ih >= H) continue;
+        for (int s = 0; s < kw; ++s) {
+          const int tw = ow + P - s;
+          if (tw < 0 || tw % S) continue;
+          const int iw = tw / S;
+          if (iw >= W) continue;
+          acc += *reinterpret_cast<const f32x4*>(base + ((size_t)ih * W + iw) * ldc + 4 * (r * kw + s));
+        }
       }
     }
+    acc += b4;
     float* o = out + (size_t)e * ldo;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      if (c < C) o[c] = acc[c] + (bias ? bias[c] : 0.f);
+      if (c < C) o[c] = acc[c];
   }
 }
 
@@ -902,6 +987,7 @@ extern "C" int crdr_epilogue_bwd(const crdr_ebwd_desc* d, const crdr_ebwd_io* io
                    al16(io->scale) && al16(io->shift);
   if (d->M > 0) {
     if (vec) hipLaunchKernelGGL(ebwd_kernel_v4, dim3(nb, cdiv(d->C, 64)), dim3(256), 0, as_stream(s), a);
+    else if (d->C <= 4 && !(d->flags & CRDR_EPI_GATE)) hipLaunchKernelGGL(ebwd_kernel_narrow, dim3(nb), dim3(256), 0, as_stream(s), a);
     else hipLaunchKernelGGL(ebwd_kernel, dim3(nb), dim3(256), 0, as_stream(s), a);
     CRDR_CHECK_LAUNCH("ebwd_kernel");
   }
@@ -918,8 +1004,11 @@ extern "C" int crdr_col2im_rgb(const float* cols, int ldc, int N, int H, int W, 
   CRDR_REQUIRE((reinterpret_cast<uintptr_t>(cols) & 15) == 0, "col2im_rgb: cols must be 16-byte aligned");
   const long long total = (long long)N * OH * OW;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(col2im_rgb_kernel, dim3((unsigned)std::min<long long>(cdiv64(total, 256), 65535)), dim3(256), 0, as_stream(s),
-                     cols, ldc, N, H, W, kh, kw, stride, pad, bias, out, ldo, OH, OW, C);
+  CRDR_REQUIRE(total < (1ll << 31), "col2im_rgb: %lld output pixels (32-bit pixel index)", total);
+  const dim3 grid((unsigned)std::min<long long>(cdiv64(total, 256), 65535));
+  if (stride == 2) hipLaunchKernelGGL(col2im_rgb_kernel<2>, grid, dim3(256), 0, as_stream(s), cols, ldc, N, H, W, kh, kw, stride, pad, bias, out, ldo, OH, OW, C);
+  else if (stride == 1) hipLaunchKernelGGL(col2im_rgb_kernel<1>, grid, dim3(256), 0, as_stream(s), cols, ldc, N, H, W, kh, kw, stride, pad, bias, out, ldo, OH, OW, C);
+  else hipLaunchKernelGGL(col2im_rgb_kernel<0>, grid, dim3(256), 0, as_stream(s), cols, ldc, N, H, W, kh, kw, stride, pad, bias, out, ldo, OH, OW, C);
   CRDR_CHECK_LAUNCH("col2im_rgb_kernel");
   return 0;
 }
@@ -1242,6 +1331,7 @@ extern "C" int crdr_adam_step_dyn(float* p, const float* g, float* m, float* v, 
 
 extern "C" int crdr_maxpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, crdr_stream_t s) {
   CRDR_REQUIRE(x && y && H >= 3 && W >= 3, "maxpool: bad arguments");
+  CRDR_REQUIRE((long long)N * H * W * C < (1ll << 31), "maxpool: %lld elements (32-bit element index)", (long long)N * H * W * C);
   const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
   hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(grid_for((int64_t)N * OH * OW * C)), dim3(256), 0, as_stream(s), x, y, N,
                      H, W, C, OH, OW);
@@ -1251,6 +1341,7 @@ extern "C" int crdr_maxpool3s2_fwd(const float* x, float* y, int N, int H, int W
 extern "C" int crdr_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
                                    crdr_stream_t s) {
   CRDR_REQUIRE(x && dy && dx && H >= 3 && W >= 3, "maxpool_bwd: bad arguments");
+  CRDR_REQUIRE((long long)N * H * W * C < (1ll << 31), "maxpool_bwd: %lld elements (32-bit element index)", (long long)N * H * W * C);
   const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
   hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(256), 0, as_stream(s), x, dy, dx,
                      N, H, W, C, OH, OW);

@@ -160,6 +160,45 @@ def test_conv_epilogues_and_slices():
     _close(dst[:, 64:160], 2 * zs, "accumulate")
 
 
+def test_epilogue_bwd_narrow_tensors():
+    """C <= 4 (the RGB ends): the one-thread-per-row form of the epilogue backward (ebwd_kernel_narrow) against autograd in float64, odd sizes,
+    several row blocks"""
+    from crdr_amd.hip import ops, lib as L
+    dev = _dev()
+    for c, h, w in ((3, 37, 41), (1, 16, 16), (4, 9, 130)):
+        n = 2
+        chl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+        z = _rand(n, c, h, w, seed=1).double().requires_grad_(True)
+        v2 = _rand(c, seed=2).double().requires_grad_(True)
+        sc = (_rand(c, seed=3) + 1.5).double().requires_grad_(True)
+        sh = _rand(c, seed=4).double().requires_grad_(True)
+        res = _rand(n, c, h, w, seed=5).double().requires_grad_(True)
+        dout = _rand(n, c, h, w, seed=6)
+        view = lambda t: t.view(1, -1, 1, 1)
+        out = F.leaky_relu(z, 0.2)
+        out.backward(dout.double())
+        dz, _, _, cs = ops.epilogue_bwd(chl(dout), chl(out.detach().float()), L.EPI_BIAS | L.EPI_LRELU)
+        _close(dz, z.grad, f"narrow ebwd lrelu dz c={c}")
+        _close(cs[0], z.grad.sum((0, 2, 3)), f"narrow ebwd dbias c={c}")
+        z.grad = None
+        out = F.relu(z) + view(v2)
+        out.backward(dout.double())
+        dz, _, _, cs = ops.epilogue_bwd(chl(dout), chl(out.detach().float()), L.EPI_BIAS | L.EPI_RELU | L.EPI_VEC2, vec2=v2.detach().float().to(dev))
+        _close(dz, z.grad, f"narrow ebwd relu dz c={c}")
+        _close(cs[0], z.grad.sum((0, 2, 3)), f"narrow ebwd relu dbias c={c}")
+        _close(cs[1], v2.grad, f"narrow ebwd dvec2 c={c}")
+        for t in (z, v2, sc, sh, res):
+            t.grad = None
+        out = (z + view(v2) + res) * view(sc) + view(sh)
+        out.backward(dout.double())
+        dz, gres, _, cs = ops.epilogue_bwd(chl(dout), chl(out.detach().float()), L.EPI_BIAS | L.EPI_VEC2 | L.EPI_RES | L.EPI_AFFINE,
+                                           vec2=v2.detach().float().to(dev), scale=sc.detach().float().to(dev), shift=sh.detach().float().to(dev))
+        _close(dz, z.grad, f"narrow ebwd affine dz c={c}")
+        _close(gres, res.grad, f"narrow ebwd gres c={c}")
+        _close(cs[2], sc.grad, f"narrow ebwd dscale c={c}", rtol=1e-3)
+        _close(cs[3], sh.grad, f"narrow ebwd dshift c={c}")
+
+
 def test_epilogue_bwd():
     from crdr_amd.hip import ops, lib as L
     dev = _dev()
