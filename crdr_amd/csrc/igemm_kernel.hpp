@@ -92,8 +92,12 @@ __device__ __forceinline__ void split_row(const IgemmArgs& p, int m, int& n, int
 // CUs; a tile walks its prologue and epilogue once, so every tile re-fetched most of what it executed outside the K loop -- a constant
 // ~6.8 us of CU time per tile whatever its K (C 64->64 k3 s2: 22.9 us per tile for 18 K-tiles of 0.9 us; its transposed twin with four
 // times the tiles: the same 6.7 us per tile), i.e. most of the time of every launch whose tiles have short K loops.
+// Register budget of the 8-wave configurations with two accumulator blocks per wave (128 x 128 and 256 x 64 tiles): two workgroups per CU =
+// four waves per SIMD = 128 registers.  They sat at 121; the row-split branches took the allocator to 133-135 and the second workgroup
+// away (the bf16x3 step, which lives on these tiles, went from 241 to 219 img/s) -- the bound is stated instead of hoped for.
+constexpr int igemm_min_waves(int waves, int blocks) { return (waves == 8 && blocks <= 2) ? 4 : 1; }
 template <int WM, int WN, int MB, int NB, bool SMALLC, bool BF3 = false, bool FAST = false>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
+__global__ __launch_bounds__(64 * WM * WN, igemm_min_waves(WM * WN, MB * NB)) void igemm_kernel(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
   constexpr int BM = 32 * WM * MB, BN = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;  // 16-byte pieces per thread per K-tile
   static_assert(AV * NT == BM * 8 && BV * NT == BN * 8, "tile/threads mismatch");

@@ -15,7 +15,7 @@ memory-side fillers, 'nomfma:' = the fillers alone):
     pk<N>x<G>       N v_pk_fma_f32 in G clusters                     ar<N>x<G>   N v_accvgpr_read_b32 in G clusters
     ldsf / ldsf128 / ldsf32 / ldsr   36 ds_read_b64 / 18 ds_read_b128 / 72 ds_read_b32 / 18 ds_read2st64_b32
     dma<N>          N LDS-DMA pieces (1 KiB each) spread evenly       dmag<N>   back to back
-    st<N>           N buffer_store_dwordx4 (scattered 64-byte segments) spread evenly
+    st<N>           N buffer_store_dwordx4 (scattered 64-byte segments) spread evenly; sth / stq / stc: 128-byte / 256-byte segments / contiguous
 """
 NSLOT = 72
 
@@ -72,10 +72,11 @@ class Body:
         self.slots[s].append("buffer_load_dwordx4 %3, %4, s40 offen lds")
         self.nd += 1
 
-    def store(self, s):
-        # 16 B per lane, the 16 lanes of a group 2 KiB apart, the four groups adjacent: 16 segments of 64 B (the epilogue's store pattern)
+    def store(self, s, kind=""):
+        # 16 B per lane, the 16 lanes of a group 2 KiB apart, the four groups adjacent: 16 segments of 64 B (the epilogue's store pattern);
+        # kind h / q / c: 8 segments of 128 B, 4 of 256 B, 1 KiB contiguous (what a lane permutation in front of the stores could buy)
         self.slots[s].append(f"s_add_u32 s40, %6, {(self.nd % 32) * 65536}")
-        self.slots[s].append("buffer_store_dwordx4 v[14:17], %12, %4, s40 offen")
+        self.slots[s].append("buffer_store_dwordx4 v[14:17], %s, %%4, s40 offen" % {"": "%12", "h": "%13", "q": "%14", "c": "%15"}[kind])
         self.nd += 1
 
     def text(self):
@@ -136,9 +137,10 @@ def pattern(name):
             for q in range(n):
                 b.dma(min(ns - 1, (q * ns) // n + 2))
         elif p.startswith("st"):
-            n = int(p[2:])
+            kind = p[2] if p[2] in "hqc" else ""
+            n = int(p[3:] if kind else p[2:])
             for q in range(n):
-                b.store((q * ns) // n)
+                b.store((q * ns) // n, kind)
         else:
             raise SystemExit("unknown part " + p)
     return b, w2
@@ -154,7 +156,7 @@ PATTERNS = [
     # the position-split form: half the transform, 16-byte filter reads
     "cv92x12+ldsf128+ldsr+dma13", "cv92x6+ldsf128+ldsr+dma13", "cv72x6+ldsf128+ldsr+dma13", "valu92+ldsf128+ldsr+dma13",
     # packed fp32, accumulator reads, stores
-    "pk72x72", "pk72x9", "ar144x9", "ar288x1", "st32", "cv144x9+st32", "nomfma:st32", "nomfma:cv144x1", "nomfma:ar288x1", "nomfma:ldsf+ldsr",
+    "pk72x72", "pk72x9", "ar144x9", "ar288x1", "st32", "sth32", "stq32", "stc32", "nomfma:sth32", "nomfma:stc32", "cv144x9+st32", "nomfma:st32", "nomfma:cv144x1", "nomfma:ar288x1", "nomfma:ldsf+ldsr",
     "nomfma:dma13", "nomfma:dma52",
     # two waves per SIMD, 36 MFMA slots each: does one wave's VALU hide under the other's MFMAs?
     # the current one-wave loop's mix and the two-wave form of it (per wave: half the positions = 36 MFMAs, half the transform)
@@ -192,6 +194,9 @@ __global__ __launch_bounds__({nt}) void probe{idx}(float* out, unsigned long lon
   unsigned ldsoff = (unsigned)(lane * 16 + (wave & 3) * 1024);
   unsigned goff = (unsigned)(lane * 16 + (wave & 3) * 1024 + (blockIdx.x & 31) * 4096);
   unsigned soff = (unsigned)((lane >> 4) * 16 + (lane & 15) * 2048 + wave * 64 + (blockIdx.x & 31) * (1 << 21));
+  unsigned soffh = (unsigned)((lane & 7) * 16 + (lane >> 3) * 2048 + wave * 128 + (blockIdx.x & 31) * (1 << 21));
+  unsigned soffq = (unsigned)((lane & 15) * 16 + (lane >> 4) * 2048 + wave * 256 + (blockIdx.x & 31) * (1 << 21));
+  unsigned soffc = (unsigned)(lane * 16 + wave * 1024 + (blockIdx.x & 31) * (1 << 21));
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gsrc), 0, 1u << 22, 0x00020000);
   __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(gdst, 0, 1u << 27, 0x00020000);
   (void)rd; (void)rs;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__({nt}) void probe{idx}(float* out, unsigned long lon
   asm volatile("v_mov_b32 v1, %8\\n v_mov_b32 v2, %9\\n v_mov_b32 v3, %10\\n v_mov_b32 v4, %11\\n"
 {asm}
       : "=&s"(t0), "=&s"(t1)
-      : "v"(ldsoff), "v"(goff), "s"({'rd' if has_store else 'rs'}), "s"(ldsbase), "s"(sbase), "s"(iters), "v"(a), "v"(b), "v"(c), "v"(d), "v"(soff)
+      : "v"(ldsoff), "v"(goff), "s"({'rd' if has_store else 'rs'}), "s"(ldsbase), "s"(sbase), "s"(iters), "v"(a), "v"(b), "v"(c), "v"(d), "v"(soff), "v"(soffh), "v"(soffq), "v"(soffc)
       : "v1", "v2", "v3", "v4", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", {clobbers(w2)});
   if (lane == 0) cyc[blockIdx.x * {nt // 64} + wave] = t1 - t0;
   if (out) out[threadIdx.x] = a;
