@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * WM * WN, igemm_min_waves(WM * WN, MB * NB)) vo
   float* sB = smem + ST * BM * 32;                         // [ST][BN*32]
   int* sTap = reinterpret_cast<int*>(smem + ST * (BM + BN) * 32);  // [<=132] packed (dh, dw, widx) of this phase
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the DMA destinations and fragment bases derived from it then cost no vector instructions)
   const int wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs (each with its own L2) in linear
   // block-id order; remap so that every XCD walks a CONTIGUOUS range of tiles ordered (M tile, phase/split, N tile):

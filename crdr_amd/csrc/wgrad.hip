@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p_,
   float* sP = smem;               // [2][32][BI]
   float* sQ = smem + 2 * 32 * BI; // [2][32][BJ]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the DMA destinations and fragment bases derived from it then cost no vector instructions)
   const int wm = wave / WN, wn = wave % WN;
   // XCD-aware order (see igemm.hip): every XCD walks a contiguous range of (pixel split, tap, channel tile) so that the
   // workgroups re-reading one pixel range -- all taps and channel tiles of a split -- share an L2.
