@@ -17,5 +17,5 @@ cut -c1-400 gpurun_out/bench_tuned.log
 cp crdr_amd/hip/tune_gfx950.json /tmp/tune_shipped.json && cp gpurun_out/tune_r5.json crdr_amd/hip/tune_gfx950.json
 timeout 1500 python -m pytest -x -q -m gpu tests/test_gpu_step.py -k "256_tuned or every_tuned" tests/test_gpu_tuned_plans.py > gpurun_out/tune_accept.log 2>&1; echo "rc=$?" >> gpurun_out/tune_accept.log
 cp /tmp/tune_shipped.json crdr_amd/hip/tune_gfx950.json; tail -4 gpurun_out/tune_accept.log
-CRDR_WINO4=0 timeout 1800 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --tune-db none --retune-k3 crdr_amd/hip/tune_gfx950.json --save-tune-db gpurun_out/tune_r5_no_f4x4.json > gpurun_out/bench_tune_no_f4x4.log 2>> gpurun_out/bench_tune.err
-cut -c1-300 gpurun_out/bench_tune_no_f4x4.log
+[ -n "$SKIP_NO_F4X4" ] || CRDR_WINO4=0 timeout 1800 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --tune-db none --retune-k3 crdr_amd/hip/tune_gfx950.json --save-tune-db gpurun_out/tune_r5_no_f4x4.json > gpurun_out/bench_tune_no_f4x4.log 2>> gpurun_out/bench_tune.err
+[ -n "$SKIP_NO_F4X4" ] || cut -c1-300 gpurun_out/bench_tune_no_f4x4.log
