@@ -281,8 +281,10 @@ def _stage3_step(bs: int = 2, size: int = 64, upstream_tol: float = 0.0):
             if only is not None and not only(n):
                 continue
             r = ref_sd[n].grad
-            if r is None or r.abs().max() == 0:
-                # analytically zero (e.g. the D head bias cancels in D(x) - D(x̂)): allow summation-order noise
+            if r is None or r.abs().max() <= 1e-7:
+                # analytically zero (e.g. the D head bias cancels in D(x) - D(x̂)): what either side holds is the rounding residue of its own
+                # summation order -- exactly 0 or a few 2^-25 .. 2^-29 (a re-tuned plan set turned the product's -3.0e-8 into -1.9e-9 against the
+                # oracle's -3.0e-8: "relative error 0.94" of nothing) -- so both are held to the same absolute floor
                 assert g is None or g.abs().max().item() <= 1e-7, f"{what}: unexpected gradient for {n}"
                 continue
             e = rel(g, r)
@@ -290,7 +292,7 @@ def _stage3_step(bs: int = 2, size: int = 64, upstream_tol: float = 0.0):
             PM.record(grp, n, e)
             t = PM.tolerance(grp, upstream_tol if (upstream_tol and _upstream(n)) else tol)
             if e > t:
-                bad.append((n, e, t))
+                bad.append((n, e, t) + ((g.flatten().tolist(), r.flatten().tolist()) if g.numel() <= 4 else ()))
         assert not bad, f"{what}: {bad[:8]} ({len(bad)})"
     cmp(captured["g"], g_ref, "G grads", only=lambda n: not n.endswith(".quantiles"))
     cmp(captured["d"], d_ref, "D grads")
