@@ -5,7 +5,9 @@
 # gradients upstream of the quantiser amplify the kernels' 1e-6 rounding differences through ReLU-mask flips, tests/test_conditioning.py:
 # which masks flip depends on the plan set, and of two databases tuned on the same kernels one measured 3e-3 there and the other 9.4e-3
 # against the 8e-3 cap -- a candidate that fails is NOT shipped, the previous database stays).  Only a candidate with
-# gpurun_out/tune_accept.log ending in `rc=0` is copied to crdr_amd/hip/tune_gfx950.json.  A second database without the
+# gpurun_out/tune_accept.log ending in `rc=0` is copied to crdr_amd/hip/tune_gfx950.json; a rejected one can still lend its direct-kernel
+# re-timings (tools/merge_tune_db.py SHIPPED CANDIDATE OUT keeps the shipped Winograd / non-Winograd choice per layer; accept OUT the same way).
+# A second database without the
 # F(4x4, 3x3) / F(3x3, 4x4) kernels (CRDR_WINO4=0: F(2x2) + direct) for bench.py's `stage3_no_f4x4` line: tools/data/tune_r5_no_f4x4.json.
 set -x
 export TMPDIR=/tmp
