@@ -398,6 +398,12 @@ def main():
         # or touched the GPU; the ranks run as a CHILD process tree (never exec from a GPU-initialised process).
         sys.exit(self_launch(a.gpus, sys.argv[1:]))
 
+    # stdout carries exactly ONE line, the JSON: native libraries write to file descriptor 1 on their own (RCCL prints a version banner through C
+    # stdio at communicator creation, which lands AFTER Python's line when it is flushed at exit) -- descriptor 1 is pointed at stderr for the
+    # duration of the run and the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from crdr_amd.hip import ops
@@ -593,7 +599,8 @@ def main():
     if ws == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.stage, a.size)
     save_tuning()
-    print(json.dumps(line), flush=True)
+    json_out.write(json.dumps(line) + "\n")
+    json_out.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
 
