@@ -479,3 +479,22 @@ def test_filter_cache_bookkeeping():
     del a
     assert not ops._is_persistent_pack(ptr)
 
+
+
+def test_merge_tune_db_keeps_the_winograd_class(tmp_path):
+    """tools/merge_tune_db.py: a candidate's entry is taken when it stays among the direct / streaming ids, kept when it would move a layer to or
+    from a Winograd id (forward ids behind the streaming variants, the two Winograd weight-gradient ids), split bits ignored"""
+    import json
+    import subprocess
+    import sys
+    sig = "v500-c27-s8-w24+1-n3"   # forward Winograd ids 36..38, weight-gradient ids 24, 25
+    shipped = {"signature": sig, "algos": {"('c', 1)": 5, "('c', 2)": 38, "('m', 3)": 7, "('g', 4)": 36 | (1 << 8), "('w', 5)": 3, "('wm', 6)": 25, "('ws', 7)": 9}}
+    cand = {"signature": sig, "algos": {"('c', 1)": 12 | (2 << 8), "('c', 2)": 4, "('m', 3)": 38, "('g', 4)": 36 | (2 << 8), "('w', 5)": 24, "('wm', 6)": 2, "('ws', 7)": 11}}
+    a, b, o = (str(tmp_path / n) for n in ("a.json", "b.json", "o.json"))
+    json.dump(shipped, open(a, "w"))
+    json.dump(cand, open(b, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "merge_tune_db.py"), a, b, o], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    out = json.load(open(o))["algos"]
+    assert out == {"('c', 1)": 12 | (2 << 8), "('c', 2)": 38, "('m', 3)": 7, "('g', 4)": 36 | (1 << 8), "('w', 5)": 3, "('wm', 6)": 25, "('ws', 7)": 11}, out
+    assert "2 entries re-timed, 5 kept" in r.stdout, r.stdout

@@ -297,7 +297,9 @@ def test_bench_reports_comm_overlap_on_a_one_rank_group():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
                         "--profile-steps", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), out_lines   # exactly the JSON line: RCCL's version banner goes to stderr
+    line = json.loads(out_lines[0])
     assert line["rccl_ranks"]["backend"] == "nccl" and line["rccl_ranks"]["allreduce_of_ones"] == 1
     assert line["ms_per_step_median"] and line["value_at_median"]
     names = [b["bucket"] for b in line["comm_overlap"]["buckets"]]
