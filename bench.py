@@ -552,18 +552,20 @@ def main():
             wbase = lib_.crdr_conv2d_num_configs() + 1 + lib_.crdr_conv2d_num_stream_configs()
             wlast = lib_.crdr_conv2d_wgrad_num_configs()
             saved, saved_flag = dict(ops._algo_cache), ops.WINOGRAD
-            ops.WINOGRAD = False
-            for k_, v_ in list(ops._algo_cache.items()):
-                is_w = k_[0] in ("w", "wg", "ws", "wm")
-                if (is_w and (v_ & 0xff) >= wlast) or (not is_w and (v_ & 0xff) >= wbase):
-                    del ops._algo_cache[k_]
-            ops.load_tune_cache(os.path.join(ROOT, "tools", "data", "tune_r3_f.json"), ignore_signature=True)
-            dx = run_stage(a, 3, a.bs, min(a.steps, 20), a.warmup, 0)
-            dx.pop("trainer")
+            try:
+                ops.WINOGRAD = False
+                for k_, v_ in list(ops._algo_cache.items()):
+                    is_w = k_[0] in ("w", "wg", "ws", "wm")
+                    if (is_w and (v_ & 0xff) >= wlast) or (not is_w and (v_ & 0xff) >= wbase):
+                        del ops._algo_cache[k_]
+                ops.load_tune_cache(os.path.join(ROOT, "tools", "data", "tune_r3_f.json"), ignore_signature=True)
+                dx = run_stage(a, 3, a.bs, min(a.steps, 20), a.warmup, 0)
+                dx.pop("trainer")
+            finally:   # (also when the run raises: the process goes on with the headline's plan set, and --save-tune-db writes that one)
+                ops._algo_cache.clear(); ops._algo_cache.update(saved); ops.WINOGRAD = saved_flag
             line["stage3_direct_only"] = {"metric": f"stage-3 training img/s at {a.size}x{a.size}", "value": round(dx["value"], 3), "unit": "img/s",
                                           "ms_per_step": round(dx["ms_per_step"], 2), "steps": min(a.steps, 20), "warmup": a.warmup, "dtype": "fp32",
                                           "config": {"workload": f"config/crdr_stage_3.yaml -b {a.bs}, CRDR_WINOGRAD=0 (no minimal-filtering kernels)"}}
-            ops._algo_cache.clear(); ops._algo_cache.update(saved); ops.WINOGRAD = saved_flag
         except Exception as e:
             line["stage3_direct_only"] = {"error": repr(e)[:300]}
     if ws == 1 and a.stage == 3 and not a.no_secondary:
@@ -577,21 +579,23 @@ def main():
             wg4 = lib_.crdr_conv2d_wgrad_num_configs() + 1
             saved = dict(ops._algo_cache)
             saved_w4 = ops.WINO4
-            ops.WINO4 = False
-            # the plan set tuned WITHOUT those kernels (tools/tune_round.sh, CRDR_WINO4=0: the tuner's choice among F(2x2) and the direct kernels for
-            # every 3x3 / 5x5 shape); whatever it lacks keeps the shipped choice unless that is an F(4x4) id
-            ops._algo_cache.clear()
-            ops.load_tune_cache(os.path.join(ROOT, "tools", "data", "tune_r5_no_f4x4.json"))
-            for k_, v_ in saved.items():
-                is_w = k_[0] in ("w", "wg", "ws", "wm")
-                if not ((is_w and (v_ & 0xff) == wg4) or (not is_w and (v_ & 0xff) == w4)):
-                    ops._algo_cache.setdefault(k_, v_)
-            nx = run_stage(a, 3, a.bs, min(a.steps, 20), a.warmup, 0)
-            nx.pop("trainer")
+            try:
+                ops.WINO4 = False
+                # the plan set tuned WITHOUT those kernels (tools/tune_round.sh, CRDR_WINO4=0: the tuner's choice among F(2x2) and the direct kernels for
+                # every 3x3 / 5x5 shape); whatever it lacks keeps the shipped choice unless that is an F(4x4) id
+                ops._algo_cache.clear()
+                ops.load_tune_cache(os.path.join(ROOT, "tools", "data", "tune_r5_no_f4x4.json"), ignore_signature=True)
+                for k_, v_ in saved.items():
+                    is_w = k_[0] in ("w", "wg", "ws", "wm")
+                    if not ((is_w and (v_ & 0xff) == wg4) or (not is_w and (v_ & 0xff) == w4)):
+                        ops._algo_cache.setdefault(k_, v_)
+                nx = run_stage(a, 3, a.bs, min(a.steps, 20), a.warmup, 0)
+                nx.pop("trainer")
+            finally:
+                ops._algo_cache.clear(); ops._algo_cache.update(saved); ops.WINO4 = saved_w4
             line["stage3_no_f4x4"] = {"metric": f"stage-3 training img/s at {a.size}x{a.size}", "value": round(nx["value"], 3), "unit": "img/s",
                                       "ms_per_step": round(nx["ms_per_step"], 2), "steps": min(a.steps, 20), "warmup": a.warmup, "dtype": "fp32",
                                       "config": {"workload": f"config/crdr_stage_3.yaml -b {a.bs}, F(4x4, 3x3) / F(3x3, 4x4) kernels off (F(2x2) + direct)"}}
-            ops._algo_cache.clear(); ops._algo_cache.update(saved); ops.WINO4 = saved_w4
         except Exception as e:
             line["stage3_no_f4x4"] = {"error": repr(e)[:300]}
     if ops.TUNE_REJECTED:   # candidates the tuner refused because they disagreed with the built-in plan (a silently de-tuned database is visible)

@@ -80,4 +80,45 @@ __device__ __forceinline__ f32x16 mfma_bf16x3(const bf16x8 ah, const bf16x8 al, 
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
+
+// ---- "bf16x6": fp32-equivalent products on the bf16 matrix path.  x = hi + mid + lo EXACTLY (hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid:
+// three 8-bit pieces of the 24-bit significand; both residuals are exact in fp32 and the last one is a bf16 number), and
+// a b = (ah + am + al)(bh + bm + bl) is evaluated as the six products of weight >= 2^-16, small terms first:  am bm, al bh, ah bl, am bh, ah bm,
+// ah bh.  Every bf16 x bf16 product is exact in the fp32 accumulator; dropped are am bl, al bm (<= 2^-24 |a b| each) and al bl (2^-32):
+// per-product relative error <= ~2^-23, the size of one fp32 rounding -- what the exact-fp32 MFMA chain pays per accumulation step anyway.
+// Six v_mfma_f32_32x32x16_bf16 (32 cycles each) per 16 k against eight v_mfma_f32_32x32x2_f32 (64 cycles each): 3/8 of the matrix time.
+// Opt-in (CRDR_CONV_BF16X6 / CRDR_WGRAD_BF16X6); the default path stays the exact fp32 instruction.
+__device__ __forceinline__ void split3_bf16x2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const f32x2 x = {x0, x1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+  const f32x2 h = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+  const f32x2 r = x - h;   // exact: x and bf16(x) share their leading 8 bits
+  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  const f32x2 m = {__builtin_bit_cast(float, mid << 16), __builtin_bit_cast(float, mid & 0xffff0000u)};
+  const f32x2 r2 = r - m;  // exact, and at most 8 significant bits are left: the conversion below does not round
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+__device__ __forceinline__ void split3_bf16x8(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  u32x4_t h, m, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned a, b, c;
+    split3_bf16x2(x[2 * e], x[2 * e + 1], a, b, c);
+    h[e] = a; m[e] = b; l[e] = c;
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  mid = __builtin_bit_cast(bf16x8, m);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+// acc += a b for one 32x32 block over 16 k (small terms first)
+__device__ __forceinline__ f32x16 mfma_bf16x6(const bf16x8 ah, const bf16x8 am, const bf16x8 al, const bf16x8 bh, const bf16x8 bm, const bf16x8 bl,
+                                              f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
 }  // namespace crdr

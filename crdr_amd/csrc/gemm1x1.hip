@@ -35,7 +35,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------------------
 // OPS: operands read by the epilogue besides the per-column vectors: bit 0 = res (CRDR_EPI_RES), bit 1 = mask (the ReLU masks)
 // NW: waves per workgroup (4: one per SIMD; 8: two per SIMD, so one wave's epilogue and stores overlap the other's MFMAs)
-template <int NB, int S, int OPS, int NW>
+// PREC = 6: fp32-equivalent split-bf16 products (common.hpp, CRDR_CONV_BF16X6).  The stages stay fp32 -- a wave's activation rows are its own and are
+// read once, so they are split where they are used, in registers; the weight fragments likewise (a pre-split weight tile would be 1.5x the LDS
+// this kernel already fills).  Six bf16 MFMAs of 32 cycles per 16 k instead of eight fp32 ones of 64: the layer is then bound by its HBM stream.
+template <int NB, int S, int OPS, int NW, int PREC = 0>
 __global__ __launch_bounds__(64 * NW) void gemm1x1_kernel(const IgemmArgs p_, const StreamArgs sa, const IgemmGroup grp) {
   constexpr int BM = 32 * NW, BN = 32 * NB, NT = 64 * NW, AV = BM * 8 / NT;
   static_assert(AV == 4, "a wave fetches its own 32 rows in four instructions");
@@ -145,6 +148,29 @@ __global__ __launch_bounds__(64 * NW) void gemm1x1_kernel(const IgemmArgs p_, co
       __builtin_amdgcn_sched_barrier(0);
       const float* fa = sA + c_slot * BM * 32 + (wave * 32) * 32;
       const float* fb = sB + kc * BN * 32;
+      if constexpr (PREC == 6) {
+        // one bf16 MFMA covers the quarter steps kk, kk + 1: a lane's 8 values are the two 16-byte slots it reads (the same k for A and B)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk += 2) {
+          bf16x8 ah, am, al;
+          {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(fa + fo[kk]), a1 = *reinterpret_cast<const f32x4*>(fa + fo[kk + 1]);
+            const float x[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            split3_bf16x8(x, ah, am, al);
+          }
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(fb + fo[kk] + j * 1024), b1 = *reinterpret_cast<const f32x4*>(fb + fo[kk + 1] + j * 1024);
+            const float x[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            bf16x8 bh, bm, bl;
+            split3_bf16x8(x, bh, bm, bl);
+            acc[j] = mfma_bf16x6(ah, am, al, bh, bm, bl, acc[j]);
+          }
+          if (kk == 0) fetch();
+        }
+        if (++c_slot == S) c_slot = 0;
+        continue;
+      }
       // fragments of k group kk + 1 are requested before the MFMAs of group kk are issued
       f32x4 af[2], bf[2][NB];
       af[0] = *reinterpret_cast<const f32x4*>(fa + fo[0]);
@@ -319,9 +345,11 @@ __global__ __launch_bounds__(64 * NW) void gemm1x1_kernel(const IgemmArgs p_, co
 struct StreamCfg {
   int nb, stages, nw;
   void (*kern[4])(const IgemmArgs, const StreamArgs, const IgemmGroup);  // by OPS
+  void (*kern6[4])(const IgemmArgs, const StreamArgs, const IgemmGroup);  // ... with bf16x6 products
 };
 #define SCFG(nb, st, nw) \
-  {nb, st, nw, {gemm1x1_kernel<nb, st, 0, nw>, gemm1x1_kernel<nb, st, 1, nw>, gemm1x1_kernel<nb, st, 2, nw>, gemm1x1_kernel<nb, st, 3, nw>}}
+  {nb, st, nw, {gemm1x1_kernel<nb, st, 0, nw>, gemm1x1_kernel<nb, st, 1, nw>, gemm1x1_kernel<nb, st, 2, nw>, gemm1x1_kernel<nb, st, 3, nw>}, \
+   {gemm1x1_kernel<nb, st, 0, nw, 6>, gemm1x1_kernel<nb, st, 1, nw, 6>, gemm1x1_kernel<nb, st, 2, nw, 6>, gemm1x1_kernel<nb, st, 3, nw, 6>}}
 static const StreamCfg kStreamCfgs[] = {
     SCFG(2, 4, 4), SCFG(3, 4, 4), SCFG(4, 4, 4), SCFG(6, 3, 4),   // one wave per SIMD, deep ring
     SCFG(2, 2, 8), SCFG(3, 2, 8), SCFG(4, 2, 8), SCFG(5, 2, 8),   // two waves per SIMD, double buffer
@@ -340,12 +368,14 @@ void stream_variant_shape(int v, int* nb, int* stages, int* nw) {
 void stream_launch(int v, const IgemmArgs& a, const StreamArgs& sa, const IgemmGroup& grp, unsigned grid, size_t lds, hipStream_t s) {
   const StreamCfg& sc = kStreamCfgs[v];
   const int ops = ((a.flags & CRDR_EPI_RES) ? 1 : 0) | ((a.flags & (CRDR_EPI_RELUMASK | CRDR_EPI_LRELUMASK)) ? 2 : 0);
-  static std::atomic<bool> attr_done[16][4];
-  if (!attr_done[v][ops].load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc.kern[ops]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done[v][ops].store(true, std::memory_order_release);
+  const int b6 = (a.flags & CRDR_CONV_BF16X6) ? 1 : 0;
+  auto kern = b6 ? sc.kern6[ops] : sc.kern[ops];
+  static std::atomic<bool> attr_done[2][16][4];
+  if (!attr_done[b6][v][ops].load(std::memory_order_acquire)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done[b6][v][ops].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(sc.kern[ops], dim3(grid), dim3(64 * sc.nw), lds, s, a, sa, grp);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * sc.nw), lds, s, a, sa, grp);
 }
 
 }  // namespace crdr

@@ -10,96 +10,105 @@
 namespace crdr {
 
 // BEGIN GENERATED (gen_igemm_parts.py)
-extern template __global__ void igemm_kernel<4, 1, 1, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 3, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 4, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 5, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 6, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 7, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 3, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 4, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 3, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 4, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 3, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 2, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 2, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 1, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 3, false, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 1, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 2, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 2, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 2, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 1, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 2, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 1, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 2, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 2, 1, true, false, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 3, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 4, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 5, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 6, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 7, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 3, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 4, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 3, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 4, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 3, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 2, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 2, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 1, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 3, false, true, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 3, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 4, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 5, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 6, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 1, 7, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 3, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 1, 2, 4, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 3, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 1, 4, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<1, 4, 1, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 1, 3, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<4, 2, 2, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 2, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 4, 1, 2, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 1, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
-extern template __global__ void igemm_kernel<2, 2, 2, 3, false, false, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 1, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 3, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 4, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 5, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 6, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 7, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 3, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 4, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 1, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 2, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 3, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 4, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 1, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 2, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 3, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 1, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 2, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 1, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 3, false, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 1, true, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, true, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, true, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, true, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, true, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, true, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, true, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, true, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, true, 0, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 1, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 3, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 4, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 5, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 6, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 7, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 3, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 4, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 1, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 2, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 3, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 4, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 1, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 2, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 3, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 1, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 2, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 1, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 3, false, 3, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, false, 6, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 4, false, 6, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, false, 6, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 1, false, 6, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 2, false, 6, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 3, false, 6, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, false, 6, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, false, 6, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 1, false, 6, false>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 1, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 2, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 3, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 4, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 5, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 6, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 1, 7, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 2, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 3, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 1, 2, 4, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 2, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 1, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 2, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 3, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 1, 4, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 1, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<1, 4, 1, 2, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 1, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 2, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 1, 3, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 1, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<4, 2, 2, 2, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 1, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 2, 1, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 4, 1, 2, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 1, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
+extern template __global__ void igemm_kernel<2, 2, 2, 3, false, 0, true>(const IgemmArgs, const IgemmTaps, const IgemmGroup);
 // END GENERATED
 
 // ------------------------------------------------------------------------------------------------------------
@@ -111,9 +120,23 @@ struct TileCfg {
   void (*kern_smallc)(const IgemmArgs, const IgemmTaps, const IgemmGroup);  // tap-major variant (Cin <= 4), nullptr where not built
   void (*kern_bf3)(const IgemmArgs, const IgemmTaps, const IgemmGroup);     // split-bf16 products (CRDR_CONV_BF16X3)
   void (*kern_fast)(const IgemmArgs, const IgemmTaps, const IgemmGroup);    // unsplit launches on the straight-line epilogue: the kernel without its split-K / general-epilogue code
+  void (*kern_bf6)(const IgemmArgs, const IgemmTaps, const IgemmGroup);     // fp32-equivalent split-bf16 products (CRDR_CONV_BF16X6), nullptr where the stages do not fit LDS
 };
-#define CFG(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false, false>, nullptr, igemm_kernel<a, b, c, d, false, true>, igemm_kernel<a, b, c, d, false, false, true>}
-#define CFGS(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false, false>, igemm_kernel<a, b, c, d, true, false>, igemm_kernel<a, b, c, d, false, true>, igemm_kernel<a, b, c, d, false, false, true>}
+// LDS bytes of a tile configuration (K-loop staging + tap table overlaid by the epilogue's transposed accumulators + column sums, then the
+// per-column vectors sV at kSvOff in the kernel, + the reducer flag of a split launch)
+static constexpr size_t cfg_lds(int wm, int wn, int mb, int nb, int prec) {
+  const size_t BM = 32 * wm * mb, BN = 32 * wn * nb;
+  const size_t staging = igemm_staging_floats((int)BM, (int)BN, prec);
+  const size_t epi = (size_t)wm * wn * 32 * 32 * (nb < 4 ? nb : 4) + (size_t)wm * 2 * BN;
+  const size_t sv_off = ((staging > epi ? staging : epi) + 3) & ~(size_t)3;
+  return (sv_off + (size_t)4 * BN + 4) * sizeof(float);
+}
+template <int a, int b, int c, int d, bool FITS = igemm_bf6_ok(a, b, c, d) && (cfg_lds(a, b, c, d, 6) <= 160 * 1024)>
+struct Bf6Kern { static constexpr void (*fn)(const IgemmArgs, const IgemmTaps, const IgemmGroup) = igemm_kernel<a, b, c, d, false, 6>; };
+template <int a, int b, int c, int d>
+struct Bf6Kern<a, b, c, d, false> { static constexpr void (*fn)(const IgemmArgs, const IgemmTaps, const IgemmGroup) = nullptr; };
+#define CFG(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false, 0>, nullptr, igemm_kernel<a, b, c, d, false, 3>, igemm_kernel<a, b, c, d, false, 0, true>, Bf6Kern<a, b, c, d>::fn}
+#define CFGS(a, b, c, d) {a, b, c, d, igemm_kernel<a, b, c, d, false, 0>, igemm_kernel<a, b, c, d, true, 0>, igemm_kernel<a, b, c, d, false, 3>, igemm_kernel<a, b, c, d, false, 0, true>, Bf6Kern<a, b, c, d>::fn}
 static const TileCfg kCfgs[] = {
     // BM=128 family (one 32-row strip per wave), BN = 32..224
     CFGS(4, 1, 1, 1), CFGS(4, 1, 1, 2), CFG(4, 1, 1, 3), CFG(4, 1, 1, 4), CFG(4, 1, 1, 5), CFG(4, 1, 1, 6),
@@ -245,9 +268,12 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
   for (int ph = 0; ph < a.nphase; ++ph) maxtaps = std::max(maxtaps, (int)(tp.tap_begin[ph + 1] - tp.tap_begin[ph]));
   const int KT = a.smallc ? a.kchunks : maxtaps * a.kchunks;
   double best = 1e300; int bc = -1, bs = 1;
+  const bool bf6 = (d->flags & CRDR_CONV_BF16X6) && !a.smallc;
+  CRDR_REQUIRE(!((d->flags & CRDR_CONV_BF16X6) && (d->flags & CRDR_CONV_BF16X3)), "conv2d: CRDR_CONV_BF16X3 and CRDR_CONV_BF16X6 are exclusive");
   for (int c = 0; c < kNumCfgs; ++c) {
     const TileCfg& t = kCfgs[c];
     if (a.smallc && !t.kern_smallc) continue;
+    if (bf6 && !t.kern_bf6) continue;
     const int BM = 32 * t.wm * t.mb, BN = 32 * t.wn * t.nb;
     const long long tiles = (long long)cdiv(a.M, BM) * cdiv(d->OC, BN) * a.nphase;
     static_assert(sizeof(kCfgTflops) / sizeof(kCfgTflops[0]) == sizeof(kCfgs) / sizeof(kCfgs[0]), "one figure per configuration");
@@ -257,8 +283,9 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
       const long long blocks = tiles * ns * G;
       // MFMA cycles of one workgroup per K-tile (waves beyond four share the SIMDs), scaled by the measured efficiency
       // (split-bf16 products: 6 MFMAs of 32 cycles per block and K-tile instead of 16 of 64, plus the operand splitting)
+      // (bf16x6: 12 MFMAs of 32 cycles per block and K-tile, the operand splitting between them)
       const double per_iter = 16.0 * t.mb * t.nb * 64.0 * std::max(1.0, t.wm * t.wn / 4.0) * (133.0 / kCfgTflops[c]) *
-                              ((d->flags & CRDR_CONV_BF16X3) && !a.smallc ? 0.3 : 1.0);
+                              ((d->flags & CRDR_CONV_BF16X3) && !a.smallc ? 0.3 : (bf6 ? 0.5 : 1.0));
       const double waves = (double)cdiv64(blocks, 256);
       double cost = waves * ((double)cdiv(KT, ns) * per_iter + 3000.0);
       // in-launch reduce: publish + ticket + acquire (~3 us) and the last arriver's slab reads (~100 GB/s per workgroup)
@@ -354,6 +381,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
     bs = 1 << ((d->reserved >> 8) & 0xf);
     CRDR_REQUIRE(bc >= 0 && bc < kNumCfgs, "conv2d: forced config %d out of range", bc);
     CRDR_REQUIRE(!a.smallc || kCfgs[bc].kern_smallc, "conv2d: config %d has no tap-major variant", bc);
+    CRDR_REQUIRE(!bf6 || kCfgs[bc].kern_bf6, "conv2d: config %d has no bf16x6 variant (its stages do not fit LDS)", bc);
     CRDR_REQUIRE(bs == 1 || KT / bs >= 2, "conv2d: forced split %d too deep for %d K-iterations", bs, KT);
     CRDR_REQUIRE(bs == 1 || !(d->flags & CRDR_CONV_NOSPLIT), "conv2d: forced split %d with CRDR_CONV_NOSPLIT", bs);
     if (bs > 1) {
@@ -384,14 +412,7 @@ static int build_plan(const crdr_conv_desc* d, Plan* pl, int G = 1, bool fallbac
     const bool applies = !a.smallc && maxtaps > 1 && a.kchunks > 1;
     a.k_cmajor = applies && (mode == 1 || (mode < 0 && d->C >= 1024)) ? 1 : 0;
   }
-  {
-    // floats: K-loop staging (+ tap table) overlaid by the epilogue's transposed accumulators + column sums, then the
-    // per-column vectors sV (kSvOff in the kernel)
-    const size_t staging = (size_t)2 * (BM + BN) * 32 + 132;
-    const size_t epi = (size_t)t.wm * t.wn * 32 * 32 * std::min(t.nb, 4) + (size_t)t.wm * 2 * BN;
-    const size_t sv_off = (std::max(staging, epi) + 3) & ~(size_t)3;
-    pl->lds = (sv_off + (size_t)4 * BN + 4) * sizeof(float);   // (+ the reducer flag of a split launch)
-  }
+  pl->lds = cfg_lds(t.wm, t.wn, t.mb, t.nb, bf6 ? 6 : 0);
   a.cs_ld = round_up(d->OC, 32);
   a.cs_rows = want_cs ? a.nphase * (int)pl->grid.x : 0;
   // split-K workspace: [tickets: CRDR_CONV_TICKETS ints, zero between launches][slabs]
@@ -535,9 +556,10 @@ static int launch_conv(const crdr_conv_desc* d, const crdr_conv_io* ios, int G, 
   }
   const TileCfg& t = kCfgs[pl.cfg];
   // (RGB-input layers stay exact: K is tiny there); 3: the FAST form of the plain kernel (same arithmetic, same order: bit-identical results)
-  const int variant = a.smallc ? 1 : ((d->flags & CRDR_CONV_BF16X3) ? 2 : ((a.fast_epi && a.nsplit == 1) ? 3 : 0));
-  auto kern = variant == 1 ? t.kern_smallc : (variant == 2 ? t.kern_bf3 : (variant == 3 ? t.kern_fast : t.kern));
-  static std::atomic<bool> attr_done[4][64];
+  const int variant = a.smallc ? 1 : ((d->flags & CRDR_CONV_BF16X3) ? 2 : ((d->flags & CRDR_CONV_BF16X6) ? 4 : ((a.fast_epi && a.nsplit == 1) ? 3 : 0)));
+  auto kern = variant == 1 ? t.kern_smallc : (variant == 2 ? t.kern_bf3 : (variant == 3 ? t.kern_fast : (variant == 4 ? t.kern_bf6 : t.kern)));
+  CRDR_REQUIRE(kern, "conv2d: config %d has no kernel for this precision", pl.cfg);
+  static std::atomic<bool> attr_done[5][64];
   if (!attr_done[variant][pl.cfg].load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[variant][pl.cfg].store(true, std::memory_order_release);

@@ -95,9 +95,25 @@ __device__ __forceinline__ void split_row(const IgemmArgs& p, int m, int& n, int
 // Register budget of the 8-wave configurations with two accumulator blocks per wave (128 x 128 and 256 x 64 tiles): two workgroups per CU =
 // four waves per SIMD = 128 registers.  They sat at 121; the row-split branches took the allocator to 133-135 and the second workgroup
 // away (the bf16x3 step, which lives on these tiles, went from 241 to 219 img/s) -- the bound is stated instead of hoped for.
-constexpr int igemm_min_waves(int waves, int blocks) { return (waves == 8 && blocks <= 2) ? 4 : 1; }
-template <int WM, int WN, int MB, int NB, bool SMALLC, bool BF3 = false, bool FAST = false>
-__global__ __launch_bounds__(64 * WM * WN, igemm_min_waves(WM * WN, MB * NB)) void igemm_kernel(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
+// PREC = 6 ("bf16x6", common.hpp): fp32-equivalent products on the bf16 matrix path.  At 3/8 of the fp32 matrix time a K-tile lasts ~0.8 us per
+// workgroup, well under the loaded-memory latency, and an LDS landing zone deep enough for that does not fit beside the operands -- so this loop
+// stages global -> REGISTERS -> LDS: a thread requests its pieces of tile t + 2 into one of two register sets (plain range-checked buffer loads:
+// 2-3 us of lead), splits the set that holds tile t + 1 into three bf16 pieces between the MFMAs of tile t, and writes them to the other of TWO LDS
+// stages of three bf16 planes each (hi / mid / lo, 192 bytes per tile row and K-tile).  A thread owns a CHUNK PAIR (8 consecutive k of one row):
+// its three 16-byte results are exactly what a lane of v_mfma_f32_32x32x16_bf16 feeds -- three ds_read_b128 per fragment, no register shuffles.
+// Tiles whose rows are not whole passes of NT / 4 rows or whose two stages pass 160 KiB have no bf16x6 form (igemm_bf6_ok).
+constexpr int igemm_min_waves(int waves, int blocks, int prec) { return prec == 6 ? (waves == 8 ? 2 : 1) : ((waves == 8 && blocks <= 2) ? 4 : 1); }
+// floats of LDS in front of the per-column vectors (host and kernel agree through this)
+constexpr int igemm_staging_floats(int BM, int BN, int prec) { return prec == 6 ? 2 * (BM + BN) * 48 + 132 : 2 * (BM + BN) * 32 + 132; }
+constexpr bool igemm_bf6_ok(int wm, int wn, int mb, int nb) {
+  const int BM = 32 * wm * mb, BN = 32 * wn * nb, R = 16 * wm * wn;
+  return BM % R == 0 && BN % R == 0 && (igemm_staging_floats(BM, BN, 6) + 4 * BN + 8) * 4 <= 160 * 1024;
+}
+template <int WM, int WN, int MB, int NB, bool SMALLC, int PREC = 0, bool FAST = false>
+__global__ __launch_bounds__(64 * WM * WN, igemm_min_waves(WM * WN, MB * NB, PREC)) void igemm_kernel(const IgemmArgs p_, const IgemmTaps tp, const IgemmGroup grp) {
+  static_assert(PREC == 0 || PREC == 3 || PREC == 6, "PREC: 0 exact fp32, 3 split-bf16 triples, 6 split-bf16 sextuples");
+  constexpr bool BF3 = PREC == 3, BF6 = PREC == 6;
+  static_assert(!BF6 || (!SMALLC && !FAST && igemm_bf6_ok(WM, WN, MB, NB)), "no bf16x6 form of this configuration");
   constexpr int BM = 32 * WM * MB, BN = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;  // 16-byte pieces per thread per K-tile
   static_assert(AV * NT == BM * 8 && BV * NT == BN * 8, "tile/threads mismatch");
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(64 * WM * WN, igemm_min_waves(WM * WN, MB * NB)) vo
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                                        // [ST][BM*32]
   float* sB = smem + ST * BM * 32;                         // [ST][BN*32]
-  int* sTap = reinterpret_cast<int*>(smem + ST * (BM + BN) * 32);  // [<=132] packed (dh, dw, widx) of this phase
+  int* sTap = reinterpret_cast<int*>(smem + (BF6 ? 2 * (BM + BN) * 48 : ST * (BM + BN) * 32));  // [<=132] packed (dh, dw, widx) of this phase
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the DMA destinations and fragment bases derived from it then cost no vector instructions)
   const int wm = wave / WN, wn = wave % WN;
@@ -197,7 +213,8 @@ __global__ __launch_bounds__(64 * WM * WN, igemm_min_waves(WM * WN, MB * NB)) vo
   }
   // per-column epilogue vectors of this N tile (neutral values where a flag is off or past Cout), read by the fast epilogue
   constexpr int kG = NB < 4 ? NB : 4;
-  constexpr int kStagingFloats = ST * (BM + BN) * 32 + 132;
+  constexpr int kStagingFloats = igemm_staging_floats(BM, BN, PREC);
+  static_assert(ST == 2, "igemm_staging_floats assumes two stages of the fp32 / bf16x3 loops");
   constexpr int kEpiFloats = WM * WN * 32 * 32 * kG + WM * 2 * BN;
   constexpr int kSvOff = ((kStagingFloats > kEpiFloats ? kStagingFloats : kEpiFloats) + 3) & ~3;
   float* sV = smem + kSvOff;  // [4][BN]: bias, vec2, scale, shift
@@ -277,6 +294,122 @@ __global__ __launch_bounds__(64 * WM * WN, igemm_min_waves(WM * WN, MB * NB)) vo
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // ---- bf16x6 (PREC = 6): staging assignment, requests, split and MFMA step (see the header comment).
+  // Stage s of A: planes [hi | mid | lo] of BM rows x 64 bytes at s6A + s * BM * 48 floats; chunk pair q of row r sits at 16-byte slot
+  // q ^ ((r >> 2) & 3) of its row in every plane (the rows a ds_read_b128 lane group reads then cover all 64 banks once).
+  constexpr int RPP6 = NT / 4;                                   // tile rows per request pass: four threads (= four chunk pairs) per row
+  constexpr int PA6 = BF6 ? BM / RPP6 : 1, PB6 = BF6 ? BN / RPP6 : 1;
+  float* s6A = smem;                                             // [2][3 planes][BM * 16]
+  float* s6B = smem + 2 * BM * 48;                               // [2][3 planes][BN * 16]
+  const int srow6 = tid >> 2, q6 = tid & 3;                      // this thread's row (of every pass) and chunk pair
+  unsigned a6_off[PA6], b6_off[PB6];
+  int a6_ih[PA6], a6_iw[PA6];
+  u32x4 ra6[2][PA6][2], rb6[2][PB6][2];                          // two register sets: the tiles in flight
+  // The descriptors again, from pointers and extents forced into scalar registers: left to the compiler they sat in vector registers in this
+  // instantiation, and every buffer load was wrapped in a waterfall loop (four v_readfirstlane, two 64-bit compares, exec save / restore and a
+  // branch per request -- and a basic-block boundary between the MFMAs).
+  auto uni64 = [](unsigned long long v) __attribute__((always_inline)) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  const __amdgpu_buffer_rsrc_t rx6 = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(p.x + base_pix * ldx))), 0,
+      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(left < 0x7fffffffull ? left : 0x7fffffffull)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw6 = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(p.w))), 0, (unsigned)__builtin_amdgcn_readfirstlane((int)p.w_bytes), 0x00020000);
+  if constexpr (BF6) {
+    static_assert(RPP6 % 16 == 0, "the slot swizzle must not depend on the pass");
+#pragma unroll
+    for (int j = 0; j < PA6; ++j) {
+      const int m = m0 + srow6 + j * RPP6;
+      int n, a, b;
+      split_row(p, m, n, a, b);
+      const bool ok = (m < p.M) && (a * p.so + poh < p.OH) && (b * p.so + pow_ < p.OW);
+      a6_ih[j] = ok ? a * p.si : -(1 << 24);
+      a6_iw[j] = ok ? b * p.si : 0;
+      a6_off[j] = ok ? (unsigned)(((long long)(n * H + a * p.si) * W + b * p.si - base_pix) * ldx + q6 * 8) * 4u : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < PB6; ++j) {
+      const int oc = n0 + srow6 + j * RPP6;
+      b6_off[j] = oc < p.wrows ? (unsigned)(oc * p.wcols + q6 * 8) * 4u : kOobOffset;
+    }
+  }
+  auto load6 = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    const int lt = cmajor ? ci : co, lc = cmajor ? co : ci;
+    const int t = __builtin_amdgcn_readfirstlane(sTap[lt]);
+    const int dh = (int)(signed char)(t & 0xff), dw = (int)(signed char)((t >> 8) & 0xff);
+    const int wi = t >> 16;
+    const bool cok0 = lc * 32 + q6 * 8 < Cin, cok1 = lc * 32 + q6 * 8 + 4 < Cin;
+    const unsigned toff = (unsigned)((dh * W + dw) * ldx + lc * 32) * 4u;
+    const unsigned woff = (unsigned)(wi * p.wrows * p.wcols + lc * 32) * 4u;
+#pragma unroll
+    for (int j = 0; j < PA6; ++j) {
+      const int ih = a6_ih[j] + dh, iw = a6_iw[j] + dw;
+      const bool ok = ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+      ra6[set][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rx6, (ok & cok0) ? a6_off[j] + toff : kOobOffset, 0, 0);
+      ra6[set][j][1] = __builtin_amdgcn_raw_buffer_load_b128(rx6, (ok & cok1) ? a6_off[j] + toff + 16u : kOobOffset, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PB6; ++j) {
+      rb6[set][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rw6, b6_off[j] == kOobOffset ? kOobOffset : b6_off[j] + woff, 0, 0);
+      rb6[set][j][1] = __builtin_amdgcn_raw_buffer_load_b128(rw6, b6_off[j] == kOobOffset ? kOobOffset : b6_off[j] + woff + 16u, 0, 0);
+    }
+    if (++ci == inner_n) { ci = 0; ++co; }
+    __builtin_amdgcn_sched_barrier(0);   // requests first: the MFMA stream behind them hides their latency
+  };
+  // register set `set` -> the three bf16 planes of LDS stage `buf`
+  auto split6 = [&](auto setc, auto bufc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value, buf = decltype(bufc)::value;
+    const int slot = (srow6 * 4 + (q6 ^ ((srow6 >> 2) & 3))) * 4;   // floats: (row, swizzled slot) inside a plane
+    float* a = s6A + buf * BM * 48 + slot;
+    float* b = s6B + buf * BN * 48 + slot;
+#pragma unroll
+    for (int j = 0; j < PA6 + PB6; ++j) {
+      float* q = j < PA6 ? a + j * RPP6 * 16 : b + (j - PA6) * RPP6 * 16;
+      constexpr int kPlaneA = BM * 16, kPlaneB = BN * 16;
+      const int plane = j < PA6 ? kPlaneA : kPlaneB;
+      const f32x4 x0 = __builtin_bit_cast(f32x4, j < PA6 ? ra6[set][j < PA6 ? j : 0][0] : rb6[set][j < PA6 ? 0 : j - PA6][0]);
+      const f32x4 x1 = __builtin_bit_cast(f32x4, j < PA6 ? ra6[set][j < PA6 ? j : 0][1] : rb6[set][j < PA6 ? 0 : j - PA6][1]);
+      const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      bf16x8 h, m, l;
+      split3_bf16x8(x, h, m, l);
+      *reinterpret_cast<bf16x8*>(q) = h;
+      *reinterpret_cast<bf16x8*>(q + plane) = m;
+      *reinterpret_cast<bf16x8*>(q + 2 * plane) = l;
+    }
+  };
+  int fo6[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) fo6[j] = (lane & 31) * 16 + (((2 * j + (lane >> 5)) ^ (((lane & 31) >> 2) & 3)) << 2);
+  // the MFMAs of stage `buf`: lane half h takes chunk pair 2 j + h of both operands for the j-th 16 k (the same k for A and B)
+  auto compute6 = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+    const float* fa6 = s6A + buf * BM * 48 + (wm * MB * 32) * 16;
+    const float* fb6 = s6B + buf * BN * 48 + (wn * NB * 32) * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 ah[MB], am[MB], al[MB], bh[NB], bm[NB], bl[NB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(fa6 + fo6[j] + i * 512);
+        am[i] = *reinterpret_cast<const bf16x8*>(fa6 + fo6[j] + i * 512 + BM * 16);
+        al[i] = *reinterpret_cast<const bf16x8*>(fa6 + fo6[j] + i * 512 + 2 * BM * 16);
+      }
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) {
+        bh[jj] = *reinterpret_cast<const bf16x8*>(fb6 + fo6[j] + jj * 512);
+        bm[jj] = *reinterpret_cast<const bf16x8*>(fb6 + fo6[j] + jj * 512 + BN * 16);
+        bl[jj] = *reinterpret_cast<const bf16x8*>(fb6 + fo6[j] + jj * 512 + 2 * BN * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) acc[i][jj] = mfma_bf16x6(ah[i], am[i], al[i], bh[jj], bm[jj], bl[jj], acc[i][jj]);
+    }
+  };
+
   const int frow = lane & 31, fh = lane >> 5;
   const float* fa = sA + (wm * MB * 32) * 32;
   const float* fb = sB + (wn * NB * 32) * 32;
@@ -348,7 +481,12 @@ __global__ __launch_bounds__(64 * WM * WN, igemm_min_waves(WM * WN, MB * NB)) vo
     if constexpr (BF3) presplit(integral_constant<int, buf ^ 1>{});
     __syncthreads();
   };
-  if (it0 < it1) fetch(0);
+  if constexpr (BF6) {
+    // prologue: tiles 0 and 1 requested (a request past the K range is range-checked garbage that is never multiplied)
+    if (it0 < it1) { load6(I0{}); load6(I1{}); }
+  } else {
+    if (it0 < it1) fetch(0);
+  }
   // (behind the first DMA so that their latencies overlap; the barrier below publishes both)
   if (FAST || p.fast_epi) {
     const int f0 = p.flags;
@@ -360,9 +498,33 @@ __global__ __launch_bounds__(64 * WM * WN, igemm_min_waves(WM * WN, MB * NB)) vo
       sV[3 * BN + c] = (live && (f0 & CRDR_EPI_AFFINE)) ? p.shift[n0 + c] : 0.f;
     }
   }
+  int it = it0;
+  if constexpr (BF6) {
+    if (it0 < it1) split6(I0{}, I0{});
+    __syncthreads();
+    // a step = [requests of tile t + 2 into the register set tile t left] [MFMAs of tile t out of stage t & 1, with the split of tile t + 1 -- in
+    // the other register set since the previous step -- into the other stage between them: one basic block, the compiler interleaves]
+    // [barrier: publishes that stage, frees this one]
+    auto step6 = [&](auto bufc) __attribute__((always_inline)) {
+      constexpr int buf = decltype(bufc)::value;
+      load6(bufc);
+      compute6(bufc);
+      split6(integral_constant<int, buf ^ 1>{}, integral_constant<int, buf ^ 1>{});
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my LDS writes are done (the requests stay in flight: no __syncthreads here)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (; it + 2 <= it1; it += 2) {
+      step6(I0{});
+      step6(I1{});
+    }
+    if (it < it1) step6(I0{});
+    __syncthreads();
+  } else {
   if constexpr (BF3) presplit(I0{});
   __syncthreads();
-  int it = it0;
   for (; it + 2 <= it1; it += 2) {
     step(I0{});
     step(I1{});
@@ -370,6 +532,7 @@ __global__ __launch_bounds__(64 * WM * WN, igemm_min_waves(WM * WN, MB * NB)) vo
   if (it < it1) {
     compute(I0{}, I0{}, I4{});
     __syncthreads();
+  }
   }
 
   // ---- epilogue.  The accumulators go through LDS (the staging buffers are free now) so that every lane handles

@@ -20,8 +20,11 @@ namespace crdr {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 static constexpr unsigned kOob = 0x80000000u;  // >= any descriptor size accepted by build_wplan (< 2 GiB)
 
-template <int WM, int WN, int MB, int NB, bool BF3 = false>
+// PREC: 0 exact fp32, 3 split-bf16 triples (CRDR_WGRAD_BF16X3), 6 fp32-equivalent split-bf16 sextuples (CRDR_WGRAD_BF16X6); the fragments run
+// down the pixel axis, so the pieces are made in registers from the lane's eight ds_read_b32 values
+template <int WM, int WN, int MB, int NB, int PREC = 0>
 __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p_, const WgradGroup grp) {
+  constexpr bool BF3 = PREC == 3, BF6 = PREC == 6;
   constexpr int BI = 32 * WM * MB, BJ = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int PV = (8 * BI + NT - 1) / NT, QV = (8 * BJ + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -114,6 +117,31 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p_,
   const float* fb = sQ + wn * NB * 32 + fcol + fh * BJ;
   auto compute = [&](auto bufc) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value;
+    if constexpr (BF6) {  // fp32-equivalent split-bf16 products (common.hpp): three exact pieces per operand, six MFMAs per 16 pixels
+#pragma unroll
+      for (int s0 = 0; s0 < 16; s0 += 8) {
+        bf16x8 ah[MB], am[MB], al[MB], bh[NB], bm[NB], bl[NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fa[buf * 32 * BI + 2 * (s0 + e) * BI + i * 32];
+          split3_bf16x8(x, ah[i], am[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fb[buf * 32 * BJ + 2 * (s0 + e) * BJ + j * 32];
+          split3_bf16x8(x, bh[j], bm[j], bl[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] = mfma_bf16x6(ah[i], am[i], al[i], bh[j], bm[j], bl[j], acc[i][j]);
+      }
+      return;
+    }
     if constexpr (BF3) {  // split-bf16 products (common.hpp): one bf16 MFMA covers the 16 pixels of eight fp32 steps
 #pragma unroll
       for (int s0 = 0; s0 < 16; s0 += 8) {
@@ -472,8 +500,9 @@ struct WCfg {
   int wm, wn, mb, nb;
   void (*kern)(const WgradArgs, const WgradGroup);
   void (*kern_bf3)(const WgradArgs, const WgradGroup);
+  void (*kern_bf6)(const WgradArgs, const WgradGroup);
 };
-#define CFG(a, b, c, d) {a, b, c, d, wgrad_kernel<a, b, c, d, false>, wgrad_kernel<a, b, c, d, true>}
+#define CFG(a, b, c, d) {a, b, c, d, wgrad_kernel<a, b, c, d, 0>, wgrad_kernel<a, b, c, d, 3>, wgrad_kernel<a, b, c, d, 6>}
 static const WCfg kWCfgs[] = {
     CFG(1, 1, 1, 1),  // 32x32
     CFG(2, 2, 1, 1),  // 64x64
@@ -544,7 +573,7 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl, int G = 1) {
       if (ns > 1 && a.ntiles / ns < 4) break;
       const long long blocks = tiles * ns * G;
       const double slots = 256.0 * std::max(1, 4 / waves_per_block);  // blocks that run at full MFMA rate at once
-      const double per_tile = 16.0 * t.mb * t.nb * 64.0 * ((d->algo & CRDR_WGRAD_BF16X3) ? 0.3 : 1.0) + 400.0;
+      const double per_tile = 16.0 * t.mb * t.nb * 64.0 * ((d->algo & CRDR_WGRAD_BF16X3) ? 0.3 : ((d->algo & CRDR_WGRAD_BF16X6) ? 0.5 : 1.0)) + 400.0;
       double cost = std::ceil(blocks / slots) * ((double)cdiv(a.ntiles, ns) * per_tile + 4000.0);
       cost += (double)ns * ntapg * d->PC * ncols * 4.0 / 1500.0;  // slab write + read
       if (cost < best) { best = cost; bc = c; bs = ns; }
@@ -639,9 +668,10 @@ static int launch_wgrad_slabs(const crdr_wgrad_desc* d, const float* const* ps, 
     return 0;
   }
   const WCfg& t = kWCfgs[pl.cfg];
-  const int bf3 = (d->algo & CRDR_WGRAD_BF16X3) ? 1 : 0;
-  auto kern = bf3 ? t.kern_bf3 : t.kern;
-  static std::atomic<bool> attr_done[2][64];
+  CRDR_REQUIRE(!((d->algo & CRDR_WGRAD_BF16X3) && (d->algo & CRDR_WGRAD_BF16X6)), "wgrad: CRDR_WGRAD_BF16X3 and CRDR_WGRAD_BF16X6 are exclusive");
+  const int bf3 = (d->algo & CRDR_WGRAD_BF16X3) ? 1 : ((d->algo & CRDR_WGRAD_BF16X6) ? 2 : 0);
+  auto kern = bf3 == 1 ? t.kern_bf3 : (bf3 == 2 ? t.kern_bf6 : t.kern);
+  static std::atomic<bool> attr_done[3][64];
   if (!attr_done[bf3][pl.cfg].load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[bf3][pl.cfg].store(true, std::memory_order_release);

@@ -141,6 +141,9 @@ class _ChainFn(torch.autograd.Function):
                                flags=_flags(lay0.act) | (L.EPI_VEC2 if lay0.vec_index is not None else 0),
                                wlayout=1 if sp.smallc else 0, device=dev, label=spec.name)
                 acts.append((bufs, cp, (n, oh, ow)))
+                if ops.RELU_MASK_SINK is not None and lay0.act == "relu" and any(ctx.needs_input_grad):   # (a no-grad pass -- the high-rate reconstruction -- has no backward to take masks for)
+                    for g in range(G):   # (test hook: the activations this node's backward takes its ReLU masks from)
+                        ops.RELU_MASK_SINK(convs[g].weight, _nchw(bufs[g], n, oh, ow, sp.out_ch), None if lay0.vec_index is None else vecs[lay0.vec_index])
                 cur, cur_hw = ys, (oh, ow)
             saved.append(acts)
         ctx.spec, ctx.saved_acts, ctx.geom = spec, saved, (n, c, h, w, ldx)

@@ -579,6 +579,10 @@ class _CharmFn(torch.autograd.Function):
             ctx.ph_call = ph_call
         run.forward(y, noise if is_train else None, ph, scale_bound, lik_bound, want_lik, True)
         ctx.run, ctx.ph = run, ph
+        if ops.RELU_MASK_SINK is not None and any(ctx.needs_input_grad):   # (test hook: the activations charm_backward takes its ReLU masks from)
+            for (kind, i), slot in plan.slot.items():
+                ops.RELU_MASK_SINK(plan.conv(kind, i, 0).weight, run.as_nchw(run.A1, slot * plan.C1, plan.C1), None)
+                ops.RELU_MASK_SINK(plan.conv(kind, i, 1).weight, run.as_nchw(run.A2, slot * plan.C2, plan.C2), None)
         yhat = run.as_nchw(run.Yh)
         mu, sigma = run.as_nchw(run.MSL, 0, run.Cy), run.as_nchw(run.MSL, run.Cy, run.Cy)
         lik_n = run.as_nchw(run.lik_n) if run.lik_n is not None else None

@@ -244,6 +244,20 @@ class PackTable:
         if self.filters is None:
             self.filters = ops.FilterTable(self.device)
         self.filters.refill({e.dst.data_ptr() for e in self.entries + self.singles})
+        if torch.cuda.is_current_stream_capturing():
+            ops.on_replay(self._replayed)   # (trainer/graphs.py: a replay runs these launches without this method)
+
+    def _replayed(self) -> None:
+        """The graph that captured refill() has just been replayed: refill()'s host-side bookkeeping without its launches.  The packs and the
+        filter caches in the device tables AS THE REPLAYED LAUNCHES SAW THEM are fresh; packs / caches that appeared since (an eager
+        validation pass at another image size, say) join the tables now and are covered from the next replay on -- until then their own
+        staleness checks (pack keys, version stamps) make their launches refill / re-transform."""
+        rewritten = {e.dst.data_ptr() for e in self.entries + self.singles}
+        for ptr in rewritten:
+            ops.bump_pack_version(ptr)
+        if self.filters is not None:
+            self.filters.replayed(rewritten)
+        self._refresh()
 
 
 def _flags(bias, act, vec2, res, gate, affine) -> int:
@@ -282,6 +296,8 @@ class _FusedConv(torch.autograd.Function):
                                  (oh, ow), bias=bias, flags=flags, vec2=vec2, res=res, scale=scale, shift=shift,
                                  gate_x=gx, gate_t=gt, sig_out=sig, wlayout=1 if spec.smallc else 0)
         ctx.spec, ctx.flags, ctx.in_hw = spec, flags, (h, w)
+        if ops.RELU_MASK_SINK is not None and act == "relu" and vec2 is None and res is None and scale is None and gx is None and any(ctx.needs_input_grad):   # (a no-grad pass -- the high-rate reconstruction -- has no backward to take masks for)
+            ops.RELU_MASK_SINK(weight, out, None)
         ctx.has = (bias is not None, vec2 is not None, res is not None, scale is not None, gx is not None)
         need_out = flags & (L.EPI_RELU | L.EPI_LRELU | L.EPI_AFFINE)
         ctx.save_for_backward(x, weight, bias, vec2, scale, shift, gt, sig, out if need_out else None)

@@ -60,7 +60,7 @@ class PackItem(C.Structure):
         "I", "J", "T", "rows", "cols", "mode", "srcJ", "dld")] + [("tstride", C.c_int64)]
 
 
-class W4FilterItem(C.Structure):  # mirrors struct crdr_w4_filter_item (312 bytes)
+class W4FilterItem(C.Structure):  # mirrors struct crdr_w4_filter_item (320 bytes)
     _fields_ = [("w", c_void_p * 16), ("u", c_void_p)] + [(n, C.c_int32) for n in (
         "G", "Cin", "Cout", "wrows", "wcols", "kchunks", "ntile", "nvar")] + [("widx", (C.c_int32 * 9) * 4), ("units", C.c_int64)]
 
@@ -95,6 +95,7 @@ class GcDesc(C.Structure):
 EPI_BIAS, EPI_RELU, EPI_LRELU, EPI_VEC2, EPI_RES, EPI_GATE, EPI_AFFINE, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64, 128
 EPI_PREADD, EPI_RELUMASK, EPI_LRELUMASK, EPI_MASKOFF, EPI_COLSUM = 256, 512, 1024, 2048, 4096
 CONV_NOSPLIT, CONV_BF16X3, WGRAD_BF16X3 = 8192, 16384, 1 << 16
+CONV_BF16X6, WGRAD_BF16X6 = 32768, 1 << 17
 MAX_GROUP = 16
 EB_PARAMS = 58
 

@@ -29,14 +29,24 @@ FORCED_CONV_ALGO = 0
 # trainers from the YAML key `precision: bf16x3` for the duration of a training step; the codec and every parity claim use
 # the exact fp32 default.
 MATRIX_BF16X3 = False
+# Opt-in fp32-EQUIVALENT matrix mode ("bf16x6", CRDR_CONV_BF16X6): every operand is split exactly into three bf16 pieces and a product is the
+# six piece products of weight >= 2^-16 with fp32 accumulation (dropped terms <= 2^-23 of the product: one fp32 rounding) at 3/8 of the exact
+# fp32 MFMA time.  Direct kernels only (tiled, streaming 1x1, direct weight gradients); the Winograd kernels stay on the exact fp32
+# instruction and remain tuner candidates beside them.  YAML key `precision: bf16x6`; held to the fp32 parity gates (tests/test_gpu_bf16x6.py).
+MATRIX_BF16X6 = False
 
 
 def _cf() -> int:
-    return L.CONV_BF16X3 if MATRIX_BF16X3 else 0
+    return L.CONV_BF16X6 if MATRIX_BF16X6 else (L.CONV_BF16X3 if MATRIX_BF16X3 else 0)
 
 
 def _wa(algo: int) -> int:
-    return int(algo) | (L.WGRAD_BF16X3 if MATRIX_BF16X3 else 0)
+    return int(algo) | (L.WGRAD_BF16X6 if MATRIX_BF16X6 else (L.WGRAD_BF16X3 if MATRIX_BF16X3 else 0))
+
+
+def _mk() -> tuple:
+    """suffix of the weight-gradient tuner keys (the conv keys carry the mode in their flags)"""
+    return (2,) if MATRIX_BF16X6 else ((1,) if MATRIX_BF16X3 else ())
 _algo_cache = {}
 TUNE_LOG = []
 
@@ -146,11 +156,59 @@ _filter_serial = [0]     # bumped when _filter_cache grows (FilterTable re-reads
 
 
 class _FilterCache:
-    __slots__ = ("u", "wkeys", "versions", "item", "nbytes")
+    __slots__ = ("u", "wkeys", "versions", "item", "nbytes", "packs", "tick")
+
+    def alive(self) -> bool:
+        """every pack this cache was derived from still lives at its address (a dead pack's address may be handed to a new, differently
+        shaped tensor: a cache keyed by that address must never be rebuilt from it)"""
+        return all((r() is not None and r().data_ptr() == p_) for r, p_ in zip(self.packs, self.wkeys))
+
+
+# Host-side bookkeeping that a captured HIP graph skips on replay (trainer/graphs.py): code that runs under capture and keeps host state in
+# step with what its launches do on the device -- functional.PackTable.refill bumps pack versions and stamps the filter caches its batched
+# launch rebuilds -- registers a callable here; SegmentGraphs.run collects them per captured segment and calls them after every replay.
+REPLAY_HOOKS = None
+
+
+def on_replay(fn) -> None:
+    if REPLAY_HOOKS is not None and fn not in REPLAY_HOOKS:
+        REPLAY_HOOKS.append(fn)
+
+
+FILTER_CACHE_BUDGET = int(__import__("os").environ.get("CRDR_FILTER_CACHE_GB", "24")) << 30   # bytes of transformed filters kept (least recently used go first)
+_filter_tick = [0]
+
+
+def _drop_dead_filter_caches() -> None:
+    dead = [k for k, e in _filter_cache.items() if not e.alive()]
+    for k in dead:
+        del _filter_cache[k]
+    if dead:
+        _filter_serial[0] += 1
+
+
+def _evict_filter_caches(need: int) -> None:
+    """Keep the caches within FILTER_CACHE_BUDGET: the least recently launched ones go first (never under graph capture; a cache a captured
+    graph launches with stays referenced by that graph's FilterTable entries and is simply re-created on its next eager use)."""
+    total = sum(e.nbytes for e in _filter_cache.values()) + need
+    if total <= FILTER_CACHE_BUDGET:
+        return
+    for k, e in sorted(_filter_cache.items(), key=lambda kv: kv[1].tick):
+        if total <= FILTER_CACHE_BUDGET:
+            break
+        total -= e.nbytes
+        del _filter_cache[k]
+    _filter_serial[0] += 1
 
 
 def register_persistent_pack(t: torch.Tensor) -> None:
     import weakref
+    old = _persistent_packs.get(t.data_ptr())
+    if old is not None and old() is not t:   # the address of a pack that died: what was derived from the old content is void
+        bump_pack_version(t.data_ptr())
+        for k in [k for k, e in _filter_cache.items() if t.data_ptr() in e.wkeys]:
+            del _filter_cache[k]
+        _filter_serial[0] += 1
     _persistent_packs[t.data_ptr()] = weakref.ref(t)
     _pack_versions.setdefault(t.data_ptr(), 0)
 
@@ -163,6 +221,10 @@ def bump_pack_version(ptr: int) -> None:
 
 def pack_version(ptr: int) -> int:
     return _pack_versions.get(ptr, 0)
+
+
+def filter_cache_bytes() -> int:
+    return sum(e.nbytes for e in _filter_cache.values())
 
 
 def filter_scope_invalidate(ptr=None) -> None:
@@ -209,11 +271,15 @@ class FilterTable:
         pack_ptrs = frozenset(pack_ptrs)
         if self._seen == _filter_serial[0] and pack_ptrs == self._packs:
             return
-        ents = [e for e in _filter_cache.values() if e.u.device == self.device and all(p_ in pack_ptrs for p_ in e.wkeys)]
+        if not torch.cuda.is_current_stream_capturing():
+            _drop_dead_filter_caches()
+        ents = [e for e in _filter_cache.values() if e.u.device == self.device and e.alive() and all(p_ in pack_ptrs for p_ in e.wkeys)]
+        if len(ents) > self.CAP:   # more caches than the device table holds: the most recently used stay in the batched rebuild, the others
+            ents = sorted(ents, key=lambda e: -e.tick)[:self.CAP]   # fall behind their packs' versions and re-transform inside their launches
+            ents.sort(key=lambda e: e.tick)
         if [id(e) for e in ents] != [id(e) for e in self.entries]:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("FilterTable: new filter caches appeared during graph capture (run eager warm-up iterations first)")
-            assert len(ents) <= self.CAP, len(ents)
             raw, pre = bytearray(), [0]
             for e in ents:
                 raw += bytes(e.item)
@@ -235,6 +301,20 @@ class FilterTable:
             for e in self.entries:
                 e.versions = tuple(pack_version(p_) for p_ in e.wkeys)
 
+    def replayed(self, pack_ptrs) -> None:
+        """A captured graph holding this table's rebuild launch has just been replayed (the packs' versions were bumped by the caller): the
+        caches in the table AS THE LAUNCH SAW IT are current; caches that appeared since join the table now, are rebuilt from the next replay
+        on, and until then stay behind their packs' versions (their launches re-transform)."""
+        for e in self.entries:
+            e.versions = tuple(pack_version(p_) for p_ in e.wkeys)
+        self._refresh(pack_ptrs)
+
+
+# Test hook: callable(weight, saved activation as an NCHW view, offset vector or None) called in grad mode by every fused conv / chain layer /
+# Charm transform with a ReLU epilogue -- the activations the product's backward derives its ReLU masks from (CRDR_EPI_RELUMASK: act > 0;
+# with CRDR_EPI_MASKOFF, where a beta vector was added after the ReLU: act - offset > 0).  tests/test_gpu_step.py hands the generator's masks
+# to the oracle (oracle.relu / generator_forward(impose=...)).  None in production.
+RELU_MASK_SINK = None
 
 WINO4_DEMOTED = [0]   # launches whose tuned / preferred F(4x4) plan was dropped because an epilogue operand was not 16-byte aligned
 
@@ -263,12 +343,19 @@ def _launch_conv(lib, d, ios, G: int, ws, ws_n, wkeys, device):
         wk = tuple(int(p_) for p_ in wkeys)
         key = (wk, G, d.reserved & 0xFF, d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.kh, d.kw, d.stride, d.pad, d.transposed, d.wrows, d.wcols)
         ent = _filter_cache.get(key)
+        if ent is not None and not ent.alive():   # (a pack died and its address was reused: drop, never trust)
+            del _filter_cache[key]
+            _filter_serial[0] += 1
+            ent = None
         if ent is None and not torch.cuda.is_current_stream_capturing():
             nb = int(lib.crdr_conv2d_filter_cache_bytes(C.byref(d), G))
             if nb:
+                _evict_filter_caches(nb)
                 ent = _FilterCache()
                 ent.u = torch.empty(nb // 4, dtype=torch.float32, device=device)
                 ent.wkeys, ent.versions, ent.nbytes = wk, None, nb
+                ent.packs = tuple(_persistent_packs[p_] for p_ in wk)
+                ent.tick = 0
                 ent.item = L.W4FilterItem()
                 L.check(lib.crdr_conv2d_filter_item(C.byref(d), G, C.byref(ent.item)), "conv2d_filter_item")
                 for g in range(G):
@@ -277,6 +364,8 @@ def _launch_conv(lib, d, ios, G: int, ws, ws_n, wkeys, device):
                 _filter_cache[key] = ent
                 _filter_serial[0] += 1
         if ent is not None:
+            _filter_tick[0] += 1
+            ent.tick = _filter_tick[0]
             vers = tuple(pack_version(p_) for p_ in wk)
             valid = ent.versions == vers   # derived from the packs' CURRENT content, not merely from the same addresses
             ent.versions = vers
@@ -302,7 +391,12 @@ def _tune_conv_launch(lib, d, ios, G: int, w_, wn_, device) -> bool:
     nb = int(lib.crdr_conv2d_filter_cache_bytes(C.byref(d), G))
     if not nb:
         return lib.crdr_conv2d_grouped(C.byref(d), ios, G, w_, wn_, _stream()) == 0
-    key = (tuple(int(ios[g].w) for g in range(G)), G, d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.kh, d.kw, d.stride, d.pad, d.transposed, d.wrows, d.wcols)
+    wk = tuple(int(ios[g].w) for g in range(G))
+    if not all(_is_persistent_pack(p_) for p_ in wk) or torch.cuda.is_current_stream_capturing():
+        # the real launch will not find a cache (sub-block / temporary packs, or a launch first seen under capture): it transforms on every call,
+        # and that is what the candidate is timed with
+        return lib.crdr_conv2d_grouped(C.byref(d), ios, G, w_, wn_, _stream()) == 0
+    key = (wk, tuple(pack_version(p_) for p_ in wk), G, d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.kh, d.kw, d.stride, d.pad, d.transposed, d.wrows, d.wcols)
     ent = _tune_filters.get(key)
     if ent is None or ent.numel() * 4 < nb:
         _tune_filters.clear()   # (one shape is tuned at a time: the previous shape's scratch is garbage)
@@ -334,6 +428,8 @@ TUNE_AGREE = {"conv": 2e-5, "wgrad": 2e-4, "wino4": 2e-5}   # wino4: the F(4x4, 
 #                                                              the output scale against float64, tests/test_gpu_wino.py; 6e-5 with round 4's 0, +-1, +-2)
 TUNE_REJECTED = []   # (key, algo, measured disagreement) of every candidate refused
 TUNE_SKIPPED = []    # keys whose tuning was put off because the call's result was all zero (no scale to compare candidates against)
+TUNE_ZERO_RETRIES = 3   # ... at most this often per key; then the built-in plan is cached for it
+_tune_zero_seen = {}
 
 
 def _wino4_id() -> int:
@@ -351,6 +447,8 @@ def _autotune(key, ncfg: int, max_log2_split: int, run, extra=(), penalty=None, 
         if reset is not None:
             reset()
         return run(a)
+    if torch.cuda.is_current_stream_capturing():
+        return 0   # timing needs host syncs: a key first seen under capture runs the built-in plan (and is tuned by a later eager call)
     fresh(0)
     ref = result().detach().clone() if result is not None else None
     ref_scale = float(ref.abs().max()) if ref is not None else 0.0
@@ -359,6 +457,10 @@ def _autotune(key, ncfg: int, max_log2_split: int, run, extra=(), penalty=None, 
         # can be compared against it, and caching the baseline plan for the key would silently de-tune it.  Keep the built-in plan for THIS
         # call only; the next call with the same key tunes on its own operands.
         TUNE_SKIPPED.append(key)
+        _tune_zero_seen[key] = _tune_zero_seen.get(key, 0) + 1
+        if _tune_zero_seen[key] >= TUNE_ZERO_RETRIES:   # persistently zero (a masked branch, a zero-initialised layer): stop paying a launch, a clone and
+            _algo_cache[key] = 0                        # a host sync per call -- the built-in plan is cached and reported
+            TUNE_LOG.append((key, 0, 0.0, 0.0))
         return 0
     best, best_t = 0, _time_call(lambda: run(0)) + (penalty() if penalty else 0.0)
     base_t = best_t
@@ -669,7 +771,7 @@ def conv2d_wgrad_raw(p: torch.Tensor, q: torch.Tensor, g: torch.Tensor, k, strid
     if algo:
         d.algo = _wa(algo)
     elif AUTOTUNE:
-        key = ("w", n, ph, pw, pc4, ldp, qh, qw, qc4, ldq, k, stride, pad, g.shape[0], g.shape[1]) + ((1,) if MATRIX_BF16X3 else ())
+        key = ("w", n, ph, pw, pc4, ldp, qh, qw, qc4, ldq, k, stride, pad, g.shape[0], g.shape[1]) + _mk()
         algo = _algo_cache.get(key)
         if algo is None:
             tmp = torch.zeros_like(g)
@@ -995,7 +1097,7 @@ def wgrad_group(n: int, h: int, w: int, ps, qs, gs, gi: int, gj: int, k: Tuple[i
                     gI=gi, gJ=gj, accumulate=int(accumulate), algo=_wa(0))
     pa, qa, ga = (C.c_void_p * G)(*[v.ptr for v in ps]), (C.c_void_p * G)(*[v.ptr for v in qs]), (C.c_void_p * G)(*[g[0] for g in gs])
     if AUTOTUNE:
-        key = ("wg", G, n, h, w, p0.c, p0.ld, q0.c, q0.ld, k, pad, gi, gj) + ((1,) if MATRIX_BF16X3 else ())
+        key = ("wg", G, n, h, w, p0.c, p0.ld, q0.c, q0.ld, k, pad, gi, gj) + _mk()
         algo = _algo_cache.get(key)
         if algo is None:
             tmp = torch.zeros(G * gi * gj * k[0] * k[1] + 64, dtype=torch.float32, device=device)
@@ -1041,7 +1143,7 @@ def wgrad_split(n: int, h: int, w: int, p: V, q: V, parts, k: Tuple[int, int], p
     d = L.WgradDesc(N=n, PH=h, PW=w, PC=p.c, ldp=p.ld, QH=h, QW=w, QC=q.c, ldq=q.ld, kh=k[0], kw=k[1], stride=1, pad=pad,
                     gI=p.c, gJ=q.c, accumulate=1, algo=_wa(0))
     if AUTOTUNE:
-        key = ("ws", n, h, w, p.c, p.ld, q.c, q.ld, k, pad) + ((1,) if MATRIX_BF16X3 else ())
+        key = ("ws", n, h, w, p.c, p.ld, q.c, q.ld, k, pad) + _mk()
         algo = _algo_cache.get(key)
         if algo is None:
             tmp = torch.zeros(p.c * q.c * k[0] * k[1], dtype=torch.float32, device=device)
@@ -1303,7 +1405,7 @@ def wgrad_multi(n: int, ph: int, pw: int, qh: int, qw: int, ps, qs, gs, gi: int,
                     gI=gi, gJ=gj, accumulate=1, algo=_wa(0))
     pa, qa, ga = (C.c_void_p * G)(*[v.ptr for v in ps]), (C.c_void_p * G)(*[v.ptr for v in qs]), (C.c_void_p * G)(*gs)
     if AUTOTUNE:
-        key = ("wm", G, n, ph, pw, pc, p0.ld, qh, qw, qc, q0.ld, k, stride, pad, gi, gj) + ((1,) if MATRIX_BF16X3 else ())
+        key = ("wm", G, n, ph, pw, pc, p0.ld, qh, qw, qc, q0.ld, k, stride, pad, gi, gj) + _mk()
         algo = _algo_cache.get(key)
         if algo is None:
             tmp = torch.zeros(G * gi * gj * k[0] * k[1] + 64, dtype=torch.float32, device=device)

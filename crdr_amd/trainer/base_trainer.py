@@ -45,9 +45,11 @@ class BaseTrainer:
         # `precision: bf16x3` (opt-in, default fp32): conv / weight-gradient products of the TRAINING STEP run as split-bf16
         # triples on the bf16 matrix path (include/crdr_hip.h, CRDR_CONV_BF16X3); validation, the codec and all parity claims
         # stay exact fp32.  The reference's own GPU convolutions run TF32 (base_trainer.py:20 + torch 1.12 defaults).
+        # `precision: bf16x6` (opt-in): the fp32-EQUIVALENT split (three exact bf16 pieces per operand, six products, CRDR_CONV_BF16X6) in the direct
+        # kernels of the training step; held to the fp32 parity gates (tests/test_gpu_bf16x6.py).
         self.precision = str(opt.get("precision", "fp32"))
-        if self.precision not in ("fp32", "bf16x3"):
-            raise ValueError(f'precision: "{self.precision}" (fp32 or bf16x3)')
+        if self.precision not in ("fp32", "bf16x3", "bf16x6"):
+            raise ValueError(f'precision: "{self.precision}" (fp32, bf16x3 or bf16x6)')
         self.graph_warmup = int(opt.get("hip_graph_warmup", 2))  # eager iterations per graph key before capturing
         self._warm = {}
         self._real_static = None
@@ -254,8 +256,8 @@ class _TrainerStepScope:
         from crdr_amd.hip import ops as _ops
         self.prev = _ops.WGRAD_DEFER
         _ops.WGRAD_DEFER = self.tr._deferred
-        self.prev_mm = _ops.MATRIX_BF16X3
-        _ops.MATRIX_BF16X3 = self.tr.precision == "bf16x3"
+        self.prev_mm = (_ops.MATRIX_BF16X3, _ops.MATRIX_BF16X6)
+        _ops.MATRIX_BF16X3, _ops.MATRIX_BF16X6 = self.tr.precision == "bf16x3", self.tr.precision == "bf16x6"
         self.inner.__enter__()
         return self
 
@@ -267,4 +269,4 @@ class _TrainerStepScope:
             if a[0] is not None and _ops.WGRAD_DEFER is not None:
                 _ops.WGRAD_DEFER.jobs, _ops.WGRAD_DEFER.off = [], 0  # an exception left reductions behind: drop them
             _ops.WGRAD_DEFER = self.prev
-            _ops.MATRIX_BF16X3 = self.prev_mm
+            _ops.MATRIX_BF16X3, _ops.MATRIX_BF16X6 = self.prev_mm

@@ -24,6 +24,7 @@ class SegmentGraphs:
         self.enabled = enabled and torch.cuda.is_available()
         self._graphs: Dict[Hashable, torch.cuda.CUDAGraph] = {}
         self._outs: Dict[Hashable, object] = {}
+        self._hooks: Dict[Hashable, list] = {}
         self._pool = None
         self._stream = torch.cuda.Stream() if self.enabled else None
 
@@ -42,6 +43,7 @@ class SegmentGraphs:
         if not self.enabled:
             return fn()
         g = self._graphs.get(key)
+        fresh = False
         if g is None:
             g = torch.cuda.CUDAGraph()
             ops.reserve_workspace(torch.cuda.current_device(), self._stream)
@@ -54,14 +56,23 @@ class SegmentGraphs:
             dbg = os.environ.get("CRDR_DEBUG_DIST", "0") == "1"
             if dbg:
                 print(f"[graphs] capture begin {key} stream={self._stream.cuda_stream:#x}", flush=True)
-            with torch.cuda.graph(g, pool=self._pool, stream=self._stream, capture_error_mode=mode):
-                out = fn()
+            ops.REPLAY_HOOKS = hooks = []
+            try:
+                with torch.cuda.graph(g, pool=self._pool, stream=self._stream, capture_error_mode=mode):
+                    out = fn()
+            finally:
+                ops.REPLAY_HOOKS = None
+            self._hooks[key] = hooks
+            fresh = True
             if dbg:
                 print(f"[graphs] capture end {key}", flush=True)
             self._pool = g.pool()
             self._graphs[key] = g
             self._outs[key] = out
         g.replay()
+        if not fresh:   # host-side bookkeeping of the code the graph replaced (ops.on_replay): on the capture pass that code itself ran
+            for h in self._hooks.get(key, ()):
+                h()
         return self._outs[key]
 
     def __len__(self):

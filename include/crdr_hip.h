@@ -79,6 +79,11 @@ int crdr_profile_read(int kind, double* flops, double* ms, long long* launches);
                                 * 3/16 of the exact-fp32 MFMA cost.  Off = exact fp32 (the default, the codec path, every parity claim).
                                 * The reference's own GPU convolutions run TF32 (base_trainer.py:20 + torch 1.12 defaults), a coarser
                                 * format than this.  Ignored by the streaming 1x1 kernel and by RGB-input (tap-major) layers. */
+#define CRDR_CONV_BF16X6 32768 /* opt-in fp32-EQUIVALENT products on the bf16 matrix path: operands split exactly into three bf16 pieces
+                                * (hi + mid + lo = x: 3 x 8 bits of the 24-bit significand), a b evaluated as the six products of weight >= 2^-16
+                                * (am bm, al bh, ah bl, am bh, ah bm, ah bh, fp32 accumulate, small terms first); dropped terms <= 2^-23 |a b|, one
+                                * fp32 rounding.  3/8 of the exact-fp32 MFMA time.  Exclusive with CRDR_CONV_BF16X3.  The Winograd kernels and the
+                                * RGB-input (tap-major) layers ignore it and stay on the exact fp32 instruction. */
 #define CRDR_CONV_NOSPLIT 8192 /* plan without split-K (the caller's workspace cannot hold the zeroed tickets, see CRDR_CONV_TICKETS) */
 
 typedef struct crdr_conv_desc {
@@ -237,6 +242,8 @@ typedef struct crdr_wgrad_desc {
                        * bit 16 (CRDR_WGRAD_BF16X3): split-bf16 products, see CRDR_CONV_BF16X3 */
 } crdr_wgrad_desc;
 #define CRDR_WGRAD_BF16X3 (1 << 16)
+#define CRDR_WGRAD_BF16X6 (1 << 17) /* fp32-equivalent split-bf16 products (see CRDR_CONV_BF16X6) in the direct weight-gradient kernels; the Winograd
+                                     * slab kernels ignore it */
 /* number of forced configurations; the LAST one (index crdr_conv2d_wgrad_num_configs() - 1) is the Winograd F(3x3, 2x2) slab kernel
  * (csrc/wino_wgrad.hip: 16 products per 2x2 tile of P and tap set instead of 36; same slabs, same deferred reduce), accepted for
  * kh = kw = 3, stride 1, QC > 4, exact fp32; its split bits divide the strips of 8 tiles instead of the 32-pixel tiles */

@@ -46,13 +46,54 @@ def convT(sd: SD, name: str, x, stride=2, pad=2, out_pad=1):
     return F.conv_transpose2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=stride, padding=pad, output_padding=out_pad)
 
 
+# ReLU with the masks of ANOTHER implementation imposed (tests only: the deterministic gate on the gradients upstream of the quantiser; the
+# sites are every ReLU of the generator -- analysis, hyper-analysis, hyper-synthesis, context model, synthesis: a flip anywhere on the way back
+# from the loss reaches the analysis transform's gradients).
+# Two correct fp32 implementations differ by summation-order noise; a pre-activation inside that noise band around zero lands on the other
+# side of it, and in the backward pass each such element adds a finite rank-one term to the weight gradients above it
+# (tests/test_conditioning.py).  As with the rounding decisions (forced_round), the oracle can adopt the device's decision -- relu(t) := t * mask
+# -- but ONLY where |t| is within MASK_WINDOW of the layer's largest pre-activation; disagreements outside the window are counted and fail
+# the test (check_imposed), as does adopting more than MASK_FRACTION of the elements.
+MASK_WINDOW = 1e-4
+MASK_FRACTION = 1e-5
+RELU_IMPOSE = None   # {"masks": {conv name: bool tensor}, "report": {...}} while generator_forward(impose=...) runs its analysis transforms
+
+
+def relu(t, site: str):
+    imp = RELU_IMPOSE
+    if imp is None or not t.requires_grad or site not in imp["masks"]:
+        return F.relu(t)
+    m = imp["masks"][site].to(t.device)
+    assert m.shape == t.shape, (site, m.shape, t.shape)
+    td = t.detach()
+    diff = (td > 0) != m
+    r = imp["report"]
+    r["elements"] = r.get("elements", 0) + t.numel()
+    r["sites"] = r.get("sites", 0) + 1
+    nflip = int(diff.sum())
+    if nflip:
+        scale = float(td.abs().max())
+        mag = td.abs()[diff]
+        r["flipped"] = r.get("flipped", 0) + nflip
+        r["outside"] = r.get("outside", 0) + int((mag > MASK_WINDOW * scale).sum())
+        r["worst"] = max(r.get("worst", 0.0), float(mag.max()) / scale)
+    return t * m.to(t.dtype)
+
+
+def check_imposed(report) -> None:
+    """every imposed site was visited, no adopted mask element outside the window, and the adopted ones are the rare boundary cases"""
+    assert report.get("sites", 0) > 0, report
+    assert report.get("outside", 0) == 0, report
+    assert report.get("flipped", 0) <= max(2, int(MASK_FRACTION * report.get("elements", 0))), report
+
+
 def bottleneck(sd: SD, p: str, x, cond=None):
     """x + 1x1(relu(3x3(relu(1x1 x)))) -- elic_layers.py:23-36; with cond the beta projections are added after each
     ReLU and after the last 1x1 (elic_interpca_beta_cond_autoencoder.py:56-66)."""
-    y = F.relu(conv(sd, p + ".conv.0", x))
+    y = relu(conv(sd, p + ".conv.0", x), p + ".conv.0")   # (with cond the product keeps relu(.) + proj: its mask is taken before the add too)
     if cond is not None:
         y = y + conv(sd, p + ".proj_1", cond)
-    y = F.relu(conv(sd, p + ".conv.2", y, pad=1))
+    y = relu(conv(sd, p + ".conv.2", y, pad=1), p + ".conv.2")
     if cond is not None:
         y = y + conv(sd, p + ".proj_2", cond)
     y = conv(sd, p + ".conv.4", y)
@@ -68,8 +109,8 @@ def res_blocks(sd: SD, p: str, x, cond=None, n=3):
 
 
 def nlam_res(sd: SD, p: str, x):
-    y = F.relu(conv(sd, p + ".c1", x))
-    y = F.relu(conv(sd, p + ".c2", y, pad=1))
+    y = relu(conv(sd, p + ".c1", x), p + ".c1")
+    y = relu(conv(sd, p + ".c2", y, pad=1), p + ".c2")
     return conv(sd, p + ".c3", y) + x  # cheng_nlam.py:31-46
 
 
@@ -150,23 +191,23 @@ def decoder(sd: SD, y_hat, q: Optional[float] = None, beta: Optional[float] = No
 
 
 def hyper_encoder(sd: SD, y, p: str = "hyperencoder"):
-    x = F.relu(conv(sd, p + ".conv1", y, pad=1))  # minnen20_hyperprior.py:23-27
-    x = F.relu(conv(sd, p + ".conv2", x, stride=2, pad=2))
+    x = relu(conv(sd, p + ".conv1", y, pad=1), p + ".conv1")  # minnen20_hyperprior.py:23-27
+    x = relu(conv(sd, p + ".conv2", x, stride=2, pad=2), p + ".conv2")
     return conv(sd, p + ".conv3", x, stride=2, pad=2)
 
 
 def hyper_decoder(sd: SD, z_hat, p: str = "hyperdecoder"):
     outs = []
     for br in ("hd_mu", "hd_std"):  # minnen20_hyperprior.py:38-57
-        x = F.relu(convT(sd, f"{p}.{br}.conv1", z_hat))
-        x = F.relu(convT(sd, f"{p}.{br}.conv2", x))
+        x = relu(convT(sd, f"{p}.{br}.conv1", z_hat), f"{p}.{br}.conv1")
+        x = relu(convT(sd, f"{p}.{br}.conv2", x), f"{p}.{br}.conv2")
         outs.append(convT(sd, f"{p}.{br}.conv3", x, stride=1, pad=1, out_pad=0))
     return torch.cat(outs, 1)
 
 
 def slice_transform(sd: SD, p: str, x):
-    x = F.relu(conv(sd, p + ".model.0", x, pad=2))  # minnen20_charm_context_model.py:26-38
-    x = F.relu(conv(sd, p + ".model.2", x, pad=2))
+    x = relu(conv(sd, p + ".model.0", x, pad=2), p + ".model.0")  # minnen20_charm_context_model.py:26-38
+    x = relu(conv(sd, p + ".model.2", x, pad=2), p + ".model.2")
     return conv(sd, p + ".model.4", x, pad=1)
 
 
@@ -398,11 +439,21 @@ def charm_forward(sd: SD, y, hyper_out, noise=None, p: str = "context_model", nu
 
 
 def generator_forward(sd: SD, x, q: Optional[float], beta: Optional[float], noise_y=None, noise_z=None, is_train=True, diag=None,
-                      forced=None, report=None):
+                      forced=None, report=None, impose=None):
     # forced = {"z": integer symbols [N,192,h,w], "y": list of 10 integer-symbol tensors} from another implementation
     """{HyperpriorCharmModel, BetaCondInterpCaHyperpriorCharmModel}.forward + get_rate_summary_dict
     (hyperprior_charm_model.py:41-79; beta_cond_interpca_hyperprior_charm_model.py:34-78; hyperprior_model.py:60-85).
     q None -> stage-1 model (no InterpCA, no beta)."""
+    # impose = {"masks": {conv name: mask}, "report": {}}: the ReLU masks of another implementation for every ReLU of this pass (see relu())
+    global RELU_IMPOSE
+    RELU_IMPOSE = impose
+    try:
+        return _generator_forward(sd, x, q, beta, noise_y, noise_z, is_train, diag, forced, report)
+    finally:
+        RELU_IMPOSE = None
+
+
+def _generator_forward(sd: SD, x, q, beta, noise_y, noise_z, is_train, diag, forced, report):
     n, _, H, W = x.shape
     y = encoder(sd, x, q)
     z = hyper_encoder(sd, y)
@@ -528,10 +579,10 @@ STAGE1 = dict(lambda_a=0.05, lambda_b=2 ** -6, target=1.5, w_mse=150.0, w_lpips=
 
 
 def stage3_g_losses(sd_g: SD, sd_d: SD, sd_lpips: SD, real, q: int, beta: float, noise_y, noise_z, hr_noise=None, cfg=STAGE3,
-                    forced=None, hr_forced=None, report=None):
+                    forced=None, hr_forced=None, report=None, impose=None):
     """Generator phase of MultirateBetaCondHrrGanRateDistortionTrainer.optimize_parameters
     (multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:19-64). Returns (loss dict, generator outputs)."""
-    out = generator_forward(sd_g, real, float(q), beta, noise_y, noise_z, forced=forced, report=report)
+    out = generator_forward(sd_g, real, float(q), beta, noise_y, noise_z, forced=forced, report=report, impose=impose)
     fake = out["fake_images"]
     if q + 1 > cfg["rate_level"] - 1:
         rel = real
@@ -565,9 +616,9 @@ def stage3_d_losses(sd_d: SD, real, fake, q: int):
     return {"d_real": l_real, "d_fake": l_fake, "d_total": l_real + l_fake}
 
 
-def stage1_losses(sd_g: SD, sd_lpips: SD, real, noise_y, noise_z, cfg=STAGE1, forced=None, report=None):
+def stage1_losses(sd_g: SD, sd_lpips: SD, real, noise_y, noise_z, cfg=STAGE1, forced=None, report=None, impose=None):
     """RateDistortionTrainer.optimize_parameters loss assembly (rate_distortion_trainer.py:57-75)."""
-    out = generator_forward(sd_g, real, None, None, noise_y, noise_z, forced=forced, report=report)
+    out = generator_forward(sd_g, real, None, None, noise_y, noise_z, forced=forced, report=report, impose=impose)
     losses = {
         "distortion": mse_loss(real, out["fake_images"], cfg["w_mse"]),
         "rate": rate_loss(out["bpp"], out["qbpp"], cfg["lambda_a"], cfg["lambda_b"], cfg["target"]),

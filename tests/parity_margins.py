@@ -11,8 +11,8 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMITTED = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_parity_margins.json") for r in (5, 4, 3)) if os.path.exists(p)),
-                 os.path.join(ROOT, "profiles", "r5_parity_margins.json"))   # the newest committed measurement
+COMMITTED = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_parity_margins.json") for r in (6, 5, 4, 3)) if os.path.exists(p)),
+                 os.path.join(ROOT, "profiles", "r6_parity_margins.json"))   # the newest committed measurement
 FACTOR = 3.0
 FLOOR = 1e-6   # a few fp32 ulps: comparisons that measured ~0 (bit-equal on the day) still get this much
 
@@ -52,6 +52,14 @@ def record_forced(report: dict) -> None:
             f[k] = max(f.get(k, 0), int(report[k]))
     if f.get("symbols"):
         f["adopted_fraction"] = f.get("adopted", 0) / f["symbols"]
+
+
+def record_imposed(report: dict) -> None:
+    """ReLU-mask decisions the oracle adopted from the device inside oracle.MASK_WINDOW (the deterministic upstream-gradient gate)"""
+    t = _measured.setdefault(_test_id(), {})
+    t["imposed_relu_masks"] = {k: (float(v) if isinstance(v, float) else int(v)) for k, v in report.items()}
+    if report.get("elements"):
+        t["imposed_relu_masks"]["flipped_fraction"] = report.get("flipped", 0) / report["elements"]
 
 
 def tolerance(group: str, cap: float) -> float:

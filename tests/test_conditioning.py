@@ -149,3 +149,58 @@ def test_the_flipped_masks_carry_it_not_the_noise_itself(reference):
     e_off = max(_by_module(gn, g0)[k] for k in UP)
     print(f"upstream discrepancy at noise 6e-6 with the rate term off: {e_off:.2e}")
     assert 0.3 * e_free < e_off < 3.0 * e_free, (e_off, e_free)
+
+
+def test_imposed_masks_are_adopted_only_inside_the_window(reference):
+    """oracle.relu / generator_forward(impose=...) -- the mechanism behind the deterministic upstream-gradient gate of tests/test_gpu_step.py.
+    (a) the oracle's OWN masks imposed change nothing and adopt nothing; (b) a mask that disagrees where the pre-activation is far from zero is
+    counted as `outside` and fails check_imposed; (c) a disagreement inside the window is adopted and moves the gradients."""
+    from oracle import crdr_oracle as O
+    shapes = reference[0]
+    sd = {k: seeded_tensor(k, s).double().requires_grad_(True) for k, s in shapes.items()}
+    x = seeded_input("image", (1, 3, 64, 64)).double()
+    ny, nz = seeded_input("noise.y", (1, 320, 4, 4), 0.5).double(), seeded_input("noise.z", (1, 192, 1, 1), 0.5).double()
+    own, pre = {}, {}
+    relu0 = O.relu
+
+    def spy(t, site):
+        if t.requires_grad:
+            own[site], pre[site] = (t.detach() > 0), t.detach().clone()
+        return relu0(t, site)
+    O.relu = spy
+    try:
+        out0 = O.generator_forward(sd, x, None, None, ny, nz)
+    finally:
+        O.relu = relu0
+    assert len(own) == 150, len(own)
+    (out0["fake_images"].square().mean() + out0["bpp"].mean()).backward()
+    g0 = {k: v.grad.clone() for k, v in sd.items() if v.grad is not None}
+
+    def run(masks):
+        for v in sd.values():
+            v.grad = None
+        imp = {"masks": masks, "report": {}}
+        out = O.generator_forward(sd, x, None, None, ny, nz, impose=imp)
+        (out["fake_images"].square().mean() + out["bpp"].mean()).backward()
+        return {k: v.grad.clone() for k, v in sd.items() if v.grad is not None}, imp["report"]
+    g1, rep = run(own)
+    O.check_imposed(rep)
+    assert rep["sites"] == 150 and rep.get("flipped", 0) == 0 and all(torch.equal(g0[k], g1[k]) for k in g0), rep
+    # (b) far from zero
+    site = "encoder.block1.block0.conv.0"
+    far = {k: v.clone() for k, v in own.items()}
+    idx = pre[site].abs().flatten().argmax()
+    far[site].view(-1)[idx] = ~far[site].view(-1)[idx]
+    _, rep = run(far)
+    assert rep["flipped"] >= 1 and rep["outside"] >= 1, rep   # (the forward goes on from the wrong activation: later sites disagree as well)
+    with pytest.raises(AssertionError):
+        O.check_imposed(rep)
+    # (c) inside the window: the element closest to zero
+    near = {k: v.clone() for k, v in own.items()}
+    idx = pre[site].abs().flatten().argmin()
+    assert float(pre[site].abs().flatten()[idx]) <= O.MASK_WINDOW * float(pre[site].abs().max())
+    near[site].view(-1)[idx] = ~near[site].view(-1)[idx]
+    g2, rep = run(near)
+    O.check_imposed(rep)
+    assert 1 <= rep["flipped"] <= 4 and rep.get("outside", 0) == 0, rep
+    assert any(not torch.equal(g0[k], g2[k]) for k in g0 if k.startswith("encoder.conv1"))

@@ -32,9 +32,10 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-def close(got, ref, what, rtol=2e-4):
-    """max |got - ref| <= rtol x max |ref|; the measured ratio is recorded (tests/parity_margins.py) and, once a measurement is
-    committed, the gate tightens to 3 x it."""
+def close(got, ref, what, rtol=2e-5):
+    """max |got - ref| <= rtol x max |ref| (default: SURVEY 8d gate (1) with a factor of two, the same figure tests/test_gpu_conv.py holds the
+    kernels to; every call of this file measured <= 3.3e-6 in profiles/r5_parity_margins.json); the measured ratio is recorded
+    (tests/parity_margins.py) and, once a measurement is committed, the gate tightens to 3 x it."""
     from tests import parity_margins as PM
     got, ref = torch.as_tensor(got).detach().cpu().double(), torch.as_tensor(ref).detach().cpu().double()
     got, ref = got.reshape(ref.shape) if got.numel() == ref.numel() else got, ref

@@ -120,6 +120,66 @@ def test_stage3_step():
     _stage3_step()
 
 
+@pytest.mark.parametrize("q,beta", [(0, 5.12), (4, 1.28)], ids=["q0", "q4"])
+def test_stage3_step_over_the_rate_index(q, beta):
+    """The trainer's branches on the rate index against the oracle's step (the benchmark cycles all five; q = 2 is test_stage3_step):
+    q = 4 takes the REAL image as the relativistic reference (multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:32-34: no high-rate
+    pass), q = 0 / 4 train sub-discriminators 0 / 4 with lambda_A[q] and their own Adam partition; the other sub-discriminators must come
+    out of the step untouched."""
+    _stage3_step(q=q, beta=beta)
+
+
+def test_stage3_two_iterations_partitioned_d_adam_matches_torch():
+    """Two real iterations at q = 1 then q = 3: the discriminator's flat, partitioned Adam against torch.optim.Adam fed the product's own
+    captured gradients with `grad = None` for the sub-discriminators a step did not run (module_list_discriminator.py:26-30 +
+    torch.optim semantics): sub-D 1 and 3 each moved once with THEIR OWN step count 1 (bias correction of a first step, not of a second),
+    sub-Ds 0 / 2 / 4 are bit-identical to their initial values and have no Adam state."""
+    from crdr_amd.trainer import build_trainer
+    tr = build_trainer(_opt(3, 2, 64))
+    _seed_params(tr.comp_model, "")
+    sd_d = _seed_params(tr.discriminator, "")
+    _seed_params(tr.perceptual_loss.lpips, "lpips.")
+    tr.loss_huge_threshold = float("inf")
+    ref = {n: torch.nn.Parameter(t.clone()) for n, t in sd_d.items()}
+    topt = torch.optim.Adam(list(ref.values()), lr=1e-4)
+    d_step = tr.d_optimizer.step
+    grads = []
+
+    def wrapped(*a, **k):
+        grads.append({n: p.grad.detach().cpu().clone() for n, p in tr.discriminator.named_parameters()})
+        return d_step(*a, **k)
+    tr.d_optimizer.step = wrapped
+    x = seeded_input("image", (2, 3, 64, 64))
+    for it, q in enumerate((1, 3), start=1):
+        log = tr.optimize_parameters(it, {"real_images": x.to(dev()), "rate_ind": torch.tensor([q]), "beta": 2.56})
+        assert log is not None
+        topt.zero_grad(set_to_none=True)
+        for n, r in ref.items():
+            if n.startswith(f"subD_list.{q}."):
+                r.grad = grads[-1][n].clone()
+                assert float(r.grad.abs().max()) > 0 or n.endswith("16.bias"), n
+        topt.step()
+    for n, p in tr.discriminator.named_parameters():
+        k = int(n.split(".")[1])
+        if k in (1, 3):
+            close(p, ref[n], f"partitioned D Adam after two iterations: {n}", 2e-6)
+            assert not torch.equal(p.detach().cpu(), sd_d[n]) or n.endswith("16.bias"), n
+        else:
+            assert torch.equal(p.detach().cpu(), sd_d[n]), f"{n}: a sub-discriminator that did not run was touched"
+    st = tr.d_optimizer.state_dict()["state"]
+    names = [n for n, _ in tr.discriminator.named_parameters()]
+    for i, n in enumerate(names):
+        k = int(n.split(".")[1])
+        step = int(st[i]["step"]) if i in st and "step" in st[i] else 0
+        assert step == (1 if k in (1, 3) else 0), (n, step)
+
+
+def test_stage3_step_under_imposed_masks():
+    """the deterministic form of the upstream-gradient gate at the small size: the oracle back-propagates through the ReLU masks the product
+    exported (all 150 generator sites, adopted only inside oracle.MASK_WINDOW), analysis / hyper-analysis gradients held to 5e-4"""
+    _stage3_step(impose_masks=True)
+
+
 def test_stage3_step_winograd():
     """the stage-3 step with every 3x3 stride-1 convolution / input gradient (generator bottlenecks, NLAM, discriminator) on the
     Winograd kernel: same oracle, same gates"""
@@ -154,20 +214,67 @@ def test_stage3_step_128_winograd_f4x4():
 # same discrepancy with the rate term off, so that part is withdrawn.)  Round 5's interpolation points bring the F(4x4) kernels' noise to
 # ~1.5e-6 (tests/test_gpu_wino.py), hence the tighter cap.
 UPSTREAM_TUNED_TOL = 8e-3   # (round 4: 2e-2 for the F(4x4) kernels at the points 0, +-1, +-2; round 5's points carry ~1/4 of that forward noise)
+# Round 6: the figure above is a draw from a heavy-tailed distribution (which masks flip depends on the plan set: two re-tunes on the same
+# kernels measured 9.4e-3 and 9.8e-3), so a cap on it tested luck and choosing the database that passed was selection on the test.  The gate
+# is now DETERMINISTIC: the product exports the ReLU masks its generator's backward used (ops.RELU_MASK_SINK: all 150 sites -- a flip in the
+# hyper-synthesis or the context model reaches the hyper-analysis gradients just as one in the analysis transform does), the oracle
+# back-propagates through THOSE masks -- adopted only where the pre-activation is within oracle.MASK_WINDOW of zero, at most oracle.MASK_FRACTION of the elements,
+# oracle.check_imposed -- exactly as it already adopts the device's rounding decisions, and the upstream gradients are held to the bound
+# below for ANY plan set (the shipped database and the rejected re-tune kept under tools/data/).  The un-imposed figure stays a recorded
+# margin (tools/parity_margins.sh), not a criterion.
+UPSTREAM_IMPOSED_TOL = 5e-4
 
 
 def _upstream(name: str) -> bool:
     return name.split(".")[0] in ("encoder", "hyperencoder")
 
 
+N_GENERATOR_RELUS = 150   # analysis 42 (3 x 6 bottleneck + 2 x 12 NLAM) + hyper-analysis 2 + hyper-synthesis 4 + context model 30 x 2 + synthesis 42
+
+
+class _MaskSink:
+    """collects, while active, the ReLU masks the product's generator saved for its backward, keyed by the oracle's conv names"""
+
+    def __init__(self, model):
+        self.names = {p.data_ptr(): n[:-len(".weight")] for n, p in model.named_parameters() if n.endswith(".weight")}
+        self.masks = {}
+
+    def __call__(self, weight, out, offset):
+        n = self.names.get(weight.data_ptr())
+        if n is not None and n not in self.masks:
+            a = out.detach()
+            if offset is not None:   # a beta vector was added after the ReLU: the backward compares act - vector (CRDR_EPI_MASKOFF), in fp32
+                a = a - offset.detach().reshape(1, -1, 1, 1)
+            self.masks[n] = (a > 0).cpu()
+
+    def __enter__(self):
+        from crdr_amd.hip import ops
+        ops.RELU_MASK_SINK = self
+        return self
+
+    def __exit__(self, *exc):
+        from crdr_amd.hip import ops
+        ops.RELU_MASK_SINK = None
+
+
+REJECTED_RETUNE = os.path.join(ROOT, "tools", "data", "tune_r5_rejected_c.json")   # the round-5 candidate that measured 9.8e-3 un-imposed
+
+
 class _ShippedPlans:
-    """what bench.py and scripts/train.py run: ops.AUTOTUNE on with the shipped perf database (crdr_amd/hip/tune_gfx950.json)"""
+    """what bench.py and scripts/train.py run: ops.AUTOTUNE on with the shipped perf database (crdr_amd/hip/tune_gfx950.json), or another
+    plan set (`db`: a database kept under tools/data/)"""
+
+    def __init__(self, db=None):
+        self.db = db
 
     def __enter__(self):
         from crdr_amd.hip import ops
         self.ops, self.keep = ops, (ops.AUTOTUNE, dict(ops._algo_cache))
         ops._algo_cache.clear()
-        assert ops.load_tune_cache(ops.DEFAULT_TUNE_DB) > 0, "the shipped perf database is not of this library build"
+        if self.db is not None:
+            assert ops.load_tune_cache(self.db, ignore_signature=True) > 0, self.db
+        else:
+            assert ops.load_tune_cache(ops.DEFAULT_TUNE_DB) > 0, "the shipped perf database is not of this library build"
         ops.AUTOTUNE = True
         self.log0 = len(ops.TUNE_LOG)
         return self
@@ -188,7 +295,7 @@ def test_stage3_step_256_tuned_vs_oracle():
     (multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:13-114), same forced-decision windows as the 64x64 test."""
     from tests import parity_margins as PM
     with _ShippedPlans() as sp:
-        _stage3_step(bs=16, size=256, upstream_tol=UPSTREAM_TUNED_TOL)
+        _stage3_step(bs=16, size=256, impose_masks=True)
         new = sp.tuned_here()
     PM.record("plans", "shapes tuned on the spot (not in the shipped database)", float(len(new)))
     assert len(new) <= 8, new
@@ -198,16 +305,28 @@ def test_stage1_step_256_tuned_vs_oracle():
     """BASELINE config #2 (bs 8, 256x256) under the shipped plans against the oracle's stage-1 step (rate_distortion_trainer.py:57-101)"""
     from tests import parity_margins as PM
     with _ShippedPlans() as sp:
-        _stage1_step(bs=8, size=256, upstream_tol=UPSTREAM_TUNED_TOL)
+        _stage1_step(bs=8, size=256, impose_masks=True)
         new = sp.tuned_here()
     PM.record("plans", "shapes tuned on the spot (not in the shipped database)", float(len(new)))
     assert len(new) <= 8, new
 
 
-def _stage3_step(bs: int = 2, size: int = 64, upstream_tol: float = 0.0):
+def test_stage1_step_256_rejected_retune_passes_the_deterministic_gate():
+    """The plan set round 5 REJECTED (a re-tune on the same kernels whose un-imposed upstream figure was 9.8e-3 against the 8e-3 cap: 121 of
+    759 entries differ from the shipped set, a dozen small hyper-path layers on the F(4x4) kernels) under the deterministic gate: with the
+    device's ReLU masks imposed its upstream gradients are as close to the oracle's as the shipped set's -- the old failure was the mask
+    lottery, not a kernel.  (If this ever fails with the masks imposed, that IS a kernel bug.)"""
+    with _ShippedPlans(REJECTED_RETUNE):
+        _stage1_step(bs=8, size=256, impose_masks=True)
+
+
+def _stage3_step(bs: int = 2, size: int = 64, upstream_tol: float = 0.0, q: int = 2, beta: float = 2.56, precision: str = "fp32",
+                 impose_masks: bool = False):
     from oracle import crdr_oracle as O
     from crdr_amd.trainer import build_trainer
-    tr = build_trainer(_opt(3, bs, size))
+    opt = _opt(3, bs, size)
+    opt["precision"] = precision
+    tr = build_trainer(opt)
     # the optimisers flattened the parameters on the device: seed in place (views are preserved)
     sd_g = _seed_params(tr.comp_model, "")
     sd_d = _seed_params(tr.discriminator, "")
@@ -215,7 +334,7 @@ def _stage3_step(bs: int = 2, size: int = 64, upstream_tol: float = 0.0):
     x = seeded_input("image", (bs, 3, size, size))
     ny = seeded_input("noise.y", (bs, 320, size // 16, size // 16), 0.5)
     nz = seeded_input("noise.z", (bs, 192, size // 64, size // 64), 0.5)
-    q, beta = 2, 2.56
+    has_hr = q + 1 <= 4   # (the top rate compares against the real image: no high-rate pass)
 
     captured = {}
     g_step, d_step, a_step = tr.g_optimizer.step, tr.d_optimizer.step, tr.aux_optimizer.step
@@ -249,16 +368,25 @@ def _stage3_step(bs: int = 2, size: int = 64, upstream_tol: float = 0.0):
         z_hats.append(o["z_hat"].detach().cpu())
         return o
     tr.comp_model.reconstruct = spy_hr
-    log = tr.optimize_parameters(1, data)
+    with _MaskSink(tr.comp_model) as sink:
+        log = tr.optimize_parameters(1, data)
     assert log is not None
+    impose = {"masks": sink.masks, "report": {}} if impose_masks else None
+    if impose_masks:
+        assert len(sink.masks) == N_GENERATOR_RELUS, sorted(sink.masks)
+        upstream_tol = UPSTREAM_IMPOSED_TOL
     syms = [t.cpu() for t in tr.comp_model.context_model.record_symbols]
-    assert len(syms) == 20 and len(z_hats) == 2
+    assert len(syms) == (20 if has_hr else 10) and len(z_hats) == (2 if has_hr else 1)
     med = sd_g["entropy_model_z.quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
     forced = {"y": syms[:10], "z": torch.round(z_hats[0] - med)}
-    hr_forced = {"y": syms[10:], "z": torch.round(z_hats[1] - med)}
+    hr_forced = {"y": syms[10:], "z": torch.round(z_hats[1] - med)} if has_hr else None
     g_ref, d_ref, rep = grad_sd(sd_g), grad_sd(sd_d), {}
-    losses, out = O.stage3_g_losses(g_ref, d_ref, sd_l, x, q, beta, ny, nz, forced=forced, hr_forced=hr_forced, report=rep)
+    losses, out = O.stage3_g_losses(g_ref, d_ref, sd_l, x, q, beta, ny, nz, forced=forced, hr_forced=hr_forced, report=rep, impose=impose)
     O.check_forced(rep, rep.get("symbols", 0))
+    if impose is not None:
+        O.check_imposed(impose["report"])
+        from tests import parity_margins as PM_
+        PM_.record_imposed(impose["report"])
     losses["total"].backward()
     d_ref = grad_sd(sd_g), grad_sd(sd_d)
     d_ref = d_ref[1]
@@ -296,6 +424,8 @@ def _stage3_step(bs: int = 2, size: int = 64, upstream_tol: float = 0.0):
         assert not bad, f"{what}: {bad[:8]} ({len(bad)})"
     cmp(captured["g"], g_ref, "G grads", only=lambda n: not n.endswith(".quantiles"))
     cmp(captured["d"], d_ref, "D grads")
+    ran = [n for n, r in d_ref.items() if r.grad is not None and float(r.grad.abs().max()) > 1e-7]
+    assert ran and all(n.startswith(f"subD_list.{q}.") for n in ran), ran[:3]
     cmp(captured["aux"], aux_ref, "aux grads", only=lambda n: n.endswith(".quantiles"))
     # the generator update really happened, with the clipped step size bounded by lr
     moved = max((p.detach() - before[n]).abs().max().item() for n, p in tr.comp_model.named_parameters())
@@ -306,10 +436,12 @@ def test_stage1_step():
     _stage1_step()
 
 
-def _stage1_step(bs: int = 2, size: int = 64, upstream_tol: float = 0.0):
+def _stage1_step(bs: int = 2, size: int = 64, upstream_tol: float = 0.0, precision: str = "fp32", impose_masks: bool = False):
     from oracle import crdr_oracle as O
     from crdr_amd.trainer import build_trainer
-    tr = build_trainer(_opt(1, bs, size))
+    opt = _opt(1, bs, size)
+    opt["precision"] = precision
+    tr = build_trainer(opt)
     sd_g = _seed_params(tr.comp_model, "")
     sd_l = _seed_params(tr.perceptual_loss.lpips, "lpips.")
     x = seeded_input("image", (bs, 3, size, size))
@@ -332,12 +464,21 @@ def _stage1_step(bs: int = 2, size: int = 64, upstream_tol: float = 0.0):
         captured.update({n: (p.grad.clone() if p.grad is not None else None) for n, p in tr.comp_model.named_parameters()})
         return g_step(*a, **k)
     tr.g_optimizer.step = wrapped
-    log = tr.optimize_parameters(1, {"real_images": x.to(dev()), "noise": {"y": ny.to(dev()), "z": nz.to(dev())}})
+    with _MaskSink(tr.comp_model) as sink:
+        log = tr.optimize_parameters(1, {"real_images": x.to(dev()), "noise": {"y": ny.to(dev()), "z": nz.to(dev())}})
+    impose = {"masks": sink.masks, "report": {}} if impose_masks else None
+    if impose_masks:
+        assert len(sink.masks) == N_GENERATOR_RELUS, sorted(sink.masks)
+        upstream_tol = UPSTREAM_IMPOSED_TOL
     med = sd_g["entropy_model_z.quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
     forced = {"y": [t.cpu() for t in tr.comp_model.context_model.record_symbols], "z": torch.round(z_hats[0] - med)}
     g_ref, rep = grad_sd(sd_g), {}
-    losses, out = O.stage1_losses(g_ref, sd_l, x, ny, nz, forced=forced, report=rep)
+    losses, out = O.stage1_losses(g_ref, sd_l, x, ny, nz, forced=forced, report=rep, impose=impose)
     O.check_forced(rep, rep.get("symbols", 0))
+    if impose is not None:
+        O.check_imposed(impose["report"])
+        from tests import parity_margins as PM_
+        PM_.record_imposed(impose["report"])
     losses["total"].backward()
     for k in ("distortion", "rate", "perceptual"):
         close(log[k], losses[k], f"loss {k}", 3e-4)

@@ -1,4 +1,4 @@
-"""Run one conv shape a few times (for rocprofv3 --pmc). Usage: python3 tools/pmc_one.py CIN H COUT K STRIDE TRANSPOSED [BS] [ALGO]"""
+"""Run one conv shape a few times (for rocprofv3 --pmc). Usage: [CRDR_PRECISION=bf16x6|bf16x3] python3 tools/pmc_one.py CIN H COUT K STRIDE TRANSPOSED [BS] [ALGO]"""
 import os
 import sys
 
@@ -12,6 +12,8 @@ ci, h, co, k, s, tr = [int(v) for v in sys.argv[1:7]]
 bs = int(sys.argv[7]) if len(sys.argv) > 7 else 16
 algo = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 dev = torch.device("cuda:0")
+ops.MATRIX_BF16X6 = os.environ.get("CRDR_PRECISION") == "bf16x6"
+ops.MATRIX_BF16X3 = os.environ.get("CRDR_PRECISION") == "bf16x3"
 p = k // 2
 oh = ops.conv_out_size(h, k, s, p, bool(tr), out_pad=(1 if (tr and s == 2) else 0))
 x = torch.randn(bs, ci, h, h, device=dev)

@@ -63,8 +63,10 @@ def main():
     ap.add_argument("--shapes", default=None)
     ap.add_argument("--dump", action="store_true", help="print every unsplit tile configuration's TFLOP/s (cost-model fitting)")
     ap.add_argument("--bf16x3", action="store_true", help="time the split-bf16 kernels (precision: bf16x3)")
+    ap.add_argument("--bf16x6", action="store_true", help="time the fp32-equivalent split-bf16 kernels (precision: bf16x6)")
     a = ap.parse_args()
     ops.MATRIX_BF16X3 = a.bf16x3
+    ops.MATRIX_BF16X6 = a.bf16x6
     dev = torch.device("cuda:0")
     lib = L.load()
     ncfg = lib.crdr_conv2d_num_configs()
