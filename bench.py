@@ -389,6 +389,9 @@ def main():
                                                       "(timed again: the Winograd kernels are new candidates for them)")
     ap.add_argument("--retune-k1", action="store_true", help="with --retune-k3: time the 1x1 launches again as well")
     ap.add_argument("--bf16x3", action="store_true", help="also time the step with precision: bf16x3 (second line `stage3_bf16x3`) even with --no-secondary")
+    ap.add_argument("--bf16x6", action="store_true", help="also time the step with precision: bf16x6 (line `stage3_bf16x6`: fp32-equivalent split-bf16 products) even with --no-secondary")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6"], help="matrix mode of the MAIN line (database builds of the opt-in modes: "
+                                                                                            "tools/tune_bf16x6.sh); the default and the headline are exact fp32")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying captured HIP graphs")
     ap.add_argument("--profile-steps", type=int, default=5, help="eager steps after the timed region used for the per-kernel roofline")
     a = ap.parse_args()
@@ -423,7 +426,7 @@ def main():
         ops.load_tune_cache(path, only_kinds=tuple(kinds.split(",")), ignore_signature=True)
     if ops.AUTOTUNE and a.retune_k3:
         ops.load_tune_cache(a.retune_k3, ignore_signature=True, skip=lambda key: (3, 3) in key or (5, 5) in key or (a.retune_k1 and (1, 1) in key))   # (conv launches and weight gradients alike)
-    main_run = run_stage(a, a.stage, a.bs, a.steps, a.warmup, a.profile_steps, a.shape_table)
+    main_run = run_stage(a, a.stage, a.bs, a.steps, a.warmup, a.profile_steps, a.shape_table, precision=a.precision)
     tr = main_run.pop("trainer")
     def save_tuning():   # (again at the end: the secondary runs tune their own shapes)
         if rk == 0 and a.save_tune_db:
@@ -441,7 +444,7 @@ def main():
     gflop = GFLOP_PER_IMG_STAGE3 if a.stage == 3 else GFLOP_PER_IMG_STAGE1
     # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over one step (counters cannot
     # be read inside this process): tools/pmc_step.py + tools/pmc_families.py, newest result committed under profiles/
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_nr = None, None, None
     tp = _newest_profile("r*_hbm_families.json")
     if a.stage == 3 and a.bs == 16 and a.size == 256 and tp:
         with open(tp) as f:
@@ -455,6 +458,7 @@ def main():
         else:
             fams_ = doc["families"]
             traffic = round(fams_.get("conv_fwd_dgrad", fams_["igemm_kernel"])["hbm_bytes_per_launch"])
+            traffic_nr = round(fams_["conv_fwd_dgrad_no_rebuild"]["hbm_bytes_per_launch"]) if "conv_fwd_dgrad_no_rebuild" in fams_ else None
             traffic_src = (f"HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from two rocprofv3 --pmc passes over one eager step at q = 2 "
                            f"with this library version ({os.path.relpath(tp, ROOT)})")
     # `achieved` / `frac`: what the matrix cores EXECUTE (a Winograd launch counted with the products it really issues), so that the one-line
@@ -464,7 +468,7 @@ def main():
     roof = {"bound": "mfma", "achieved": ex_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ex_tf / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None,
             "achieved_effective": ig["tflops"] if ig else None, "frac_effective": round(ig["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if ig else None,
-            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic": traffic, "traffic_without_filter_rebuild": traffic_nr, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": round(main_run["alg_bytes_per_igemm_launch"]) if main_run["alg_bytes_per_igemm_launch"] else None,
             "flop_convention": "dense: 2 * Cin * Cout * kh * kw per output pixel (input pixel for transposed convs), zero-padding taps at "
                                "the borders included (5x5 at 16x16: 14 % of the counted taps multiply padding)",
@@ -483,9 +487,13 @@ def main():
                            "frac": round(value / ws * gflop / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}}
     line = {"metric": f"stage-{a.stage} training img/s at {a.size}x{a.size}", "value": round(value, 3), "unit": "img/s",
             "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(main_run["ms_per_step"], 2),
+            "value_convention": ("`value` = images / wall time over the K timed steps with the rate index CYCLED q = step mod 5 (the expectation over the reference's "
+                                 "uniform draw, interpca_hyperprior_model.py:28-29; 4 of 5 steps carry the no-grad high-rate pass, so steps differ by design): "
+                                 + ("K is a whole number of cycles, the mean IS the per-cycle cost" if a.steps % 5 == 0 else f"K = {a.steps} is not a whole number of cycles")
+                                 + "; the median step (`ms_per_step_median`, `value_at_median`) is a q < 4 step and reads slower than the mean"),
             "ms_per_step_median": round(main_run["median_ms"], 2) if main_run["median_ms"] else None,
             "value_at_median": round(ws * a.bs / main_run["median_ms"] * 1e3, 3) if main_run["median_ms"] else None,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "autotune": bool(ops.AUTOTUNE), "hip_graphs": main_run["graphs"], "rccl_ranks": rccl,
             "peak_device_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             "config": {"workload": f"config/crdr_stage_{a.stage}.yaml -b {a.bs}: full GAN step (G + 5x CLIC21GVAE D + LPIPS-Alex, random-init weights), "
@@ -541,6 +549,33 @@ def main():
                 "parity": "tests/test_gpu_bf16x3.py: kernels within 3 * 2^-16 * sum|a||b|, step losses <= 1e-3, gradients <= 5e-3 vs the oracle"}
         except Exception as e:
             line["stage3_bf16x3"] = {"error": repr(e)[:300]}
+    if ws == 1 and a.stage == 3 and (a.bf16x6 or not a.no_secondary):
+        # the fp32-EQUIVALENT split: `precision: bf16x6` (three exact bf16 pieces per operand, six products of weight >= 2^-16, fp32 accumulate:
+        # per-product error ~2^-23, one fp32 rounding) in the direct kernels -- tiled, streaming 1x1, direct weight gradients; the Winograd
+        # kernels stay on the exact fp32 instruction and remain the tuner's choice where they are faster.  Held to the UNCHANGED fp32 parity gates
+        # (tests/test_gpu_bf16x6.py); a second line, the headline stays the exact fp32 instruction.
+        try:
+            tr = None
+            torch.cuda.empty_cache()
+            b6 = run_stage(a, 3, a.bs, a.steps, a.warmup, a.profile_steps, precision="bf16x6")
+            b6.pop("trainer")
+            i6, w6 = b6["igemm"], b6["wgrad"]
+            d6 = (i6.get("direct") or i6) if i6 else None
+            line["stage3_bf16x6"] = {
+                "metric": f"stage-3 training img/s at {a.size}x{a.size}", "value": round(b6["value"], 3), "unit": "img/s",
+                "ms_per_step": round(b6["ms_per_step"], 2), "steps": a.steps, "warmup": a.warmup, "dtype": "bf16x6 (three exact bf16 pieces per fp32 operand, six products, fp32 accumulate)",
+                "config": {"workload": f"config/crdr_stage_3.yaml -b {a.bs} + precision: bf16x6"},
+                "roofline": {"bound": "mfma", "achieved": d6["tflops"] if d6 else None, "peak": round(2500.0 / 6, 1), "unit": "TFLOP/s",
+                             "frac": round(d6["tflops"] / (2500.0 / 6), 4) if d6 else None,
+                             "note": "DIRECT conv forward / input-gradient launches (tiled + streaming 1x1, the ones that run bf16x6), dense fp32-equivalent FLOPs "
+                                     "over HIP-event time; peak = dense bf16 MFMA peak / 6 (six bf16 MFMAs per product term).  The family beside them:",
+                             "family_effective_tflops": i6["tflops"] if i6 else None,
+                             "winograd_f4x4": i6.get("winograd_f4x4") if i6 else None, "direct": d6},
+                "wgrad": {"tflops": w6["tflops"] if w6 else None, "direct": (w6.get("direct") if w6 else None)},
+                "parity": "tests/test_gpu_bf16x6.py: kernels <= 4e-6 of the output scale vs float64 (the exact-fp32 kernels' own worst) and within 2^-21 sum|a||b| "
+                          "elementwise; the full-size stage-3 / stage-1 steps against the oracle at the fp32 gates of tests/test_gpu_step.py"}
+        except Exception as e:
+            line["stage3_bf16x6"] = {"error": repr(e)[:300]}
     if ws == 1 and a.stage == 3 and not a.no_secondary:
         # third line, for the record: the same fp32 step with the Winograd kernels taken out of the tuner's candidates (every conv on
         # the implicit-GEMM / streaming kernels, every weight gradient on the direct slab kernel) -- what the headline would be

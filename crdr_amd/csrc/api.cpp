@@ -67,5 +67,5 @@ extern "C" int crdr_profile_read(int kind, double* flops, double* ms, long long*
 }
 
 extern "C" const char* crdr_last_error(void) { return crdr::g_err; }
-extern "C" int crdr_version(void) { return 500; }
+extern "C" int crdr_version(void) { return 600; }
 extern "C" const char* crdr_arch(void) { return "gfx950"; }

@@ -110,10 +110,21 @@ __device__ __forceinline__ Wino4Tile wino4_tile(const IgemmArgs& p, int vb, int 
   }
   t.gidx = q / T;
   const int r = q - t.gidx * T;
-  t.phase = r % nph;
-  const int r1 = r / nph;
-  const int tn = fstat ? r1 / gx : r1 % gyn;
-  t.patch = fstat ? r1 % gx : r1 / gyn;
+  // filter-stationary: (N tile, phase) outermost -- ONE block of transformed filters (36 positions x K x 64 channels: 2.4 MB at K = 256) stays in
+  // the XCD's L2 while the patches stream past it (round 6; before, the phases of a patch ran back to back and an XCD's 32 concurrent
+  // workgroups cycled through every block of the launch each round: T 256->256 k5 s2 fetched 2.9 GB for 0.34 GB of operands)
+  int tn;
+  if (fstat) {
+    const int combo = r / gx;
+    t.patch = r - combo * gx;
+    tn = combo / nph;
+    t.phase = combo - tn * nph;
+  } else {
+    t.phase = r % nph;
+    const int r1 = r / nph;
+    tn = r1 % gyn;
+    t.patch = r1 / gyn;
+  }
   t.tn = tn;
   if constexpr (GEO == 2) {
     t.n = 2 * t.patch;   // (first image of the pair; wave th works on image n + th)
@@ -1077,9 +1088,14 @@ int wino4_launch(const crdr_conv_desc* d, IgemmArgs a, const IgemmTaps& taps, co
     attr_done.store(true, std::memory_order_release);
   }
   const size_t lds = (size_t)(kLdsFloats4 + 2 * 4 * kBN4 + 4) * sizeof(float);   // (+ the split-K ticket flag)
-  // tile order: filter-stationary where one pass over the transformed filters is more bytes than one pass over the input
+  // tile order by a traffic estimate (each XCD has its own 4 MB L2; an XCD's ~32 concurrent workgroups walk consecutive tiles).  Patch-major: the
+  // input once, but every round of resident workgroups touches every filter block of the launch again on every XCD unless they all fit L2
+  // together.  Filter-stationary: the filters once, the input once per (N tile, phase).
   const double u_bytes = (double)ntile * a.so * a.so * a.kchunks * (kUSlots4 * 16.0), x_bytes = (double)d->N * d->H * d->W * d->C * 4.0;
-  const int gyn_arg = u_bytes > x_bytes ? -ntile : ntile;
+  const double ncombo = (double)ntile * a.so * a.so, rounds = std::max(1.0, (double)total * nsplit / std::max(ncu, 1));
+  const double est_patch = x_bytes + 8.0 * u_bytes * (u_bytes > 3.0e6 ? rounds : 1.0), est_fstat = u_bytes + ncombo * x_bytes;
+  static const int force_order = [] { const char* e = getenv("CRDR_W4_ORDER"); return e ? atoi(e) : -1; }();   // experiments: 0 patch-major, 1 filter-stationary
+  const int gyn_arg = (force_order >= 0 ? force_order == 1 : est_fstat < est_patch) ? -ntile : ntile;
   hipLaunchKernelGGL(kerns[w4_epi_class(a.flags)][nsplit > 1 ? 1 : 0][mode == 4 ? 1 : 0][geo], dim3(std::min(total * nsplit, ncu)), dim3(kNT4), lds, s, a, grp, gx, gyn_arg, G);
   CRDR_CHECK_LAUNCH("wino4_kernel");
   return 0;

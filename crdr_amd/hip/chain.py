@@ -100,6 +100,19 @@ def _nchw(buf, n, h, w, c):
     return buf.view(n, h, w, buf.shape[1]).permute(0, 3, 1, 2)[:, :c]
 
 
+# A forward pass kept for a SECOND backward (round 6).  The stage-3 step evaluates the discriminator on the reconstruction twice with unchanged
+# weights: in the generator phase (D frozen, the adversarial term's gradient flows to the image) and in the discriminator phase (image detached,
+# the gradient flows to D's weights) -- the reference even does it three times (multirate_hr_rgan_beta_cond_rate_distortion_trainer.py:52, 92,
+# 98).  Same input, same weights, same launches: the activations of the first pass ARE those of the second.  With KEEP_HANDLES a list, every
+# chain forward appends a handle (spec, saved activations, geometry, input, outputs); run_chain_reuse(handle) is then an autograd node whose
+# forward launches nothing and whose backward is _ChainFn.backward on the kept activations.
+KEEP_HANDLES = None
+
+
+class ChainHandle:
+    __slots__ = ("spec", "saved", "geom", "x", "outs", "oc")
+
+
 class _ChainFn(torch.autograd.Function):
     """(x, spec, scale, shift, nvec, *vecs, *params) -> tuple of G outputs (NCHW views).  The parameters are passed only so
     that autograd sees the node as differentiable when x is detached (discriminator phase); their gradients are
@@ -150,6 +163,10 @@ class _ChainFn(torch.autograd.Function):
         ctx.save_for_backward(x, scale, shift, *vecs)
         bufs, cp, (n_, oh, ow) = saved[-1][-1]
         oc = spec.unit(0, spec.U - 1).layers[-1].conv.spec.out_ch
+        if KEEP_HANDLES is not None and not vecs and scale is None:
+            hd = ChainHandle()
+            hd.spec, hd.saved, hd.geom, hd.x, hd.oc = spec, saved, (n, c, h, w, ldx), x, oc
+            KEEP_HANDLES.append(hd)
         return tuple(_nchw(b, n_, oh, ow, oc) for b in bufs)
 
     @staticmethod
@@ -311,3 +328,30 @@ class _ChainFn(torch.autograd.Function):
 
 def run_chain(x, spec: ChainSpec, scale=None, shift=None, vecs=()):
     return _ChainFn.apply(x, spec, scale, shift, len(vecs), *vecs, *spec.parameters())
+
+
+class _ChainReuseFn(torch.autograd.Function):
+    """(handle, *params) -> the kept forward's outputs; backward = _ChainFn.backward on the kept activations (weight and bias gradients into the
+    flat .grad slots; no gradient for the chain input: it was produced by another graph and is treated as detached)"""
+
+    @staticmethod
+    def forward(ctx, handle: ChainHandle, *params):
+        ctx.spec, ctx.saved_acts, ctx.geom = handle.spec, handle.saved, handle.geom
+        ctx.nrest = len(params)
+        ctx.save_for_backward(handle.x, None, None)
+        bufs, cp, (n_, oh, ow) = handle.saved[-1][-1]
+        return tuple(_nchw(b, n_, oh, ow, handle.oc) for b in bufs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        class _View:   # _ChainFn.backward reads needs_input_grad[0] (the input: detached here) and [5 + i] (beta vectors: none)
+            needs_input_grad = (False,) * 8
+        for name in ("spec", "saved_acts", "geom", "nrest", "saved_tensors"):
+            setattr(_View, name, getattr(ctx, name))
+        _ChainFn.backward(_View, *douts)
+        return (None,) * (1 + ctx.nrest)
+
+
+def run_chain_reuse(handle: ChainHandle):
+    """The outputs of a chain forward kept by KEEP_HANDLES, as a differentiable function of the chain's parameters (see above)."""
+    return _ChainReuseFn.apply(handle, *handle.spec.parameters())

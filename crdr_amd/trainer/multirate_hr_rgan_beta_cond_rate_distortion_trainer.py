@@ -20,6 +20,7 @@ from typing import Dict
 import numpy as np
 import torch
 
+from crdr_amd.hip import chain as _chain
 from crdr_amd.hip import ops as _ops
 from crdr_amd.utils.registry import TRAINER_REGISTRY
 
@@ -31,6 +32,8 @@ from .multirate_hr_rgan_rate_distortion_trainer import MultirateHighRateRGANRate
 class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDistortionTrainer):
     def __init__(self, opt, relative_score_rate_delta=1) -> None:
         super().__init__(opt, relative_score_rate_delta)
+        # `reuse_d_forward` (default on): the discriminator phase takes D(x_hat) from the generator phase's forward instead of evaluating it again
+        self.reuse_d_forward = bool(opt.get("reuse_d_forward", __import__("os").environ.get("CRDR_REUSE_D_FORWARD", "1") != "0"))
         seed = int(opt.get("cond_seed", 0))
         self._q_gen = torch.Generator().manual_seed(seed)
         self._b_rng = np.random.default_rng(seed)
@@ -85,11 +88,20 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         percep = self.perceptual_loss(real_p, fake)
         with torch.no_grad():
             real_d = self.discriminator(relative.detach(), **other)
-        fake_g = self.discriminator(fake, **other)
+        # D(x_hat) is needed again by the discriminator phase with the same weights (the reference evaluates it three times per iteration,
+        # ...beta_cond_...trainer.py:52, 92, 98): a chain-built discriminator keeps this pass's activations for that phase's backward
+        keep = self.reuse_d_forward
+        if keep:
+            _chain.KEEP_HANDLES = []
+        try:
+            fake_g = self.discriminator(fake, **other)
+        finally:
+            handles, _chain.KEEP_HANDLES = _chain.KEEP_HANDLES, None
+        d_handle = handles[0] if (keep and handles is not None and len(handles) == 1) else None
         adv = (self.gan_loss.forward_diff(real_d, fake_g, is_real=False, is_disc=False)
                + self.gan_loss.forward_diff(fake_g, real_d, is_real=True, is_disc=False)) / 2
         return {"bpp": bpp, "other": other, "terms": {"distortion": dist_loss, "perceptual": percep, "adv": adv},
-                "nonrate": dist_loss + beta_t * (percep + adv), "extra": {"real": real_p, "fake": fake.detach(), "q": q}}
+                "nonrate": dist_loss + beta_t * (percep + adv), "extra": {"real": real_p, "fake": fake.detach(), "q": q, "d_handle": d_handle}}
 
     def _seg_generator(self, real, cond: Dict, noise, current_iter: int) -> Dict:
         f = self._g_forward(real, cond, noise, current_iter)
@@ -109,10 +121,15 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         q = ctx["q"]
         self.discriminator.requires_grad_(True)
         self.d_optimizer.zero_grad(partitions=self._d_parts(q))
-        # one pass over [x̂; x] (the discriminator has no batch statistics -- norm_type none -- so this equals the
-        # reference's two separate calls per sample) halves the launches and doubles the rows of every GEMM
-        both = self.discriminator(torch.cat([ctx["fake"], ctx["real"]], dim=0), rate_ind=q)
-        fake_d, real_d = both[: both.shape[0] // 2], both[both.shape[0] // 2:]
+        if ctx.get("d_handle") is not None:
+            # D(x_hat): the generator phase's forward (same weights, same input) -- nothing is launched, the backward runs on its activations
+            fake_d = _chain.run_chain_reuse(ctx["d_handle"])[0]
+            real_d = self.discriminator(ctx["real"], rate_ind=q)
+        else:
+            # one pass over [x̂; x] (the discriminator has no batch statistics -- norm_type none -- so this equals the
+            # reference's two separate calls per sample) halves the launches and doubles the rows of every GEMM
+            both = self.discriminator(torch.cat([ctx["fake"], ctx["real"]], dim=0), rate_ind=q)
+            fake_d, real_d = both[: both.shape[0] // 2], both[both.shape[0] // 2:]
         l_d_real = self.gan_loss.forward_diff(real_d, fake_d.detach(), is_real=True, is_disc=True) * 0.5
         l_d_fake = self.gan_loss.forward_diff(fake_d, real_d.detach(), is_real=False, is_disc=True) * 0.5
         (l_d_real + l_d_fake).backward()

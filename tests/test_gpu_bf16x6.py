@@ -154,3 +154,37 @@ def test_bf16x6_mode_is_opt_in_and_exclusive():
     wp = ops.pack_weight(_rand(32, 32, 3, 3, seed=2).to(dev), False)
     with pytest.raises(L.CrdrHipError, match="exclusive"):
         ops.conv2d_raw(x, wp, 32, (3, 3), 1, 1, False, (8, 8), flags=L.CONV_BF16X3 | L.CONV_BF16X6)
+
+
+def test_bf16x6_stage3_step_at_the_fp32_gates():
+    """One stage-3 step with `precision: bf16x6` through tests/test_gpu_step.py's own comparison (same function, same gates as the exact-fp32
+    test: losses 3e-4, gradients 5e-3, the analysis / hyper-analysis transforms under the imposed-mask gate of 5e-4) at 64 x 64 on built-in plans,
+    and the mode does not leak out of the step."""
+    from crdr_amd.hip import ops
+    from tests.test_gpu_step import _stage3_step
+    _stage3_step(precision="bf16x6", impose_masks=True)
+    assert ops.MATRIX_BF16X6 is False and ops.MATRIX_BF16X3 is False, "the mode must not leak out of the training step"
+
+
+def test_bf16x6_stage3_step_256_tuned_vs_oracle():
+    """BASELINE config #3 (bs 16, 256 x 256) with `precision: bf16x6` on the shipped plan set of that mode (the database's bf16x6 entries: the
+    tuner's choice between the split-bf16 direct kernels and the exact-fp32 Winograd kernels per shape) against the oracle at the UNCHANGED
+    fp32 gates of test_stage3_step_256_tuned_vs_oracle."""
+    from tests import parity_margins as PM
+    from tests.test_gpu_step import _ShippedPlans, _stage3_step
+    with _ShippedPlans() as sp:
+        _stage3_step(bs=16, size=256, precision="bf16x6", impose_masks=True)
+        new = sp.tuned_here()
+    PM.record("plans", "shapes tuned on the spot (not in the shipped database)", float(len(new)))
+    assert len(new) <= 8, new
+
+
+def test_bf16x6_stage1_step_256_tuned_vs_oracle():
+    """BASELINE config #2 (bs 8, 256 x 256) likewise"""
+    from tests import parity_margins as PM
+    from tests.test_gpu_step import _ShippedPlans, _stage1_step
+    with _ShippedPlans() as sp:
+        _stage1_step(bs=8, size=256, precision="bf16x6", impose_masks=True)
+        new = sp.tuned_here()
+    PM.record("plans", "shapes tuned on the spot (not in the shipped database)", float(len(new)))
+    assert len(new) <= 8, new

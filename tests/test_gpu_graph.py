@@ -68,3 +68,41 @@ def test_skip_gate_inside_graph():
         assert torch.isfinite(p).all()
     tr.g_optimizer.host_step_counts()
     assert tr.g_optimizer.param_groups[0]["step"] == 0
+
+
+def test_filter_caches_created_after_capture_follow_the_replayed_updates():
+    """Persistent F(4x4) filter caches are valid by the version counters of their weight packs, and those counters used to advance only when
+    Python ran PackTable.refill -- which a captured optimiser segment does not.  A cache created AFTER the capture (an eager evaluation pass at
+    another image size) was filled once, stamped, and then trusted forever while the replays went on updating the packs on the device.  Now
+    SegmentGraphs.run calls the refill's host-side bookkeeping after every replay (ops.on_replay / PackTable._replayed): the packs' versions
+    advance, a cache the replayed rebuild launch did not cover falls behind and re-transforms, and it joins the device table for the next
+    replay.  Checked against a forced re-transform, bit for bit."""
+    from crdr_amd.hip import ops
+    ops.PREFER_WINOGRAD = 4
+    try:
+        tr = _trainer(1, True)
+        x = seeded_input("image", (2, 3, 64, 64)).to(dev())
+        xe = seeded_input("eval image", (1, 3, 128, 128)).to(dev())
+        noise = {"y": seeded_input("noise.y", (2, 320, 4, 4), 0.5).to(dev()), "z": seeded_input("noise.z", (2, 192, 1, 1), 0.5).to(dev())}
+        for it in range(1, 5):
+            assert tr.optimize_parameters(it, {"real_images": x, "noise": noise}) is not None
+        assert len(tr.graphs) == 2
+        n0 = len(ops._filter_cache)
+        assert n0 > 0, "the warm-up created no F(4x4) filter cache: the test would be vacuous"
+        def evaluate():
+            with torch.no_grad():
+                return tr.comp_model.run_model(xe, is_train=False)["fake_images"].clone()
+        out1 = evaluate()
+        assert len(ops._filter_cache) > n0, "the evaluation shapes created no new cache"
+        st0 = dict(ops.FILTER_SCOPE_STATS)
+        for it in range(5, 8):   # replays only: the packs change on the device
+            assert tr.optimize_parameters(it, {"real_images": x, "noise": noise}) is not None
+        out2 = evaluate()
+        ops.filter_scope_invalidate()    # every cache dropped: the next pass transforms from the current packs
+        out3 = evaluate()
+        assert not torch.equal(out1, out2), "three optimiser steps must have moved the reconstruction"
+        assert torch.equal(out2, out3), "an evaluation pass after graph replays ran on filters transformed from OLD weights"
+        assert ops.FILTER_SCOPE_STATS["batched"] > st0["batched"] or ops.FILTER_SCOPE_STATS["filled"] > st0["filled"]
+    finally:
+        ops.PREFER_WINOGRAD = False
+        ops.filter_scope_invalidate()

@@ -29,11 +29,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DB = os.path.join(ROOT, "crdr_amd", "hip", "tune_gfx950.json")
 BF16 = 16384
+BF16X6 = 32768
 # measured over all 759 entries of the v371 database (profiles/r4_plan_replay.json): tuned vs built-in <= 5.5e-6 (column sums 5.6e-6),
 # vs float64 <= 3.7e-6 (exact fp32) / 5.4e-6 (bf16x3 entries); the gates sit at ~3x those
 TOL_PLAN = 1e-5      # tuned plan against the built-in plan (fp32 summation order only)
 TOL_F64 = 2e-5       # against float64, exact-fp32 entries
 TOL_F64_BF16X3 = 2e-5  # opt-in bf16x3 entries (split-bf16 triples: per-product error 3 * 2^-16, random in sign)
+TOL_F64_BF16X6 = 4e-6  # opt-in bf16x6 entries (fp32-equivalent: three exact pieces, six products) on DIRECT kernels: the exact-fp32 direct kernels' own
+#                        worst over the round-5 database (profiles/r5_plan_replay.json); entries of that mode whose plan is a Winograd id run the
+#                        exact-fp32 Winograd kernels and keep those kernels' gate
 RESULTS = {}
 
 
@@ -64,6 +68,7 @@ class _Replay:
         from crdr_amd.hip import ops
         self.ops = ops
         self.keep = (ops.AUTOTUNE, dict(ops._algo_cache), ops._autotune, ops.MATRIX_BF16X3, ops.WGRAD_DEFER)
+        self.keep6 = ops.MATRIX_BF16X6
         ops._algo_cache.clear()
         assert ops.load_tune_cache(DB) > 0, "the shipped perf database is not of this library build (signature mismatch)"
 
@@ -76,12 +81,14 @@ class _Replay:
     def __exit__(self, *exc):
         ops = self.ops
         ops.AUTOTUNE, cache, ops._autotune, ops.MATRIX_BF16X3, ops.WGRAD_DEFER = self.keep
+        ops.MATRIX_BF16X6 = self.keep6
         ops._algo_cache.clear()
         ops._algo_cache.update(cache)
 
-    def mode(self, tuned: bool, bf16x3: bool):
+    def mode(self, tuned: bool, prec: int):
+        """prec: 0 exact fp32, 3 / 6 the split-bf16 modes the entry was tuned in"""
         self.ops.AUTOTUNE = tuned
-        self.ops.MATRIX_BF16X3 = bf16x3
+        self.ops.MATRIX_BF16X3, self.ops.MATRIX_BF16X6 = prec == 3, prec == 6
 
 
 def _sel(n, cap):
@@ -201,8 +208,8 @@ def _replay_conv(rp, key, algo, seed):
     else:
         _, G, n, h, w, oh, ow, c, oc, k, stride, pad, tr, ldx, ldy, flags, ldres, ldpre, ldmask, wrows, wcols, wlayout = key
         ldg = 0
-    bf = bool(flags & BF16)
-    f = flags & ~BF16
+    bf = 3 if (flags & BF16) else (6 if (flags & BF16X6) else 0)
+    f = flags & ~(BF16 | BF16X6)
     self_res = kind == "g" and (f & L.EPI_RES)      # conv_group: pure accumulation = residual epilogue with the output as its operand
     T = k[0] * k[1]
     fan = c * T / (stride * stride if tr else 1)
@@ -318,7 +325,7 @@ def _replay_conv(rp, key, algo, seed):
         if sref is not None:
             out["sig_vs_f64"] = float((sigt[gpix[0], gpix[1], gpix[2], :oc].cpu().double() - sref).abs().max())
     out["vs_f64"], out["builtin_vs_f64"], out["pixels"] = e64, e64b, int(pix[0].numel())
-    out["bf16x3"] = bf
+    out["bf16x3"], out["bf16x6"] = bf == 3, bf == 6
     return out
 
 
@@ -344,7 +351,7 @@ def _replay_wgrad(rp, key, algo, seed):
     from crdr_amd.hip import ops
     dev = _dev()
     kind = key[0]
-    bf = len(key) > {"w": 15, "wg": 13, "wm": 16, "ws": 10}[kind]
+    bf = {1: 3, 2: 6}[key[-1]] if len(key) > {"w": 15, "wg": 13, "wm": 16, "ws": 10}[kind] else 0   # (key suffix: ops._mk)
     if kind == "w":
         _, n, ph, pw, pc, ldp, qh, qw, qc, ldq, k, stride, pad, gi, gj = key[:15]
         G = 1
@@ -384,7 +391,7 @@ def _replay_wgrad(rp, key, algo, seed):
     gb = launch(False)
     gt = launch(True)
     scale = max(float(t.abs().max()) for t in gb) + 1e-20
-    out = {"vs_builtin": max(float((a - b).abs().max()) for a, b in zip(gt, gb)) / scale, "bf16x3": bf}
+    out = {"vs_builtin": max(float((a - b).abs().max()) for a, b in zip(gt, gb)) / scale, "bf16x3": bf == 3, "bf16x6": bf == 6}
     isel, jsel = _sel(gi, 32), _sel(gj, 32)
     e = eb = 0.0
     for g in sorted({0, G - 1}):
@@ -419,7 +426,7 @@ def _tolerances(key, r):
     depth = _depth(key)
     wg = key[0].startswith("w")
     plan = max(TOL_PLAN, (1.5e-7 if not wg else 2.5e-7) * depth ** 0.5)
-    f64 = TOL_F64_BF16X3 if r["bf16x3"] else TOL_F64
+    f64 = TOL_F64_BF16X3 if r["bf16x3"] else (TOL_F64_BF16X6 if r.get("bf16x6") else TOL_F64)
     if r.get("wino4"):   # the F(4x4, 3x3) / F(3x3, 4x4) Winograd kernels (points 0, +-3/4, +-5/4: tests/test_gpu_wino.py measures 0.4e-6 .. 5.2e-6
         plan, f64 = max(plan, 2e-5), 2e-5   # against float64; round 4's points 0, +-1, +-2 needed 6e-5 here)
     if os.environ.get("CRDR_PLAN_REPLAY_MEASURE") == "1":   # first measurement of a new database: gross errors only
@@ -447,9 +454,11 @@ def _run_kind(kind, replay):
                 nwino += (algo & 0xFF) > ncfg + nstr   # (the F(4x4) kernel's ids may carry K splits in bits 8..11)
                 nsplit += algo >= 256
             r["wino4"] = bool(kind in ("c", "g", "m") and lib.crdr_conv2d_num_wino_configs() > 2 and (algo & 0xFF) == ncfg + 1 + nstr + 2)
+            r["wino"] = bool(kind in ("c", "g", "m") and (algo & 0xFF) > ncfg + nstr)
             if kind.startswith("w"):   # weight-gradient entries: the Winograd slab kernels are the last configuration and the id behind it
                 nwino += (algo & 0xFF) >= lib.crdr_conv2d_wgrad_num_configs()
                 r["wino4"] = (algo & 0xFF) == lib.crdr_conv2d_wgrad_num_configs() + 1   # F(3x3, 4x4): the same transform constants
+                r["wino"] = (algo & 0xFF) >= lib.crdr_conv2d_wgrad_num_configs()
             tol_plan, tol64 = _tolerances(key, r)
             rows.append({"key": repr(key), "algo": algo, "depth": _depth(key), **{k: v for k, v in r.items()}})
             fails = [n for n, v, t in (("vs_builtin", r["vs_builtin"], tol_plan), ("vs_f64", r["vs_f64"], tol64),
@@ -466,9 +475,13 @@ def _run_kind(kind, replay):
         return max([r[name] for r in rows if name in r and pred(r)] + [0.0])
     RESULTS[kind] = {"entries": len(entries), "failed": len(bad), "streaming_1x1_ids": int(nstream), "winograd_ids": int(nwino),
                      "split_ids": int(nsplit),
-                     "worst": {"vs_builtin": worst("vs_builtin"), "vs_f64": worst("vs_f64", lambda r: not r["bf16x3"]),
+                     "bf16x6_entries": sum(1 for r in rows if r.get("bf16x6")),
+                     "worst": {"vs_builtin": worst("vs_builtin"), "vs_f64": worst("vs_f64", lambda r: not r["bf16x3"] and not r.get("bf16x6")),
                                "vs_f64_bf16x3": worst("vs_f64", lambda r: r["bf16x3"]),
-                               "builtin_vs_f64": worst("builtin_vs_f64", lambda r: not r["bf16x3"]),
+                               "vs_f64_bf16x6_direct": worst("vs_f64", lambda r: r.get("bf16x6") and not r.get("wino4") and not r.get("wino")),
+                               "vs_f64_exact_direct": worst("vs_f64", lambda r: not r["bf16x3"] and not r.get("bf16x6") and not r.get("wino4") and not r.get("wino")),
+                               "builtin_vs_f64": worst("builtin_vs_f64", lambda r: not r["bf16x3"] and not r.get("bf16x6")),
+                               "builtin_vs_f64_bf16x6": worst("builtin_vs_f64", lambda r: r.get("bf16x6")),
                                "colsum_vs_builtin": worst("colsum_vs_builtin"),
                                "vs_builtin_over_sqrt_depth": max([r["vs_builtin"] / r["depth"] ** 0.5 for r in rows] + [0.0])}}
     path = os.environ.get("CRDR_PLAN_REPLAY_DUMP")
