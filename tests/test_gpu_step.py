@@ -174,12 +174,6 @@ def test_stage3_two_iterations_partitioned_d_adam_matches_torch():
         assert step == (1 if k in (1, 3) else 0), (n, step)
 
 
-def test_stage3_step_under_imposed_masks():
-    """the deterministic form of the upstream-gradient gate at the small size: the oracle back-propagates through the ReLU masks the product
-    exported (all 150 generator sites, adopted only inside oracle.MASK_WINDOW), analysis / hyper-analysis gradients held to 5e-4"""
-    _stage3_step(impose_masks=True)
-
-
 def test_stage3_step_winograd():
     """the stage-3 step with every 3x3 stride-1 convolution / input gradient (generator bottlenecks, NLAM, discriminator) on the
     Winograd kernel: same oracle, same gates"""

@@ -463,7 +463,7 @@ def _run_kind(kind, replay):
             rows.append({"key": repr(key), "algo": algo, "depth": _depth(key), **{k: v for k, v in r.items()}})
             fails = [n for n, v, t in (("vs_builtin", r["vs_builtin"], tol_plan), ("vs_f64", r["vs_f64"], tol64),
                                        ("builtin_vs_f64", r["builtin_vs_f64"], tol64),
-                                       ("colsum_vs_builtin", r.get("colsum_vs_builtin", 0.0), 5 * tol_plan if not r["wino4"] else tol_plan),
+                                       ("colsum_vs_builtin", r.get("colsum_vs_builtin", 0.0), 5 * tol_plan if not r["wino4"] else (2 * tol_plan if r.get("bf16x6") else tol_plan)),   # (bf16x6 entries on an F(4x4) id: the baseline is the split-bf16 direct kernel, another kernel family)
                                        ("sig_vs_builtin", r.get("sig_vs_builtin", 0.0), 1e-5),
                                        ("sig_vs_f64", r.get("sig_vs_f64", 0.0), 1e-4)) if not v <= t]
             if fails:
