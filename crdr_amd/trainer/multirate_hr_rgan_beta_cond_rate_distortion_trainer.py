@@ -86,22 +86,26 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         dist_loss = self.distortion_loss(real_p, fake, **other)
         assert self.perceptual_loss
         percep = self.perceptual_loss(real_p, fake)
-        with torch.no_grad():
-            real_d = self.discriminator(relative.detach(), **other)
         # D(x_hat) is needed again by the discriminator phase with the same weights (the reference evaluates it three times per iteration,
-        # ...beta_cond_...trainer.py:52, 92, 98): a chain-built discriminator keeps this pass's activations for that phase's backward
+        # ...beta_cond_...trainer.py:52, 92, 98): a chain-built discriminator keeps this pass's activations for that phase's backward.  At the top
+        # rate the relativistic reference IS the real image, so D(x) of this phase serves the discriminator phase as well.
         keep = self.reuse_d_forward
-        if keep:
-            _chain.KEEP_HANDLES = []
-        try:
-            fake_g = self.discriminator(fake, **other)
-        finally:
-            handles, _chain.KEEP_HANDLES = _chain.KEEP_HANDLES, None
-        d_handle = handles[0] if (keep and handles is not None and len(handles) == 1) else None
+
+        def d_keep(img, on: bool):
+            if on:
+                _chain.KEEP_HANDLES = []
+            try:
+                out = self.discriminator(img, **other)
+            finally:
+                handles, _chain.KEEP_HANDLES = _chain.KEEP_HANDLES, None
+            return out, (handles[0] if (on and handles is not None and len(handles) == 1) else None)
+        with torch.no_grad():
+            real_d, d_real_handle = d_keep(relative.detach(), keep and relative is real_p)
+        fake_g, d_handle = d_keep(fake, keep)
         adv = (self.gan_loss.forward_diff(real_d, fake_g, is_real=False, is_disc=False)
                + self.gan_loss.forward_diff(fake_g, real_d, is_real=True, is_disc=False)) / 2
         return {"bpp": bpp, "other": other, "terms": {"distortion": dist_loss, "perceptual": percep, "adv": adv},
-                "nonrate": dist_loss + beta_t * (percep + adv), "extra": {"real": real_p, "fake": fake.detach(), "q": q, "d_handle": d_handle}}
+                "nonrate": dist_loss + beta_t * (percep + adv), "extra": {"real": real_p, "fake": fake.detach(), "q": q, "d_handle": d_handle, "d_real_handle": d_real_handle}}
 
     def _seg_generator(self, real, cond: Dict, noise, current_iter: int) -> Dict:
         f = self._g_forward(real, cond, noise, current_iter)
@@ -124,7 +128,8 @@ class MultirateBetaCondHrrGanRateDistortionTrainer(MultirateHighRateRGANRateDist
         if ctx.get("d_handle") is not None:
             # D(x_hat): the generator phase's forward (same weights, same input) -- nothing is launched, the backward runs on its activations
             fake_d = _chain.run_chain_reuse(ctx["d_handle"])[0]
-            real_d = self.discriminator(ctx["real"], rate_ind=q)
+            real_d = (_chain.run_chain_reuse(ctx["d_real_handle"])[0] if ctx.get("d_real_handle") is not None
+                      else self.discriminator(ctx["real"], rate_ind=q))
         else:
             # one pass over [x̂; x] (the discriminator has no batch statistics -- norm_type none -- so this equals the
             # reference's two separate calls per sample) halves the launches and doubles the rows of every GEMM
