@@ -313,11 +313,239 @@ static void gdn_fused_launch(const GdnFusedArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(gdn_fused_fwd_kernel<NS>, dim3(std::min(a.tiles, 256)), dim3(256), lds, s, a);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Fused backward: TWO passes of the same persistent form (gamma in registers, 64-pixel tiles through LDS by LDS-DMA, double buffered)
+// replace the norm pass + four elementwise kernels + the 1x1 launch of the nine-launch form (72 -> 40 B per element with the weight
+// gradient's CRDR_WGRAD_SQUARE_Q launch and the column sums folded into the first pass):
+//   phase 0:  n = beta + gamma x^2 (the forward's mix, recomputed);  u = dy n^(-1/2) [dy n^(1/2)],  dn = -1/2 dy x n^(-3/2) [1/2 dy x n^(-1/2)];
+//             reads x (LDS tile) and dy, writes dn and u, and leaves the per-workgroup column sums of dn (the beta gradient) in `colpart`
+//   phase 1:  w = gamma^T dn,  dx = u + 2 x w;  reads dn (LDS tile), x and u, writes dx
+// The matrix operands are SWAPPED against the forward kernel -- gamma is the A operand, the pixel tile the B operand -- so that a lane's
+// four accumulator elements are four CONSECUTIVE CHANNELS of one pixel (row 16 rb + ln, channels col0 + 16 cb + 4 lg ..): every operand
+// and result of the epilogue is one 16-byte access per (rb, cb), straight from / to global memory in registers (64-byte row segments; the
+// two halves of a 128-byte line are touched by consecutive instructions of the same wave), requested at the top of the tile and hidden
+// behind its matrix loop.  No LDS traffic and no barrier after the matrix loop: one barrier per tile (the buffer hand-over).
+// ------------------------------------------------------------------------------------------------------------
+struct GdnBwdArgs {
+  const float* src;    // the tile operand: x (phase 0) or dn (phase 1)
+  const float* pack;   // phase 0: gamma_eff [CP][CP] (row = output channel i); phase 1: its transpose (row = input channel j)
+  const float* beta;   // beta_eff [C] (phase 0)
+  const float* r0;     // phase 0: dy; phase 1: x
+  const float* r1;     // phase 1: u
+  float* o0;           // phase 0: dn; phase 1: dx
+  float* o1;           // phase 0: u
+  float* colpart;      // phase 0: [gridDim.x][CP] column sums of dn over the workgroup's tiles
+  long long M;
+  int C, CP, ld_src, ld_r0, ld_r1, ld_o0, ld_o1, inverse, tiles;
+  unsigned pack_bytes;
+};
+
+template <int NS, int PHASE>
+__global__ __launch_bounds__(256) void gdn_fused_bwd_kernel(const GdnBwdArgs p) {
+  constexpr int BM = kGdnBM, NCB = NS / 4, NBX = NS / 2, XF = NBX * BM * 32;
+  constexpr int NST = PHASE == 0 ? 2 * NS : NS;   // stores per thread and tile (the youngest requests at the top of the next tile)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sX = smem;                    // [2][NBX][BM * 32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lg = lane >> 4;
+  const int col0 = wave * 16 * NCB;
+  if ((int)blockIdx.x >= p.tiles) return;
+  f32x4 B[NCB][NS];
+  {
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack), 0, p.pack_bytes, 0x00020000);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int row = col0 + 16 * cb + ln, k = 16 * s + 4 * lg;
+        const bool ok = row < p.CP && k < p.CP;
+        B[cb][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? ((unsigned)row * p.CP + k) * 4u : 0x80000000u, 0, 0));
+      }
+  }
+  const int srow = tid >> 3;
+  const int csrc = (tid & 7) ^ ((srow >> 1) & 7);
+  unsigned xoff[NBX][2];
+#pragma unroll
+  for (int kc = 0; kc < NBX; ++kc)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int chx = 32 * kc + csrc * 4;
+      xoff[kc][j] = chx < p.C ? ((unsigned)(srow + 32 * j) * p.ld_src + chx) * 4u : 0x80000000u;
+    }
+  // the lane's channels: ch(cb) = col0 + 16 cb + 4 lg .. + 3 of pixel row 16 rb + ln; channel groups past C are masked by the range check
+  // (0x80000000 + anything a tile can add stays out of range)
+  f32x4 bta[NCB];
+  bool chok[NCB];
+  int xe[NCB];   // phase 0: float offset of (row ln, channels ch(cb)) inside an x tile; row block rb adds 512 rb (the swizzle repeats every 16 rows)
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int ch = col0 + 16 * cb + 4 * lg;
+    chok[cb] = ch < p.C;
+    bta[cb] = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (PHASE == 0 && chok[cb]) bta[cb] = *reinterpret_cast<const f32x4*>(p.beta + ch);
+    xe[cb] = (ch >> 5) * BM * 32 + lds_off(ln, (ch & 31) >> 2);
+  }
+  auto lane_off = [&](int ld, int cb, int rb) __attribute__((always_inline)) {
+    return chok[cb] ? ((unsigned)(16 * rb + ln) * ld + col0 + 16 * cb + 4 * lg) * 4u : 0x80000000u;
+  };
+  // a tile's descriptor ends at its last valid row (rows past the tensor: loads give zeros, stores are dropped); a tile past the last one
+  // has no bytes at all, so that the prefetch below needs no branch (and the waits count the same requests on every path)
+  auto tile_rsrc = [&](const float* base, int ld, long long m0) __attribute__((always_inline)) {
+    const long long left = p.M - m0;
+    const long long bytes = left <= 0 ? 0 : ((left < BM ? left : BM) - 1) * ld * 4ll + p.C * 4ll;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + (left <= 0 ? 0 : m0 * ld), 0, (unsigned)std::min<long long>(bytes, 0x7fffffffll), 0x00020000);
+  };
+  auto fetch = [&](long long m0, int buf) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rx = tile_rsrc(p.src, p.ld_src, m0);
+#pragma unroll
+    for (int kc = 0; kc < NBX; ++kc)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (gdn_lds_ptr_t)(sX + buf * XF + kc * BM * 32 + wave * 8 * 32 + j * 32 * 32), 16, (int)xoff[kc][j], 0, 0, 0);
+  };
+  f32x4 csum[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) csum[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int t = blockIdx.x, cur = 0;
+  fetch((long long)t * BM, 0);
+  bool first = true;
+  for (; t < p.tiles; t += gridDim.x, cur ^= 1) {
+    const long long m0 = (long long)t * BM;
+    // this tile has landed (everything but the previous tile's NST stores); every wave is done with the other buffer
+    if (first) gdn_wait_barrier<0>();
+    else gdn_wait_barrier<NST>();
+    first = false;
+    // the epilogue's register operands first (they are waited for first), then the next tile
+    f32x4 r0[4][NCB], r1[4][NCB];
+    {
+      const __amdgpu_buffer_rsrc_t q0 = tile_rsrc(p.r0, p.ld_r0, m0);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) r0[rb][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q0, lane_off(p.ld_r0, cb, rb), 0, 0));
+      if constexpr (PHASE == 1) {
+        const __amdgpu_buffer_rsrc_t q1 = tile_rsrc(p.r1, p.ld_r1, m0);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) r1[rb][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q1, lane_off(p.ld_r1, cb, rb), 0, 0));
+      }
+    }
+    fetch((long long)(t + (int)gridDim.x) * BM, cur ^ 1);
+    f32x4 acc[4][NCB];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* xt = sX + cur * XF;
+    auto a_ptr = [&](int g) __attribute__((always_inline)) {
+      const int s = g >> 2, rb = g & 3;
+      return reinterpret_cast<const f32x4*>(xt + (s >> 1) * BM * 32 + lds_off(16 * rb + ln, 4 * (s & 1) + lg));
+    };
+    f32x4 a_nxt = *a_ptr(0);
+#pragma unroll
+    for (int g = 0; g < NS * 4; ++g) {
+      const int s = g >> 2, rb = g & 3;
+      f32x4 a = PHASE == 0 ? a_nxt * a_nxt : a_nxt;
+      if (g + 1 < NS * 4) a_nxt = *a_ptr(g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[cb][s][e], a[e], acc[rb][cb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // acc[rb][cb][i] is (pixel row 16 rb + ln, channel col0 + 16 cb + 4 lg + i)
+    if constexpr (PHASE == 0) {
+      const __amdgpu_buffer_rsrc_t w0 = tile_rsrc(p.o0, p.ld_o0, m0), w1 = tile_rsrc(p.o1, p.ld_o1, m0);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xt + xe[cb] + 512 * rb);
+          const f32x4 g = r0[rb][cb];
+          f32x4 dn, u;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float n = acc[rb][cb][i] + bta[cb][i];
+            const float rs = __builtin_amdgcn_rsqf(n);
+            if (p.inverse) { u[i] = g[i] * __builtin_amdgcn_sqrtf(n); dn[i] = 0.5f * g[i] * xv[i] * rs; }
+            else { u[i] = g[i] * rs; dn[i] = -0.5f * u[i] * xv[i] * (rs * rs); }
+          }
+          csum[cb] += dn;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, dn), w0, lane_off(p.ld_o0, cb, rb), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, u), w1, lane_off(p.ld_o1, cb, rb), 0, 0);
+        }
+    } else {
+      const __amdgpu_buffer_rsrc_t w0 = tile_rsrc(p.o0, p.ld_o0, m0);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const f32x4 dx = r1[rb][cb] + 2.0f * r0[rb][cb] * acc[rb][cb];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, dx), w0, lane_off(p.ld_o0, cb, rb), 0, 0);
+        }
+    }
+  }
+  if constexpr (PHASE == 0) {   // the workgroup's column sums of dn: over the 16 pixel lanes of a lane group, in a fixed order
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = csum[cb][i];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+        csum[cb][i] = v;
+      }
+      const int ch = col0 + 16 * cb + 4 * lg;
+      if (ln == 0 && ch < p.CP) *reinterpret_cast<f32x4*>(p.colpart + (size_t)blockIdx.x * p.CP + ch) = csum[cb];
+    }
+  }
+}
+
+template <int NS, int PHASE>
+static void gdn_bwd_launch(const GdnBwdArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)2 * (NS / 2) * kGdnBM * 32 * sizeof(float);
+  static std::atomic<bool> done{false};
+  if (!done.load(std::memory_order_acquire)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gdn_fused_bwd_kernel<NS, PHASE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((gdn_fused_bwd_kernel<NS, PHASE>), dim3(std::min(a.tiles, 256)), dim3(256), lds, s, a);
+}
+
+template <int PHASE>
+static void gdn_bwd_dispatch(const GdnBwdArgs& a, hipStream_t s) {
+  if (a.C <= 64) gdn_bwd_launch<4, PHASE>(a, s);
+  else if (a.C <= 128) gdn_bwd_launch<8, PHASE>(a, s);
+  else gdn_bwd_launch<12, PHASE>(a, s);
+}
+
+// the beta gradient: the first pass's per-workgroup column sums [parts][CP], added in a fixed order (32 channels per workgroup; 8 row
+// groups, then the groups)
+__global__ __launch_bounds__(256) void gdn_colpart_sum_kernel(const float* colpart, int parts, int CP, int C, float* dbeta_eff) {
+  __shared__ float part[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
+  float sum = 0.f;
+  if (c < C) {
+#pragma unroll 8
+    for (int q = r; q < parts; q += 8) sum += colpart[(size_t)q * CP + c];
+  }
+  part[r][threadIdx.x & 31] = sum;
+  __syncthreads();
+  if (r == 0 && c < C) {
+    float v = part[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v += part[k][threadIdx.x];
+    dbeta_eff[c] = v;
+  }
+}
+
 static inline int grid1(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(cdiv64(n, 256), 1), 8192); }
 
 struct GdnLayout {
   int CP;
-  size_t beta_eff, pack_f, pack_b, x2, norm, dn, u, w, dg, db, conv_ws, end;
+  size_t beta_eff, pack_f, pack_b, x2, norm, dn, u, w, dg, db, colpart, conv_ws, end;
   size_t conv_ws_bytes;
 };
 
@@ -340,8 +568,11 @@ static int gdn_layout(const crdr_gdn_desc* d, int backward, GdnLayout* L) {
   const size_t MC = (size_t)d->M * d->C;
   L->beta_eff = take(CP); L->pack_f = take((size_t)CP * CP); L->pack_b = take((size_t)CP * CP);
   L->x2 = take(MC); L->norm = take(MC);
-  L->dn = L->u = L->w = L->dg = L->db = 0;
-  if (backward) { L->dn = take(MC); L->u = take(MC); L->w = take(MC); L->dg = take((size_t)d->C * d->C); L->db = take(d->C); }
+  L->dn = L->u = L->w = L->dg = L->db = L->colpart = 0;
+  if (backward) {
+    L->dn = take(MC); L->u = take(MC); L->w = take(MC); L->dg = take((size_t)d->C * d->C); L->db = take(d->C);
+    L->colpart = take((size_t)256 * CP);
+  }
   crdr_conv_desc cd;
   if (int rc = gdn_conv_desc(d, &cd, CP)) return rc;
   size_t cw = crdr_conv2d_workspace(&cd);
@@ -351,12 +582,20 @@ static int gdn_layout(const crdr_gdn_desc* d, int backward, GdnLayout* L) {
     wd.N = (int32_t)d->M; wd.PH = 1; wd.PW = 1; wd.PC = d->C; wd.ldp = d->C; wd.QH = 1; wd.QW = 1; wd.QC = d->C; wd.ldq = d->C;
     wd.kh = 1; wd.kw = 1; wd.stride = 1; wd.pad = 0; wd.gI = d->C; wd.gJ = d->C;
     cw = std::max(cw, crdr_conv2d_wgrad_workspace(&wd));
+    wd.algo = CRDR_WGRAD_SQUARE_Q; wd.ldq = d->ldx;   // the fused backward's launch
+    cw = std::max(cw, crdr_conv2d_wgrad_workspace(&wd));
     cw = std::max(cw, crdr_colsum_workspace(d->M, d->C));
   }
   L->conv_ws_bytes = cw;
   L->conv_ws = take((cw + 3) / 4);
   L->end = off;
   return 0;
+}
+
+// CRDR_GDN_UNFUSED_BWD=1: the nine-launch backward (the form the fused one is A/B-tested against; read at every call)
+static bool gdn_unfused_backward() {
+  const char* e = getenv("CRDR_GDN_UNFUSED_BWD");
+  return e && e[0] == '1';
 }
 
 static bool gdn_fused_ok(const crdr_gdn_desc* d, const GdnLayout& L) {
@@ -439,6 +678,41 @@ extern "C" int crdr_gdn_bwd(const crdr_gdn_desc* d, const float* x, const float*
   CRDR_REQUIRE(ws_bytes >= L.end && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "gdn_bwd: workspace too small or misaligned (%zu < %zu)", ws_bytes, L.end);
   CRDR_REQUIRE(lddy % 4 == 0 && lddx % 4 == 0, "gdn_bwd: strides must be multiples of 4");
   char* w8 = (char*)ws;
+  crdr_wgrad_desc wd;
+  memset(&wd, 0, sizeof(wd));
+  wd.N = (int32_t)d->M; wd.PH = 1; wd.PW = 1; wd.PC = d->C; wd.ldp = d->C; wd.QH = 1; wd.QW = 1; wd.QC = d->C; wd.ldq = d->C;
+  wd.kh = 1; wd.kw = 1; wd.stride = 1; wd.pad = 0; wd.gI = d->C; wd.gJ = d->C; wd.accumulate = 0;
+  const float ped = d->reparam_offset * d->reparam_offset;
+  if (gdn_fused_ok(d, L) && (long long)128 * lddy * 4 < (1ll << 31) && (long long)128 * lddx * 4 < (1ll << 31) && !gdn_unfused_backward()) {
+    // reparametrisation, two fused passes, the gamma gradient straight from (dn, x) with the square taken in the kernel, the chain rule
+    hipLaunchKernelGGL(gdn_reparam_kernel, dim3(grid1((int64_t)L.CP * L.CP)), dim3(256), 0, as_stream(s), beta, gamma, d->C, L.CP,
+                       sqrtf(d->beta_min + ped), d->reparam_offset, ped, (float*)(w8 + L.beta_eff), (float*)(w8 + L.pack_f), (float*)(w8 + L.pack_b));
+    CRDR_CHECK_LAUNCH("gdn_reparam");
+    float *dn = (float*)(w8 + L.dn), *u = (float*)(w8 + L.u), *dg = (float*)(w8 + L.dg), *parts = (float*)(w8 + L.colpart);
+    GdnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = d->M; a.C = d->C; a.CP = L.CP; a.inverse = d->inverse; a.tiles = (int)((d->M + kGdnBM - 1) / kGdnBM);
+    a.pack_bytes = (unsigned)((size_t)L.CP * L.CP * 4);
+    a.beta = (const float*)(w8 + L.beta_eff); a.colpart = parts;
+    a.src = x; a.ld_src = d->ldx; a.pack = (const float*)(w8 + L.pack_f); a.r0 = dy; a.ld_r0 = lddy;
+    a.o0 = dn; a.ld_o0 = d->C; a.o1 = u; a.ld_o1 = d->C;
+    gdn_bwd_dispatch<0>(a, as_stream(s));
+    CRDR_CHECK_LAUNCH("gdn_fused_bwd<0>");
+    a.src = dn; a.ld_src = d->C; a.pack = (const float*)(w8 + L.pack_b); a.r0 = x; a.ld_r0 = d->ldx; a.r1 = u; a.ld_r1 = d->C;
+    a.o0 = dx; a.ld_o0 = lddx; a.o1 = nullptr; a.ld_o1 = 0;
+    gdn_bwd_dispatch<1>(a, as_stream(s));
+    CRDR_CHECK_LAUNCH("gdn_fused_bwd<1>");
+    wd.ldq = d->ldx; wd.algo = CRDR_WGRAD_SQUARE_Q;
+    if (int rc = crdr_conv2d_wgrad(&wd, dn, x, dg, w8 + L.conv_ws, L.conv_ws_bytes, s)) return rc;
+    float* db = (float*)(w8 + L.db);
+    hipLaunchKernelGGL(gdn_colpart_sum_kernel, dim3((d->C + 31) / 32), dim3(256), 0, as_stream(s), (const float*)parts, std::min(a.tiles, 256), L.CP,
+                       d->C, db);
+    CRDR_CHECK_LAUNCH("gdn_colpart_sum");
+    hipLaunchKernelGGL(gdn_reparam_bwd_kernel, dim3(grid1((int64_t)d->C * d->C)), dim3(256), 0, as_stream(s), (const float*)dg,
+                       (const float*)db, gamma, beta, d->C, sqrtf(d->beta_min + ped), d->reparam_offset, dgamma, dbeta);
+    CRDR_CHECK_LAUNCH("gdn_reparam_bwd");
+    return 0;
+  }
   if (int rc = gdn_norm(d, L, w8, x, beta, gamma, s)) return rc;  // recomputed: cheaper than keeping M x C floats alive
   const int g = grid1(d->M * (d->C / 4));
   float *dn = (float*)(w8 + L.dn), *u = (float*)(w8 + L.u), *w = (float*)(w8 + L.w);
@@ -454,10 +728,6 @@ extern "C" int crdr_gdn_bwd(const crdr_gdn_desc* d, const float* x, const float*
   hipLaunchKernelGGL(gdn_bwd_finish_kernel, dim3(g), dim3(256), 0, as_stream(s), x, d->ldx, (const float*)u, (const float*)w, d->M,
                      d->C / 4, dx, lddx);
   CRDR_CHECK_LAUNCH("gdn_bwd_finish");
-  crdr_wgrad_desc wd;
-  memset(&wd, 0, sizeof(wd));
-  wd.N = (int32_t)d->M; wd.PH = 1; wd.PW = 1; wd.PC = d->C; wd.ldp = d->C; wd.QH = 1; wd.QW = 1; wd.QC = d->C; wd.ldq = d->C;
-  wd.kh = 1; wd.kw = 1; wd.stride = 1; wd.pad = 0; wd.gI = d->C; wd.gJ = d->C; wd.accumulate = 0;
   float *dg = (float*)(w8 + L.dg), *db = (float*)(w8 + L.db);
   if (gdn_fused_ok(d, L)) {   // the fused norm pass squares on the fly: the weight gradient still wants x^2 in memory
     hipLaunchKernelGGL(gdn_square_kernel, dim3(grid1(d->M * (d->C / 4))), dim3(256), 0, as_stream(s), x, d->ldx, d->M, d->C / 4,
@@ -466,7 +736,6 @@ extern "C" int crdr_gdn_bwd(const crdr_gdn_desc* d, const float* x, const float*
   }
   if (int rc = crdr_conv2d_wgrad(&wd, dn, (const float*)(w8 + L.x2), dg, w8 + L.conv_ws, L.conv_ws_bytes, s)) return rc;
   if (int rc = crdr_colsum(dn, d->C, d->M, d->C, db, 0, w8 + L.conv_ws, L.conv_ws_bytes, s)) return rc;
-  const float ped = d->reparam_offset * d->reparam_offset;
   hipLaunchKernelGGL(gdn_reparam_bwd_kernel, dim3(grid1((int64_t)d->C * d->C)), dim3(256), 0, as_stream(s), (const float*)dg,
                      (const float*)db, gamma, beta, d->C, sqrtf(d->beta_min + ped), d->reparam_offset, dgamma, dbeta);
   CRDR_CHECK_LAUNCH("gdn_reparam_bwd");

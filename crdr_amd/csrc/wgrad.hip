@@ -22,9 +22,12 @@ static constexpr unsigned kOob = 0x80000000u;  // >= any descriptor size accepte
 
 // PREC: 0 exact fp32, 3 split-bf16 triples (CRDR_WGRAD_BF16X3), 6 fp32-equivalent split-bf16 sextuples (CRDR_WGRAD_BF16X6); the fragments run
 // down the pixel axis, so the pieces are made in registers from the lane's eight ds_read_b32 values
-template <int WM, int WN, int MB, int NB, int PREC = 0>
+// SQQ (CRDR_WGRAD_SQUARE_Q): the gathered operand enters SQUARED (g = sum P Q^2: the gamma gradient of a GDN layer, gdn.hip, without an x^2 tensor
+// in memory); exact fp32 only, built for the configurations the GDN sizes take (CFGQ below)
+template <int WM, int WN, int MB, int NB, int PREC = 0, bool SQQ = false>
 __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p_, const WgradGroup grp) {
   constexpr bool BF3 = PREC == 3, BF6 = PREC == 6;
+  static_assert(!SQQ || PREC == 0, "the squared form is exact fp32");
   constexpr int BI = 32 * WM * MB, BJ = 32 * WN * NB, NT = 64 * WM * WN;
   constexpr int PV = (8 * BI + NT - 1) / NT, QV = (8 * BJ + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -173,7 +176,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(const WgradArgs p_,
 #pragma unroll
       for (int i = 0; i < MB; ++i) af[i] = fa[buf * 32 * BI + 2 * s * BI + i * 32];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) bf[j] = fb[buf * 32 * BJ + 2 * s * BJ + j * 32];
+      for (int j = 0; j < NB; ++j) {
+        bf[j] = fb[buf * 32 * BJ + 2 * s * BJ + j * 32];
+        if constexpr (SQQ) bf[j] *= bf[j];
+      }
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -501,34 +507,37 @@ struct WCfg {
   void (*kern)(const WgradArgs, const WgradGroup);
   void (*kern_bf3)(const WgradArgs, const WgradGroup);
   void (*kern_bf6)(const WgradArgs, const WgradGroup);
+  void (*kern_sq)(const WgradArgs, const WgradGroup);   // CRDR_WGRAD_SQUARE_Q (nullptr where not built)
 };
-#define CFG(a, b, c, d) {a, b, c, d, wgrad_kernel<a, b, c, d, 0>, wgrad_kernel<a, b, c, d, 3>, wgrad_kernel<a, b, c, d, 6>}
+#define CFG(a, b, c, d) {a, b, c, d, wgrad_kernel<a, b, c, d, 0>, wgrad_kernel<a, b, c, d, 3>, wgrad_kernel<a, b, c, d, 6>, nullptr}
+#define CFGQ(a, b, c, d) {a, b, c, d, wgrad_kernel<a, b, c, d, 0>, wgrad_kernel<a, b, c, d, 3>, wgrad_kernel<a, b, c, d, 6>, wgrad_kernel<a, b, c, d, 0, true>}
 static const WCfg kWCfgs[] = {
     CFG(1, 1, 1, 1),  // 32x32
-    CFG(2, 2, 1, 1),  // 64x64
-    CFG(2, 2, 2, 2),  // 128x128
+    CFGQ(2, 2, 1, 1),  // 64x64
+    CFGQ(2, 2, 2, 2),  // 128x128
     CFG(2, 2, 2, 1),  // 128x64
     CFG(2, 2, 1, 2),  // 64x128
-    CFG(4, 1, 1, 1),  // 128x32
+    CFGQ(4, 1, 1, 1),  // 128x32
     CFG(1, 4, 1, 1),  // 32x128
     CFG(3, 1, 1, 3),  // 96x96
     CFG(3, 1, 1, 2),  // 96x64
     CFG(2, 3, 1, 1),  // 64x96
     CFG(5, 1, 1, 2),  // 160x64
     CFG(5, 1, 1, 1),  // 160x32
-    CFG(7, 1, 1, 1),  // 224x32
+    CFGQ(7, 1, 1, 1),  // 224x32
     CFG(7, 1, 1, 2),  // 224x64
-    CFG(4, 2, 1, 1),  // 128x64 (8 waves)
+    CFGQ(4, 2, 1, 1),  // 128x64 (8 waves)
     CFG(2, 4, 1, 1),  // 64x128 (8 waves)
     CFG(4, 2, 1, 2),  // 128x128 (8 waves)
     CFG(3, 2, 1, 1),  // 96x64 (6 waves)
-    CFG(3, 3, 1, 1),  // 96x96 (9 waves)
+    CFGQ(3, 3, 1, 1),  // 96x96 (9 waves)
     CFG(2, 2, 1, 1),  // dup guard (kept for index stability)
     CFG(4, 4, 1, 1),  // 128x128 (16 waves)
     CFG(2, 1, 1, 1),  // 64x32
     CFG(1, 2, 1, 1),  // 32x64
 };
 #undef CFG
+#undef CFGQ
 static const int kNumWCfgs = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
 
 struct WPlan {
@@ -564,8 +573,11 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl, int G = 1) {
   a.d_hw = make_fastdiv((unsigned)(d->PH * d->PW));
   a.d_w = make_fastdiv((unsigned)d->PW);
   double best = 1e300; int bc = -1, bs = 1;
+  const bool sqq = (d->algo & CRDR_WGRAD_SQUARE_Q) != 0;
+  CRDR_REQUIRE(!sqq || !(d->algo & (CRDR_WGRAD_BF16X3 | CRDR_WGRAD_BF16X6)), "wgrad: CRDR_WGRAD_SQUARE_Q is exact fp32");
   for (int c = 0; c < kNumWCfgs; ++c) {
     const WCfg& t = kWCfgs[c];
+    if (sqq && !t.kern_sq) continue;
     const int BI = 32 * t.wm * t.mb, BJ = 32 * t.wn * t.nb;
     const long long tiles = (long long)cdiv(d->PC, BI) * cdiv(ncols, BJ) * ntapg;
     const int waves_per_block = t.wm * t.wn;
@@ -617,6 +629,7 @@ static int build_wplan(const crdr_wgrad_desc* d, WPlan* pl, int G = 1) {
     bc = (d->algo & 0xff) - 1;
     bs = 1 << ((d->algo >> 8) & 0xf);
     CRDR_REQUIRE(bc >= 0 && bc < kNumWCfgs, "wgrad: forced config %d out of range", bc);
+    CRDR_REQUIRE(!sqq || kWCfgs[bc].kern_sq, "wgrad: config %d has no CRDR_WGRAD_SQUARE_Q form", bc);
     CRDR_REQUIRE(bs == 1 || a.ntiles / bs >= 1, "wgrad: forced split %d too deep for %d pixel tiles", bs, a.ntiles);
   }
   CRDR_REQUIRE(bc >= 0, "wgrad: no tile config");
@@ -670,11 +683,13 @@ static int launch_wgrad_slabs(const crdr_wgrad_desc* d, const float* const* ps, 
   const WCfg& t = kWCfgs[pl.cfg];
   CRDR_REQUIRE(!((d->algo & CRDR_WGRAD_BF16X3) && (d->algo & CRDR_WGRAD_BF16X6)), "wgrad: CRDR_WGRAD_BF16X3 and CRDR_WGRAD_BF16X6 are exclusive");
   const int bf3 = (d->algo & CRDR_WGRAD_BF16X3) ? 1 : ((d->algo & CRDR_WGRAD_BF16X6) ? 2 : 0);
-  auto kern = bf3 == 1 ? t.kern_bf3 : (bf3 == 2 ? t.kern_bf6 : t.kern);
-  static std::atomic<bool> attr_done[3][64];
-  if (!attr_done[bf3][pl.cfg].load(std::memory_order_acquire)) {
+  const bool sq = (d->algo & CRDR_WGRAD_SQUARE_Q) != 0;
+  CRDR_REQUIRE(!sq || pl.wino == 0, "wgrad: CRDR_WGRAD_SQUARE_Q with a Winograd id");
+  auto kern = sq ? t.kern_sq : (bf3 == 1 ? t.kern_bf3 : (bf3 == 2 ? t.kern_bf6 : t.kern));
+  static std::atomic<bool> attr_done[4][64];
+  if (!attr_done[sq ? 3 : bf3][pl.cfg].load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done[bf3][pl.cfg].store(true, std::memory_order_release);
+    attr_done[sq ? 3 : bf3][pl.cfg].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(kern, pl.grid, dim3(64 * t.wm * t.wn), pl.lds, as_stream(s), a, grp);
   CRDR_CHECK_LAUNCH("wgrad_kernel");

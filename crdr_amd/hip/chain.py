@@ -110,7 +110,16 @@ KEEP_HANDLES = None
 
 
 class ChainHandle:
-    __slots__ = ("spec", "saved", "geom", "x", "outs", "oc")
+    __slots__ = ("spec", "saved", "geom", "x", "oc")
+
+
+class _KeptCtx:
+    """what _ChainFn.backward reads of its ctx, for a backward on kept activations: the chain input counts as detached
+    (needs_input_grad[0]), there are no beta vectors ([5 + i])"""
+    needs_input_grad = (False,) * 8
+
+    def __init__(self, ctx):
+        self.spec, self.saved_acts, self.geom, self.nrest, self.saved_tensors = ctx.spec, ctx.saved_acts, ctx.geom, ctx.nrest, ctx.saved_tensors
 
 
 class _ChainFn(torch.autograd.Function):
@@ -344,11 +353,7 @@ class _ChainReuseFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
-        class _View:   # _ChainFn.backward reads needs_input_grad[0] (the input: detached here) and [5 + i] (beta vectors: none)
-            needs_input_grad = (False,) * 8
-        for name in ("spec", "saved_acts", "geom", "nrest", "saved_tensors"):
-            setattr(_View, name, getattr(ctx, name))
-        _ChainFn.backward(_View, *douts)
+        _ChainFn.backward(_KeptCtx(ctx), *douts)
         return (None,) * (1 + ctx.nrest)
 
 

@@ -96,6 +96,7 @@ EPI_BIAS, EPI_RELU, EPI_LRELU, EPI_VEC2, EPI_RES, EPI_GATE, EPI_AFFINE, EPI_ACCU
 EPI_PREADD, EPI_RELUMASK, EPI_LRELUMASK, EPI_MASKOFF, EPI_COLSUM = 256, 512, 1024, 2048, 4096
 CONV_NOSPLIT, CONV_BF16X3, WGRAD_BF16X3 = 8192, 16384, 1 << 16
 CONV_BF16X6, WGRAD_BF16X6 = 32768, 1 << 17
+WGRAD_SQUARE_Q = 1 << 18   # crdr_hip.h: the gathered operand enters squared (the GDN gamma gradient)
 MAX_GROUP = 16
 EB_PARAMS = 58
 

@@ -242,6 +242,8 @@ typedef struct crdr_wgrad_desc {
                        * bit 16 (CRDR_WGRAD_BF16X3): split-bf16 products, see CRDR_CONV_BF16X3 */
 } crdr_wgrad_desc;
 #define CRDR_WGRAD_BF16X3 (1 << 16)
+#define CRDR_WGRAD_SQUARE_Q (1 << 18) /* the gathered operand enters squared: g = sum P Q^2 (the gamma gradient of a GDN layer without an x^2 tensor in
+                                      * memory); exact fp32, direct kernels, a subset of the tile configurations (others are refused when forced) */
 #define CRDR_WGRAD_BF16X6 (1 << 17) /* fp32-equivalent split-bf16 products (see CRDR_CONV_BF16X6) in the direct weight-gradient kernels; the Winograd
                                      * slab kernels ignore it */
 /* number of forced configurations; the LAST one (index crdr_conv2d_wgrad_num_configs() - 1) is the Winograd F(3x3, 2x2) slab kernel

@@ -88,3 +88,83 @@ def test_gdn_forward_is_stable_beside_a_loaded_chip(c):
             y = m(x)
             assert torch.equal(y, y0), f"run {rep} differs from the unloaded run"
         torch.cuda.synchronize()
+
+
+def _gdn_f64(m, x, cot, inverse):
+    """float64 value and gradients of the op on the device, from the formula (compressai's parametrisation with its LowerBound rule is
+    covered by the oracle test above: here the parameters sit above their bounds)"""
+    ped = 2.0 ** -36
+    gp = m.gamma.detach().double().requires_grad_(True)
+    bp = m.beta.detach().double().requires_grad_(True)
+    gam = torch.clamp(gp, min=2.0 ** -18) ** 2 - ped
+    bet = torch.clamp(bp, min=(1e-6 + ped) ** 0.5) ** 2 - ped
+    xd = x.detach().double().requires_grad_(True)
+    n = torch.einsum("ij,njhw->nihw", gam, xd * xd) + bet.view(1, -1, 1, 1)
+    y = xd * torch.sqrt(n) if inverse else xd / torch.sqrt(n)
+    (y * cot.double()).sum().backward()
+    return y.detach(), xd.grad, bp.grad, gp.grad
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("c,n,h,w", [(192, 2, 100, 100), (128, 3, 90, 77), (100, 2, 100, 90), (64, 4, 75, 75), (192, 1, 5, 5)])
+def test_gdn_fused_backward_many_tiles_vs_float64(inverse, c, n, h, w, monkeypatch):
+    """The two-pass fused backward (gdn.hip: gdn_fused_bwd_kernel, the CRDR_WGRAD_SQUARE_Q weight gradient, the per-workgroup column sums)
+    with more 64-pixel tiles than workgroups, ragged last tiles and channel counts that do not fill the padded blocks: against float64 and
+    against the nine-launch form (CRDR_GDN_UNFUSED_BWD=1)."""
+    from crdr_amd.models.layer.gdn import GDN
+    d = dev()
+    m = GDN(c, inverse=inverse)
+    g = torch.Generator().manual_seed(11 + c + int(inverse))
+    with torch.no_grad():
+        m.gamma.copy_(torch.sqrt(torch.rand(c, c, generator=g) * 0.02 + 2.0 ** -36))
+        m.beta.copy_(torch.sqrt(torch.rand(c, generator=g) + 0.5))
+    m.to(d)
+    x = (torch.randn(n, c, h, w, generator=g) * 2.0).to(d).contiguous(memory_format=torch.channels_last)
+    cot = torch.randn(n, c, h, w, generator=g).to(d).contiguous(memory_format=torch.channels_last)
+    _, dx64, db64, dg64 = _gdn_f64(m, x, cot, inverse)
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        xd = x.clone().requires_grad_(True)
+        (m(xd) * cot).sum().backward()
+        torch.cuda.synchronize()
+        return xd.grad.clone(), m.beta.grad.clone(), m.gamma.grad.clone()
+    fused = run()
+    again = run()
+    monkeypatch.setenv("CRDR_GDN_UNFUSED_BWD", "1")
+    plain = run()
+    monkeypatch.delenv("CRDR_GDN_UNFUSED_BWD")
+    for name, a, b, r, tol in (("dx", fused[0], plain[0], dx64, 2e-5), ("dbeta", fused[1], plain[1], db64, 5e-5),
+                                ("dgamma", fused[2], plain[2], dg64, 5e-5)):
+        e_f, e_p = rel(a.double(), r), rel(b.double(), r)
+        assert e_f < tol, (name, e_f, e_p)
+        assert e_f < 3 * e_p + 2e-6, (name, e_f, e_p)   # no worse than the nine-launch form
+    assert all(torch.equal(a, b) for a, b in zip(fused, again)), "the fused backward is not run-to-run identical"
+
+
+def test_wgrad_square_q_equals_wgrad_of_the_squared_operand():
+    """CRDR_WGRAD_SQUARE_Q (wgrad.hip): g = sum P Q^2 with the square taken inside the kernel -- the same bits as the launch on a squared
+    copy (same configuration and split), and refused together with the split-bf16 forms."""
+    from crdr_amd.hip import lib as L, ops
+    d = dev()
+    g_ = torch.Generator().manual_seed(5)
+    for c in (192, 128, 64):
+        p = torch.randn(3, c, 50, 41, generator=g_).to(d).contiguous(memory_format=torch.channels_last)
+        q = torch.randn(3, c, 50, 41, generator=g_).to(d).contiguous(memory_format=torch.channels_last)
+        q2 = (q * q).contiguous(memory_format=torch.channels_last)
+        for cfg in range(L.load().crdr_conv2d_wgrad_num_configs()):
+            for ls in (0, 3):
+                a = (cfg + 1) | (ls << 8)
+                g0, g1 = torch.empty(c, c, 1, 1, device=d), torch.empty(c, c, 1, 1, device=d)
+                try:
+                    ops.conv2d_wgrad_raw(p, q, g1, (1, 1), 1, 0, False, algo=a | L.WGRAD_SQUARE_Q)
+                except L.CrdrHipError:
+                    continue   # configurations without a squared form
+                ops.conv2d_wgrad_raw(p, q2, g0, (1, 1), 1, 0, False, algo=a)
+                assert torch.equal(g0, g1), (c, cfg, ls)
+        g1 = torch.empty(c, c, 1, 1, device=d)
+        ops.conv2d_wgrad_raw(p, q, g1, (1, 1), 1, 0, False, algo=L.WGRAD_SQUARE_Q)   # the plan's own choice among the squared forms
+        ref = torch.einsum("nihw,njhw->ij", p.double(), q.double() ** 2)
+        assert rel(g1.view(c, c).double(), ref) < 2e-5
+        with pytest.raises(L.CrdrHipError):
+            ops.conv2d_wgrad_raw(p, q, g1, (1, 1), 1, 0, False, algo=L.WGRAD_SQUARE_Q | L.WGRAD_BF16X6)

@@ -41,6 +41,8 @@ SHAPES = {
     "charm128": (128, 16, 32, 3, 1, 0, 1),
     "nlam160": (160, 16, 160, 3, 1, 0, 3),
     "D256s2": (256, 64, 256, 3, 2, 0, 5),
+    "gdn192": (192, 128, 192, 1, 1, 0, 0),     # the GDN channel mix and its gamma gradient (gdn.hip)
+    "gdn192@32": (192, 32, 192, 1, 1, 0, 0),
 }
 
 
