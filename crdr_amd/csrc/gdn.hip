@@ -8,8 +8,9 @@
 // pedestal = reparam_offset^2, bound_beta = sqrt(beta_min + pedestal), bound_gamma = reparam_offset; the max() carries the
 // LowerBound gradient rule (pass where v >= bound or the gradient would raise v).
 //
-// The channel mix (a C x C GEMV per pixel) runs on the fp32 matrix cores as a 1x1 launch of the implicit-GEMM kernel on
-// x^2; the rest are single-pass elementwise kernels (16 B per lane).  Not on the CRDR training path -- the ELIC
+// Up to 192 channels the forward and the backward are fused persistent kernels (below); beyond, the channel mix (a C x C GEMV
+// per pixel) runs on the fp32 matrix cores as a 1x1 launch of the implicit-GEMM kernel on x^2 and the rest are single-pass
+// elementwise kernels (16 B per lane).  Not on the CRDR training path -- the ELIC
 // transforms use ReLU bottlenecks -- so this is a registered optional op, parity-tested and profiled on its own.
 
 #include <algorithm>
@@ -314,94 +315,97 @@ static void gdn_fused_launch(const GdnFusedArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Fused backward: TWO passes of the same persistent form (gamma in registers, 64-pixel tiles through LDS by LDS-DMA, double buffered)
-// replace the norm pass + four elementwise kernels + the 1x1 launch of the nine-launch form (72 -> 40 B per element with the weight
-// gradient's CRDR_WGRAD_SQUARE_Q launch and the column sums folded into the first pass):
-//   phase 0:  n = beta + gamma x^2 (the forward's mix, recomputed);  u = dy n^(-1/2) [dy n^(1/2)],  dn = -1/2 dy x n^(-3/2) [1/2 dy x n^(-1/2)];
-//             reads x (LDS tile) and dy, writes dn and u, and leaves the per-workgroup column sums of dn (the beta gradient) in `colpart`
-//   phase 1:  w = gamma^T dn,  dx = u + 2 x w;  reads dn (LDS tile), x and u, writes dx
-// The matrix operands are SWAPPED against the forward kernel -- gamma is the A operand, the pixel tile the B operand -- so that a lane's
-// four accumulator elements are four CONSECUTIVE CHANNELS of one pixel (row 16 rb + ln, channels col0 + 16 cb + 4 lg ..): every operand
-// and result of the epilogue is one 16-byte access per (rb, cb), straight from / to global memory in registers (64-byte row segments; the
-// two halves of a 128-byte line are touched by consecutive instructions of the same wave), requested at the top of the tile and hidden
-// behind its matrix loop.  No LDS traffic and no barrier after the matrix loop: one barrier per tile (the buffer hand-over).
+// The backward in ONE pass: both channel mixes of a tile inside the same workgroup.  gamma (for n = beta + gamma x^2) stays in registers
+// as in the forward kernel; its transpose (for w = gamma^T dn) does NOT fit beside it (2 x 144 registers per lane at 192 channels left the
+// allocator 89 spills) and is STREAMED instead: every K step's fragments (NCB x 16 bytes per lane) come from the L2-resident pack through a
+// ring of three steps, requested three steps (144 MFMAs) ahead.  dn crosses the waves through a third LDS tile (each wave writes its
+// channels in the tile image the matrix loop reads; one barrier), u = dy n^(-1/2) never leaves the registers that received dy.
+// HBM traffic: x and dy in, dn (for the weight gradient) and dx out -- 16 B per element, against 32 B for a two-pass form (x, dy -> dn, u; dn, x, u -> dx: measured 248 + 236 us at 16 x 192 x 128 x 128, both passes bound by
+// their 16 B per element at ~5 TB/s with the matrix loop only partly hidden; this kernel: 403 us), and the two matrix loops of a tile (2 x 576 MFMAs) hide the tile's 192 KB.
 // ------------------------------------------------------------------------------------------------------------
-struct GdnBwdArgs {
-  const float* src;    // the tile operand: x (phase 0) or dn (phase 1)
-  const float* pack;   // phase 0: gamma_eff [CP][CP] (row = output channel i); phase 1: its transpose (row = input channel j)
-  const float* beta;   // beta_eff [C] (phase 0)
-  const float* r0;     // phase 0: dy; phase 1: x
-  const float* r1;     // phase 1: u
-  float* o0;           // phase 0: dn; phase 1: dx
-  float* o1;           // phase 0: u
-  float* colpart;      // phase 0: [gridDim.x][CP] column sums of dn over the workgroup's tiles
+struct GdnBwd1Args {
+  const float* x;
+  const float* dy;
+  const float* pack_f;   // gamma_eff [CP][CP] (row = output channel i)
+  const float* pack_b;   // its transpose (row = input channel j)
+  const float* beta;     // beta_eff [C]
+  float* dn;             // [M][ld_dn]
+  float* dx;
+  float* colpart;        // [gridDim.x][CP]
   long long M;
-  int C, CP, ld_src, ld_r0, ld_r1, ld_o0, ld_o1, inverse, tiles;
+  int C, CP, ldx, lddy, ld_dn, lddx, inverse, tiles;
   unsigned pack_bytes;
 };
 
-template <int NS, int PHASE>
-__global__ __launch_bounds__(256) void gdn_fused_bwd_kernel(const GdnBwdArgs p) {
+template <int NS, bool INV>
+__global__ __launch_bounds__(256) void gdn_bwd_onepass_kernel(const GdnBwd1Args p) {
   constexpr int BM = kGdnBM, NCB = NS / 4, NBX = NS / 2, XF = NBX * BM * 32;
-  constexpr int NST = PHASE == 0 ? 2 * NS : NS;   // stores per thread and tile (the youngest requests at the top of the next tile)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sX = smem;                    // [2][NBX][BM * 32]
+  float* sX = smem;             // [2][NBX][BM * 32]
+  float* sD = smem + 2 * XF;    // [NBX][BM * 32]: dn of the current tile
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, lg = lane >> 4;
   const int col0 = wave * 16 * NCB;
   if ((int)blockIdx.x >= p.tiles) return;
-  f32x4 B[NCB][NS];
+  f32x4 Bf[NCB][NS];
   {
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack), 0, p.pack_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack_f), 0, p.pack_bytes, 0x00020000);
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const int row = col0 + 16 * cb + ln, k = 16 * s + 4 * lg;
-        const bool ok = row < p.CP && k < p.CP;
-        B[cb][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? ((unsigned)row * p.CP + k) * 4u : 0x80000000u, 0, 0));
+        const unsigned off = (row < p.CP && k < p.CP) ? ((unsigned)row * p.CP + k) * 4u : 0x80000000u;
+        Bf[cb][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rf, off, 0, 0));
       }
   }
+  // the transposed pack, streamed: K step s of channel block cb is 16 bytes at boff[cb] + 64 s (K steps past the pack: zeros)
+  const __amdgpu_buffer_rsrc_t rpb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack_b), 0, p.pack_bytes, 0x00020000);
+  unsigned boff[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int row = col0 + 16 * cb + ln;
+    boff[cb] = row < p.CP ? ((unsigned)row * p.CP + 4 * lg) * 4u : 0x80000000u;
+  }
+  constexpr int RING = 3;
+  auto load_b = [&](int s, f32x4 (&dst)[NCB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+      dst[cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpb, 16 * s < p.CP ? boff[cb] + 64u * s : 0x80000000u, 0, 0));
+  };
   const int srow = tid >> 3;
   const int csrc = (tid & 7) ^ ((srow >> 1) & 7);
-  unsigned xoff[NBX][2];
-#pragma unroll
-  for (int kc = 0; kc < NBX; ++kc)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int chx = 32 * kc + csrc * 4;
-      xoff[kc][j] = chx < p.C ? ((unsigned)(srow + 32 * j) * p.ld_src + chx) * 4u : 0x80000000u;
-    }
-  // the lane's channels: ch(cb) = col0 + 16 cb + 4 lg .. + 3 of pixel row 16 rb + ln; channel groups past C are masked by the range check
-  // (0x80000000 + anything a tile can add stays out of range)
-  f32x4 bta[NCB];
+  // request offsets are rebuilt from a few per-lane bases inside the tile loop (the bases are made opaque there): hoisted out of the loop as
+  // loop invariants, the ~60 offsets of a tile's requests do not fit beside gamma and come back from scratch memory
+  unsigned xbase = ((unsigned)srow * p.ldx + csrc * 4) * 4u;
+  float* sBeta = smem + 3 * XF;   // [64 NCB]
+  for (int c = tid; c < 64 * NCB; c += 256) sBeta[c] = c < p.C ? p.beta[c] : 1.f;
   bool chok[NCB];
-  int xe[NCB];   // phase 0: float offset of (row ln, channels ch(cb)) inside an x tile; row block rb adds 512 rb (the swizzle repeats every 16 rows)
+  int xe[NCB];   // float offset of (row ln, channels ch(cb) .. + 3) inside a tile image; row block rb adds 512 rb
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
     const int ch = col0 + 16 * cb + 4 * lg;
     chok[cb] = ch < p.C;
-    bta[cb] = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (PHASE == 0 && chok[cb]) bta[cb] = *reinterpret_cast<const f32x4*>(p.beta + ch);
     xe[cb] = (ch >> 5) * BM * 32 + lds_off(ln, (ch & 31) >> 2);
   }
-  auto lane_off = [&](int ld, int cb, int rb) __attribute__((always_inline)) {
-    return chok[cb] ? ((unsigned)(16 * rb + ln) * ld + col0 + 16 * cb + 4 * lg) * 4u : 0x80000000u;
+  unsigned lb_dy = ((unsigned)ln * p.lddy + col0 + 4 * lg) * 4u, lb_dn = ((unsigned)ln * p.ld_dn + col0 + 4 * lg) * 4u,
+           lb_dx = ((unsigned)ln * p.lddx + col0 + 4 * lg) * 4u;
+  auto lane_off = [&](unsigned lb, int ld, int cb, int rb) __attribute__((always_inline)) {
+    return chok[cb] ? lb + (unsigned)(16 * rb * ld * 4 + 64 * cb) : 0x80000000u;
   };
-  // a tile's descriptor ends at its last valid row (rows past the tensor: loads give zeros, stores are dropped); a tile past the last one
-  // has no bytes at all, so that the prefetch below needs no branch (and the waits count the same requests on every path)
   auto tile_rsrc = [&](const float* base, int ld, long long m0) __attribute__((always_inline)) {
     const long long left = p.M - m0;
     const long long bytes = left <= 0 ? 0 : ((left < BM ? left : BM) - 1) * ld * 4ll + p.C * 4ll;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + (left <= 0 ? 0 : m0 * ld), 0, (unsigned)std::min<long long>(bytes, 0x7fffffffll), 0x00020000);
   };
   auto fetch = [&](long long m0, int buf) __attribute__((always_inline)) {
-    const __amdgpu_buffer_rsrc_t rx = tile_rsrc(p.src, p.ld_src, m0);
+    const __amdgpu_buffer_rsrc_t rx = tile_rsrc(p.x, p.ldx, m0);
 #pragma unroll
     for (int kc = 0; kc < NBX; ++kc)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (gdn_lds_ptr_t)(sX + buf * XF + kc * BM * 32 + wave * 8 * 32 + j * 32 * 32), 16, (int)xoff[kc][j], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (gdn_lds_ptr_t)(sX + buf * XF + kc * BM * 32 + wave * 8 * 32 + j * 32 * 32), 16,
+                                                 (int)(32 * kc + csrc * 4 < p.C ? xbase + (unsigned)(128 * kc + j * 32 * p.ldx * 4) : 0x80000000u), 0, 0, 0);
   };
   f32x4 csum[NCB];
 #pragma unroll
@@ -411,114 +415,136 @@ __global__ __launch_bounds__(256) void gdn_fused_bwd_kernel(const GdnBwdArgs p) 
   bool first = true;
   for (; t < p.tiles; t += gridDim.x, cur ^= 1) {
     const long long m0 = (long long)t * BM;
-    // this tile has landed (everything but the previous tile's NST stores); every wave is done with the other buffer
+    asm volatile("" : "+v"(xbase), "+v"(lb_dy), "+v"(lb_dn), "+v"(lb_dx));
+    // x of this tile has landed (everything but the previous tile's 2 NS stores); every wave is done with the other x buffer and with sD
     if (first) gdn_wait_barrier<0>();
-    else gdn_wait_barrier<NST>();
+    else gdn_wait_barrier<2 * NS>();
     first = false;
-    // the epilogue's register operands first (they are waited for first), then the next tile
-    f32x4 r0[4][NCB], r1[4][NCB];
+    f32x4 g[4][NCB];   // dy, then u
     {
-      const __amdgpu_buffer_rsrc_t q0 = tile_rsrc(p.r0, p.ld_r0, m0);
+      const __amdgpu_buffer_rsrc_t q0 = tile_rsrc(p.dy, p.lddy, m0);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) r0[rb][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q0, lane_off(p.ld_r0, cb, rb), 0, 0));
-      if constexpr (PHASE == 1) {
-        const __amdgpu_buffer_rsrc_t q1 = tile_rsrc(p.r1, p.ld_r1, m0);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) r1[rb][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q1, lane_off(p.ld_r1, cb, rb), 0, 0));
-      }
+        for (int cb = 0; cb < NCB; ++cb) g[rb][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q0, lane_off(lb_dy, p.lddy, cb, rb), 0, 0));
     }
     fetch((long long)(t + (int)gridDim.x) * BM, cur ^ 1);
-    f32x4 acc[4][NCB];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     float* xt = sX + cur * XF;
-    auto a_ptr = [&](int g) __attribute__((always_inline)) {
-      const int s = g >> 2, rb = g & 3;
-      return reinterpret_cast<const f32x4*>(xt + (s >> 1) * BM * 32 + lds_off(16 * rb + ln, 4 * (s & 1) + lg));
+    f32x4 acc[4][NCB];
+    auto a_ptr = [&](const float* tile, int gi) __attribute__((always_inline)) {
+      const int s = gi >> 2, rb = gi & 3;
+      return reinterpret_cast<const f32x4*>(tile + (s >> 1) * BM * 32 + lds_off(16 * rb + ln, 4 * (s & 1) + lg));
     };
-    f32x4 a_nxt = *a_ptr(0);
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = 0; g < NS * 4; ++g) {
-      const int s = g >> 2, rb = g & 3;
-      f32x4 a = PHASE == 0 ? a_nxt * a_nxt : a_nxt;
-      if (g + 1 < NS * 4) a_nxt = *a_ptr(g + 1);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // first mix: acc[rb][cb][i] = sum_k gamma[ch][k] x^2(pixel row 16 rb + ln, k)
+    zero_acc();
+    {
+      f32x4 a_nxt = *a_ptr(xt, 0);
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[cb][s][e], a[e], acc[rb][cb], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int gi = 0; gi < NS * 4; ++gi) {
+        const int s = gi >> 2, rb = gi & 3;
+        f32x4 a = a_nxt * a_nxt;
+        if (gi + 1 < NS * 4) a_nxt = *a_ptr(xt, gi + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[cb][s][e], a[e], acc[rb][cb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    // acc[rb][cb][i] is (pixel row 16 rb + ln, channel col0 + 16 cb + 4 lg + i)
-    if constexpr (PHASE == 0) {
-      const __amdgpu_buffer_rsrc_t w0 = tile_rsrc(p.o0, p.ld_o0, m0), w1 = tile_rsrc(p.o1, p.ld_o1, m0);
+    // the second mix's first K steps, requested ahead of the epilogue's stores (requests return in order)
+    f32x4 ring[RING][NCB];
+#pragma unroll
+    for (int r = 0; r < RING; ++r) load_b(r, ring[r]);
+    {
+      const __amdgpu_buffer_rsrc_t w0 = tile_rsrc(p.dn, p.ld_dn, m0);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
           const f32x4 xv = *reinterpret_cast<const f32x4*>(xt + xe[cb] + 512 * rb);
-          const f32x4 g = r0[rb][cb];
+          const f32x4 gy = g[rb][cb];
+          const f32x4 bta = *reinterpret_cast<const f32x4*>(sBeta + col0 + 16 * cb + 4 * lg);
           f32x4 dn, u;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float n = acc[rb][cb][i] + bta[cb][i];
+            const float n = acc[rb][cb][i] + bta[i];
             const float rs = __builtin_amdgcn_rsqf(n);
-            if (p.inverse) { u[i] = g[i] * __builtin_amdgcn_sqrtf(n); dn[i] = 0.5f * g[i] * xv[i] * rs; }
-            else { u[i] = g[i] * rs; dn[i] = -0.5f * u[i] * xv[i] * (rs * rs); }
+            if constexpr (INV) { u[i] = gy[i] * __builtin_amdgcn_sqrtf(n); dn[i] = 0.5f * gy[i] * xv[i] * rs; }
+            else { u[i] = gy[i] * rs; dn[i] = -0.5f * u[i] * xv[i] * (rs * rs); }
           }
+          g[rb][cb] = u;
           csum[cb] += dn;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, dn), w0, lane_off(p.ld_o0, cb, rb), 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, u), w1, lane_off(p.ld_o1, cb, rb), 0, 0);
+          *reinterpret_cast<f32x4*>(sD + xe[cb] + 512 * rb) = dn;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, dn), w0, lane_off(lb_dn, p.ld_dn, cb, rb), 0, 0);
         }
-    } else {
-      const __amdgpu_buffer_rsrc_t w0 = tile_rsrc(p.o0, p.ld_o0, m0);
+    }
+    gdn_wait_barrier<63>();   // every wave's dn is in sD (lgkmcnt(0) + barrier; vector memory is not waited for)
+    // second mix: acc[rb][cb][i] = sum_k gamma[k][ch] dn(pixel row 16 rb + ln, k)
+    zero_acc();
+    {
+      f32x4 a_nxt = *a_ptr(sD, 0);
+#pragma unroll
+      for (int gi = 0; gi < NS * 4; ++gi) {
+        const int s = gi >> 2, rb = gi & 3;
+        f32x4 a = a_nxt;
+        if (gi + 1 < NS * 4) a_nxt = *a_ptr(sD, gi + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[s % RING][cb][e], a[e], acc[rb][cb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rb == 3 && s + RING < NS) load_b(s + RING, ring[s % RING]);
+      }
+    }
+    {
+      const __amdgpu_buffer_rsrc_t w1 = tile_rsrc(p.dx, p.lddx, m0);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-          const f32x4 dx = r1[rb][cb] + 2.0f * r0[rb][cb] * acc[rb][cb];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, dx), w0, lane_off(p.ld_o0, cb, rb), 0, 0);
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xt + xe[cb] + 512 * rb);
+          const f32x4 dx = g[rb][cb] + 2.0f * xv * acc[rb][cb];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, dx), w1, lane_off(lb_dx, p.lddx, cb, rb), 0, 0);
         }
     }
   }
-  if constexpr (PHASE == 0) {   // the workgroup's column sums of dn: over the 16 pixel lanes of a lane group, in a fixed order
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
+  for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = csum[cb][i];
+    for (int i = 0; i < 4; ++i) {
+      float v = csum[cb][i];
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
-        csum[cb][i] = v;
-      }
-      const int ch = col0 + 16 * cb + 4 * lg;
-      if (ln == 0 && ch < p.CP) *reinterpret_cast<f32x4*>(p.colpart + (size_t)blockIdx.x * p.CP + ch) = csum[cb];
+      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+      csum[cb][i] = v;
     }
+    const int ch = col0 + 16 * cb + 4 * lg;
+    if (ln == 0 && ch < p.CP) *reinterpret_cast<f32x4*>(p.colpart + (size_t)blockIdx.x * p.CP + ch) = csum[cb];
   }
 }
 
-template <int NS, int PHASE>
-static void gdn_bwd_launch(const GdnBwdArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)2 * (NS / 2) * kGdnBM * 32 * sizeof(float);
+template <int NS, bool INV>
+static void gdn_bwd1_launch_dir(const GdnBwd1Args& a, hipStream_t s) {
+  const size_t lds = ((size_t)3 * (NS / 2) * kGdnBM * 32 + 64 * (NS / 4)) * sizeof(float);
   static std::atomic<bool> done{false};
   if (!done.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gdn_fused_bwd_kernel<NS, PHASE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gdn_bwd_onepass_kernel<NS, INV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done.store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL((gdn_fused_bwd_kernel<NS, PHASE>), dim3(std::min(a.tiles, 256)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((gdn_bwd_onepass_kernel<NS, INV>), dim3(std::min(a.tiles, 256)), dim3(256), lds, s, a);
 }
 
-template <int PHASE>
-static void gdn_bwd_dispatch(const GdnBwdArgs& a, hipStream_t s) {
-  if (a.C <= 64) gdn_bwd_launch<4, PHASE>(a, s);
-  else if (a.C <= 128) gdn_bwd_launch<8, PHASE>(a, s);
-  else gdn_bwd_launch<12, PHASE>(a, s);
+template <int NS>
+static void gdn_bwd1_launch(const GdnBwd1Args& a, hipStream_t s) {
+  if (a.inverse) gdn_bwd1_launch_dir<NS, true>(a, s);
+  else gdn_bwd1_launch_dir<NS, false>(a, s);
 }
 
 // the beta gradient: the first pass's per-workgroup column sums [parts][CP], added in a fixed order (32 channels per workgroup; 8 row
@@ -684,28 +710,25 @@ extern "C" int crdr_gdn_bwd(const crdr_gdn_desc* d, const float* x, const float*
   wd.kh = 1; wd.kw = 1; wd.stride = 1; wd.pad = 0; wd.gI = d->C; wd.gJ = d->C; wd.accumulate = 0;
   const float ped = d->reparam_offset * d->reparam_offset;
   if (gdn_fused_ok(d, L) && (long long)128 * lddy * 4 < (1ll << 31) && (long long)128 * lddx * 4 < (1ll << 31) && !gdn_unfused_backward()) {
-    // reparametrisation, two fused passes, the gamma gradient straight from (dn, x) with the square taken in the kernel, the chain rule
+    // reparametrisation, ONE pass over (x, dy) -> (dx, dn, column sums), the gamma gradient straight from (dn, x) with the square taken in the
+    // kernel, the chain rule through the parametrisation
     hipLaunchKernelGGL(gdn_reparam_kernel, dim3(grid1((int64_t)L.CP * L.CP)), dim3(256), 0, as_stream(s), beta, gamma, d->C, L.CP,
                        sqrtf(d->beta_min + ped), d->reparam_offset, ped, (float*)(w8 + L.beta_eff), (float*)(w8 + L.pack_f), (float*)(w8 + L.pack_b));
     CRDR_CHECK_LAUNCH("gdn_reparam");
-    float *dn = (float*)(w8 + L.dn), *u = (float*)(w8 + L.u), *dg = (float*)(w8 + L.dg), *parts = (float*)(w8 + L.colpart);
-    GdnBwdArgs a;
-    memset(&a, 0, sizeof(a));
-    a.M = d->M; a.C = d->C; a.CP = L.CP; a.inverse = d->inverse; a.tiles = (int)((d->M + kGdnBM - 1) / kGdnBM);
-    a.pack_bytes = (unsigned)((size_t)L.CP * L.CP * 4);
-    a.beta = (const float*)(w8 + L.beta_eff); a.colpart = parts;
-    a.src = x; a.ld_src = d->ldx; a.pack = (const float*)(w8 + L.pack_f); a.r0 = dy; a.ld_r0 = lddy;
-    a.o0 = dn; a.ld_o0 = d->C; a.o1 = u; a.ld_o1 = d->C;
-    gdn_bwd_dispatch<0>(a, as_stream(s));
-    CRDR_CHECK_LAUNCH("gdn_fused_bwd<0>");
-    a.src = dn; a.ld_src = d->C; a.pack = (const float*)(w8 + L.pack_b); a.r0 = x; a.ld_r0 = d->ldx; a.r1 = u; a.ld_r1 = d->C;
-    a.o0 = dx; a.ld_o0 = lddx; a.o1 = nullptr; a.ld_o1 = 0;
-    gdn_bwd_dispatch<1>(a, as_stream(s));
-    CRDR_CHECK_LAUNCH("gdn_fused_bwd<1>");
+    float *dn = (float*)(w8 + L.dn), *dg = (float*)(w8 + L.dg), *parts = (float*)(w8 + L.colpart);
+    GdnBwd1Args b;
+    memset(&b, 0, sizeof(b));
+    b.x = x; b.dy = dy; b.pack_f = (const float*)(w8 + L.pack_f); b.pack_b = (const float*)(w8 + L.pack_b); b.beta = (const float*)(w8 + L.beta_eff);
+    b.dn = dn; b.dx = dx; b.colpart = parts; b.M = d->M; b.C = d->C; b.CP = L.CP; b.ldx = d->ldx; b.lddy = lddy; b.ld_dn = d->C; b.lddx = lddx;
+    b.inverse = d->inverse; b.tiles = (int)((d->M + kGdnBM - 1) / kGdnBM); b.pack_bytes = (unsigned)((size_t)L.CP * L.CP * 4);
+    if (d->C <= 64) gdn_bwd1_launch<4>(b, as_stream(s));
+    else if (d->C <= 128) gdn_bwd1_launch<8>(b, as_stream(s));
+    else gdn_bwd1_launch<12>(b, as_stream(s));
+    CRDR_CHECK_LAUNCH("gdn_bwd_onepass");
     wd.ldq = d->ldx; wd.algo = CRDR_WGRAD_SQUARE_Q;
     if (int rc = crdr_conv2d_wgrad(&wd, dn, x, dg, w8 + L.conv_ws, L.conv_ws_bytes, s)) return rc;
     float* db = (float*)(w8 + L.db);
-    hipLaunchKernelGGL(gdn_colpart_sum_kernel, dim3((d->C + 31) / 32), dim3(256), 0, as_stream(s), (const float*)parts, std::min(a.tiles, 256), L.CP,
+    hipLaunchKernelGGL(gdn_colpart_sum_kernel, dim3((d->C + 31) / 32), dim3(256), 0, as_stream(s), (const float*)parts, std::min(b.tiles, 256), L.CP,
                        d->C, db);
     CRDR_CHECK_LAUNCH("gdn_colpart_sum");
     hipLaunchKernelGGL(gdn_reparam_bwd_kernel, dim3(grid1((int64_t)d->C * d->C)), dim3(256), 0, as_stream(s), (const float*)dg,

@@ -522,7 +522,8 @@ int crdr_eb_quantile_loss(const float* quantiles, const float* params, const flo
 /*   beta, gamma are the STORED parameters of compressai's NonNegativeParametrizer:                                  */
 /*   v_eff = max(v, bound)^2 - reparam_offset^2, bound_beta = sqrt(beta_min + reparam_offset^2), bound_gamma =        */
 /*   reparam_offset (defaults beta_min 1e-6, reparam_offset 2^-18); the backward applies the LowerBound gradient rule.  */
-/*   The C x C channel mix runs as a 1x1 launch of the MFMA conv kernel on x^2.  dbeta / dgamma ACCUMULATE.            */
+/*   C <= 192: forward and backward are fused persistent kernels (gamma in registers, one pass over x / over x and dy);  */
+/*   larger C: the channel mix runs as a 1x1 launch of the MFMA conv kernel on x^2.  dbeta / dgamma ACCUMULATE.          */
 /* ------------------------------------------------------------------------------------------------ */
 typedef struct crdr_gdn_desc {
   int64_t M; /* pixels */

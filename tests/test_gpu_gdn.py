@@ -108,7 +108,7 @@ def _gdn_f64(m, x, cot, inverse):
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("c,n,h,w", [(192, 2, 100, 100), (128, 3, 90, 77), (100, 2, 100, 90), (64, 4, 75, 75), (192, 1, 5, 5)])
 def test_gdn_fused_backward_many_tiles_vs_float64(inverse, c, n, h, w, monkeypatch):
-    """The two-pass fused backward (gdn.hip: gdn_fused_bwd_kernel, the CRDR_WGRAD_SQUARE_Q weight gradient, the per-workgroup column sums)
+    """The one-pass fused backward (gdn.hip: gdn_bwd_onepass_kernel, the CRDR_WGRAD_SQUARE_Q weight gradient, the per-workgroup column sums)
     with more 64-pixel tiles than workgroups, ragged last tiles and channel counts that do not fill the padded blocks: against float64 and
     against the nine-launch form (CRDR_GDN_UNFUSED_BWD=1)."""
     from crdr_amd.models.layer.gdn import GDN
@@ -168,3 +168,36 @@ def test_wgrad_square_q_equals_wgrad_of_the_squared_operand():
         assert rel(g1.view(c, c).double(), ref) < 2e-5
         with pytest.raises(L.CrdrHipError):
             ops.conv2d_wgrad_raw(p, q, g1, (1, 1), 1, 0, False, algo=L.WGRAD_SQUARE_Q | L.WGRAD_BF16X6)
+
+
+@pytest.mark.parametrize("c", [192, 128])
+def test_gdn_backward_is_stable_beside_a_loaded_chip(c):
+    """The one-pass backward hands dn from wave to wave through an LDS tile and reuses it and the x buffers from tile to tile: with more
+    tiles than CUs and a second stream keeping the chip unevenly busy, every run must give the bits of the unloaded run."""
+    from crdr_amd.models.layer.gdn import GDN
+    d = dev()
+    m = GDN(c)
+    g = torch.Generator().manual_seed(17 + c)
+    with torch.no_grad():
+        m.gamma.copy_(torch.sqrt(torch.rand(c, c, generator=g) * 0.02 + 2.0 ** -36))
+        m.beta.copy_(torch.sqrt(torch.rand(c, generator=g) + 0.5))
+    m.to(d)
+    x = (torch.randn(8, c, 96, 96, generator=g) * 2.0).to(d).contiguous(memory_format=torch.channels_last)
+    cot = torch.randn(8, c, 96, 96, generator=g).to(d).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        xd = x.clone().requires_grad_(True)
+        (m(xd) * cot).sum().backward()
+        return xd.grad, m.beta.grad.clone(), m.gamma.grad.clone()
+    ref = [t.clone() for t in run()]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=d)
+    a = torch.randn(4096, 4096, device=d)
+    for rep in range(10):
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 3):
+                a = torch.tanh(a @ a * 1e-3)
+        got = run()
+        assert all(torch.equal(p, q) for p, q in zip(got, ref)), f"run {rep} differs from the unloaded run"
+    torch.cuda.synchronize()

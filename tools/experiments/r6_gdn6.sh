@@ -15,7 +15,7 @@ for v in sys.argv[1:]:
     f = glob.glob(f"gpurun_out/gdnexp_{v}/**/*kernel_trace.csv", recursive=True)[0]
     t = {}
     for r in csv.DictReader(open(f)):
-        for name in ("gdn_fused_bwd_kernel<12, 0>", "gdn_fused_bwd_kernel<12, 1>", "gdn_fused_fwd_kernel"):
+        for name in ("gdn_fused_bwd_kernel<12, 0>", "gdn_fused_bwd_kernel<12, 1>", "gdn_bwd_onepass_kernel", "gdn_fused_fwd_kernel"):
             if name in r["Kernel_Name"]:
                 t.setdefault(name, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("variant", v, {k: round(sum(x[-4:]) / len(x[-4:]), 1) for k, x in t.items()})
