@@ -119,18 +119,20 @@ __global__ __launch_bounds__(256) void gdn_reparam_bwd_kernel(const float* dgamm
 // ------------------------------------------------------------------------------------------------------------
 // Fused forward: ONE kernel reads x once and writes y once (8 B per element of HBM traffic; the four-kernel form above
 // moves 28 B).  A persistent workgroup (4 waves, one per SIMD) keeps gamma_eff IN REGISTERS for the whole launch -- wave w owns the
-// output channels [16 NCB w, 16 NCB (w + 1)) and holds their gamma rows as B fragments of v_mfma_f32_16x16x4_f32 (NCB x NS x 4
+// output channels [16 NCB w, 16 NCB (w + 1)) and holds their gamma rows as A fragments of v_mfma_f32_16x16x4_f32 (NCB x NS x 4
 // registers per lane: 144 at 192 channels) -- and walks tiles of 64 pixels: the x tile goes to LDS by LDS-DMA as chunk images [64 rows]
-// [32 floats] (the igemm A-tile image: 128-byte rows, XOR-swizzled 16-byte slots), double buffered (the next tile is requested at the
-// top of the current one; counted vmcnt waits keep the previous tile's stores out of the wait), every wave reads each pixel row's 16
-// channels of a K step with one ds_read_b128, squares them on the way to the matrix cores (exact fp32 MFMA; the k order inside a step
-// is the lane group's, the same on both operands), and the epilogue -- n = acc + beta, y = x rsqrt(n) or x sqrt(n) -- takes x from the
-// LDS tile again, writes y over it in place and, after one barrier, the tile leaves with 16-byte stores of whole 128-byte row segments.
-// No barrier and no LDS traffic for gamma inside a tile: the first form of this kernel (128-row tiles, gamma streamed through LDS in
-// six K slabs with a barrier each) ran the mix at 65 - 77 TFLOP/s.
+// [32 floats] (the igemm A-tile image: 128-byte rows, XOR-swizzled 16-byte slots), double buffered, every wave reads each pixel row's 16
+// channels of a K step with one ds_read_b128 and squares them on the way to the matrix cores (exact fp32 MFMA, the pixel tile as the B
+// operand: a lane's four accumulator elements are four consecutive channels of one pixel), and the epilogue -- n = acc + beta,
+// y = x rsqrt(n) or x sqrt(n) -- takes x from the LDS tile with one 16-byte read per (row block, channel block) and keeps y in registers.
+// Every vector-memory request of a tile is issued INSIDE the matrix loop, one per group of MFMAs and behind them: the next tile's NS
+// LDS-DMA requests in the first half of the groups, the previous tile's NS result stores (64-byte row segments) in the second -- issued
+// in a row at the top / bottom of the tile they cost 22 + 10 us of a 200 us launch.  One barrier per tile (the buffer hand-over); no LDS
+// traffic for gamma.  History: 128-row tiles with gamma streamed through LDS in six K slabs (a barrier each): 65 - 77 TFLOP/s of the mix;
+// gamma in registers, results rewritten in the LDS tile in place (three barriers per tile), packed squares: 92 - 100; this form: 106 - 115.
 // Roofline: 2 C^2 FLOP against 8 C bytes per pixel = C / 4 FLOP per byte: at C = 192 the exact-fp32 matrix peak
 // (157 TFLOP/s) caps the op at 3.3 TB/s = 0.41 of the HBM peak, at C = 128 at 0.61.
-// mode 0: y = GDN / IGDN(x); mode 1: y = n (the norm, for the backward pass).  C <= 192; K and the channel blocks are padded to
+// mode 0: y = GDN / IGDN(x); mode 1: y = n (the norm, for the unfused backward).  C <= 192; K and the channel blocks are padded to
 // NS = 4, 8 or 12 steps of 16 (the padding multiplies zeros: x beyond C is zero-filled by the DMA's range check).
 // ------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* gdn_lds_ptr_t;
@@ -146,6 +148,15 @@ struct GdnFusedArgs {
 
 constexpr int kGdnBM = 64;
 
+// x^2 of a fragment with FOUR scalar multiplies: the packed form (v_pk_mul_f32, what a vector multiply compiles to) costs ~22 cycles of
+// issue beside MFMAs where a plain v_mul_f32 costs 4 -- two per group of 12 MFMAs were 13 % of the forward kernel
+__device__ __forceinline__ f32x4 gdn_square4(f32x4 v) {
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("v_mul_f32 %0, %1, %1" : "=v"(r[i]) : "v"(v[i]));
+  return r;
+}
+
 template <int VM>
 __device__ __forceinline__ void gdn_wait_barrier() {   // vmcnt(VM) lgkmcnt(0), then the workgroup barrier
   __builtin_amdgcn_sched_barrier(0);
@@ -154,7 +165,7 @@ __device__ __forceinline__ void gdn_wait_barrier() {   // vmcnt(VM) lgkmcnt(0), 
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NS>
+template <int NS, int OP>   // OP 0: y = x n^(-1/2) (GDN); 1: y = x n^(1/2) (IGDN); 2: y = n
 __global__ __launch_bounds__(256) void gdn_fused_fwd_kernel(const GdnFusedArgs p) {
   constexpr int BM = kGdnBM, NCB = NS / 4, NBX = NS / 2, XF = NBX * BM * 32;   // NBX chunk images of 32 channels; XF floats per x tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -182,136 +193,142 @@ __global__ __launch_bounds__(256) void gdn_fused_fwd_kernel(const GdnFusedArgs p
   // staging assignment (as igemm): thread fills slot (tid & 7) of rows (tid >> 3) + 32 j with source chunk slot ^ swizzle(row)
   const int srow = tid >> 3;
   const int csrc = (tid & 7) ^ ((srow >> 1) & 7);
-  // tile-independent lane offsets, once per launch (every instruction between two tiles' MFMAs is matrix time lost: the per-tile part
-  // of the address arithmetic was ~1 500 instructions around 576 MFMAs).  Rows past the tensor's end need no test of their own: the
-  // descriptors of a tile end at its last valid row, so the range check drops them.
-  unsigned xoff[NBX][2], yoff[NBX][2];
+  // tile-independent lane offsets, once per launch (every instruction between two tiles' MFMAs is matrix time lost).  Rows past the
+  // tensor's end need no test of their own: the descriptors of a tile end at its last valid row, so the range check drops them.
+  unsigned xoff[NBX][2];
 #pragma unroll
   for (int kc = 0; kc < NBX; ++kc)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int row = srow + 32 * j;
       const int chx = 32 * kc + csrc * 4;                                       // DMA: this lane's source chunk (swizzled)
-      xoff[kc][j] = chx < p.C ? ((unsigned)row * p.ldx + chx) * 4u : 0x80000000u;
-      const int chy = 32 * kc + (((tid & 7) ^ ((row >> 1) & 7)) << 2);           // stores: the channel its LDS slot holds
-      yoff[kc][j] = chy < p.C ? ((unsigned)row * p.ldy + chy) * 4u : 0x80000000u;
+      xoff[kc][j] = chx < p.C ? ((unsigned)(srow + 32 * j) * p.ldx + chx) * 4u : 0x80000000u;
     }
-  int eoff[NCB][4];   // float offset inside an x tile of (row 4 lg + i, channel col0 + 16 cb + ln); row block rb adds 512 rb
+  // the lane's results: channels ch(cb) = col0 + 16 cb + 4 lg .. + 3 of pixel row 16 rb + ln (gamma is the A operand of the MFMAs, the pixel
+  // tile the B operand: four accumulator elements = four consecutive channels, one 16-byte access per (rb, cb) on either side)
+  bool chok[NCB];
+  int xe[NCB];   // float offset of (row ln, channels ch(cb)) inside an x tile; row block rb adds 512 rb (the swizzle repeats every 16 rows)
 #pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = col0 + 16 * cb + ln;
-      eoff[cb][i] = (ch >> 5) * BM * 32 + lds_off(4 * lg + i, (ch & 31) >> 2) + (ch & 3);
-    }
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int ch = col0 + 16 * cb + 4 * lg;
+    chok[cb] = ch < p.C;
+    xe[cb] = (ch >> 5) * BM * 32 + lds_off(ln, (ch & 31) >> 2);
+  }
+  const unsigned ybase = ((unsigned)ln * p.ldy + col0 + 4 * lg) * 4u;
   auto tile_rsrc = [&](const float* base, int ld, long long m0) __attribute__((always_inline)) {
     const long long left = p.M - m0;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + m0 * ld, 0,
-                                             (unsigned)std::min<long long>(((left < BM ? left : BM) - 1) * ld * 4ll + p.C * 4ll, 0x7fffffffll), 0x00020000);
+    const long long bytes = left <= 0 ? 0 : ((left < BM ? left : BM) - 1) * ld * 4ll + p.C * 4ll;   // (a tile past the last one: no bytes at all)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + (left <= 0 ? 0 : m0 * ld), 0, (unsigned)std::min<long long>(bytes, 0x7fffffffll), 0x00020000);
   };
   // an x tile: chunk image kc, rows srow + 32 j, j < 2: NS requests
+  // request q (< NS) of a tile: chunk image q >> 1, rows srow + 32 (q & 1)
+  auto fetch_piece = [&](const __amdgpu_buffer_rsrc_t rx, int buf, int q) __attribute__((always_inline)) {
+    const int kc = q >> 1, j = q & 1;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (gdn_lds_ptr_t)(sX + buf * XF + kc * BM * 32 + wave * 8 * 32 + j * 32 * 32), 16, (int)xoff[kc][j], 0, 0, 0);
+  };
   auto fetch_x = [&](long long m0, int buf) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rx = tile_rsrc(p.x, p.ldx, m0);
 #pragma unroll
-    for (int kc = 0; kc < NBX; ++kc)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (gdn_lds_ptr_t)(sX + buf * XF + kc * BM * 32 + wave * 8 * 32 + j * 32 * 32), 16, (int)xoff[kc][j], 0, 0, 0);
+    for (int q = 0; q < NS; ++q) fetch_piece(rx, buf, q);
   };
   int t = blockIdx.x, cur = 0;
   fetch_x((long long)t * BM, 0);
   bool first = true;
+  // the results of a tile leave during the NEXT tile's matrix loop (one store per group, behind its MFMAs): before the first tile the
+  // descriptor is empty and the NS stores are dropped, so that every tile issues the same requests
+  f32x4 yout[4][NCB];
+  __amdgpu_buffer_rsrc_t ry_prev = tile_rsrc(p.y, p.ldy, p.M);
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) yout[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto store_piece = [&](const __amdgpu_buffer_rsrc_t ry, int q) __attribute__((always_inline)) {
+    const int rb = q / NCB, cb = q % NCB;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, yout[rb][cb]), ry,
+                                           chok[cb] ? ybase + (unsigned)(16 * rb * p.ldy * 4 + 64 * cb) : 0x80000000u, 0, 0);
+  };
   for (; t < p.tiles; t += gridDim.x, cur ^= 1) {
     const long long m0 = (long long)t * BM;
-    const int tn = t + (int)gridDim.x;
-    // this tile's x has landed (everything but the previous tile's NS stores, the youngest requests); every wave is done with the other
-    // buffer (its stores have read their LDS operands)
+    // this tile's x has landed (everything but the NS result stores issued after its requests, the youngest ones); every wave is done with the other
+    // buffer (matrix loop AND epilogue: the results leave from registers, nothing is rewritten in LDS -- this is the only barrier of a tile)
     if (first) gdn_wait_barrier<0>();
     else gdn_wait_barrier<NS>();
     first = false;
-    if (tn < p.tiles) fetch_x((long long)tn * BM, cur ^ 1);
+    // the next tile's NS requests go out one per group of the matrix loop, behind that group's MFMAs (an LDS-DMA request issued among bare
+    // MFMAs costs ~60 cycles of issue; twelve in a row at the top of the tile were 22 us of the launch).  No branch: past the last tile the
+    // descriptor is empty
+    const __amdgpu_buffer_rsrc_t rnext = tile_rsrc(p.x, p.ldx, (long long)(t + (int)gridDim.x) * BM);
     f32x4 acc[4][NCB];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     float* xt = sX + cur * XF;
-    // NS x 4 groups (K step s, row block rb) of 4 NCB MFMAs; the A fragment of group g + 1 (pixel row 16 rb + ln, channels 16 s + 4 lg .. + 3:
-    // chunk image s >> 1, slot 4 (s & 1) + lg) is requested BEFORE the MFMAs of group g are issued and squared after them -- left to the
-    // compiler every ds_read_b128 sat directly in front of its use with a full lgkmcnt(0) wait (12 MFMAs per exposed LDS latency: 53 %
-    // of the matrix peak)
-    auto a_ptr = [&](int g) __attribute__((always_inline)) {
-      const int s = g >> 2, rb = g & 3;
+    // 2 NS groups (K step s, row blocks rb, rb + 1) of 8 NCB MFMAs on 2 NCB independent accumulators (with one row block per group -- three
+    // accumulators in turn -- the loop ran at 44 cycles per MFMA, with two at 40; the instruction's issue rate is 32, its dependent latency
+    // 40).  The pixel fragments of group g + 1 (pixel rows 16 rb + ln, channels 16 s + 4 lg .. + 3: chunk image s >> 1, slot 4 (s & 1) + lg) are
+    // requested BEFORE the MFMAs of group g are issued and squared after them -- left to the compiler every ds_read_b128 sat directly in
+    // front of its use with a full lgkmcnt(0) wait
+    auto a_ptr = [&](int s, int rb) __attribute__((always_inline)) {
       return reinterpret_cast<const f32x4*>(xt + (s >> 1) * BM * 32 + lds_off(16 * rb + ln, 4 * (s & 1) + lg));
     };
-    f32x4 a_nxt = *a_ptr(0);
+    f32x4 n0 = *a_ptr(0, 0), n1 = *a_ptr(0, 1);
 #pragma unroll
-    for (int g = 0; g < NS * 4; ++g) {
-      const int s = g >> 2, rb = g & 3;
-      f32x4 a = a_nxt * a_nxt;
-      if (g + 1 < NS * 4) a_nxt = *a_ptr(g + 1);
+    for (int g = 0; g < NS * 2; ++g) {
+      const int s = g >> 1, rb = 2 * (g & 1);
+      const f32x4 a0 = gdn_square4(n0), a1 = gdn_square4(n1);
+      if (g + 1 < NS * 2) { n0 = *a_ptr((g + 1) >> 1, 2 * ((g + 1) & 1)); n1 = *a_ptr((g + 1) >> 1, 2 * ((g + 1) & 1) + 1); }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], B[cb][s][e], acc[rb][cb], 0, 0, 0);
+        for (int cb = 0; cb < NCB; ++cb) {
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[cb][s][e], a0[e], acc[rb][cb], 0, 0, 0);
+          acc[rb + 1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[cb][s][e], a1[e], acc[rb + 1][cb], 0, 0, 0);
+        }
+      if (g < NS) fetch_piece(rnext, cur ^ 1, g);
+      else store_piece(ry_prev, g - NS);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // epilogue: acc[rb][cb][i] is (row 16 rb + 4 lg + i, channel col0 + 16 cb + ln); x sits in chunk image channel >> 5 at slot
-    // (channel & 31) >> 2 (swizzled), element channel & 3 -- rewritten in place with y
-    // (per channel block: the 16 x values first, then the arithmetic, then the 16 writes -- element by element the compiler must assume a
-    // write aliases the next read and waits on the LDS queue 48 times; the mode switch sits outside the element loops)
-    auto epilogue = [&](auto fn) __attribute__((always_inline)) {
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const float bta = sBeta[col0 + 16 * cb + ln];
-        float xv[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb) xv[i][rb] = xt[eoff[cb][i] + 512 * rb];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb) xv[i][rb] = fn(xv[i][rb], acc[rb][cb][i] + bta);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb) xt[eoff[cb][i] + 512 * rb] = xv[i][rb];
-      }
-    };
-    // (v_rsq_f32 / v_sqrt_f32: 1 ulp, one instruction each; the library sqrtf + division pair is ~25 and the epilogue of a wave that owns
-    // its SIMD is not hidden behind anything.  n >= beta_min > 0: no denormal path)
-    // Every wave's K loop reads ALL channels of the tile as its A operand and the epilogue overwrites the wave's own channels in place:
-    // no wave may start writing before the slowest one has issued -- and received -- its last fragment (the last K step reads exactly
-    // wave 3's channels).  Without this barrier the kernel was correct only while the four waves stayed within one epilogue of each
-    // other, which nothing guarantees beside an RCCL kernel, a second resident workgroup (C <= 128) or a profiler.
-    gdn_wait_barrier<63>();
-    if (p.mode) epilogue([](float, float n) { return n; });
-    else if (p.inverse) epilogue([](float xv, float n) { return xv * __builtin_amdgcn_sqrtf(n); });
-    else epilogue([](float xv, float n) { return xv * __builtin_amdgcn_rsqf(n); });
-    gdn_wait_barrier<63>();   // (lgkmcnt(0) + barrier: every wave's y is in the tile; vector memory is not waited for)
-    // 16-byte stores, 8 rows x 128 B per wave instruction: NS per thread, always (so that the wait at the top can count them)
+    // epilogue: acc[rb][cb][i] is (pixel row 16 rb + ln, channel ch(cb) + i); x comes from the LDS tile again, the result leaves with one
+    // 16-byte store per (rb, cb) -- 64-byte row segments, the two halves of a 128-byte line in consecutive instructions of the wave.
+    // (v_rsq_f32 / v_sqrt_f32: 1 ulp, one instruction each; n >= beta_min > 0: no denormal path)
     const __amdgpu_buffer_rsrc_t ry = tile_rsrc(p.y, p.ldy, m0);
 #pragma unroll
-    for (int kc = 0; kc < NBX; ++kc)
+    for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xt + kc * BM * 32 + (srow + 32 * j) * 32 + (tid & 7) * 4);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, yoff[kc][j], 0, 0);
+      for (int cb = 0; cb < NCB; ++cb) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xt + xe[cb] + 512 * rb);
+        const f32x4 bta = *reinterpret_cast<const f32x4*>(sBeta + col0 + 16 * cb + 4 * lg);
+        f32x4 y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float n = acc[rb][cb][i] + bta[i];
+          y[i] = OP == 2 ? n : (OP == 1 ? xv[i] * __builtin_amdgcn_sqrtf(n) : xv[i] * __builtin_amdgcn_rsqf(n));
+        }
+        yout[rb][cb] = y;
       }
+    ry_prev = ry;
   }
+#pragma unroll
+  for (int q = 0; q < NS; ++q) store_piece(ry_prev, q);   // the last tile's results
+}
+
+template <int NS, int OP>
+static void gdn_fused_launch_op(const GdnFusedArgs& a, hipStream_t s) {
+  const size_t lds = ((size_t)2 * (NS / 2) * kGdnBM * 32 + 64 * (NS / 4)) * sizeof(float);
+  static std::atomic<bool> done{false};
+  if (!done.load(std::memory_order_acquire)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gdn_fused_fwd_kernel<NS, OP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((gdn_fused_fwd_kernel<NS, OP>), dim3(std::min(a.tiles, 256)), dim3(256), lds, s, a);
 }
 
 template <int NS>
 static void gdn_fused_launch(const GdnFusedArgs& a, hipStream_t s) {
-  const size_t lds = ((size_t)2 * (NS / 2) * kGdnBM * 32 + 64 * (NS / 4)) * sizeof(float);
-  static std::atomic<bool> done{false};
-  if (!done.load(std::memory_order_acquire)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gdn_fused_fwd_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done.store(true, std::memory_order_release);
-  }
-  hipLaunchKernelGGL(gdn_fused_fwd_kernel<NS>, dim3(std::min(a.tiles, 256)), dim3(256), lds, s, a);
+  if (a.mode) gdn_fused_launch_op<NS, 2>(a, s);
+  else if (a.inverse) gdn_fused_launch_op<NS, 1>(a, s);
+  else gdn_fused_launch_op<NS, 0>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -398,14 +415,16 @@ __global__ __launch_bounds__(256) void gdn_bwd_onepass_kernel(const GdnBwd1Args 
     const long long bytes = left <= 0 ? 0 : ((left < BM ? left : BM) - 1) * ld * 4ll + p.C * 4ll;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + (left <= 0 ? 0 : m0 * ld), 0, (unsigned)std::min<long long>(bytes, 0x7fffffffll), 0x00020000);
   };
+  // request q (< NS) of an x tile: chunk image q >> 1, rows srow + 32 (q & 1)
+  auto fetch_piece = [&](const __amdgpu_buffer_rsrc_t rx, int buf, int q) __attribute__((always_inline)) {
+    const int kc = q >> 1, j = q & 1;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (gdn_lds_ptr_t)(sX + buf * XF + kc * BM * 32 + wave * 8 * 32 + j * 32 * 32), 16,
+                                             (int)(32 * kc + csrc * 4 < p.C ? xbase + (unsigned)(128 * kc + j * 32 * p.ldx * 4) : 0x80000000u), 0, 0, 0);
+  };
   auto fetch = [&](long long m0, int buf) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rx = tile_rsrc(p.x, p.ldx, m0);
 #pragma unroll
-    for (int kc = 0; kc < NBX; ++kc)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (gdn_lds_ptr_t)(sX + buf * XF + kc * BM * 32 + wave * 8 * 32 + j * 32 * 32), 16,
-                                                 (int)(32 * kc + csrc * 4 < p.C ? xbase + (unsigned)(128 * kc + j * 32 * p.ldx * 4) : 0x80000000u), 0, 0, 0);
+    for (int q = 0; q < NS; ++q) fetch_piece(rx, buf, q);
   };
   f32x4 csum[NCB];
 #pragma unroll
@@ -420,19 +439,14 @@ __global__ __launch_bounds__(256) void gdn_bwd_onepass_kernel(const GdnBwd1Args 
     if (first) gdn_wait_barrier<0>();
     else gdn_wait_barrier<2 * NS>();
     first = false;
-    f32x4 g[4][NCB];   // dy, then u
-    {
-      const __amdgpu_buffer_rsrc_t q0 = tile_rsrc(p.dy, p.lddy, m0);
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) g[rb][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q0, lane_off(lb_dy, p.lddy, cb, rb), 0, 0));
-    }
-    fetch((long long)(t + (int)gridDim.x) * BM, cur ^ 1);
+    // dy (then u) in registers; its NS requests and the next x tile's NS LDS-DMA requests go out one of each per group of the first matrix
+    // loop, behind that group's MFMAs (issued in a row at the top of the tile they cost the launch 40 us)
+    f32x4 g[4][NCB];
+    const __amdgpu_buffer_rsrc_t q0 = tile_rsrc(p.dy, p.lddy, m0);
+    const __amdgpu_buffer_rsrc_t rnext = tile_rsrc(p.x, p.ldx, (long long)(t + (int)gridDim.x) * BM);
     float* xt = sX + cur * XF;
     f32x4 acc[4][NCB];
-    auto a_ptr = [&](const float* tile, int gi) __attribute__((always_inline)) {
-      const int s = gi >> 2, rb = gi & 3;
+    auto a_ptr = [&](const float* tile, int s, int rb) __attribute__((always_inline)) {
       return reinterpret_cast<const f32x4*>(tile + (s >> 1) * BM * 32 + lds_off(16 * rb + ln, 4 * (s & 1) + lg));
     };
     auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -441,20 +455,29 @@ __global__ __launch_bounds__(256) void gdn_bwd_onepass_kernel(const GdnBwd1Args 
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // first mix: acc[rb][cb][i] = sum_k gamma[ch][k] x^2(pixel row 16 rb + ln, k)
+    // first mix: acc[rb][cb][i] = sum_k gamma[ch][k] x^2(pixel row 16 rb + ln, k); 2 NS groups (K step, row-block pair) of 8 NCB MFMAs on 2 NCB
+    // independent accumulators, fragments of the next group requested before a group's MFMAs (see the forward kernel)
     zero_acc();
     {
-      f32x4 a_nxt = *a_ptr(xt, 0);
+      f32x4 n0 = *a_ptr(xt, 0, 0), n1 = *a_ptr(xt, 0, 1);
 #pragma unroll
-      for (int gi = 0; gi < NS * 4; ++gi) {
-        const int s = gi >> 2, rb = gi & 3;
-        f32x4 a = a_nxt * a_nxt;
-        if (gi + 1 < NS * 4) a_nxt = *a_ptr(xt, gi + 1);
+      for (int gi = 0; gi < NS * 2; ++gi) {
+        const int s = gi >> 1, rb = 2 * (gi & 1);
+        const f32x4 a0 = gdn_square4(n0), a1 = gdn_square4(n1);
+        if (gi + 1 < NS * 2) { n0 = *a_ptr(xt, (gi + 1) >> 1, 2 * ((gi + 1) & 1)); n1 = *a_ptr(xt, (gi + 1) >> 1, 2 * ((gi + 1) & 1) + 1); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[cb][s][e], a[e], acc[rb][cb], 0, 0, 0);
+          for (int cb = 0; cb < NCB; ++cb) {
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[cb][s][e], a0[e], acc[rb][cb], 0, 0, 0);
+            acc[rb + 1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[cb][s][e], a1[e], acc[rb + 1][cb], 0, 0, 0);
+          }
+        if (gi < NS) {
+          const int qr = gi / NCB, qc = gi % NCB;
+          g[qr][qc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q0, lane_off(lb_dy, p.lddy, qc, qr), 0, 0));
+          fetch_piece(rnext, cur ^ 1, gi);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -489,19 +512,22 @@ __global__ __launch_bounds__(256) void gdn_bwd_onepass_kernel(const GdnBwd1Args 
     // second mix: acc[rb][cb][i] = sum_k gamma[k][ch] dn(pixel row 16 rb + ln, k)
     zero_acc();
     {
-      f32x4 a_nxt = *a_ptr(sD, 0);
+      f32x4 n0 = *a_ptr(sD, 0, 0), n1 = *a_ptr(sD, 0, 1);
 #pragma unroll
-      for (int gi = 0; gi < NS * 4; ++gi) {
-        const int s = gi >> 2, rb = gi & 3;
-        f32x4 a = a_nxt;
-        if (gi + 1 < NS * 4) a_nxt = *a_ptr(sD, gi + 1);
+      for (int gi = 0; gi < NS * 2; ++gi) {
+        const int s = gi >> 1, rb = 2 * (gi & 1);
+        const f32x4 a0 = n0, a1 = n1;
+        if (gi + 1 < NS * 2) { n0 = *a_ptr(sD, (gi + 1) >> 1, 2 * ((gi + 1) & 1)); n1 = *a_ptr(sD, (gi + 1) >> 1, 2 * ((gi + 1) & 1) + 1); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[s % RING][cb][e], a[e], acc[rb][cb], 0, 0, 0);
+          for (int cb = 0; cb < NCB; ++cb) {
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[s % RING][cb][e], a0[e], acc[rb][cb], 0, 0, 0);
+            acc[rb + 1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[s % RING][cb][e], a1[e], acc[rb + 1][cb], 0, 0, 0);
+          }
         __builtin_amdgcn_sched_barrier(0);
-        if (rb == 3 && s + RING < NS) load_b(s + RING, ring[s % RING]);
+        if (rb == 2 && s + RING < NS) load_b(s + RING, ring[s % RING]);
       }
     }
     {
