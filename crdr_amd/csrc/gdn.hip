@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void gdn_reparam_bwd_kernel(const float* dgamm
 // LDS-DMA requests in the first half of the groups, the previous tile's NS result stores (64-byte row segments) in the second -- issued
 // in a row at the top / bottom of the tile they cost 22 + 10 us of a 200 us launch.  One barrier per tile (the buffer hand-over); no LDS
 // traffic for gamma.  History: 128-row tiles with gamma streamed through LDS in six K slabs (a barrier each): 65 - 77 TFLOP/s of the mix;
-// gamma in registers, results rewritten in the LDS tile in place (three barriers per tile), packed squares: 92 - 100; this form: 106 - 115.
+// gamma in registers, results rewritten in the LDS tile in place (three barriers per tile): 92 - 100; this form: 107 - 118.
 // Roofline: 2 C^2 FLOP against 8 C bytes per pixel = C / 4 FLOP per byte: at C = 192 the exact-fp32 matrix peak
 // (157 TFLOP/s) caps the op at 3.3 TB/s = 0.41 of the HBM peak, at C = 128 at 0.61.
 // mode 0: y = GDN / IGDN(x); mode 1: y = n (the norm, for the unfused backward).  C <= 192; K and the channel blocks are padded to
@@ -148,14 +148,10 @@ struct GdnFusedArgs {
 
 constexpr int kGdnBM = 64;
 
-// x^2 of a fragment with FOUR scalar multiplies: the packed form (v_pk_mul_f32, what a vector multiply compiles to) costs ~22 cycles of
-// issue beside MFMAs where a plain v_mul_f32 costs 4 -- two per group of 12 MFMAs were 13 % of the forward kernel
-__device__ __forceinline__ f32x4 gdn_square4(f32x4 v) {
-  f32x4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) asm volatile("v_mul_f32 %0, %1, %1" : "=v"(r[i]) : "v"(v[i]));
-  return r;
-}
+// x^2 of a fragment on the way to the matrix cores: two v_pk_mul_f32.  Nothing vector hides beside an exact-fp32 MFMA and a packed
+// instruction costs the wave what a scalar one does, so the fewer the better: four v_mul_f32 by inline assembly measured
+// 2.5 % slower on the forward kernel (184 against 180 us)
+__device__ __forceinline__ f32x4 gdn_square4(f32x4 v) { return v * v; }
 
 template <int VM>
 __device__ __forceinline__ void gdn_wait_barrier() {   // vmcnt(VM) lgkmcnt(0), then the workgroup barrier
