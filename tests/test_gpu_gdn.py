@@ -106,7 +106,8 @@ def _gdn_f64(m, x, cot, inverse):
 
 
 @pytest.mark.parametrize("inverse", [False, True])
-@pytest.mark.parametrize("c,n,h,w", [(192, 2, 100, 100), (128, 3, 90, 77), (100, 2, 100, 90), (64, 4, 75, 75), (192, 1, 5, 5)])
+@pytest.mark.parametrize("c,n,h,w", [(192, 2, 100, 100), (128, 3, 90, 77), (100, 2, 100, 90), (64, 4, 75, 75), (192, 1, 5, 5), (160, 2, 70, 70),
+                                     (36, 3, 80, 80)])
 def test_gdn_fused_backward_many_tiles_vs_float64(inverse, c, n, h, w, monkeypatch):
     """The one-pass fused backward (gdn.hip: gdn_bwd_onepass_kernel, the CRDR_WGRAD_SQUARE_Q weight gradient, the per-workgroup column sums)
     with more 64-pixel tiles than workgroups, ragged last tiles and channel counts that do not fill the padded blocks: against float64 and
