@@ -569,6 +569,164 @@ static void gdn_bwd1_launch(const GdnBwd1Args& a, hipStream_t s) {
   else gdn_bwd1_launch_dir<NS, false>(a, s);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The gamma gradient dgamma_eff[i][j] = sum_p dn[p][i] x[p][j]^2 (a C x C result over M pixels) as a persistent kernel: the WHOLE result
+// stays in the accumulators of one workgroup -- wave (wi, wj) of 2 x 2 owns the (8 NS x 8 NS)-channel quadrant as (NS / 2)^2 blocks of
+// v_mfma_f32_16x16x4_f32 (144 registers per lane at 192 channels) -- while the workgroup walks 32-pixel tiles of dn and x (LDS-DMA, three
+// stages, the chunk images of the kernels above; the requests ride behind the K steps' MFMAs).  A K step is four pixels: NS / 2 fragments of
+// dn (A operand: lane (ln, lg) holds dn[pixel 4 k + lg][i0 + ln]) and NS / 2 of x (B operand, squared on the way), one 4-byte LDS read
+// each, for (NS / 2)^2 MFMAs.  Every workgroup leaves its partial C x C sum; gdn_dgamma_finish_kernel adds them in a fixed order and chains
+// the result through the parametrisation.  Against the tiled weight-gradient kernel with CRDR_WGRAD_SQUARE_Q (no LDS-resident result,
+// split over 128 slabs and a separate reduction): 268 us at 16 x 192 x 128 x 128.
+// ------------------------------------------------------------------------------------------------------------
+struct GdnDgArgs {
+  const float* dn;     // [M][ld_dn]
+  const float* x;      // [M][ldx]
+  float* part;         // [gridDim.x][CH * CH], CH = 16 NS
+  long long M;
+  int C, ld_dn, ldx, tiles;   // tiles of 32 pixels
+};
+
+constexpr int kGdnDgBP = 32;
+
+template <int NS>
+__global__ __launch_bounds__(256) void gdn_dgamma_kernel(const GdnDgArgs p) {
+  constexpr int BP = kGdnDgBP, NBX = NS / 2, TF = NBX * BP * 32, HB = NS / 2, CH = 16 * NS;   // TF floats per operand tile; HB blocks per quadrant side
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sP = smem;            // [3][NBX][BP * 32]  dn
+  float* sQ = smem + 3 * TF;   // [3][NBX][BP * 32]  x
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lg = lane >> 4;
+  const int i0 = (wave >> 1) * 16 * HB, j0 = (wave & 1) * 16 * HB;
+  if ((int)blockIdx.x >= p.tiles) return;
+  // staging: thread fills slot (tid & 7) of row (tid >> 3) (32 rows: one request per chunk image and operand) with source chunk slot ^ swizzle(row)
+  const int srow = tid >> 3;
+  const int csrc = (tid & 7) ^ ((srow >> 1) & 7);
+  unsigned pbase = ((unsigned)srow * p.ld_dn + csrc * 4) * 4u, qbase = ((unsigned)srow * p.ldx + csrc * 4) * 4u;
+  auto tile_rsrc = [&](const float* base, int ld, long long m0) __attribute__((always_inline)) {
+    const long long left = p.M - m0;
+    const long long bytes = left <= 0 ? 0 : ((left < BP ? left : BP) - 1) * ld * 4ll + p.C * 4ll;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + (left <= 0 ? 0 : m0 * ld), 0, (unsigned)std::min<long long>(bytes, 0x7fffffffll), 0x00020000);
+  };
+  // request q (< 2 NBX) of a tile pair: operand q & 1 (0: dn, 1: x), chunk image q >> 1
+  auto fetch_piece = [&](const __amdgpu_buffer_rsrc_t rp, const __amdgpu_buffer_rsrc_t rq, int buf, int q) __attribute__((always_inline)) {
+    const int kc = q >> 1;
+    const bool ok = 32 * kc + csrc * 4 < p.C;
+    if (q & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (gdn_lds_ptr_t)(sQ + buf * TF + kc * BP * 32 + wave * 8 * 32), 16, (int)(ok ? qbase + 128u * kc : 0x80000000u), 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (gdn_lds_ptr_t)(sP + buf * TF + kc * BP * 32 + wave * 8 * 32), 16, (int)(ok ? pbase + 128u * kc : 0x80000000u), 0, 0, 0);
+  };
+  // fragment offsets inside an operand tile: block b of a quadrant, lane's channel c = c0 + 16 b + ln, pixel row 4 k + lg: chunk image c >> 5,
+  // slot (c & 31) >> 2 swizzled by the row, element c & 3.  The swizzle term ((row >> 1) & 7 = (2 k + (lg >> 1)) & 7) depends on k: the offset
+  // is rebuilt per K step from the lane's slot and element (two integer instructions per fragment)
+  int pim[HB], pslot[HB], qim[HB], qslot[HB];
+#pragma unroll
+  for (int b = 0; b < HB; ++b) {
+    const int ci = i0 + 16 * b + ln, cj = j0 + 16 * b + ln;
+    pim[b] = (ci >> 5) * BP * 32 + (ci & 3) + 32 * lg; pslot[b] = (ci & 31) >> 2;
+    qim[b] = (cj >> 5) * BP * 32 + (cj & 3) + 32 * lg; qslot[b] = (cj & 31) >> 2;
+  }
+  f32x4 acc[HB][HB];
+#pragma unroll
+  for (int a = 0; a < HB; ++a)
+#pragma unroll
+    for (int b = 0; b < HB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // three stages: tile n is read while tile n + 1 is landing and tile n + 2 is requested (a 32-pixel tile computes for ~4 us: with two
+  // stages the next tile's requests, issued during this one, would be waited for at its end)
+  int t = blockIdx.x, cur = 0;
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const long long m0 = (long long)(t + st * (int)gridDim.x) * BP;
+    const __amdgpu_buffer_rsrc_t rp = tile_rsrc(p.dn, p.ld_dn, m0), rq = tile_rsrc(p.x, p.ldx, m0);
+#pragma unroll
+    for (int q = 0; q < 2 * NBX; ++q) fetch_piece(rp, rq, st, q);
+  }
+  for (; t < p.tiles; t += gridDim.x, cur = cur == 2 ? 0 : cur + 1) {
+    asm volatile("" : "+v"(pbase), "+v"(qbase));
+    gdn_wait_barrier<NS>();   // this tile pair has landed (the next one's NS requests may be in flight); every wave is done with the stage requested next
+    const long long mn = (long long)(t + 2 * (int)gridDim.x) * BP;
+    const __amdgpu_buffer_rsrc_t rp = tile_rsrc(p.dn, p.ld_dn, mn), rq = tile_rsrc(p.x, p.ldx, mn);
+    const int nxt = cur == 0 ? 2 : cur - 1;   // (cur + 2) mod 3
+    const float* tp = sP + cur * TF;
+    const float* tq = sQ + cur * TF;
+    auto frags = [&](int k, float (&fa)[HB], float (&fb)[HB]) __attribute__((always_inline)) {
+      const int sw = (2 * k + (lg >> 1)) & 7;
+#pragma unroll
+      for (int b = 0; b < HB; ++b) {
+        fa[b] = tp[pim[b] + 128 * k + ((pslot[b] ^ sw) << 2)];
+        fb[b] = tq[qim[b] + 128 * k + ((qslot[b] ^ sw) << 2)];
+      }
+    };
+    float na[HB], nb[HB];
+    frags(0, na, nb);
+#pragma unroll
+    for (int k = 0; k < BP / 4; ++k) {
+      float fa[HB], fb[HB];
+#pragma unroll
+      for (int b = 0; b < HB; ++b) { fa[b] = na[b]; fb[b] = nb[b] * nb[b]; }
+      if (k + 1 < BP / 4) frags(k + 1, na, nb);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < HB; ++a)
+#pragma unroll
+        for (int b = 0; b < HB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      // the tile pair after next: 2 NBX requests over the BP / 4 = 8 K steps
+#pragma unroll
+      for (int q = k * (2 * NBX) / (BP / 4); q < (k + 1) * (2 * NBX) / (BP / 4); ++q) fetch_piece(rp, rq, nxt, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // acc[a][b][r] is (channel i0 + 16 a + 4 lg + r, channel j0 + 16 b + ln)
+  float* out = p.part + (size_t)blockIdx.x * CH * CH;
+#pragma unroll
+  for (int a = 0; a < HB; ++a)
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(size_t)(i0 + 16 * a + 4 * lg + r) * CH + j0 + 16 * b + ln] = acc[a][b][r];
+}
+
+// dgamma_p[i][j] += chain(sum over the workgroups' partials), as gdn_reparam_bwd_kernel does for the gamma half.  A workgroup owns 64 consecutive
+// results; its four waves take every fourth partial (four loads in flight each) and meet in LDS, added in a fixed order
+__global__ __launch_bounds__(256) void gdn_dgamma_finish_kernel(const float* part, int parts, int CH, const float* gamma_p, int C, float bound_g,
+                                                                float* dgamma_p) {
+  __shared__ float red[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const bool ok = e < C * C;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (ok) {
+    const int i = e / C, j = e - i * C;
+    const float* src = part + (size_t)i * CH + j;
+    const size_t st = (size_t)CH * CH;
+    int q = w;
+    for (; q + 12 < parts; q += 16) {
+      s0 += src[(size_t)q * st]; s1 += src[(size_t)(q + 4) * st]; s2 += src[(size_t)(q + 8) * st]; s3 += src[(size_t)(q + 12) * st];
+    }
+    for (; q < parts; q += 4) s0 += src[(size_t)q * st];
+  }
+  red[w][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && ok) {
+    const float sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const float v = gamma_p[e], g = sum * 2.0f * fmaxf(v, bound_g);
+    dgamma_p[e] += (v >= bound_g || g < 0.f) ? g : 0.f;
+  }
+}
+
+// workgroups of the gamma-gradient kernel: every one leaves a CH x CH partial that the finish kernel reads back, so small problems use fewer
+// (at least four 32-pixel tiles each)
+static int gdn_dgamma_grid(int tiles) { return std::max(1, std::min((tiles + 3) / 4, 256)); }
+
+template <int NS>
+static void gdn_dgamma_launch(const GdnDgArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)6 * (NS / 2) * kGdnDgBP * 32 * sizeof(float);
+  static std::atomic<bool> done{false};
+  if (!done.load(std::memory_order_acquire)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gdn_dgamma_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(gdn_dgamma_kernel<NS>, dim3(gdn_dgamma_grid(a.tiles)), dim3(256), lds, s, a);
+}
+
 // the beta gradient: the first pass's per-workgroup column sums [parts][CP], added in a fixed order (32 channels per workgroup; 8 row
 // groups, then the groups)
 __global__ __launch_bounds__(256) void gdn_colpart_sum_kernel(const float* colpart, int parts, int CP, int C, float* dbeta_eff) {
@@ -591,9 +749,30 @@ __global__ __launch_bounds__(256) void gdn_colpart_sum_kernel(const float* colpa
 
 static inline int grid1(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(cdiv64(n, 256), 1), 8192); }
 
+// dbeta_p[c] += chain(sum over the workgroups' column sums), as gdn_reparam_bwd_kernel does for the beta half
+__global__ __launch_bounds__(256) void gdn_dbeta_finish_kernel(const float* colpart, int parts, int CP, int C, const float* beta_p, float bound_b,
+                                                               float* dbeta_p) {
+  __shared__ float part[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
+  float sum = 0.f;
+  if (c < C) {
+#pragma unroll 8
+    for (int q = r; q < parts; q += 8) sum += colpart[(size_t)q * CP + c];
+  }
+  part[r][threadIdx.x & 31] = sum;
+  __syncthreads();
+  if (r == 0 && c < C) {
+    float v = part[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v += part[k][threadIdx.x];
+    const float b = beta_p[c], gb = v * 2.0f * fmaxf(b, bound_b);
+    dbeta_p[c] += (b >= bound_b || gb < 0.f) ? gb : 0.f;
+  }
+}
+
 struct GdnLayout {
   int CP;
-  size_t beta_eff, pack_f, pack_b, x2, norm, dn, u, w, dg, db, colpart, conv_ws, end;
+  size_t beta_eff, pack_f, pack_b, x2, norm, dn, u, w, dg, db, colpart, gpart, conv_ws, end;
   size_t conv_ws_bytes;
 };
 
@@ -616,10 +795,14 @@ static int gdn_layout(const crdr_gdn_desc* d, int backward, GdnLayout* L) {
   const size_t MC = (size_t)d->M * d->C;
   L->beta_eff = take(CP); L->pack_f = take((size_t)CP * CP); L->pack_b = take((size_t)CP * CP);
   L->x2 = take(MC); L->norm = take(MC);
-  L->dn = L->u = L->w = L->dg = L->db = L->colpart = 0;
+  L->dn = L->u = L->w = L->dg = L->db = L->colpart = L->gpart = 0;
   if (backward) {
     L->dn = take(MC); L->u = take(MC); L->w = take(MC); L->dg = take((size_t)d->C * d->C); L->db = take(d->C);
     L->colpart = take((size_t)256 * CP);
+    if (CP <= 192) {   // the persistent gamma-gradient kernel's per-workgroup partial sums
+      const int ch = CP <= 64 ? 64 : (CP <= 128 ? 128 : 192);
+      L->gpart = take((size_t)std::min<long long>((d->M + kGdnDgBP - 1) / kGdnDgBP, 256) * ch * ch);
+    }
   }
   crdr_conv_desc cd;
   if (int rc = gdn_conv_desc(d, &cd, CP)) return rc;
@@ -747,15 +930,34 @@ extern "C" int crdr_gdn_bwd(const crdr_gdn_desc* d, const float* x, const float*
     else if (d->C <= 128) gdn_bwd1_launch<8>(b, as_stream(s));
     else gdn_bwd1_launch<12>(b, as_stream(s));
     CRDR_CHECK_LAUNCH("gdn_bwd_onepass");
-    wd.ldq = d->ldx; wd.algo = CRDR_WGRAD_SQUARE_Q;
-    if (int rc = crdr_conv2d_wgrad(&wd, dn, x, dg, w8 + L.conv_ws, L.conv_ws_bytes, s)) return rc;
-    float* db = (float*)(w8 + L.db);
-    hipLaunchKernelGGL(gdn_colpart_sum_kernel, dim3((d->C + 31) / 32), dim3(256), 0, as_stream(s), (const float*)parts, std::min(b.tiles, 256), L.CP,
-                       d->C, db);
-    CRDR_CHECK_LAUNCH("gdn_colpart_sum");
-    hipLaunchKernelGGL(gdn_reparam_bwd_kernel, dim3(grid1((int64_t)d->C * d->C)), dim3(256), 0, as_stream(s), (const float*)dg,
-                       (const float*)db, gamma, beta, d->C, sqrtf(d->beta_min + ped), d->reparam_offset, dgamma, dbeta);
-    CRDR_CHECK_LAUNCH("gdn_reparam_bwd");
+    const char* via = getenv("CRDR_GDN_DGAMMA");
+    if (via && via[0] == 'w') {   // CRDR_GDN_DGAMMA=wgrad: the gamma gradient by the tiled weight-gradient kernel (the form the persistent one is measured against)
+      wd.ldq = d->ldx; wd.algo = CRDR_WGRAD_SQUARE_Q;
+      if (int rc = crdr_conv2d_wgrad(&wd, dn, x, dg, w8 + L.conv_ws, L.conv_ws_bytes, s)) return rc;
+      float* db = (float*)(w8 + L.db);
+      hipLaunchKernelGGL(gdn_colpart_sum_kernel, dim3((d->C + 31) / 32), dim3(256), 0, as_stream(s), (const float*)parts, std::min(b.tiles, 256), L.CP,
+                         d->C, db);
+      CRDR_CHECK_LAUNCH("gdn_colpart_sum");
+      hipLaunchKernelGGL(gdn_reparam_bwd_kernel, dim3(grid1((int64_t)d->C * d->C)), dim3(256), 0, as_stream(s), (const float*)dg,
+                         (const float*)db, gamma, beta, d->C, sqrtf(d->beta_min + ped), d->reparam_offset, dgamma, dbeta);
+      CRDR_CHECK_LAUNCH("gdn_reparam_bwd");
+      return 0;
+    }
+    GdnDgArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.dn = dn; ga.x = x; ga.part = (float*)(w8 + L.gpart); ga.M = d->M; ga.C = d->C; ga.ld_dn = d->C; ga.ldx = d->ldx;
+    ga.tiles = (int)((d->M + kGdnDgBP - 1) / kGdnDgBP);
+    const int ch = d->C <= 64 ? 64 : (d->C <= 128 ? 128 : 192);
+    if (d->C <= 64) gdn_dgamma_launch<4>(ga, as_stream(s));
+    else if (d->C <= 128) gdn_dgamma_launch<8>(ga, as_stream(s));
+    else gdn_dgamma_launch<12>(ga, as_stream(s));
+    CRDR_CHECK_LAUNCH("gdn_dgamma");
+    hipLaunchKernelGGL(gdn_dgamma_finish_kernel, dim3((d->C * d->C + 63) / 64), dim3(256), 0, as_stream(s), (const float*)ga.part,
+                       gdn_dgamma_grid(ga.tiles), ch, gamma, d->C, d->reparam_offset, dgamma);
+    CRDR_CHECK_LAUNCH("gdn_dgamma_finish");
+    hipLaunchKernelGGL(gdn_dbeta_finish_kernel, dim3((d->C + 31) / 32), dim3(256), 0, as_stream(s), (const float*)parts, std::min(b.tiles, 256), L.CP,
+                       d->C, beta, sqrtf(d->beta_min + ped), dbeta);
+    CRDR_CHECK_LAUNCH("gdn_dbeta_finish");
     return 0;
   }
   if (int rc = gdn_norm(d, L, w8, x, beta, gamma, s)) return rc;  // recomputed: cheaper than keeping M x C floats alive
