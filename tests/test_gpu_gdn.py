@@ -202,3 +202,31 @@ def test_gdn_backward_is_stable_beside_a_loaded_chip(c):
         got = run()
         assert all(torch.equal(p, q) for p, q in zip(got, ref)), f"run {rep} differs from the unloaded run"
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("c", [192, 100])
+def test_gdn_gamma_gradient_routes_agree(c, monkeypatch):
+    """The persistent gamma-gradient kernel (default) against the route through crdr_conv2d_wgrad with CRDR_WGRAD_SQUARE_Q
+    (CRDR_GDN_DGAMMA=wgrad): same sums in a different order."""
+    from crdr_amd.models.layer.gdn import GDN
+    d = dev()
+    m = GDN(c)
+    g = torch.Generator().manual_seed(23 + c)
+    with torch.no_grad():
+        m.gamma.copy_(torch.sqrt(torch.rand(c, c, generator=g) * 0.02 + 2.0 ** -36))
+        m.beta.copy_(torch.sqrt(torch.rand(c, generator=g) + 0.5))
+    m.to(d)
+    x = (torch.randn(2, c, 90, 90, generator=g) * 2.0).to(d).contiguous(memory_format=torch.channels_last)
+    cot = torch.randn(2, c, 90, 90, generator=g).to(d).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        xd = x.clone().requires_grad_(True)
+        (m(xd) * cot).sum().backward()
+        torch.cuda.synchronize()
+        return xd.grad.clone(), m.beta.grad.clone(), m.gamma.grad.clone()
+    own = run()
+    monkeypatch.setenv("CRDR_GDN_DGAMMA", "wgrad")
+    via = run()
+    assert torch.equal(own[0], via[0])   # dx does not depend on the route
+    assert rel(own[1], via[1]) < 1e-6 and rel(own[2], via[2]) < 1e-5, (rel(own[1], via[1]), rel(own[2], via[2]))
