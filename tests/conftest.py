@@ -13,6 +13,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle (stock torch on the host) is the slow half of every parity test, and torch's default -- one thread per physical core, 128 on
+    # the GPU boxes, whose cores are shared between GPU slots -- is its WORST setting there: the stage-3 oracle step at N = 4 takes 26-30 s
+    # at 128 threads, 9.7 s at 64, 5.2 s at 32, 3.5 s at 16 (tools/experiments/r6_oracle_threads.py).  (A different split of oneDNN's
+    # reductions moves the oracle's values by rounding only, far below every tolerance the comparisons hold.)
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
 
 
 @pytest.fixture(scope="session")
