@@ -333,8 +333,9 @@ static void gdn_fused_launch(const GdnFusedArgs& a, hipStream_t s) {
 // allocator 89 spills) and is STREAMED instead: every K step's fragments (NCB x 16 bytes per lane) come from the L2-resident pack through a
 // ring of three steps, requested three steps (144 MFMAs) ahead.  dn crosses the waves through a third LDS tile (each wave writes its
 // channels in the tile image the matrix loop reads; one barrier), u = dy n^(-1/2) never leaves the registers that received dy.
-// HBM traffic: x and dy in, dn (for the weight gradient) and dx out -- 16 B per element, against 32 B for a two-pass form (x, dy -> dn, u; dn, x, u -> dx: measured 248 + 236 us at 16 x 192 x 128 x 128, both passes bound by
-// their 16 B per element at ~5 TB/s with the matrix loop only partly hidden; this kernel: 403 us), and the two matrix loops of a tile (2 x 576 MFMAs) hide the tile's 192 KB.
+// HBM traffic: x and dy in, dn (for the gamma gradient) and dx out -- 16 B per element, against 32 B for a two-pass form (x, dy -> dn, u;
+// dn, x, u -> dx: measured 248 + 236 us at 16 x 192 x 128 x 128, both passes bound by their 16 B per element at ~5 TB/s with the matrix loop
+// only partly hidden; this kernel: 375 - 400 us), and the two matrix loops of a tile (2 x 576 MFMAs) hide the tile's 192 KB.
 // ------------------------------------------------------------------------------------------------------------
 struct GdnBwd1Args {
   const float* x;
