@@ -27,6 +27,7 @@ def main():
         import gc
         import json
         import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 16))   # (the trainer builds -- host-side initialisation -- are this process's CPU work: tests/conftest.py)
         with open(sys.argv[2]) as f:
             specs = json.load(f)
         for spec in specs:
