@@ -423,6 +423,10 @@ def main():
     os.dup2(2, 1)
     import torch
     import torch.distributed as dist
+    if torch.get_num_threads() > 16:
+        # this process's host work is building the trainers (weight initialisation, packs): torch's default of one thread per physical core is the
+        # slowest setting for it on the many-core GPU boxes (profiles/r6_oracle_threads.txt); never raised (torchrun sets OMP_NUM_THREADS for its ranks)
+        torch.set_num_threads(16)
     from crdr_amd.hip import ops
     from crdr_amd.trainer import dist as D
     local = D.init_from_env()
